@@ -1,0 +1,156 @@
+'use strict';
+/*
+ * The benchmark scenes of BASELINE.json, written once against the FlexLight scene API
+ * (Scene / Transform / Plane / Cuboid / importObj ...).  Each builder takes an `engine`-shaped
+ * object {scene, camera, config} and only uses members that exist on the reference's classes,
+ * so the SAME builder drives either the reference's modules/scene.js (tools/ref_goldens.js, to
+ * produce golden arrays) or this repo's host layer (js/scene.js).
+ *
+ * What each builder restates (scene *definitions* = benchmark inputs, SURVEY.md §8d):
+ *   cornell      examples/cornell.js:17-71      config 1
+ *   cornell_obj  examples/obj.js:27-65 with ?model=cornell   config 2
+ *   dragon       examples/dragon.js:18-95 (dragon_lp.obj)     configs 3, 4
+ *   theater      examples/theater.js:18-75      config 5
+ * `frame` is the BASELINE configuration the scene is quoted on.
+ */
+
+const rep = (n, v) => { const out = []; for (let i = 0; i < n; i++) out.push(v); return out; };
+const flat = a => a.reduce((p, c) => p.concat(Array.isArray(c) ? flat(c) : [c]), []);
+
+async function cornell (engine) {
+  const scene = engine.scene, camera = engine.camera;
+  // 128x128 roughness/metallicity/emissiveness checker, two 64-row bands (cornell.js:18-31)
+  const rowA = flat([rep(64, [1, 0, 0.4]), rep(64, [0.1, 1, 0])]);
+  const rowB = flat([rep(64, [0.1, 1, 0]), rep(64, [1, 0, 0.4])]);
+  const caro = await scene.textureFromRME(flat([rep(64, rowA), rep(64, rowB)]), 128, 128);
+  scene.pbrTextures.push(caro);
+  camera.z = -20;
+  scene.primaryLightSources = [[0, 4, 0]];
+  scene.primaryLightSources[0].intensity = 160;
+  const bottom = scene.Plane([-5, -5, -21], [5, -5, -21], [5, -5, 5], [-5, -5, 5]);
+  const top = scene.Plane([-5, 5, -21], [-5, 5, 5], [5, 5, 5], [5, 5, -21]);
+  const back = scene.Plane([-5, -5, 5], [5, -5, 5], [5, 5, 5], [-5, 5, 5]);
+  const front = scene.Plane([-5, -5, -21], [-5, 5, -21], [5, 5, -21], [5, -5, -21]);
+  const left = scene.Plane([-5, -5, -21], [-5, -5, 5], [-5, 5, 5], [-5, 5, -21]);
+  const right = scene.Plane([5, -5, -21], [5, 5, -21], [5, 5, 5], [5, -5, 5]);
+  [bottom, top, back, front, left, right].forEach(p => { p.color = [230, 230, 230]; });
+  left.color = [220, 0, 0];
+  right.color = [0, 150, 0];
+  const cube = [[], []];
+  cube[0] = scene.Cuboid(-3, -1.5, -5, -2, -1, 1);
+  cube[0].textureNums = [-1, 0, -1];
+  const x = 0, x2 = 3, y = -5, y2 = -1, z = -1, z2 = 2;
+  cube[1] = scene.Cuboid(0, 3, -5, -1, -1, 2);
+  const b0 = [x + 1, y, z], b1 = [x2, y, z + 1], b2 = [x2 - 1, y, z2], b3 = [x, y, z2 - 1];
+  const t0 = [x + 1, y2, z], t1 = [x2, y2, z + 1], t2 = [x2 - 1, y2, z2], t3 = [x, y2, z2 - 1];
+  cube[1][0] = scene.Plane(t0, t1, t2, t3);
+  cube[1][1] = scene.Plane(t1, b1, b2, t2);
+  cube[1][2] = scene.Plane(t2, b2, b3, t3);
+  cube[1][3] = scene.Plane(b3, b2, b1, b0);
+  cube[1][4] = scene.Plane(t3, b3, b0, t0);
+  cube[1][5] = scene.Plane(t0, b0, b1, t1);
+  scene.queue.push(cube, [bottom, top, back, front, left, right]);
+}
+cornell.frame = { width: 256, height: 256, samplesPerRay: 1, maxReflections: 1, filter: false };
+
+async function cornellObj (engine) {
+  const scene = engine.scene, camera = engine.camera;
+  camera.x = 0; camera.y = 1; camera.z = 0;
+  camera.fx = -2.38; camera.fy = 0.2;
+  scene.primaryLightSources = [[50, 50.9, -10]];
+  scene.primaryLightSources[0].intensity = 50000;
+  scene.primaryLightSources[0].variation = 0;
+  scene.ambientLight = [0.01, 0.01, 0.01];
+  const mtl = await scene.importMtl('objects/cornell.mtl');
+  const obj = await scene.importObj('objects/cornell.obj', mtl);
+  obj.move(5, 0, -5);
+  scene.queue.push(obj);
+}
+cornellObj.frame = { width: 1920, height: 1080, samplesPerRay: 4, maxReflections: 3, filter: true };
+
+async function dragon (engine) {
+  const scene = engine.scene, camera = engine.camera;
+  camera.x = -10; camera.y = 14; camera.z = -10;
+  camera.fx = -0.9; camera.fy = 0.45;
+  scene.primaryLightSources = [[50, 70, 50]];
+  scene.primaryLightSources[0].intensity = 50000;
+  scene.primaryLightSources[0].variation = 10;
+  scene.ambientLight = [0.1, 0.1, 0.1];
+  const plane = scene.Plane([-500, -1, -500], [500, -1, -500], [500, -1, 500], [-500, -1, 500]);
+  plane.roughness = 1;
+  plane.metallicity = 0.8;
+  scene.queue.push(plane);
+  const dragonTransform = scene.Transform();
+  dragonTransform.move(15, 0, 15);
+  dragonTransform.scale(0.5);
+  const obj = await scene.importObj('objects/dragon_lp.obj');
+  obj.transform = dragonTransform;
+  obj.roughness = 0;
+  obj.metallicity = 1;
+  obj.translucency = 1;
+  obj.ior = 1.5;
+  obj.color = [255, 100, 100];
+  scene.queue.push(obj);
+  const monkeTransform = scene.Transform();
+  monkeTransform.move(5, 1, 12);
+  monkeTransform.scale(2);
+  const monke = await scene.importObj('objects/monke_smooth.obj');
+  monke.transform = monkeTransform;
+  monke.roughness = 0.1;
+  monke.metallicity = 1;
+  monke.color = [255, 200, 100];
+  scene.queue.push(monke);
+  const sphere = await scene.importObj('objects/sphere.obj');
+  sphere.scale(4);
+  sphere.move(15, 3, 0);
+  sphere.metallicity = 1;
+  sphere.roughness = 0;
+  sphere.translucency = 1;
+  sphere.ior = 1.5;
+  scene.queue.push(sphere);
+  scene.generateBVH();
+  // examples/dragon.js:98-110: the per-tick monkey rotation, frozen at its first evaluation.
+  const p = monkeTransform.position;
+  const d = [camera.x - p[0], camera.y - p[1], camera.z - p[2]];
+  const r = Math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  const theta = Math.sign(d[2]) * Math.acos(d[0] / Math.sqrt(d[0] * d[0] + d[2] * d[2])) - Math.PI * 0.5;
+  const psi = Math.acos(d[1] / r) - Math.PI * 0.5;
+  monkeTransform.rotateSpherical(theta, psi);
+}
+dragon.frame = { width: 1920, height: 1080, samplesPerRay: 8, maxReflections: 4, filter: false };
+
+async function theater (engine) {
+  const scene = engine.scene, camera = engine.camera;
+  scene.textures.push(await engine.loadImage('textures/holz.jpg'));
+  scene.standardTextureSizes = [512, 512];
+  const roughTex = await scene.textureFromRME([1, 0.3, 0], 1, 1);
+  const smoothTex = await scene.textureFromRME([0.4, 0.2, 0], 1, 1);
+  const backMirrorTex = await scene.textureFromRME(flat([
+    rep(11, [1, 0.1, 0]), rep(10, [0, 0.5, 0]), [1, 0.1, 0], rep(11, [1, 0.1, 0])
+  ]), 11, 3);
+  scene.pbrTextures.push(roughTex, smoothTex, backMirrorTex);
+  scene.translucencyTextures.push(await scene.textureFromTPO([1, 0, 0.6], 1, 1));
+  camera.x = 35; camera.y = 35; camera.z = -53;
+  camera.fx = 0.47; camera.fy = 0.44;
+  scene.primaryLightSources = [
+    [-58.03, 26, 7.5], [-58.03, 26, -10.5],
+    [43.03, 26, 0], [43.03, 26, -11.5],
+    [-20, 26, -40], [-10, 26, -40], [0, 26, -40], [10, 26, -40], [20, 26, -40]
+  ];
+  scene.ambientLight = [0, 0, 0];
+  for (let i = 0; i < 9; i++) scene.primaryLightSources[i].intensity = 1000;
+  const bottom = scene.Plane([-43.03, 0, -28], [43.03, 0, -28], [43.03, 0, 27.28], [-43.03, 0, 27.28]);
+  const back = scene.Plane([-24.5, 0, 27.28], [24.5, 0, 27.28], [24.5, 22, 27.28], [-24.5, 22, 27.28]);
+  const left = scene.Plane([-43.03, 0, 0], [-24.5, 0, 27.28], [-24.5, 22, 27.28], [-43.03, 22, 0]);
+  const right = scene.Plane([43.03, 0, 0], [43.03, 22, 0], [24.5, 22, 27.28], [24.5, 0, 27.28]);
+  bottom.textureNums = [0, 1, -1];
+  back.textureNums = [-1, 2, -1];
+  left.textureNums = [-1, 0, -1];
+  right.textureNums = [-1, 0, -1];
+  const cube = scene.Cuboid(-3, 3, 0, 17, 2, 8);
+  cube.color = [255, 80, 120];
+  scene.queue.push([bottom, back, left, right, cube]);
+}
+theater.frame = { width: 1920, height: 1080, samplesPerRay: 16, maxReflections: 6, filter: false };
+
+module.exports = { cornell, cornell_obj: cornellObj, dragon, theater };
