@@ -1,0 +1,152 @@
+/*
+ * flexlight_hip.h — C ABI of libflexlight_hip.so: FlexLight's path-tracing inner loop on MI355X.
+ *
+ * The reference has no plugin / FFI interface; the boundary this library sits behind is the
+ * duck-typed renderer object FlexLight selects by string (flexlight.js:106-129, constructed
+ * flexlight.js:113, members modules/pathtracerWGL2.js:25-78,143,167,191).  Every entry point
+ * below replaces one piece of what that object does with the WebGL2 driver; the JavaScript
+ * renderer (web-ray-tracer_amd/js/pathtracerHIP.js) binds them through the N-API shim
+ * (web-ray-tracer_amd/napi/flexlight_napi.cc), tests and bench.py bind them through ctypes.
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every host pointer, the library
+ * copies in during the call and keeps nothing; every function returns 0 on success and a
+ * non-zero flx_status otherwise, with text from flx_last_error(); nothing throws or aborts.
+ * A context is bound to one GPU and is not thread-safe.  There is NO CPU fallback: without a
+ * GPU flx_context_create fails.
+ */
+#ifndef FLEXLIGHT_HIP_H
+#define FLEXLIGHT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int flx_status;
+enum {
+  FLX_OK = 0,
+  FLX_ERR_INVALID = 1,      /* bad argument / inconsistent sizes */
+  FLX_ERR_DEVICE = 2,       /* HIP runtime error (message has the hipError string) */
+  FLX_ERR_NO_SCENE = 3,     /* render before scene / transforms upload */
+  FLX_ERR_NO_GPU = 4        /* no usable gfx950 device */
+};
+
+typedef struct flx_context flx_context;
+
+/* Host view of the flattened scene: SURVEY.md §8a rows D1–D6.  All pointers are host memory. */
+typedef struct flx_scene_view {
+  const float *geometry;        /* D1: 12 f32 per entry, n_entries_padded entries (scene.js:224-298) */
+  const float *attributes;      /* D2: 28 f32 per entry, same index (scene.js:635-641) */
+  uint32_t n_entries_padded;    /* multiple of 256; zero entries terminate traversal */
+  const int32_t *ids;           /* D3: entry index of every triangle (scene.js:267,302) */
+  uint32_t n_ids;
+  const float *rotation;        /* D4: per transform 24 f32: forward then inverse std140 mat3 (scene.js:500-521) */
+  const float *shift;           /* D4: per transform 8 f32: position xyz_, -position xyz_ */
+  uint32_t n_transforms;
+  const float *lights;          /* D5: per light x y z intensity variation 0 (pathtracerWGL2.js:143-165) */
+  uint32_t n_lights;
+  const uint8_t *atlas[3];      /* D6: RGBA8 atlases: 0 albedo (tex), 1 pbr, 2 translucency; may be NULL */
+  uint32_t atlas_w[3], atlas_h[3];
+} flx_scene_view;
+
+/* Per-frame uniforms: SURVEY.md §8a row D7 (modules/pathtracerWGL2.js:329-347) plus the tile policy. */
+typedef struct flx_frame_params {
+  uint32_t width, height;       /* canvas size */
+  float camera[3];              /* cameraPosition */
+  float view_matrix[9];         /* row-major rows as built at pathtracerWGL2.js:312-318 */
+  int32_t samples;              /* config.samplesPerRay */
+  int32_t max_reflections;      /* config.maxReflections */
+  float min_importancy;         /* config.minImportancy */
+  int32_t use_filter;           /* config.filter: write the five G-buffers and run the denoise chain */
+  int32_t is_temporal;          /* config.temporal (only the fract/floor split of fragment:626-629; no history pass) */
+  int32_t hdr;                  /* config.hdr, final filter tone map */
+  float ambient[3];             /* scene.ambientLight */
+  float random_seed;            /* 0 unless temporal (pathtracerWGL2.js:347) */
+  int32_t texture_width;        /* floor(2048 / standardTextureSizes[0]) */
+  /* Tile policy (multi-GPU): the frame is cut into strips of tile_rows image rows,
+   * strip s belongs to the context with s % tile_count == tile_index.  0/0/0 or x/0/1 = whole frame. */
+  uint32_t tile_rows, tile_index, tile_count;
+} flx_frame_params;
+
+/* Work counters of one frame; identical numbers come out of the CPU oracle for the same frame and
+ * feed the algorithmic-bytes roofline of SURVEY.md §8d. */
+typedef struct flx_counters {
+  uint64_t primary_visits;      /* D1 entries fetched by the primary-visibility walks (P0) */
+  uint64_t closest_visits;      /* ... by rayTracer walks (T1) */
+  uint64_t shadow_visits;       /* ... by shadowTest walks (T2) */
+  uint64_t closest_walks;
+  uint64_t shadow_walks;
+  uint64_t shades;              /* bounce iterations executed (S1) */
+  uint64_t primary_hits;        /* pixels with a primary hit */
+  uint64_t atlas_texels;        /* atlas texels fetched (S5) */
+} flx_counters;
+
+/* Optional float32 pre-quantisation G-buffers (row D8), W*H*4 floats each, packed like the radiance. */
+typedef struct flx_gbuffers {
+  float *color;                 /* renderColor */
+  float *color_ip;              /* renderColorIp */
+  float *original_color;        /* renderOriginalColor */
+  float *id;                    /* renderId */
+  float *original_id;           /* renderOriginalId */
+} flx_gbuffers;
+
+/* ---- life cycle -------------------------------------------------------------------------------- */
+/* Replaces canvas.getContext('webgl2') + prepareEngine() (pathtracerWGL2.js:60-68,556-788). */
+flx_status flx_context_create(int device, flx_context **out);
+/* Replaces halt()'s gl.loseContext() (pathtracerWGL2.js:70-77). */
+void flx_context_destroy(flx_context *ctx);
+const char *flx_last_error(const flx_context *ctx);     /* ctx may be NULL: last creation error */
+
+/* ---- uploads ----------------------------------------------------------------------------------- */
+/* Replaces updateScene()'s two texImage2D uploads + idBuffer (pathtracerWGL2.js:167-189,367-368). */
+flx_status flx_scene_upload(flx_context *ctx, const float *geometry, const float *attributes,
+                            uint32_t n_entries_padded, const int32_t *ids, uint32_t n_ids);
+/* Replaces the per-frame UBO fill from Transform.buildWGL2Arrays() (pathtracerWGL2.js:361-365). */
+flx_status flx_transforms_upload(flx_context *ctx, const float *rotation, const float *shift, uint32_t n_transforms);
+/* Replaces updatePrimaryLightSources() (pathtracerWGL2.js:143-165). n_lights may be 0. */
+flx_status flx_lights_upload(flx_context *ctx, const float *lights, uint32_t n_lights);
+/* Replaces #updateAtlas (pathtracerWGL2.js:85-104); which: 0 albedo, 1 pbr, 2 translucency. rgba NULL = none. */
+flx_status flx_atlas_upload(flx_context *ctx, int which, const uint8_t *rgba, uint32_t width, uint32_t height);
+/* All of the above from one view. */
+flx_status flx_scene_upload_view(flx_context *ctx, const flx_scene_view *scene);
+
+/* ---- one frame ---------------------------------------------------------------------------------- */
+/* Number of image rows the tile policy of `params` assigns to this context (whole frame: height). */
+uint32_t flx_tile_row_count(const flx_frame_params *params);
+/* Image row (0 = top) of the context's k-th packed row. */
+uint32_t flx_tile_row_at(const flx_frame_params *params, uint32_t k);
+
+/* Replaces renderFrame() (pathtracerWGL2.js:375-554) for one frame: path-trace pass and, with
+ * use_filter, the denoise chain.  out_rgba: flx_tile_row_count()*width*4 floats (host), rows packed
+ * in strip order, top row first; without filter = renderColor of fragment:631 (miss pixels 0,0,0,0),
+ * with filter = the final filter's canvas colour.  gbuffers / counters may be NULL. */
+flx_status flx_render(flx_context *ctx, const flx_frame_params *params, float *out_rgba,
+                      const flx_gbuffers *gbuffers, flx_counters *counters);
+/* Same, output left in DEVICE memory (d_out_rgba is a device pointer on the context's GPU, e.g. a
+ * torch tensor's data_ptr) and enqueued on the context's stream without a host sync: for the
+ * multi-GPU gather over RCCL.  Call flx_sync before reading on another stream. */
+flx_status flx_render_device(flx_context *ctx, const flx_frame_params *params, void *d_out_rgba);
+flx_status flx_sync(flx_context *ctx);
+/* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. NULL restores it. */
+flx_status flx_set_stream(flx_context *ctx, void *hip_stream);
+/* Counters of the last flx_render_device frame (collected only when enabled; costs atomics). */
+flx_status flx_set_counters_enabled(flx_context *ctx, int enabled);
+flx_status flx_get_counters(flx_context *ctx, flx_counters *out);
+/* GPU time of the last frame between HIP events on the context's stream, and of its dominant
+ * (trace) kernel alone; milliseconds. */
+flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_kernel_ms);
+
+/* ---- diagnostics --------------------------------------------------------------------------------- */
+/* Evaluate one of include/flx_math.h's routines on the GPU for n inputs (b may be NULL for unary
+ * functions); used by tests to prove CPU/GPU bit equality.  fn: 0 sin 1 cos 2 tan 3 acos 4 atan2
+ * 5 exp 6 pow 7 tanh 8 floor 9 sqrt 10 div. */
+flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, const float *b, float *out, uint32_t n);
+/* Device name / CU count of the context's GPU. */
+flx_status flx_device_info(flx_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units);
+const char *flx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLEXLIGHT_HIP_H */

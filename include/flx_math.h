@@ -253,4 +253,26 @@ FLX_HD float flx_tanh(float x) {
 /* pow(2.0, -i) for small non-negative integer i (fragment:560): exact. */
 FLX_HD float flx_exp2_neg_int(int i) { return (i < 126) ? flx_u2f((uint32_t)(127 - i) << 23) : 0.0f; }
 
+
+/* ---- small host-side helper shared by oracle and library --------------------------------------- */
+/* Inverse of a row-major 3x3 (the viewMatrix), adjugate / determinant in double, rounded to float:
+ * primary rays are V^-1 * (ndc.x, ndc.y, 1)  (SURVEY.md §8a row P0). */
+FLX_HD void flx_invert3x3(const float m[9], float out[9]) {
+  double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  double det = a * A + b * B + c * C;
+  double r = 1.0 / det;
+  out[0] = (float)(A * r); out[1] = (float)(-(b * i - c * h) * r); out[2] = (float)((b * f - c * e) * r);
+  out[3] = (float)(B * r); out[4] = (float)((a * i - c * g) * r);  out[5] = (float)(-(a * f - c * d) * r);
+  out[6] = (float)(C * r); out[7] = (float)(-(a * h - b * g) * r); out[8] = (float)((a * e - b * d) * r);
+}
+
+/* float -> uint as GLSL's uint(x) for the in-range values the path produces, with the out-of-range
+ * cases (undefined in GLSL) pinned: negative / NaN -> 0, too large -> 0xffffffff. */
+FLX_HD uint32_t flx_f2uint(float x) {
+  if (!(x > 0.0f)) return 0u;
+  if (x >= 4294967296.0f) return 0xffffffffu;
+  return (uint32_t)x;
+}
+
 #endif /* FLX_MATH_H */

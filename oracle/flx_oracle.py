@@ -1,0 +1,60 @@
+"""ctypes binding of the CPU oracle (oracle/libflx_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(_HERE, "..", "web-ray-tracer_amd"))
+from flexlight_hip.scene_io import Counters, FrameParams, GBuffers, SceneView  # noqa: E402
+
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libflx_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.flx_oracle_render.argtypes = [C.POINTER(SceneView), C.POINTER(FrameParams), C.POINTER(C.c_float),
+                                           C.POINTER(GBuffers), C.POINTER(Counters), C.c_int]
+        _LIB.flx_oracle_render.restype = C.c_int
+        _LIB.flx_oracle_filter.argtypes = [C.POINTER(FrameParams), C.POINTER(GBuffers), C.POINTER(C.c_float), C.c_int]
+        _LIB.flx_oracle_filter.restype = C.c_int
+    return _LIB
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def tile_rows(params):
+    tr, tc, ti = params.tile_rows, params.tile_count, params.tile_index
+    if tr == 0 or tc <= 1:
+        return list(range(params.height))
+    return [y for y in range(params.height) if (y // tr) % tc == ti]
+
+
+def render(scene, params, gbuffers=False, threads=0):
+    """Returns (rgba [rows, W, 4] float32, counters dict, gbuffers dict or None)."""
+    view = scene.view()
+    rows = len(tile_rows(params))
+    out = np.zeros((rows, params.width, 4), np.float32)
+    cnt = Counters()
+    gb, gbs = None, None
+    if gbuffers:
+        gbs = {n: np.zeros((rows, params.width, 4), np.float32) for n, _ in GBuffers._fields_}
+        gb = GBuffers(*[_fp(gbs[n]) for n, _ in GBuffers._fields_])
+    rc = lib().flx_oracle_render(C.byref(view), C.byref(params), _fp(out), C.byref(gb) if gb else None, C.byref(cnt), threads)
+    if rc != 0:
+        raise RuntimeError("flx_oracle_render failed: %d" % rc)
+    return out, cnt.as_dict(), gbs
