@@ -1,0 +1,43 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (test infrastructure): built on demand with gcc."""
+    import flx_oracle
+    flx_oracle.build()
+    flx_oracle.lib()
+    return flx_oracle
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """One flx_context on GPU 0 through the C ABI.  No fallback: a missing library or GPU is an error."""
+    from flexlight_hip import capi
+    ctx = capi.Context(0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="session")
+def scenes():
+    from flexlight_hip.scene_io import Scene
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Scene.golden(name)
+        return cache[name]
+    return get

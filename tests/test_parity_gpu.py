@@ -1,0 +1,78 @@
+"""GPU parity: libflexlight_hip.so (through the C ABI) against the CPU oracle on the same inputs.
+
+Inputs are the arrays the reference's own scene.js emits for the BASELINE scenes (tests/golden/ref_*).
+Bar: per-channel RMS <= 1e-4 (BASELINE.json north_star); because both sides share include/flx_math.h
+and are compiled without FMA contraction we additionally expect — and assert — bit equality, and
+identical work counters (entries visited, shades, walks)."""
+import numpy as np
+import pytest
+
+from parity_util import assert_parity
+
+pytestmark = pytest.mark.gpu
+
+# (scene, width, height, samples, max_reflections): sizes the oracle finishes in seconds.
+CASES = [
+    ("cornell", 256, 256, 1, 1),          # BASELINE config 1, full size
+    ("cornell", 128, 96, 3, 4),
+    ("cornell_obj", 320, 180, 4, 3),      # config 2 scene, reduced frame, filter off
+    ("dragon", 320, 180, 2, 4),           # config 3 scene, reduced frame
+    ("theater", 320, 180, 2, 6),          # config 5 scene (9 lights, atlases), reduced frame
+]
+
+
+@pytest.mark.parametrize("name,w,h,spp,bounces", CASES)
+def test_radiance_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounces):
+    sc = scenes(name)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+    hip.update_scene(sc)
+    got, got_cnt, _ = hip.render(p, counters=True)
+    want, want_cnt, _ = oracle.render(sc, p)
+    rms, mism = assert_parity(got, want, name)
+    assert mism == 0, "%s: %d of %d floats differ in bits (rms %s)" % (name, mism, got.size, rms)
+    assert got_cnt == want_cnt
+    assert (got[..., 3] == 1).sum() == want_cnt["primary_hits"]
+
+
+def test_tiles_reassemble_full_frame(hip, scenes):
+    """Row-strip tile policy (multi-GPU split): strips dealt round-robin reproduce the whole frame."""
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    full, _, _ = hip.render(sc.frame_params(width=96, height=80, samples=2, max_reflections=3, use_filter=0))
+    for tile_rows, count in ((8, 2), (8, 3), (16, 4), (5, 3)):
+        frame = np.full_like(full, np.nan)
+        seen = 0
+        for index in range(count):
+            p = sc.frame_params(width=96, height=80, samples=2, max_reflections=3, use_filter=0, tile=(tile_rows, index, count))
+            part, _, _ = hip.render(p)
+            rows = hip.tile_rows(p)
+            assert part.shape[0] == len(rows)
+            frame[rows] = part
+            seen += len(rows)
+        assert seen == 80
+        assert np.array_equal(frame, full, equal_nan=True)
+
+
+def test_counters_off_same_image(hip, scenes):
+    sc = scenes("theater")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=160, height=90, samples=1, max_reflections=3, use_filter=0)
+    a, _, _ = hip.render(p, counters=True)
+    b, none, _ = hip.render(p)
+    assert none is None
+    assert np.array_equal(a, b, equal_nan=True)
+
+
+def test_errors_are_reported_not_thrown(hip, scenes):
+    from flexlight_hip import capi
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=0, height=8)
+    with pytest.raises(capi.FlexLightHipError, match="width"):
+        hip.render(p)
+    fresh = capi.Context(0)
+    try:
+        with pytest.raises(capi.FlexLightHipError, match="before"):
+            fresh.render(sc.frame_params(width=8, height=8))
+    finally:
+        fresh.close()

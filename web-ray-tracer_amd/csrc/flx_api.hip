@@ -1,0 +1,402 @@
+/*
+ * flx_api.hip — the C ABI of include/flexlight_hip.h: context, uploads, one-frame driver.
+ *
+ * Host-side counterpart of what modules/pathtracerWGL2.js does around its draw call: keep the
+ * scene arrays resident on the GPU (here: plain device buffers in HBM, uploaded once and reused
+ * every frame; the reference re-uploads lights and transforms per frame, pathtracerWGL2.js:258-262,
+ * 361-365), derive the per-frame constants, launch, hand the radiance back.  No CPU fallback.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "flexlight_hip.h"
+#include "flx_kernels.h"
+
+using namespace flx;
+
+static thread_local std::string g_create_error;
+
+struct flx_context {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+  /* resident scene */
+  float4 *d_geometry = nullptr, *d_attributes = nullptr, *d_rotation = nullptr, *d_shift = nullptr;
+  int32_t *d_ids = nullptr;
+  float *d_lights = nullptr;
+  uchar4 *d_atlas[3] = { nullptr, nullptr, nullptr };
+  uint32_t atlas_w[3] = { 0, 0, 0 }, atlas_h[3] = { 0, 0, 0 };
+  uint32_t n_entries = 0, n_ids = 0, n_transforms = 0, n_lights = 0;
+  uint32_t max_transform = 0;                   /* largest transform number an entry names */
+  bool have_scene = false, have_transforms = false;
+  /* frame workspace */
+  float4 *d_out = nullptr;
+  size_t out_capacity = 0;                       /* pixels */
+  float4 *d_gb[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  size_t gb_capacity = 0;
+  unsigned long long *d_counters = nullptr;
+  bool counters_enabled = false;
+  flx_counters last_counters = {};
+  hipEvent_t ev_frame0 = nullptr, ev_frame1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+  bool timed = false;
+};
+
+#define FLX_HIP(ctx, expr)                                                                    \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+      return FLX_ERR_DEVICE;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+static flx_status fail(flx_context *ctx, flx_status code, const char *msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+extern "C" const char *flx_version(void) { return "flexlight-hip 0.1 (gfx950)"; }
+
+extern "C" const char *flx_last_error(const flx_context *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" flx_status flx_context_create(int device, flx_context **out) {
+  if (!out) { g_create_error = "flx_context_create: out is NULL"; return FLX_ERR_INVALID; }
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_create_error = std::string("flx_context_create: no HIP device (") + hipGetErrorString(e) + "); this library has no CPU path";
+    return FLX_ERR_NO_GPU;
+  }
+  if (device < 0 || device >= n) { g_create_error = "flx_context_create: device index out of range"; return FLX_ERR_INVALID; }
+  flx_context *ctx = new flx_context();
+  ctx->device = device;
+  auto bail = [&](const char *what, hipError_t err) {
+    g_create_error = std::string(what) + ": " + hipGetErrorString(err);
+    delete ctx;
+    return FLX_ERR_DEVICE;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail("hipSetDevice", e);
+  if ((e = hipGetDeviceProperties(&ctx->prop, device)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  ctx->stream = ctx->own_stream;
+  if ((e = hipEventCreate(&ctx->ev_frame0)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev_frame1)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev_k0)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  *out = ctx;
+  return FLX_OK;
+}
+
+extern "C" void flx_context_destroy(flx_context *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
+                   ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
+                   ctx->d_gb[3], ctx->d_gb[4], ctx->d_counters };
+  for (void *b : bufs) if (b) (void)hipFree(b);
+  for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+template <typename T>
+static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t bytes) {
+  if (*dst) { FLX_HIP(ctx, hipFree(*dst)); *dst = nullptr; }
+  if (bytes == 0) return FLX_OK;
+  FLX_HIP(ctx, hipMalloc(dst, bytes));
+  FLX_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));          /* the caller's buffer is not retained */
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, const float *attributes, uint32_t n_entries_padded,
+                                       const int32_t *ids, uint32_t n_ids) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!geometry || !attributes || n_entries_padded == 0) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: empty scene");
+  if (n_ids && !ids) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: ids is NULL");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->have_scene = false;
+  /* Validate the skip list on the host: a skip that leaves the array would make the walk read out of
+   * bounds on the GPU (the shader's texelFetch would be robust-access clamped; we refuse instead). */
+  uint32_t max_transform = 0;
+  for (uint32_t i = 0; i < n_entries_padded; i++) {
+    const float *e = geometry + (size_t)i * 12;
+    if (e[10] != 0.0f) {
+      if (!(e[9] >= 0.0f && e[9] < 1048576.0f)) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: transform number out of range");
+      if ((uint32_t)e[9] > max_transform) max_transform = (uint32_t)e[9];
+    }
+    if (e[10] == 1.0f) {
+      float skip = e[6];
+      if (!(skip >= 0.0f) || (double)i + (double)skip >= (double)n_entries_padded)
+        return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: AABB skip count leaves the entry array");
+    } else if (e[10] != 0.0f && e[10] != 2.0f) {
+      return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: entry type is not 0, 1 or 2");
+    }
+  }
+  flx_status s;
+  if ((s = upload(ctx, &ctx->d_geometry, geometry, (size_t)n_entries_padded * 48))) return s;
+  if ((s = upload(ctx, &ctx->d_attributes, attributes, (size_t)n_entries_padded * 112))) return s;
+  if ((s = upload(ctx, &ctx->d_ids, ids, (size_t)n_ids * 4))) return s;
+  ctx->n_entries = n_entries_padded;
+  ctx->n_ids = n_ids;
+  ctx->max_transform = max_transform;
+  ctx->have_scene = true;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_transforms_upload(flx_context *ctx, const float *rotation, const float *shift, uint32_t n_transforms) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!rotation || !shift || n_transforms == 0) return fail(ctx, FLX_ERR_INVALID, "flx_transforms_upload: need at least the identity transform");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  flx_status s;
+  if ((s = upload(ctx, &ctx->d_rotation, rotation, (size_t)n_transforms * 96))) return s;
+  if ((s = upload(ctx, &ctx->d_shift, shift, (size_t)n_transforms * 32))) return s;
+  ctx->n_transforms = n_transforms;
+  ctx->have_transforms = true;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_lights_upload(flx_context *ctx, const float *lights, uint32_t n_lights) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (n_lights && !lights) return fail(ctx, FLX_ERR_INVALID, "flx_lights_upload: lights is NULL");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  flx_status s;
+  if ((s = upload(ctx, &ctx->d_lights, lights, (size_t)n_lights * 24))) return s;
+  ctx->n_lights = n_lights;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_atlas_upload(flx_context *ctx, int which, const uint8_t *rgba, uint32_t width, uint32_t height) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (which < 0 || which > 2) return fail(ctx, FLX_ERR_INVALID, "flx_atlas_upload: which must be 0, 1 or 2");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  size_t bytes = rgba ? (size_t)width * height * 4 : 0;
+  flx_status s;
+  if ((s = upload(ctx, &ctx->d_atlas[which], rgba, bytes))) return s;
+  ctx->atlas_w[which] = bytes ? width : 0;
+  ctx->atlas_h[which] = bytes ? height : 0;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_scene_upload_view(flx_context *ctx, const flx_scene_view *v) {
+  if (!ctx || !v) return FLX_ERR_INVALID;
+  flx_status s;
+  if ((s = flx_scene_upload(ctx, v->geometry, v->attributes, v->n_entries_padded, v->ids, v->n_ids))) return s;
+  if ((s = flx_transforms_upload(ctx, v->rotation, v->shift, v->n_transforms))) return s;
+  if ((s = flx_lights_upload(ctx, v->lights, v->n_lights))) return s;
+  for (int i = 0; i < 3; i++)
+    if ((s = flx_atlas_upload(ctx, i, v->atlas[i], v->atlas_w[i], v->atlas_h[i]))) return s;
+  return FLX_OK;
+}
+
+/* ---- tile policy ------------------------------------------------------------------------------------ */
+static void tile_normalise(const flx_frame_params *p, uint32_t &tr, uint32_t &ti, uint32_t &tc) {
+  tr = p->tile_rows; ti = p->tile_index; tc = p->tile_count;
+  if (tr == 0 || tc <= 1) { tr = p->height ? p->height : 1; ti = 0; tc = 1; }
+}
+extern "C" uint32_t flx_tile_row_count(const flx_frame_params *p) {
+  if (!p) return 0;
+  uint32_t tr, ti, tc;
+  tile_normalise(p, tr, ti, tc);
+  if (ti >= tc) return 0;
+  uint32_t strips = (p->height + tr - 1) / tr, n = 0;
+  for (uint32_t s = ti; s < strips; s += tc) {
+    uint32_t y0 = s * tr, y1 = y0 + tr;
+    if (y1 > p->height) y1 = p->height;
+    n += y1 - y0;
+  }
+  return n;
+}
+extern "C" uint32_t flx_tile_row_at(const flx_frame_params *p, uint32_t k) {
+  uint32_t tr, ti, tc;
+  tile_normalise(p, tr, ti, tc);
+  uint32_t strip = k / tr;
+  return (strip * tc + ti) * tr + (k - strip * tr);
+}
+
+static flx_status make_frame(flx_context *ctx, const flx_frame_params *p, DeviceScene &sc, DeviceFrame &fr) {
+  if (!p) return fail(ctx, FLX_ERR_INVALID, "frame params are NULL");
+  if (!ctx->have_scene || !ctx->have_transforms) return fail(ctx, FLX_ERR_NO_SCENE, "render before flx_scene_upload / flx_transforms_upload");
+  if (p->width == 0 || p->height == 0 || p->samples < 1 || p->max_reflections < 0 || p->texture_width < 1)
+    return fail(ctx, FLX_ERR_INVALID, "frame params: width/height/samples/texture_width must be positive");
+  if (p->tile_count > 1 && p->tile_index >= p->tile_count) return fail(ctx, FLX_ERR_INVALID, "frame params: tile_index >= tile_count");
+  sc.geometry = ctx->d_geometry; sc.attributes = ctx->d_attributes;
+  sc.rotation = ctx->d_rotation; sc.shift = ctx->d_shift; sc.lights = ctx->d_lights;
+  for (int i = 0; i < 3; i++) { sc.atlas[i] = ctx->d_atlas[i]; sc.atlas_w[i] = ctx->atlas_w[i]; sc.atlas_h[i] = ctx->atlas_h[i]; }
+  sc.n_entries = ctx->n_entries; sc.n_lights = ctx->n_lights;
+  uint32_t tr, ti, tc;
+  tile_normalise(p, tr, ti, tc);
+  fr.width = p->width; fr.height = p->height;
+  fr.rows = flx_tile_row_count(p);
+  fr.tile_rows = tr; fr.tile_index = ti; fr.tile_count = tc;
+  memcpy(fr.camera, p->camera, sizeof fr.camera);
+  flx_invert3x3(p->view_matrix, fr.inv_view);
+  fr.view_row2[0] = p->view_matrix[6]; fr.view_row2[1] = p->view_matrix[7]; fr.view_row2[2] = p->view_matrix[8];
+  fr.samples = p->samples; fr.max_reflections = p->max_reflections;
+  fr.min_importancy = p->min_importancy;
+  fr.use_filter = p->use_filter; fr.is_temporal = p->is_temporal;
+  memcpy(fr.ambient, p->ambient, sizeof fr.ambient);
+  fr.random_seed = p->random_seed;
+  fr.texture_width = (float)p->texture_width;
+  /* An entry names a transform; the shader indexes the UBO unchecked, we refuse an index past the upload. */
+  if (ctx->max_transform >= ctx->n_transforms) return fail(ctx, FLX_ERR_INVALID, "scene names a transform that was not uploaded");
+  return FLX_OK;
+}
+
+static flx_status ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels) {
+  if (*cap >= pixels && *buf) return FLX_OK;
+  if (*buf) { FLX_HIP(ctx, hipFree(*buf)); *buf = nullptr; *cap = 0; }
+  FLX_HIP(ctx, hipMalloc(buf, pixels * sizeof(float4)));
+  *cap = pixels;
+  return FLX_OK;
+}
+
+static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
+  unsigned long long *cnt = ctx->counters_enabled ? ctx->d_counters : nullptr;
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
+  if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  launch_trace_pixels(sc, fr, d_out, gb, cnt, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  ctx->timed = true;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_render_device(flx_context *ctx, const flx_frame_params *params, void *d_out_rgba) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render_device: output pointer is NULL");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceScene sc; DeviceFrame fr;
+  flx_status s = make_frame(ctx, params, sc, fr);
+  if (s) return s;
+  if (params->use_filter) return fail(ctx, FLX_ERR_INVALID, "flx_render_device: filter chain not available on the device-output path yet");
+  GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  return run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
+}
+
+extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *params, float *out_rgba, const flx_gbuffers *gbuffers,
+                                 flx_counters *counters) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render: out_rgba is NULL");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceScene sc; DeviceFrame fr;
+  flx_status s = make_frame(ctx, params, sc, fr);
+  if (s) return s;
+  if (gbuffers && !params->use_filter) return fail(ctx, FLX_ERR_INVALID, "flx_render: G-buffers are only produced with use_filter = 1");
+  const size_t pixels = (size_t)fr.rows * fr.width;
+  if (pixels == 0) return FLX_OK;
+  if ((s = ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
+  GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  if (params->use_filter) {
+    if (ctx->gb_capacity < pixels) {
+      for (int i = 0; i < 5; i++) {
+        size_t cap = 0;
+        if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
+        if ((s = ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
+      }
+      ctx->gb_capacity = pixels;
+    }
+    gb.color = ctx->d_gb[0]; gb.color_ip = ctx->d_gb[1]; gb.original_color = ctx->d_gb[2]; gb.id = ctx->d_gb[3]; gb.original_id = ctx->d_gb[4];
+  }
+  const bool saved = ctx->counters_enabled;
+  if (counters) ctx->counters_enabled = true;
+  s = run_frame(ctx, sc, fr, ctx->d_out, gb);
+  ctx->counters_enabled = saved;
+  if (s) return s;
+  FLX_HIP(ctx, hipMemcpyAsync(out_rgba, ctx->d_out, pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  if (gbuffers) {
+    float *dst[5] = { gbuffers->color, gbuffers->color_ip, gbuffers->original_color, gbuffers->id, gbuffers->original_id };
+    for (int i = 0; i < 5; i++)
+      if (dst[i]) FLX_HIP(ctx, hipMemcpyAsync(dst[i], ctx->d_gb[i], pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  unsigned long long host_cnt[8];
+  if (counters) FLX_HIP(ctx, hipMemcpyAsync(host_cnt, ctx->d_counters, sizeof host_cnt, hipMemcpyDeviceToHost, ctx->stream));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (counters) {
+    memcpy(counters, host_cnt, sizeof host_cnt);
+    ctx->last_counters = *counters;
+  }
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_sync(flx_context *ctx) {
+  if (!ctx) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_set_stream(flx_context *ctx, void *hip_stream) {
+  if (!ctx) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  ctx->timed = false;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_set_counters_enabled(flx_context *ctx, int enabled) {
+  if (!ctx) return FLX_ERR_INVALID;
+  ctx->counters_enabled = enabled != 0;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_get_counters(flx_context *ctx, flx_counters *out) {
+  if (!ctx || !out) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  unsigned long long host_cnt[8];
+  FLX_HIP(ctx, hipMemcpy(host_cnt, ctx->d_counters, sizeof host_cnt, hipMemcpyDeviceToHost));
+  memcpy(out, host_cnt, sizeof host_cnt);
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_kernel_ms) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!ctx->timed) return fail(ctx, FLX_ERR_INVALID, "flx_last_frame_ms: no frame rendered yet");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipEventSynchronize(ctx->ev_frame1));
+  float a = 0.f, b = 0.f;
+  FLX_HIP(ctx, hipEventElapsedTime(&a, ctx->ev_frame0, ctx->ev_frame1));
+  FLX_HIP(ctx, hipEventElapsedTime(&b, ctx->ev_k0, ctx->ev_k1));
+  if (frame_ms) *frame_ms = a;
+  if (trace_kernel_ms) *trace_kernel_ms = b;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, const float *b, float *out, uint32_t n) {
+  if (!ctx || !a || !out) return FLX_ERR_INVALID;
+  if (n == 0) return FLX_OK;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  float *d_a = nullptr, *d_b = nullptr, *d_o = nullptr;
+  FLX_HIP(ctx, hipMalloc(&d_a, (size_t)n * 4));
+  FLX_HIP(ctx, hipMalloc(&d_o, (size_t)n * 4));
+  FLX_HIP(ctx, hipMemcpy(d_a, a, (size_t)n * 4, hipMemcpyHostToDevice));
+  if (b) {
+    FLX_HIP(ctx, hipMalloc(&d_b, (size_t)n * 4));
+    FLX_HIP(ctx, hipMemcpy(d_b, b, (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  launch_debug_math(fn, d_a, d_b, d_o, n, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FLX_HIP(ctx, hipMemcpy(out, d_o, (size_t)n * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_a); (void)hipFree(d_o); if (d_b) (void)hipFree(d_b);
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_device_info(flx_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (name && name_len) { snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName); }
+  if (compute_units) *compute_units = (uint32_t)ctx->prop.multiProcessorCount;
+  return FLX_OK;
+}

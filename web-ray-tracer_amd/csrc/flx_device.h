@@ -1,0 +1,515 @@
+/*
+ * flx_device.h — device-side building blocks of the HIP path tracer (gfx950).
+ *
+ * The arithmetic of every routine is the reference shader's, operation for operation
+ * (shaders/pathtracer_fragment.glsl; cited per function), with GLSL built-ins expanded as
+ * include/flx_math.h pins them, so that results equal the CPU oracle's bit for bit when compiled
+ * with -ffp-contract=off.  What is NOT the shader's: the memory layout (flat float4 arrays instead
+ * of textures), the primary-ray kernel (the reference rasterises) and the way work
+ * is mapped to wave64 lanes (flx_kernels.hip).
+ */
+#ifndef FLX_DEVICE_H
+#define FLX_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flx_math.h"
+
+#define FLX_DEV __device__ __forceinline__
+
+namespace flx {
+
+constexpr float PHI = 1.61803398874989484820459f;     /* fragment:5 */
+constexpr float SQRT3 = 1.7320508075688772f;          /* fragment:6 */
+constexpr float INV_PI = 0.3183098861837907f;         /* fragment:10 */
+constexpr float INV_256 = 0.00390625f;                /* fragment:11 */
+constexpr float INV_255 = 0.00392156862745098f;       /* fragment:12 */
+constexpr float PI_F = 3.141592653589793f;            /* fragment:4 */
+constexpr float BIAS = FLX_BIAS;
+constexpr float POW32 = FLX_POW32;
+constexpr float NEAR_VIEW_DEPTH = 0.5f;               /* SURVEY §8a P0 */
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct M3 { f3 c0, c1, c2; };                          /* columns, like GLSL mat3 */
+
+FLX_DEV f3 F3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+FLX_DEV f3 operator+(f3 a, f3 b) { return F3(a.x + b.x, a.y + b.y, a.z + b.z); }
+FLX_DEV f3 operator-(f3 a, f3 b) { return F3(a.x - b.x, a.y - b.y, a.z - b.z); }
+FLX_DEV f3 operator*(f3 a, f3 b) { return F3(a.x * b.x, a.y * b.y, a.z * b.z); }
+FLX_DEV f3 operator/(f3 a, f3 b) { return F3(a.x / b.x, a.y / b.y, a.z / b.z); }
+FLX_DEV f3 operator*(f3 a, float s) { return F3(a.x * s, a.y * s, a.z * s); }
+FLX_DEV f3 operator/(f3 a, float s) { return F3(a.x / s, a.y / s, a.z / s); }
+FLX_DEV f3 operator-(f3 a) { return F3(-a.x, -a.y, -a.z); }
+FLX_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+FLX_DEV f3 cross(f3 a, f3 b) { return F3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+FLX_DEV float length(f3 a) { return flx_sqrt(dot(a, a)); }
+FLX_DEV f3 normalize(f3 a) { return a / length(a); }
+FLX_DEV float distance(f3 a, f3 b) { return length(a - b); }
+FLX_DEV f3 mix(f3 a, f3 b, float t) { return F3(flx_mix(a.x, b.x, t), flx_mix(a.y, b.y, t), flx_mix(a.z, b.z, t)); }
+FLX_DEV f3 mul(const M3 &m, f3 v) {
+  return F3((m.c0.x * v.x + m.c1.x * v.y) + m.c2.x * v.z,
+            (m.c0.y * v.x + m.c1.y * v.y) + m.c2.y * v.z,
+            (m.c0.z * v.x + m.c1.z * v.y) + m.c2.z * v.z);
+}
+FLX_DEV f3 reflect(f3 I, f3 N) { return I - N * (2.0f * dot(N, I)); }
+FLX_DEV f3 refract(f3 I, f3 N, float eta) {
+  float d = dot(N, I);
+  float k = 1.0f - eta * eta * (1.0f - d * d);
+  if (k < 0.0f) return F3(0.0f, 0.0f, 0.0f);
+  return I * eta - N * (eta * d + flx_sqrt(k));
+}
+
+struct Ray { f3 origin, dir; };                        /* fragment:19-22 */
+struct Material { f3 albedo, rme, tpo; };              /* fragment:24-28 */
+struct Hit { f3 suv; int transformId; int triangleId; };   /* fragment:30-34 */
+
+/* Device-resident scene: the flat arrays of SURVEY §8a D1–D6 (no textures, no 256-entry rows). */
+struct DeviceScene {
+  const float4 *geometry;       /* 3 x float4 per entry */
+  const float4 *attributes;     /* 7 x float4 per entry */
+  const float4 *rotation;       /* 3 x float4 (std140 columns) per matrix, 2 matrices per transform */
+  const float4 *shift;          /* 1 x float4 per vector, 2 per transform */
+  const float *lights;          /* 6 floats per light */
+  const uchar4 *atlas[3];
+  uint32_t atlas_w[3], atlas_h[3];
+  uint32_t n_entries;           /* padded entry count = loop bound (fragment:181-184) */
+  uint32_t n_lights;
+};
+
+/* Per-frame constants (flx_frame_params + what the host derives from it). */
+struct DeviceFrame {
+  uint32_t width, height;       /* full canvas */
+  uint32_t rows;                /* packed rows this context renders */
+  uint32_t tile_rows, tile_index, tile_count;
+  float camera[3];
+  float inv_view[9];            /* row-major inverse of viewMatrix */
+  float view_row2[3];
+  int samples, max_reflections;
+  float min_importancy;
+  int use_filter, is_temporal;
+  float ambient[3];
+  float random_seed;
+  float texture_width;
+};
+
+struct WorkCounters {           /* per-thread tallies, mirrors flx_counters */
+  uint32_t primary_visits, closest_visits, shadow_visits, closest_walks, shadow_walks, shades, primary_hits, atlas_texels;
+};
+
+FLX_DEV M3 rotation_at(const DeviceScene &sc, int i) {
+  float4 a = sc.rotation[3 * i], b = sc.rotation[3 * i + 1], c = sc.rotation[3 * i + 2];
+  M3 m; m.c0 = F3(a.x, a.y, a.z); m.c1 = F3(b.x, b.y, b.z); m.c2 = F3(c.x, c.y, c.z);
+  return m;
+}
+FLX_DEV f3 shift_at(const DeviceScene &sc, int i) { float4 s = sc.shift[i]; return F3(s.x, s.y, s.z); }
+
+/* image row (0 = top) of packed row k under the tile policy */
+FLX_DEV uint32_t image_row(const DeviceFrame &fr, uint32_t k) {
+  if (fr.tile_count <= 1u) return k;
+  uint32_t strip = k / fr.tile_rows;
+  return (strip * fr.tile_count + fr.tile_index) * fr.tile_rows + (k - strip * fr.tile_rows);
+}
+
+/* fragment:91-105 */
+FLX_DEV float to4BitRepresentation(float a, float b) {
+  uint32_t aui = flx_f2uint(a * 255.0f) & 240u;
+  uint32_t bui = (flx_f2uint(b * 255.0f) & 240u) >> 4;
+  return (float)(aui | bui) * INV_255;
+}
+FLX_DEV float normalToSphearical4BitRepresentation(f3 n) {
+  float phi = (flx_atan2(n.z, n.x) * INV_PI) * 0.5f + 0.5f;
+  float theta = (flx_atan2(n.x, n.y) * INV_PI) * 0.5f + 0.5f;
+  return to4BitRepresentation(phi, theta);
+}
+FLX_DEV f3 combineNormalRME(f3 n, f3 rme) {
+  return F3(normalToSphearical4BitRepresentation(n), rme.x, to4BitRepresentation(rme.y, rme.z));
+}
+
+/* fragment:108-117; NEAREST + REPEAT lookup in an RGBA8 atlas */
+template <bool COUNT>
+FLX_DEV f3 fetchTexVal(const DeviceScene &sc, const DeviceFrame &fr, int which, float u, float v, float texNum, f3 defaultVal,
+                       WorkCounters &cnt) {
+  if (texNum == -1.0f) return defaultVal;
+  const uchar4 *atlas = sc.atlas[which];
+  uint32_t W = atlas ? sc.atlas_w[which] : 1u, H = atlas ? sc.atlas_h[which] : 1u;
+  float tw = fr.texture_width;
+  float atlasHeightFactor = (float)W / (float)H;
+  float cx = (u + flx_mod(texNum, tw)) / tw;
+  float cy = ((v + flx_floor(texNum / tw)) * atlasHeightFactor) / tw;
+  if (COUNT) cnt.atlas_texels++;
+  if (!atlas) return F3(0.0f, 0.0f, 0.0f);
+  float fx = flx_fract(cx) * (float)W, fy = flx_fract(cy) * (float)H;
+  uint32_t ix = flx_f2uint(fx), iy = flx_f2uint(fy);
+  if (ix >= W) ix = W - 1u;
+  if (iy >= H) iy = H - 1u;
+  uchar4 t = atlas[(size_t)iy * W + ix];
+  return F3((float)t.x / 255.0f, (float)t.y / 255.0f, (float)t.z / 255.0f);
+}
+
+/* fragment:119-121 */
+FLX_DEV f4 noise(float random_seed, float nx, float ny, float seed) {
+  float d = nx * 12.9898f + ny * 78.233f;
+  float k = seed + random_seed * PHI;
+  f4 r;
+  r.x = flx_fract(flx_sin(d + 53.0f * k) * 43758.5453f) * 2.0f - 1.0f;
+  r.y = flx_fract(flx_sin(d + 59.0f * k) * 43758.5453f) * 2.0f - 1.0f;
+  r.z = flx_fract(flx_sin(d + 61.0f * k) * 43758.5453f) * 2.0f - 1.0f;
+  r.w = flx_fract(flx_sin(d + 67.0f * k) * 43758.5453f) * 2.0f - 1.0f;
+  return r;
+}
+
+/* fragment:123-140; returns false on miss, else suv */
+FLX_DEV bool moellerTrumbore(f3 a, f3 b, f3 c, const Ray &ray, float l, f3 &suv) {
+  f3 edge1 = b - a;
+  f3 edge2 = c - a;
+  f3 pvec = cross(ray.dir, edge2);
+  float det = dot(edge1, pvec);
+  if (flx_abs(det) < BIAS) return false;
+  float inv_det = 1.0f / det;
+  f3 tvec = ray.origin - a;
+  float u = dot(tvec, pvec) * inv_det;
+  if (u < BIAS || u > 1.0f) return false;
+  f3 qvec = cross(tvec, edge1);
+  float v = dot(ray.dir, qvec) * inv_det;
+  float uvSum = u + v;
+  if (v < BIAS || uvSum > 1.0f) return false;
+  float s = dot(edge2, qvec) * inv_det;
+  if (s > l || s <= BIAS) return false;
+  suv = F3(s, u, v);
+  return s != 0.0f;             /* fragment:217 tests intersection.x != 0.0 */
+}
+
+/* fragment:143-158 */
+FLX_DEV bool moellerTrumboreCull(f3 a, f3 b, f3 c, const Ray &ray, float l) {
+  f3 edge1 = b - a;
+  f3 edge2 = c - a;
+  f3 pvec = cross(ray.dir, edge2);
+  float det = dot(edge1, pvec);
+  float invDet = 1.0f / det;
+  if (det < BIAS) return false;
+  f3 tvec = ray.origin - a;
+  float u = dot(tvec, pvec) * invDet;
+  if (u < BIAS || u > 1.0f) return false;
+  f3 qvec = cross(tvec, edge1);
+  float v = dot(ray.dir, qvec) * invDet;
+  if (v < BIAS || u + v > 1.0f) return false;
+  float s = dot(edge2, qvec) * invDet;
+  return (s <= l && s > BIAS);
+}
+
+/* Primary-visibility triangle rule: front faces only, inclusive edges, near plane. */
+FLX_DEV bool moellerTrumborePrimary(f3 a, f3 b, f3 c, const Ray &ray, float l, float viewDepthPerS, f3 &suv) {
+  f3 edge1 = b - a;
+  f3 edge2 = c - a;
+  f3 pvec = cross(ray.dir, edge2);
+  float det = dot(edge1, pvec);
+  if (!(det < 0.0f)) return false;
+  float inv_det = 1.0f / det;
+  f3 tvec = ray.origin - a;
+  float u = dot(tvec, pvec) * inv_det;
+  if (!(u >= 0.0f && u <= 1.0f)) return false;
+  f3 qvec = cross(tvec, edge1);
+  float v = dot(ray.dir, qvec) * inv_det;
+  if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+  float s = dot(edge2, qvec) * inv_det;
+  if (!(s < l) || !(s * viewDepthPerS >= NEAR_VIEW_DEPTH)) return false;
+  suv = F3(s, u, v);
+  return s != 0.0f;
+}
+
+/* fragment:161-167 */
+FLX_DEV bool rayCuboid(float l, const Ray &ray, f3 minCorner, f3 maxCorner) {
+  f3 v0 = (minCorner - ray.origin) / ray.dir;
+  f3 v1 = (maxCorner - ray.origin) / ray.dir;
+  float tmin = flx_max(flx_max(flx_min(v0.x, v1.x), flx_min(v0.y, v1.y)), flx_min(v0.z, v1.z));
+  float tmax = flx_min(flx_min(flx_max(v0.x, v1.x), flx_max(v0.y, v1.y)), flx_max(v0.z, v1.z));
+  return tmax >= flx_max(tmin, BIAS) && tmin < l;
+}
+
+/* fragment:172-227 (PRIMARY = false) and the primary-visibility walk (PRIMARY = true). */
+template <bool PRIMARY>
+FLX_DEV Hit rayTracer(const DeviceScene &sc, const Ray &ray, float viewDepthPerS, uint32_t &visits) {
+  Ray tR = ray;
+  int cachedTI = 0;
+  Hit hit; hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
+  float minLen = POW32;
+  const int size = (int)sc.n_entries;
+  for (int i = 0; i < size; i++) {
+    float4 e0 = sc.geometry[3 * i], e1 = sc.geometry[3 * i + 1], e2 = sc.geometry[3 * i + 2];
+    visits++;
+    int tI = (int)e2.y << 1;
+    if (tI != cachedTI) {
+      int iI = tI + 1;
+      M3 rotationII = rotation_at(sc, iI);
+      cachedTI = tI;
+      tR.origin = mul(rotationII, ray.origin + shift_at(sc, iI));
+      tR.dir = mul(rotationII, ray.dir);
+    }
+    if (e2.z == 0.0f) return hit;
+    if (e2.z == 1.0f) {
+      if (!rayCuboid(minLen, tR, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y))) i += (int)e1.z;
+    } else {
+      f3 suv;
+      f3 a = F3(e0.x, e0.y, e0.z), b = F3(e0.w, e1.x, e1.y), c = F3(e1.z, e1.w, e2.x);
+      bool h = PRIMARY ? moellerTrumborePrimary(a, b, c, tR, minLen, viewDepthPerS, suv) : moellerTrumbore(a, b, c, tR, minLen, suv);
+      if (h) {
+        hit.suv = suv; hit.transformId = tI; hit.triangleId = i;
+        minLen = suv.x;
+      }
+    }
+  }
+  return hit;
+}
+
+/* fragment:231-280 */
+FLX_DEV bool shadowTest(const DeviceScene &sc, const Ray &ray, float l, uint32_t &visits) {
+  Ray tR = ray;
+  int cachedTI = 0;
+  const float minLen = l;
+  const int size = (int)sc.n_entries;
+  for (int i = 0; i < size; i++) {
+    float4 e0 = sc.geometry[3 * i], e1 = sc.geometry[3 * i + 1], e2 = sc.geometry[3 * i + 2];
+    visits++;
+    int tI = (int)e2.y << 1;
+    if (tI != cachedTI) {
+      int iI = tI + 1;
+      M3 rotationII = rotation_at(sc, iI);
+      cachedTI = tI;
+      tR.origin = mul(rotationII, ray.origin + shift_at(sc, iI));
+      tR.dir = normalize(mul(rotationII, ray.dir));
+    }
+    if (e2.z == 0.0f) return false;
+    if (e2.z == 1.0f) {
+      if (!rayCuboid(minLen, tR, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y))) i += (int)e1.z;
+    } else {
+      if (moellerTrumboreCull(F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y), F3(e1.z, e1.w, e2.x), tR, minLen)) return true;
+    }
+  }
+  return false;
+}
+
+/* fragment:282-302 */
+FLX_DEV float trowbridgeReitz(float alpha, float NdotH) {
+  float numerator = alpha * alpha;
+  float denom = NdotH * NdotH * (numerator - 1.0f) + 1.0f;
+  return numerator / flx_max(PI_F * denom * denom, BIAS);
+}
+FLX_DEV float schlickBeckmann(float alpha, float NdotX) {
+  float k = alpha * 0.5f;
+  float denominator = NdotX * (1.0f - k) + k;
+  denominator = flx_max(denominator, BIAS);
+  return NdotX / denominator;
+}
+FLX_DEV float smith(float alpha, float NdotV, float NdotL) { return schlickBeckmann(alpha, NdotV) * schlickBeckmann(alpha, NdotL); }
+FLX_DEV f3 fresnel(f3 F0, float theta) {
+  float p = flx_pow5(1.0f - theta);
+  return F3(F0.x + (1.0f - F0.x) * p, F0.y + (1.0f - F0.y) * p, F0.z + (1.0f - F0.z) * p);
+}
+
+/* fragment:304-334 */
+FLX_DEV f3 forwardTrace(const Material &material, f3 lightDir, float strength, f3 N, f3 V) {
+  float lenP1 = 1.0f + length(lightDir);
+  float brightness = strength / (lenP1 * lenP1);
+  f3 L = normalize(lightDir);
+  f3 H = normalize(V + L);
+  float VdotH = flx_max(dot(V, H), 0.0f);
+  float NdotL = flx_max(dot(N, L), 0.0f);
+  float NdotH = flx_max(dot(N, H), 0.0f);
+  float NdotV = flx_max(dot(N, V), 0.0f);
+  float alpha = material.rme.x * material.rme.x;
+  float BRDF = flx_mix(1.0f, NdotV, material.rme.y);
+  f3 F0 = material.albedo * BRDF;
+  f3 Ks = fresnel(F0, VdotH);
+  float oneMinusMetal = 1.0f - material.rme.y;
+  f3 Kd = F3((1.0f - Ks.x) * oneMinusMetal, (1.0f - Ks.y) * oneMinusMetal, (1.0f - Ks.z) * oneMinusMetal);
+  f3 lambert = material.albedo * INV_PI;
+  float tr = trowbridgeReitz(alpha, NdotH);
+  float sm = smith(alpha, NdotV, NdotL);
+  f3 cookTorranceNumerator = (Ks * tr) * sm;
+  float cookTorranceDenominator = 4.0f * NdotV * NdotL;
+  cookTorranceDenominator = flx_max(cookTorranceDenominator, BIAS);
+  f3 cookTorrance = cookTorranceNumerator / cookTorranceDenominator;
+  f3 radiance = Kd * lambert + cookTorrance;
+  return (radiance * NdotL) * brightness;
+}
+
+/* The shader's global variables + MRT outputs that survive across samples (fragment:83-89, 74-79). */
+struct PixelState {
+  float firstRayLength, glassFilter, originalRMEx, originalTPOx;
+  f3 originalColor;
+  f4 renderId, renderOriginalId;
+  float ndc_x, ndc_y;
+};
+
+/* fragment:400-461 */
+template <bool COUNT>
+FLX_DEV f3 reservoirSample(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, const Material &material, const Ray &ray,
+                           f4 randomVec, f3 N, f3 smoothNormal, float geometryOffset, bool dontFilter, int i, WorkCounters &cnt) {
+  f3 localColor = F3(0.0f, 0.0f, 0.0f);
+  float reservoirLength = 0.0f;
+  float totalWeight = 0.0f;
+  int reservoirNum = 0;
+  float reservoirWeight = 0.0f;
+  f3 reservoirLightDir = F3(0.0f, 0.0f, 0.0f);
+  f4 n0 = noise(fr.random_seed, randomVec.z, randomVec.w, BIAS);
+  float lastRandomX = n0.x, lastRandomY = n0.y;
+  const int size = (int)sc.n_lights;
+  for (int j = 0; j < size; j++) {
+    const float *lt = sc.lights + 6 * j;
+    float strength = lt[3], variation = lt[4];
+    if (strength <= 0.0f) continue;
+    reservoirLength += 1.0f;
+    f3 light = F3(lt[0], lt[1], lt[2]) + F3(randomVec.x, randomVec.y, randomVec.z) * variation;
+    f3 dir = light - ray.origin;
+    f3 colorForLight = forwardTrace(material, dir, strength, N, -ray.dir);
+    localColor = localColor + colorForLight;
+    float weight = length(colorForLight);
+    totalWeight += weight;
+    if (flx_abs(lastRandomY) * totalWeight <= weight) {
+      reservoirNum = j;
+      reservoirWeight = weight;
+      reservoirLightDir = dir;
+    }
+    f4 n1 = noise(fr.random_seed, lastRandomX, lastRandomY, BIAS);
+    lastRandomX = n1.z; lastRandomY = n1.w;
+  }
+  f3 unitLightDir = normalize(reservoirLightDir);
+  bool showColor = reservoirLength == 0.0f || reservoirWeight == 0.0f;
+  bool showShadow = dot(smoothNormal, unitLightDir) <= BIAS;
+  f3 baseLuminance = F3(material.rme.z, material.rme.z, material.rme.z);
+  if (dontFilter || i == 0) ps.renderId.w = (float)((reservoirNum % 128) << 1) * INV_255;
+  if (showColor) return localColor + baseLuminance;
+  if (showShadow) {
+    if (dontFilter || i == 0) ps.renderId.w += INV_255;
+    return baseLuminance;
+  }
+  Ray lightRay;
+  lightRay.origin = ray.origin + smoothNormal * geometryOffset;
+  lightRay.dir = unitLightDir;
+  if (COUNT) cnt.shadow_walks++;
+  if (shadowTest(sc, lightRay, length(reservoirLightDir), cnt.shadow_visits)) {
+    if (dontFilter || i == 0) ps.renderId.w += INV_255;
+    return baseLuminance;
+  }
+  return localColor + baseLuminance;
+}
+
+/* State of one path between bounces (what lightTrace keeps in locals, fragment:464-474). */
+struct PathState {
+  Ray ray;
+  f3 lastHitPoint;
+  f3 finalColor, importancyFactor;
+  Hit hit;
+  bool dontFilter;
+};
+
+/* One iteration of lightTrace's bounce loop (fragment:476-595).  Returns false when the path ends
+ * (no next hit).  The loop guard of fragment:475 is evaluated by the caller. */
+template <bool COUNT>
+FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, PathState &p, f3 camera, float cosSampleN, int i,
+                    WorkCounters &cnt) {
+  float fi = (float)i;
+  if (COUNT) cnt.shades++;
+  Hit hit = p.hit;
+  M3 rTI = rotation_at(sc, hit.transformId);
+  f3 sTI = shift_at(sc, hit.transformId);
+  p.ray.origin = p.ray.dir * hit.suv.x + p.ray.origin;
+  f3 uvw = F3(1.0f - hit.suv.y - hit.suv.z, hit.suv.y, hit.suv.z);
+  float4 g0 = sc.geometry[3 * hit.triangleId], g1 = sc.geometry[3 * hit.triangleId + 1], g2 = sc.geometry[3 * hit.triangleId + 2];
+  f3 t0v = mul(rTI, F3(g0.x, g0.y, g0.z));
+  f3 t1v = mul(rTI, F3(g0.w, g1.x, g1.y));
+  f3 t2v = mul(rTI, F3(g1.z, g1.w, g2.x));
+  f3 offsetRayTarget = p.ray.origin - sTI;
+  f3 geometryNormal = normalize(cross(t0v - t1v, t0v - t2v));
+  f3 diffs = F3(distance(offsetRayTarget, t0v), distance(offsetRayTarget, t1v), distance(offsetRayTarget, t2v));
+  const float4 *at = sc.attributes + 7 * (size_t)hit.triangleId;
+  float4 a0 = at[0], a1 = at[1], a2 = at[2], a3 = at[3], a4 = at[4], a5 = at[5], a6 = at[6];
+  f3 n0 = mul(rTI, F3(a0.x, a0.y, a0.z));
+  f3 n1 = mul(rTI, F3(a0.w, a1.x, a1.y));
+  f3 n2 = mul(rTI, F3(a1.z, a1.w, a2.x));
+  f3 smoothNormal = normalize(F3((n0.x * uvw.x + n1.x * uvw.y) + n2.x * uvw.z,
+                                 (n0.y * uvw.x + n1.y * uvw.y) + n2.y * uvw.z,
+                                 (n0.z * uvw.x + n1.z * uvw.y) + n2.z * uvw.z));
+  f3 angles = F3(flx_acos(flx_abs(dot(geometryNormal, n0))), flx_acos(flx_abs(dot(geometryNormal, n1))),
+                 flx_acos(flx_abs(dot(geometryNormal, n2))));
+  f3 angleTan = F3(flx_clamp(flx_tan(angles.x), 0.0f, 1.0f), flx_clamp(flx_tan(angles.y), 0.0f, 1.0f),
+                   flx_clamp(flx_tan(angles.z), 0.0f, 1.0f));
+  float geometryOffset = dot(diffs * angleTan, uvw);
+  /* uv0 = a2.yz, uv1 = (a2.w, a3.x), uv2 = a3.yz */
+  float bu = (a2.y * uvw.x + a2.w * uvw.y) + a3.y * uvw.z;
+  float bv = (a2.z * uvw.x + a3.x * uvw.y) + a3.z * uvw.z;
+  Material material;
+  material.albedo = fetchTexVal<COUNT>(sc, fr, 0, bu, bv, a3.w, F3(a4.z, a4.w, a5.x), cnt);
+  material.rme = fetchTexVal<COUNT>(sc, fr, 1, bu, bv, a4.x, F3(a5.y, a5.z, a5.w), cnt);
+  material.tpo = fetchTexVal<COUNT>(sc, fr, 2, bu, bv, a4.y, F3(a6.x, a6.y, a6.z), cnt);
+
+  p.ray.dir = normalize(p.ray.origin - p.lastHitPoint);
+  float signDir = flx_sign(dot(p.ray.dir, smoothNormal));
+  smoothNormal = smoothNormal * (-signDir);
+
+  f4 randomVec = noise(fr.random_seed, ps.ndc_x, ps.ndc_y, fi + cosSampleN);
+  f3 randomSpheareVec = normalize(smoothNormal + normalize(F3(randomVec.x, randomVec.y, randomVec.z)));
+  float BRDF = flx_mix(1.0f, flx_abs(dot(smoothNormal, p.ray.dir)), material.rme.y);
+  float roughnessBRDF = material.rme.x * BRDF;
+  f3 roughNormal = normalize(mix(smoothNormal, randomSpheareVec, roughnessBRDF));
+  f3 H = normalize(roughNormal - p.ray.dir);
+  float VdotH = flx_max(dot(-p.ray.dir, H), 0.0f);
+  f3 F0 = material.albedo * BRDF;
+  f3 f = fresnel(F0, VdotH);
+  float fresnelReflect = flx_max(f.x, flx_max(f.y, f.z));
+  bool isSolid = material.tpo.x * fresnelReflect <= flx_abs(randomVec.w);
+
+  if (p.dontFilter) {
+    ps.originalTPOx = material.tpo.x;
+    ps.originalColor = ps.originalColor * material.albedo;
+    ps.originalRMEx += material.rme.x;
+    if (fr.use_filter) {               /* renderId feeds only the filter's G-buffer */
+      float scale = flx_exp2_neg_int(i);
+      f3 cn = combineNormalRME(smoothNormal, material.rme);
+      f4 upd; upd.x = scale * cn.x; upd.y = scale * cn.y; upd.z = scale * cn.z; upd.w = scale * 0.0f;
+      ps.renderId.x += upd.x; ps.renderId.y += upd.y; ps.renderId.z += upd.z; ps.renderId.w += upd.w;
+      if (i == 0) {
+        ps.renderOriginalId.x += upd.x; ps.renderOriginalId.y += upd.y; ps.renderOriginalId.z += upd.z; ps.renderOriginalId.w += upd.w;
+      }
+    }
+    p.dontFilter = (material.rme.x < 0.01f && isSolid) || !isSolid;
+    if (isSolid && material.tpo.x > 0.01f) {
+      ps.glassFilter += 1.0f;
+      p.dontFilter = false;
+    }
+  } else {
+    p.importancyFactor = p.importancyFactor * material.albedo;
+  }
+
+  if (i == 1) ps.firstRayLength = flx_min(length(p.ray.origin - p.lastHitPoint) / length(p.lastHitPoint - camera), ps.firstRayLength);
+  f3 localColor = reservoirSample<COUNT>(sc, fr, ps, material, p.ray, randomVec, roughNormal * (-signDir), smoothNormal * (-signDir),
+                                         geometryOffset, p.dontFilter, i, cnt);
+  p.finalColor = p.finalColor + localColor * p.importancyFactor;
+  if (isSolid) {
+    p.ray.dir = normalize(mix(reflect(p.ray.dir, smoothNormal), randomSpheareVec, roughnessBRDF));
+  } else {
+    float eta = flx_mix(1.0f / material.tpo.z, material.tpo.z, flx_max(signDir, 0.0f));
+    p.ray.dir = normalize(mix(refract(p.ray.dir, smoothNormal, eta), randomSpheareVec, roughnessBRDF));
+  }
+  if (COUNT) cnt.closest_walks++;
+  p.hit = rayTracer<false>(sc, p.ray, 0.0f, cnt.closest_visits);
+  if (p.hit.triangleId == -1) return false;
+  p.lastHitPoint = p.ray.origin;
+  return true;
+}
+
+/* Primary ray of pixel (px, py_gl): unit direction, NDC, view depth per unit s. */
+FLX_DEV f3 primary_dir(const DeviceFrame &fr, uint32_t px, uint32_t py_gl, float &nx, float &ny, float &viewDepthPerS) {
+  nx = ((float)px + 0.5f) / (float)fr.width * 2.0f - 1.0f;
+  ny = ((float)py_gl + 0.5f) / (float)fr.height * 2.0f - 1.0f;
+  const float *iv = fr.inv_view;
+  f3 d = F3((iv[0] * nx + iv[1] * ny) + iv[2], (iv[3] * nx + iv[4] * ny) + iv[5], (iv[6] * nx + iv[7] * ny) + iv[8]);
+  d = normalize(d);
+  viewDepthPerS = dot(F3(fr.view_row2[0], fr.view_row2[1], fr.view_row2[2]), d);
+  return d;
+}
+
+}  // namespace flx
+#endif

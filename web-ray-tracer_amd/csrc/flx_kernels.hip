@@ -1,0 +1,135 @@
+/*
+ * flx_kernels.hip — HIP kernels of the path tracer for gfx950 (wave64, no MFMA: divergent traversal).
+ *
+ * Launch geometry: the frame a context renders is W x rows pixels (rows = the packed rows its tile
+ * policy owns).  A workgroup is 256 threads = 4 waves; each wave covers an 8x8 pixel tile (lanes of a
+ * wave are neighbours on screen, so their rays enter the same part of the skip list and their 48-byte
+ * entry loads hit the same cache lines); a workgroup covers 16x16.
+ */
+#include "flx_kernels.h"
+
+namespace flx {
+
+__device__ __forceinline__ void tile_pixel(const DeviceFrame &fr, uint32_t &px, uint32_t &k) {
+  const uint32_t tiles_x = (fr.width + 15u) >> 4;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  px = (tx << 4) + ((wave & 1u) << 3) + (lane & 7u);
+  k = (ty << 4) + ((wave >> 1) << 3) + (lane >> 3);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(const WorkCounters &c, unsigned long long *out) {
+  if (!COUNT) return;
+  uint32_t v[8] = { c.primary_visits, c.closest_visits, c.shadow_visits, c.closest_walks, c.shadow_walks, c.shades, c.primary_hits, c.atlas_texels };
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    unsigned long long x = v[j];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63u) == 0u && x) atomicAdd(out + j, x);
+  }
+}
+
+/* ---- v1: one thread per pixel, the whole fragment program (fragment:601-646) --------------------- */
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
+                                                      unsigned long long *__restrict__ counters) {
+  uint32_t px, k;
+  tile_pixel(fr, px, k);
+  WorkCounters cnt = {};
+  if (px < fr.width && k < fr.rows) {
+    const uint32_t row = image_row(fr, k);
+    const uint32_t py_gl = fr.height - 1u - row;
+    PixelState ps;
+    ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
+    ps.originalColor = F3(0.0f, 0.0f, 0.0f);
+    ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+    ps.renderOriginalId = ps.renderId;
+    float viewDepthPerS;
+    f3 dir0 = primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+    const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
+    Ray pr; pr.origin = camera; pr.dir = dir0;
+    Hit hit0 = rayTracer<true>(sc, pr, viewDepthPerS, cnt.primary_visits);
+    const size_t o = (size_t)k * fr.width + px;
+    float4 color = make_float4(0.f, 0.f, 0.f, 0.f), colorIp = color, origColor = color, rid = color, roid = color;
+    if (hit0.triangleId != -1) {
+      if (COUNT) cnt.primary_hits++;
+      f3 finalColor = F3(0.0f, 0.0f, 0.0f);
+      for (int s = 0; s < fr.samples; s++) {
+        float cosSampleN = flx_cos((float)s);
+        PathState p;
+        p.dontFilter = true;
+        p.finalColor = F3(0.0f, 0.0f, 0.0f);
+        p.importancyFactor = F3(1.0f, 1.0f, 1.0f);
+        ps.originalColor = F3(1.0f, 1.0f, 1.0f);
+        p.ray.origin = camera; p.ray.dir = dir0;
+        p.lastHitPoint = camera;
+        p.hit = hit0;
+        for (int i = 0; i < fr.max_reflections && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3; i++) {
+          if (!bounce<COUNT>(sc, fr, ps, p, camera, cosSampleN, i, cnt)) break;
+        }
+        finalColor = finalColor + (p.finalColor + p.importancyFactor * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]));
+      }
+      float invSamples = 1.0f / (float)fr.samples;
+      finalColor = finalColor * invSamples;
+      if (fr.use_filter == 1) {
+        color = make_float4(flx_fract(finalColor.x), flx_fract(finalColor.y), flx_fract(finalColor.z), 1.0f);
+        colorIp = make_float4(flx_floor(finalColor.x) * INV_256, flx_floor(finalColor.y) * INV_256, flx_floor(finalColor.z) * INV_256, ps.glassFilter);
+      } else {
+        finalColor = finalColor * ps.originalColor;
+        if (fr.is_temporal == 1) {
+          color = make_float4(flx_fract(finalColor.x), flx_fract(finalColor.y), flx_fract(finalColor.z), 1.0f);
+          colorIp = make_float4(flx_floor(finalColor.x) * INV_256, flx_floor(finalColor.y) * INV_256, flx_floor(finalColor.z) * INV_256, 1.0f);
+        } else {
+          color = make_float4(finalColor.x, finalColor.y, finalColor.z, 1.0f);
+        }
+      }
+      origColor = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, flx_min(ps.originalRMEx, ps.firstRayLength) + INV_255);
+      rid = make_float4(ps.renderId.x, ps.renderId.y, ps.renderId.z, ps.renderId.w + INV_255);
+      roid = make_float4(0.0f, 0.0f, 0.0f, ps.originalTPOx + INV_255);
+    }
+    if (out) out[o] = color;
+    if (gb.color) gb.color[o] = color;
+    if (gb.color_ip) gb.color_ip[o] = colorIp;
+    if (gb.original_color) gb.original_color[o] = origColor;
+    if (gb.id) gb.id[o] = rid;
+    if (gb.original_id) gb.original_id[o] = roid;
+  }
+  flush_counters<COUNT>(cnt, counters);
+}
+
+void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *out, const GBufferPtrs &gb,
+                         unsigned long long *counters, hipStream_t stream) {
+  const uint32_t tiles = ((fr.width + 15u) >> 4) * ((fr.rows + 15u) >> 4);
+  if (counters) hipLaunchKernelGGL(k_trace_pixels<true>, dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+  else hipLaunchKernelGGL(k_trace_pixels<false>, dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+}
+
+/* ---- diagnostics: include/flx_math.h on the device ------------------------------------------------ */
+__global__ void k_debug_math(int fn, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = a[i], y = b ? b[i] : 0.0f, r;
+  switch (fn) {
+    case 0: r = flx_sin(x); break;
+    case 1: r = flx_cos(x); break;
+    case 2: r = flx_tan(x); break;
+    case 3: r = flx_acos(x); break;
+    case 4: r = flx_atan2(x, y); break;
+    case 5: r = flx_exp(x); break;
+    case 6: r = flx_pow(x, y); break;
+    case 7: r = flx_tanh(x); break;
+    case 8: r = flx_floor(x); break;
+    case 9: r = flx_sqrt(x); break;
+    case 10: r = x / y; break;
+    default: r = flx_nanf(); break;
+  }
+  out[i] = r;
+}
+
+void launch_debug_math(int fn, const float *a, const float *b, float *out, uint32_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(k_debug_math, dim3((n + 255u) / 256u), dim3(256), 0, stream, fn, a, b, out, n);
+}
+
+}  // namespace flx
