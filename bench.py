@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""bench.py — Mray/s of the FlexLight path-tracing hot path on MI355X (BASELINE.json metric).
+
+A "step" is one frame of the workload through libflexlight_hip.so's C ABI with the scene resident in
+HBM: path-trace pass (+ denoise chain when the workload has filter on) and, for N > 1, the RCCL
+all-gather of the row-strip tiles plus the reassembly of the frame on every rank.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dragon|cornell_obj|cornell|theater]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* from the environment).  The frame is cut into strips of --tile-rows image rows dealt
+round-robin to the ranks: total work is fixed as N grows -> "scaling": "strong".
+
+Rank 0 prints ONE JSON line: metric/value as BASELINE.json defines them (nominal path segments
+spp x bounces x W x H per second), a "roofline" object for the dominant kernel (algorithmic bytes per
+launch from the frame's work counters / its HIP-event duration, against the 8 TB/s HBM peak) and a
+"cpu_baseline" object (the CPU oracle timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+WORKLOADS = {
+    # name: (scene fixture, BASELINE.json config it is)
+    "dragon": ("dragon", "configs[2]: dragon.obj (dragon_lp.obj, 73 694 entries) 1080p, 8 spp, 4 bounces"),
+    "cornell_obj": ("cornell_obj", "configs[1]: cornell.obj 1080p, 4 spp, 3 bounces, filter on"),
+    "cornell": ("cornell", "configs[0]: examples/cornell.js 256x256, 1 spp, 1 bounce, filter off"),
+    "theater": ("theater", "configs[4]: examples/theater.js 1080p, 16 spp, 6 bounces"),
+}
+
+
+def algorithmic_bytes(cnt, n_lights, pixels, use_filter):
+    """B_frame = 48 N_visit + 160 N_shade + 24 L N_shade + 4 N_tex + B_out W H (+ B_filter)."""
+    visits = cnt["primary_visits"] + cnt["closest_visits"] + cnt["shadow_visits"]
+    b = 48 * visits + 160 * cnt["shades"] + 24 * n_lights * cnt["shades"] + 4 * cnt["atlas_texels"]
+    b += (20 if use_filter else 16) * pixels
+    if use_filter:
+        b += 224 * pixels
+    return b
+
+
+def cpu_baseline(scene, params_full, seconds_budget=20.0):
+    """CPU oracle (kind 'port': this repo's C restatement of the reference GLSL — the reference has no
+    CPU path) on a bounded sample of the same workload: the same scene/spp/bounces on a centred
+    sub-resolution frame, sized from a quick probe so that it costs about `seconds_budget` of CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import flx_oracle
+    threads = min(16, os.cpu_count() or 1)
+    spp, bounces = params_full.samples, params_full.max_reflections
+    probe = scene.frame_params(width=240, height=135, samples=spp, max_reflections=bounces, use_filter=0)
+    t0 = time.time()
+    flx_oracle.render(scene, probe, threads=threads)
+    dt = max(time.time() - t0, 1e-3)
+    scale = max(1.0, min(8.0, (seconds_budget / dt) ** 0.5))
+    w, h = int(240 * scale) // 8 * 8, int(135 * scale) // 8 * 8
+    p = scene.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+    t0 = time.time()
+    flx_oracle.render(scene, p, threads=threads)
+    dt = time.time() - t0
+    return {
+        "value": spp * bounces * w * h / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
+        "sample": "same scene/spp/bounces, %dx%d frame (%.1f s of CPU oracle, %d OpenMP threads)" % (w, h, dt, threads),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from flexlight_hip import capi
+    from flexlight_hip.scene_io import Scene
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    fixture, config_name = WORKLOADS[args.workload]
+    scene = Scene.golden(fixture)
+    full = scene.frame_params(width=args.width, height=args.height)
+    use_filter = int(full.use_filter)
+    W, H = full.width, full.height
+    tile = (args.tile_rows, rank, world) if world > 1 else (0, 0, 0)
+    params = scene.frame_params(width=args.width, height=args.height, tile=tile)
+    if use_filter and world > 1:
+        raise SystemExit("filter-on workloads are single-GPU for now (the filter is not pixel-independent, SURVEY.md §8e)")
+
+    ctx = capi.Context(local_rank)
+    ctx.update_scene(scene)
+    stream = torch.cuda.Stream()              # a real (non-null) stream shared by the kernels and the RCCL gather:
+    torch.cuda.set_stream(stream)             # no host sync between trace kernel, all-gather and reassembly
+    ctx.set_stream(stream.cuda_stream)
+
+    rows_local = ctx.tile_row_count(params)
+    strips = (H + args.tile_rows - 1) // args.tile_rows if world > 1 else 1
+    rows_max = ((strips + world - 1) // world) * args.tile_rows if world > 1 else H
+    local = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda")
+    gathered = torch.empty((world, rows_max, W, 4), dtype=torch.float32, device="cuda") if world > 1 else None
+    frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if world > 1 else None
+    if world > 1:
+        # image row of every (rank, packed row) slot, -1 for padding
+        src_rank, src_row, dst_row = [], [], []
+        for r in range(world):
+            pr = scene.frame_params(width=args.width, height=args.height, tile=(args.tile_rows, r, world))
+            for k, y in enumerate(capi.Context.tile_rows(pr)):
+                src_rank.append(r); src_row.append(k); dst_row.append(y)
+        src_index = torch.tensor([r * rows_max + k for r, k in zip(src_rank, src_row)], device="cuda")
+        dst_index = torch.tensor(dst_row, device="cuda")
+        assert sorted(dst_row) == list(range(H))
+
+    host_out = None
+    if use_filter:
+        host_out = np.zeros((rows_local, W, 4), np.float32)
+
+    def step():
+        if use_filter:
+            # filter-on frames go through flx_render (host output); the chain runs on the GPU.
+            ctx.render(params)
+            return
+        ctx.render_device(params, local.data_ptr())
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+            frame.index_copy_(0, dst_index, gathered.view(world * rows_max, W, 4).index_select(0, src_index))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # Dominant-kernel duration, measured live with HIP events on the launch stream, outside the timed
+    # region so the event syncs do not perturb it: same frame, K more launches.
+    for _ in range(min(args.steps, 10)):
+        if use_filter:
+            ctx.render(params)
+        else:
+            ctx.render_device(params, local.data_ptr())
+        frame_ms, trace_ms = ctx.last_frame_ms()
+        kernel_ms.append(trace_ms)
+    # Work counters of this rank's share of the frame (a counted launch; not timed).
+    ctx.set_counters_enabled(True)
+    if use_filter:
+        _, cnt, _ = ctx.render(params, counters=True)
+    else:
+        ctx.render_device(params, local.data_ptr())
+        ctx.sync()
+        cnt = ctx.get_counters()
+    ctx.set_counters_enabled(False)
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        spp, bounces = full.samples, full.max_reflections
+        rays = spp * bounces * W * H
+        ms_per_step = elapsed / args.steps * 1e3
+        value = rays / (elapsed / args.steps) / 1e6
+        n_lights = scene.arrays["lights"].size // 6
+        k_ms = float(np.mean(kernel_ms))
+        bytes_launch = algorithmic_bytes(cnt, n_lights, rows_local * W, use_filter)
+        achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        line = {
+            "metric": "Mray/s at 1080p (spp x bounces x pixels / s)", "value": value, "unit": "Mray/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": config_name, "width": W, "height": H, "spp": spp, "bounces": bounces, "filter": bool(use_filter),
+                "scene_entries": int(scene.meta["textureLength"]), "parallelism": "row-strip tiles x%d, %d rows/strip, RCCL all-gather" % (world, args.tile_rows) if world > 1 else "single GPU",
+                "rays_per_frame": rays,
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_trace_pixels", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": k_ms,
+                "note": "algorithmic bytes = 48 B x entries visited + 160 B x shades + 24 B x lights x shades + 4 B x texels + 16 B x pixels (SURVEY.md 8d); the <=12 MB scene is cache resident, real HBM traffic is far lower",
+            },
+            "counters": cnt,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene, full)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

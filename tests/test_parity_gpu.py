@@ -67,7 +67,8 @@ def test_errors_are_reported_not_thrown(hip, scenes):
     from flexlight_hip import capi
     sc = scenes("cornell")
     hip.update_scene(sc)
-    p = sc.frame_params(width=0, height=8)
+    p = sc.frame_params(width=8, height=8)
+    p.width = 0
     with pytest.raises(capi.FlexLightHipError, match="width"):
         hip.render(p)
     fresh = capi.Context(0)
