@@ -137,6 +137,11 @@ flx_status flx_get_counters(flx_context *ctx, flx_counters *out);
  * (trace) kernel alone; milliseconds. */
 flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_kernel_ms);
 
+/* Kernel organisation of the path-trace pass: 0 = automatic (persistent path kernel; the
+ * sample-sequential per-pixel kernel when use_filter needs the cross-sample G-buffer state),
+ * 1 = per-pixel kernel, 2 = persistent path kernel.  Results are identical; for A/B timing and tests. */
+flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
+
 /* ---- diagnostics --------------------------------------------------------------------------------- */
 /* Evaluate one of include/flx_math.h's routines on the GPU for n inputs (b may be NULL for unary
  * functions); used by tests to prove CPU/GPU bit equality.  fn: 0 sin 1 cos 2 tan 3 acos 4 atan2

@@ -39,6 +39,11 @@ struct flx_context {
   size_t out_capacity = 0;                       /* pixels */
   float4 *d_gb[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
   size_t gb_capacity = 0;
+  /* v2 pipeline workspace: primary hits, per-(sample,pixel) radiance, last sample's originalColor, item queue */
+  float4 *d_hits = nullptr, *d_samples = nullptr, *d_last = nullptr;
+  size_t hits_capacity = 0, samples_capacity = 0, last_capacity = 0;
+  uint32_t *d_queue = nullptr;
+  int pipeline = 0;                              /* 0 auto, 1 thread-per-pixel megakernel, 2 persistent paths */
   unsigned long long *d_counters = nullptr;
   bool counters_enabled = false;
   flx_counters last_counters = {};
@@ -90,6 +95,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_k0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   *out = ctx;
   return FLX_OK;
 }
@@ -100,7 +106,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
-                   ctx->d_gb[3], ctx->d_gb[4], ctx->d_counters };
+                   ctx->d_gb[3], ctx->d_gb[4], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue };
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -261,14 +267,47 @@ static flx_status ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, siz
 
 static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
   unsigned long long *cnt = ctx->counters_enabled ? ctx->d_counters : nullptr;
+  /* The G-buffer accumulators of the filter path carry state from sample to sample (fragment:83-89),
+   * so filter frames use the sample-sequential kernel; everything else runs the persistent pipeline. */
+  const bool persistent = ctx->pipeline == 2 || (ctx->pipeline == 0 && !fr.use_filter);
+  if (persistent && fr.use_filter) return fail(ctx, FLX_ERR_INVALID, "pipeline 2 does not produce the filter G-buffers");
+  const size_t P = (size_t)fr.rows * fr.width;
+  if (persistent) {
+    flx_status s;
+    if ((s = ensure_pixels(ctx, &ctx->d_hits, &ctx->hits_capacity, P))) return s;
+    if ((s = ensure_pixels(ctx, &ctx->d_last, &ctx->last_capacity, P))) return s;
+    if ((s = ensure_pixels(ctx, &ctx->d_samples, &ctx->samples_capacity, P * (size_t)fr.samples))) return s;
+    if ((double)path_item_count(fr) + 1024.0 >= 4294967296.0) return fail(ctx, FLX_ERR_INVALID, "frame too large: more than 2^32 path items");
+  }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
   if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), ctx->stream));
-  FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-  launch_trace_pixels(sc, fr, d_out, gb, cnt, ctx->stream);
-  FLX_HIP(ctx, hipGetLastError());
-  FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  if (!persistent) {
+    FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    launch_trace_pixels(sc, fr, d_out, gb, cnt, ctx->stream);
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  } else {
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
+    launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+    /* persistent grid: enough workgroups to fill every CU at the kernel's occupancy; surplus ones find the queue dry */
+    const uint32_t blocks = (uint32_t)ctx->prop.multiProcessorCount * 8u;
+    launch_paths(sc, fr, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue, blocks, cnt, ctx->stream);
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
+    FLX_HIP(ctx, hipGetLastError());
+  }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
   ctx->timed = true;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_set_pipeline(flx_context *ctx, int pipeline) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (pipeline < 0 || pipeline > 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_pipeline: 0 auto, 1 per-pixel, 2 persistent paths");
+  ctx->pipeline = pipeline;
   return FLX_OK;
 }
 

@@ -343,10 +343,30 @@ struct PixelState {
   float ndc_x, ndc_y;
 };
 
-/* fragment:400-461 */
-template <bool COUNT>
-FLX_DEV f3 reservoirSample(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, const Material &material, const Ray &ray,
-                           f4 randomVec, f3 N, f3 smoothNormal, float geometryOffset, bool dontFilter, int i, WorkCounters &cnt) {
+/* State of one path between bounces (what lightTrace keeps in locals, fragment:464-474). */
+struct PathState {
+  Ray ray;
+  f3 lastHitPoint;
+  f3 finalColor, importancyFactor;
+  Hit hit;
+  bool dontFilter;
+};
+
+/* What one bounce's shading hands to the traversal stage: the reservoir's light sample
+ * (fragment:400-461 up to the shadowTest call) and the two rays to walk. */
+struct ShadeOut {
+  f3 litColor;          /* localColor + baseLuminance: returned when the picked light is visible */
+  f3 baseLuminance;     /* returned when it is shadowed */
+  Ray shadowRay;        /* fragment:452-453 */
+  float shadowLen;      /* length(reservoirLightDir), fragment:455 */
+  bool needShadow;      /* false: showColor / showShadow decided it without a walk (fragment:438-450) */
+  bool shadowedNoWalk;  /* the showShadow early-out */
+  bool markId;          /* dontFilter || i == 0: renderId.w is written by this bounce */
+};
+
+/* fragment:400-453: everything of reservoirSample before the shadow ray is walked. */
+FLX_DEV void reservoirPick(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, const Material &material, const Ray &ray,
+                           f4 randomVec, f3 N, f3 smoothNormal, float geometryOffset, bool dontFilter, int i, ShadeOut &so) {
   f3 localColor = F3(0.0f, 0.0f, 0.0f);
   float reservoirLength = 0.0f;
   float totalWeight = 0.0f;
@@ -378,38 +398,23 @@ FLX_DEV f3 reservoirSample(const DeviceScene &sc, const DeviceFrame &fr, PixelSt
   f3 unitLightDir = normalize(reservoirLightDir);
   bool showColor = reservoirLength == 0.0f || reservoirWeight == 0.0f;
   bool showShadow = dot(smoothNormal, unitLightDir) <= BIAS;
-  f3 baseLuminance = F3(material.rme.z, material.rme.z, material.rme.z);
-  if (dontFilter || i == 0) ps.renderId.w = (float)((reservoirNum % 128) << 1) * INV_255;
-  if (showColor) return localColor + baseLuminance;
-  if (showShadow) {
-    if (dontFilter || i == 0) ps.renderId.w += INV_255;
-    return baseLuminance;
-  }
-  Ray lightRay;
-  lightRay.origin = ray.origin + smoothNormal * geometryOffset;
-  lightRay.dir = unitLightDir;
-  if (COUNT) cnt.shadow_walks++;
-  if (shadowTest(sc, lightRay, length(reservoirLightDir), cnt.shadow_visits)) {
-    if (dontFilter || i == 0) ps.renderId.w += INV_255;
-    return baseLuminance;
-  }
-  return localColor + baseLuminance;
+  so.baseLuminance = F3(material.rme.z, material.rme.z, material.rme.z);
+  so.litColor = localColor + so.baseLuminance;
+  so.markId = dontFilter || i == 0;
+  if (so.markId) ps.renderId.w = (float)((reservoirNum % 128) << 1) * INV_255;
+  so.needShadow = !showColor && !showShadow;
+  so.shadowedNoWalk = !showColor && showShadow;
+  so.shadowRay.origin = ray.origin + smoothNormal * geometryOffset;
+  so.shadowRay.dir = unitLightDir;
+  so.shadowLen = length(reservoirLightDir);
 }
 
-/* State of one path between bounces (what lightTrace keeps in locals, fragment:464-474). */
-struct PathState {
-  Ray ray;
-  f3 lastHitPoint;
-  f3 finalColor, importancyFactor;
-  Hit hit;
-  bool dontFilter;
-};
-
-/* One iteration of lightTrace's bounce loop (fragment:476-595).  Returns false when the path ends
- * (no next hit).  The loop guard of fragment:475 is evaluated by the caller. */
+/* One iteration of lightTrace's bounce loop up to its two traversals (fragment:476-589): surface
+ * fetch, material, RNG, Fresnel choice, filter bookkeeping, light pick, next direction.  On return
+ * p.ray is the next ray to walk with rayTracer (fragment:591) and `so` describes the shadow ray. */
 template <bool COUNT>
-FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, PathState &p, f3 camera, float cosSampleN, int i,
-                    WorkCounters &cnt) {
+FLX_DEV void bounceShade(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, PathState &p, f3 camera, float cosSampleN, int i,
+                         ShadeOut &so, WorkCounters &cnt) {
   float fi = (float)i;
   if (COUNT) cnt.shades++;
   Hit hit = p.hit;
@@ -484,17 +489,92 @@ FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps
   }
 
   if (i == 1) ps.firstRayLength = flx_min(length(p.ray.origin - p.lastHitPoint) / length(p.lastHitPoint - camera), ps.firstRayLength);
-  f3 localColor = reservoirSample<COUNT>(sc, fr, ps, material, p.ray, randomVec, roughNormal * (-signDir), smoothNormal * (-signDir),
-                                         geometryOffset, p.dontFilter, i, cnt);
-  p.finalColor = p.finalColor + localColor * p.importancyFactor;
+  reservoirPick(sc, fr, ps, material, p.ray, randomVec, roughNormal * (-signDir), smoothNormal * (-signDir), geometryOffset, p.dontFilter, i, so);
   if (isSolid) {
     p.ray.dir = normalize(mix(reflect(p.ray.dir, smoothNormal), randomSpheareVec, roughnessBRDF));
   } else {
     float eta = flx_mix(1.0f / material.tpo.z, material.tpo.z, flx_max(signDir, 0.0f));
     p.ray.dir = normalize(mix(refract(p.ray.dir, smoothNormal, eta), randomSpheareVec, roughnessBRDF));
   }
-  if (COUNT) cnt.closest_walks++;
-  p.hit = rayTracer<false>(sc, p.ray, 0.0f, cnt.closest_visits);
+}
+
+/* The two traversals of one bounce in ONE loop: shadowTest (fragment:231-280) on so.shadowRay, then
+ * rayTracer (fragment:172-227) on the next ray.  The reference runs them back to back; they are
+ * independent (the next direction does not depend on the shadow result), so each lane simply
+ * starts its closest-hit walk the moment its own shadow walk ends instead of waiting for the
+ * slowest shadow ray of the wave: wave time is max(n_shadow + n_closest) rather than
+ * max(n_shadow) + max(n_closest).  Per ray the entries visited, their order and every arithmetic
+ * operation are unchanged. */
+template <bool COUNT>
+FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, const Ray &shadowRay, float shadowLen, const Ray &nextRay,
+                        bool &shadowed, Hit &hit, WorkCounters &cnt) {
+  const int size = (int)sc.n_entries;
+  shadowed = false;
+  hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
+  int mode = needShadow ? 0 : 1;                 /* 0 shadow walk, 1 closest walk, 2 done */
+  Ray src = needShadow ? shadowRay : nextRay;
+  Ray tR = src;
+  int cachedTI = 0;
+  float minLen = needShadow ? shadowLen : POW32;
+  int i = 0;
+  if (COUNT) { if (needShadow) cnt.shadow_walks++; cnt.closest_walks++; }
+  while (mode != 2) {
+    bool endWalk = false;
+    float4 e0 = sc.geometry[3 * i], e1 = sc.geometry[3 * i + 1], e2 = sc.geometry[3 * i + 2];
+    if (COUNT) { if (mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
+    int tI = (int)e2.y << 1;
+    if (tI != cachedTI) {
+      int iI = tI + 1;
+      M3 rotationII = rotation_at(sc, iI);
+      cachedTI = tI;
+      tR.origin = mul(rotationII, src.origin + shift_at(sc, iI));
+      f3 d = mul(rotationII, src.dir);
+      tR.dir = (mode == 0) ? normalize(d) : d;      /* fragment:261 normalises, fragment:201 does not */
+    }
+    if (e2.z == 0.0f) {
+      endWalk = true;
+    } else if (e2.z == 1.0f) {
+      if (!rayCuboid(minLen, tR, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y))) i += (int)e1.z;
+    } else {
+      f3 a = F3(e0.x, e0.y, e0.z), b = F3(e0.w, e1.x, e1.y), c = F3(e1.z, e1.w, e2.x);
+      if (mode == 0) {
+        if (moellerTrumboreCull(a, b, c, tR, minLen)) { shadowed = true; endWalk = true; }
+      } else {
+        f3 suv;
+        if (moellerTrumbore(a, b, c, tR, minLen, suv)) {
+          hit.suv = suv; hit.transformId = tI; hit.triangleId = i;
+          minLen = suv.x;
+        }
+      }
+    }
+    i++;
+    if (endWalk || i >= size) {
+      if (mode == 0) {                            /* shadow walk over: start the closest-hit walk */
+        mode = 1; src = nextRay; tR = nextRay; cachedTI = 0; minLen = POW32; i = 0;
+      } else {
+        mode = 2;
+      }
+    }
+  }
+}
+
+/* fragment:445-460 + 580: fold the shadow result into the path. */
+FLX_DEV void bounceFinish(PixelState &ps, PathState &p, const ShadeOut &so, bool shadowedByWalk) {
+  bool shadowed = so.shadowedNoWalk || (so.needShadow && shadowedByWalk);
+  if (shadowed && so.markId) ps.renderId.w += INV_255;
+  f3 localColor = shadowed ? so.baseLuminance : so.litColor;
+  p.finalColor = p.finalColor + localColor * p.importancyFactor;
+}
+
+/* One full bounce iteration (fragment:476-595); false when the path ends on a miss (fragment:593). */
+template <bool COUNT>
+FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, PathState &p, f3 camera, float cosSampleN, int i,
+                    WorkCounters &cnt) {
+  ShadeOut so;
+  bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, i, so, cnt);
+  bool shadowed;
+  walkBounce<COUNT>(sc, so.needShadow, so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
+  bounceFinish(ps, p, so, shadowed);
   if (p.hit.triangleId == -1) return false;
   p.lastHitPoint = p.ray.origin;
   return true;

@@ -106,6 +106,190 @@ void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *o
   else hipLaunchKernelGGL(k_trace_pixels<false>, dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
 }
 
+/* ---- v2: primary kernel + persistent path kernel with lane refill + resolve ---------------------- */
+/*
+ * Work item = one (pixel, sample) path.  Items are numbered [8x8 tile][sample][lane] so that the 64
+ * items a wave draws together are one sample of one screen tile.  A wave is persistent: every lane
+ * runs "one bounce per loop trip" (shade -> shadow walk + closest-hit walk -> fold), and at the top of
+ * each trip the lanes whose path has ended draw fresh items (wave-level compaction / restart): the
+ * wave64 never idles on the tail of its longest path, and all lanes are always in the same stage,
+ * so the long shading code is never executed for a handful of lanes.  Items come from a global
+ * counter in chunks of PATH_CHUNK per wave (one atomic per chunk, ~65 k atomics per 1080p x 8 frame).
+ * Each path writes its radiance to its own slot; k_resolve adds the samples of a pixel in sample
+ * order, so the frame equals the sequential shader's bit for bit.
+ */
+constexpr uint32_t PATH_CHUNK = 256;
+
+__device__ __forceinline__ void tile8_pixel(const DeviceFrame &fr, uint32_t tile, uint32_t lane, uint32_t &px, uint32_t &k) {
+  const uint32_t tiles_x = (fr.width + 7u) >> 3;
+  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+  px = (tx << 3) + (lane & 7u);
+  k = (ty << 3) + (lane >> 3);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ hits,
+                                                 unsigned long long *__restrict__ counters) {
+  const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+  uint32_t px, k;
+  tile8_pixel(fr, tile, threadIdx.x & 63u, px, k);
+  WorkCounters cnt = {};
+  if (px < fr.width && k < fr.rows) {
+    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+    float nx, ny, viewDepthPerS;
+    Ray pr;
+    pr.dir = primary_dir(fr, px, py_gl, nx, ny, viewDepthPerS);
+    pr.origin = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
+    Hit h = rayTracer<true>(sc, pr, viewDepthPerS, cnt.primary_visits);
+    if (COUNT && h.triangleId != -1) cnt.primary_hits++;
+    hits[(size_t)k * fr.width + px] = make_float4(h.suv.x, h.suv.y, h.suv.z, __int_as_float(h.triangleId));
+  }
+  flush_counters<COUNT>(cnt, counters);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_paths(DeviceScene sc, DeviceFrame fr, const float4 *__restrict__ hits,
+                                               float4 *__restrict__ sampleRadiance, float4 *__restrict__ lastOriginal,
+                                               uint32_t *__restrict__ queue, uint32_t total_items,
+                                               unsigned long long *__restrict__ counters) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t S = (uint32_t)fr.samples;
+  const size_t P = (size_t)fr.rows * fr.width;
+  const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
+  WorkCounters cnt = {};
+  bool alive = false;
+  PathState p;
+  PixelState ps;
+  int bounceIdx = 0;
+  float cosSampleN = 0.0f;
+  size_t slot = 0;              /* where this path's radiance goes */
+  uint32_t sampleIdx = 0;
+  uint32_t chunkNext = 0, chunkEnd = 0;      /* wave-uniform */
+  bool itemsLeft = true;                     /* wave-uniform */
+  auto finishPath = [&]() {                  /* fragment:598 + what main() needs from the last sample */
+    const f3 r = p.finalColor + p.importancyFactor * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]);
+    sampleRadiance[slot] = make_float4(r.x, r.y, r.z, 1.0f);
+    if (sampleIdx == S - 1u)
+      lastOriginal[slot - (size_t)sampleIdx * P] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 1.0f);
+  };
+
+  for (;;) {
+    /* -- refill: dead lanes draw new items until the wave is full or the queue is dry ------------ */
+    for (;;) {
+      const unsigned long long idle = __ballot(!alive);
+      if (idle == 0ull) break;
+      if (chunkNext == chunkEnd) {
+        if (!itemsLeft) break;
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(queue, PATH_CHUNK);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base >= total_items) { itemsLeft = false; break; }
+        chunkNext = base;
+        chunkEnd = (base + PATH_CHUNK < total_items) ? base + PATH_CHUNK : total_items;
+      }
+      const uint32_t nIdle = (uint32_t)__popcll(idle);
+      const uint32_t avail = chunkEnd - chunkNext;
+      const uint32_t take = nIdle < avail ? nIdle : avail;
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+      if (!alive && rank < take) {
+        const uint32_t item = chunkNext + rank;
+        const uint32_t l = item & 63u, ts = item >> 6;
+        const uint32_t s = ts % S, tile = ts / S;
+        uint32_t px, k;
+        tile8_pixel(fr, tile, l, px, k);
+        if (px < fr.width && k < fr.rows) {
+          const size_t o = (size_t)k * fr.width + px;
+          const float4 h = hits[o];
+          const int tri = __float_as_int(h.w);
+          if (tri != -1) {
+            const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+            float viewDepthPerS;
+            const f3 dir0 = primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+            ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
+            ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+            ps.renderOriginalId = ps.renderId;
+            ps.originalColor = F3(1.0f, 1.0f, 1.0f);
+            p.dontFilter = true;
+            p.finalColor = F3(0.0f, 0.0f, 0.0f);
+            p.importancyFactor = F3(1.0f, 1.0f, 1.0f);
+            p.ray.origin = camera; p.ray.dir = dir0;
+            p.lastHitPoint = camera;
+            p.hit.suv = F3(h.x, h.y, h.z);
+            p.hit.triangleId = tri;
+            p.hit.transformId = (int)sc.geometry[3 * tri + 2].y << 1;
+            cosSampleN = flx_cos((float)s);
+            bounceIdx = 0;
+            sampleIdx = s;
+            slot = (size_t)s * P + o;
+            /* loop guard of fragment:475 before the first bounce (fails only for bounces = 0 or minImportancy > 1) */
+            alive = fr.max_reflections > 0 && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3;
+            if (!alive) finishPath();
+          }
+        }
+      }
+      chunkNext += take;
+    }
+    if (__ballot(alive) == 0ull) break;
+
+    /* -- one bounce for every live lane (fragment:475-596) ------------------------------------------ */
+    if (alive) {
+      bool cont = bounce<COUNT>(sc, fr, ps, p, camera, cosSampleN, bounceIdx, cnt);
+      bounceIdx++;
+      if (cont) cont = bounceIdx < fr.max_reflections && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3;
+      if (!cont) { finishPath(); alive = false; }
+    }
+  }
+  flush_counters<COUNT>(cnt, counters);
+}
+
+/* fragment:608-632 for one pixel: add the samples in order, average, apply originalColor of the last
+ * sample (the shader's global still holds it after the loop). */
+__global__ __launch_bounds__(256) void k_resolve(DeviceFrame fr, const float4 *__restrict__ hits, const float4 *__restrict__ sampleRadiance,
+                                                 const float4 *__restrict__ lastOriginal, float4 *__restrict__ out) {
+  const size_t P = (size_t)fr.rows * fr.width;
+  const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (o >= P) return;
+  float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (__float_as_int(hits[o].w) != -1) {
+    f3 finalColor = F3(0.0f, 0.0f, 0.0f);
+    for (int s = 0; s < fr.samples; s++) {
+      const float4 r = sampleRadiance[(size_t)s * P + o];
+      finalColor = finalColor + F3(r.x, r.y, r.z);
+    }
+    const float invSamples = 1.0f / (float)fr.samples;
+    finalColor = finalColor * invSamples;
+    const float4 oc = lastOriginal[o];
+    finalColor = finalColor * F3(oc.x, oc.y, oc.z);
+    if (fr.is_temporal == 1) color = make_float4(flx_fract(finalColor.x), flx_fract(finalColor.y), flx_fract(finalColor.z), 1.0f);
+    else color = make_float4(finalColor.x, finalColor.y, finalColor.z, 1.0f);
+  }
+  out[o] = color;
+}
+
+uint32_t path_item_count(const DeviceFrame &fr) {
+  return ((fr.width + 7u) >> 3) * ((fr.rows + 7u) >> 3) * (uint32_t)fr.samples * 64u;
+}
+
+void launch_primary(const DeviceScene &sc, const DeviceFrame &fr, float4 *hits, unsigned long long *counters, hipStream_t stream) {
+  const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.rows + 7u) >> 3);
+  const uint32_t blocks = (tiles + 3u) / 4u;
+  if (counters) hipLaunchKernelGGL(k_primary<true>, dim3(blocks), dim3(256), 0, stream, sc, fr, hits, counters);
+  else hipLaunchKernelGGL(k_primary<false>, dim3(blocks), dim3(256), 0, stream, sc, fr, hits, counters);
+}
+
+void launch_paths(const DeviceScene &sc, const DeviceFrame &fr, const float4 *hits, float4 *sampleRadiance, float4 *lastOriginal,
+                  uint32_t *queue, uint32_t blocks, unsigned long long *counters, hipStream_t stream) {
+  const uint32_t total = path_item_count(fr);
+  if (counters) hipLaunchKernelGGL(k_paths<true>, dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+  else hipLaunchKernelGGL(k_paths<false>, dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+}
+
+void launch_resolve(const DeviceFrame &fr, const float4 *hits, const float4 *sampleRadiance, const float4 *lastOriginal, float4 *out,
+                    hipStream_t stream) {
+  const size_t P = (size_t)fr.rows * fr.width;
+  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((P + 255) / 256)), dim3(256), 0, stream, fr, hits, sampleRadiance, lastOriginal, out);
+}
+
 /* ---- diagnostics: include/flx_math.h on the device ------------------------------------------------ */
 __global__ void k_debug_math(int fn, const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out, uint32_t n) {
   uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

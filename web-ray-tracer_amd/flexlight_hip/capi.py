@@ -18,7 +18,7 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version",
+    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline",
 ]
 
 
@@ -54,6 +54,7 @@ def _load():
         "flx_debug_math": (C.c_int, [vp, C.c_int, fp, fp, fp, u32]),
         "flx_device_info": (C.c_int, [vp, C.c_char_p, u32, C.POINTER(u32)]),
         "flx_version": (C.c_char_p, []),
+        "flx_set_pipeline": (C.c_int, [vp, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -153,6 +154,10 @@ class Context:
 
     def set_counters_enabled(self, on):
         self._check(LIB.flx_set_counters_enabled(self._h, int(bool(on))), "flx_set_counters_enabled")
+
+    def set_pipeline(self, pipeline):
+        """0 auto, 1 per-pixel kernel, 2 persistent path kernel (same results)."""
+        self._check(LIB.flx_set_pipeline(self._h, int(pipeline)), "flx_set_pipeline")
 
     def get_counters(self):
         cnt = Counters()
