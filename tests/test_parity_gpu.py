@@ -25,7 +25,7 @@ CASES = [
 _ORACLE_CACHE = {}
 
 
-@pytest.mark.parametrize("pipeline", [2, 1], ids=["persistent", "per_pixel"])
+@pytest.mark.parametrize("pipeline", [3, 2, 1], ids=["wavefront", "persistent", "per_pixel"])
 @pytest.mark.parametrize("name,w,h,spp,bounces", CASES)
 def test_radiance_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounces, pipeline):
     sc = scenes(name)

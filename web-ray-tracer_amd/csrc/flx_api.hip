@@ -43,7 +43,13 @@ struct flx_context {
   float4 *d_hits = nullptr, *d_samples = nullptr, *d_last = nullptr;
   size_t hits_capacity = 0, samples_capacity = 0, last_capacity = 0;
   uint32_t *d_queue = nullptr;
-  int pipeline = 0;                              /* 0 auto, 1 thread-per-pixel megakernel, 2 persistent paths */
+  /* pipeline 3 (wavefront) workspace */
+  float4 *d_rec = nullptr;
+  size_t rec_capacity = 0;                       /* float4 units */
+  uint32_t *d_live[2] = { nullptr, nullptr };
+  size_t live_capacity = 0;
+  uint32_t *d_wfcounts = nullptr;                /* counts[WF_MAX_BOUNCES+2] then walkQueue[WF_MAX_BOUNCES+2] */
+  int pipeline = 0;                              /* 0 auto, 1 per-pixel megakernel, 2 persistent paths, 3 wavefront */
   unsigned long long *d_counters = nullptr;
   bool counters_enabled = false;
   flx_counters last_counters = {};
@@ -96,6 +102,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_wfcounts, 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   *out = ctx;
   return FLX_OK;
 }
@@ -106,7 +113,8 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
-                   ctx->d_gb[3], ctx->d_gb[4], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue };
+                   ctx->d_gb[3], ctx->d_gb[4], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
+                   ctx->d_rec, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts };
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -268,34 +276,60 @@ static flx_status ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, siz
 static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
   unsigned long long *cnt = ctx->counters_enabled ? ctx->d_counters : nullptr;
   /* The G-buffer accumulators of the filter path carry state from sample to sample (fragment:83-89),
-   * so filter frames use the sample-sequential kernel; everything else runs the persistent pipeline. */
-  const bool persistent = ctx->pipeline == 2 || (ctx->pipeline == 0 && !fr.use_filter);
-  if (persistent && fr.use_filter) return fail(ctx, FLX_ERR_INVALID, "pipeline 2 does not produce the filter G-buffers");
+   * so filter frames use the sample-sequential kernel; everything else runs the wavefront pipeline. */
+  int pipeline = ctx->pipeline;
+  if (pipeline == 0) pipeline = fr.use_filter ? 1 : 3;
+  if (pipeline == 3 && fr.max_reflections > WF_MAX_BOUNCES) pipeline = 2;
+  if (pipeline != 1 && fr.use_filter) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the filter G-buffers");
   const size_t P = (size_t)fr.rows * fr.width;
-  if (persistent) {
+  const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+  if (pipeline != 1) {
     flx_status s;
     if ((s = ensure_pixels(ctx, &ctx->d_hits, &ctx->hits_capacity, P))) return s;
     if ((s = ensure_pixels(ctx, &ctx->d_last, &ctx->last_capacity, P))) return s;
     if ((s = ensure_pixels(ctx, &ctx->d_samples, &ctx->samples_capacity, P * (size_t)fr.samples))) return s;
-    if ((double)path_item_count(fr) + 1024.0 >= 4294967296.0) return fail(ctx, FLX_ERR_INVALID, "frame too large: more than 2^32 path items");
+    if ((double)path_item_count(fr) + 1.0e6 >= 4294967296.0) return fail(ctx, FLX_ERR_INVALID, "frame too large: more than 2^32 path items");
+  }
+  if (pipeline == 3) {
+    flx_status s;
+    if ((s = ensure_pixels(ctx, &ctx->d_rec, &ctx->rec_capacity, (size_t)path_item_count(fr) * 8))) return s;
+    const size_t need = wavefront_live_capacity(fr, cus);
+    if (ctx->live_capacity < need) {
+      for (int i = 0; i < 2; i++) {
+        if (ctx->d_live[i]) { FLX_HIP(ctx, hipFree(ctx->d_live[i])); ctx->d_live[i] = nullptr; }
+        FLX_HIP(ctx, hipMalloc(&ctx->d_live[i], need * sizeof(uint32_t)));
+      }
+      ctx->live_capacity = need;
+    }
   }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
   if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), ctx->stream));
-  if (!persistent) {
+  if (pipeline == 1) {
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     launch_trace_pixels(sc, fr, d_out, gb, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
-  } else {
+  } else if (pipeline == 2) {
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_queue, 0, sizeof(uint32_t), ctx->stream));
     launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     /* persistent grid: enough workgroups to fill every CU at the kernel's occupancy; surplus ones find the queue dry */
-    const uint32_t blocks = (uint32_t)ctx->prop.multiProcessorCount * 8u;
-    launch_paths(sc, fr, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue, blocks, cnt, ctx->stream);
+    launch_paths(sc, fr, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue, cus * 8u, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+    launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
+    FLX_HIP(ctx, hipGetLastError());
+  } else {
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t), ctx->stream));
+    launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
+    FLX_HIP(ctx, hipGetLastError());
+    WavefrontBuffers wb;
+    wb.rec = ctx->d_rec; wb.live[0] = ctx->d_live[0]; wb.live[1] = ctx->d_live[1];
+    wb.counts = ctx->d_wfcounts; wb.walkQueue = ctx->d_wfcounts + (WF_MAX_BOUNCES + 2);
+    wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
+    launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->ev_k0, ctx->ev_k1, ctx->stream);
+    FLX_HIP(ctx, hipGetLastError());
     launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
   }
@@ -306,7 +340,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
 
 extern "C" flx_status flx_set_pipeline(flx_context *ctx, int pipeline) {
   if (!ctx) return FLX_ERR_INVALID;
-  if (pipeline < 0 || pipeline > 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_pipeline: 0 auto, 1 per-pixel, 2 persistent paths");
+  if (pipeline < 0 || pipeline > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_pipeline: 0 auto, 1 per-pixel, 2 persistent paths, 3 wavefront");
   ctx->pipeline = pipeline;
   return FLX_OK;
 }

@@ -498,64 +498,85 @@ FLX_DEV void bounceShade(const DeviceScene &sc, const DeviceFrame &fr, PixelStat
   }
 }
 
+/* State of one skip-list walk, advanced one entry per walkStep(): the loop bodies of rayTracer
+ * (fragment:184-224) and shadowTest (fragment:240-277) with their loop variables made explicit so
+ * that a lane can suspend / resume a walk and the scheduler above can refill idle lanes. */
+struct WalkState {
+  Ray src;            /* the ray in world space */
+  Ray tR;             /* the ray in the object space of transform cachedTI (fragment:174,233) */
+  float minLen;       /* fragment:179 / :236 */
+  int i;              /* next entry */
+  int cachedTI;
+  int mode;           /* 0 shadowTest, 1 rayTracer, 2 finished */
+  bool shadowed;      /* result of the shadow walk */
+  f3 suv;             /* closest hit so far */
+  int tri, hitTI;     /* entry index (-1: none) and 2 * transform number of the closest hit */
+};
+
+FLX_DEV void walkStart(WalkState &w, int mode, const Ray &ray, float len) {
+  w.mode = mode; w.src = ray; w.tR = ray; w.cachedTI = 0; w.minLen = len; w.i = 0;
+}
+FLX_DEV void walkClearResults(WalkState &w) {
+  w.shadowed = false; w.suv = F3(0.0f, 0.0f, 0.0f); w.tri = -1; w.hitTI = 0;
+}
+
+/* Visit entry w.i.  Returns true when the current walk (shadow or closest) has ended. */
+template <bool COUNT>
+FLX_DEV bool walkStep(const DeviceScene &sc, WalkState &w, WorkCounters &cnt) {
+  bool endWalk = false;
+  const int i = w.i;
+  float4 e0 = sc.geometry[3 * i], e1 = sc.geometry[3 * i + 1], e2 = sc.geometry[3 * i + 2];
+  if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
+  int tI = (int)e2.y << 1;
+  if (tI != w.cachedTI) {
+    int iI = tI + 1;
+    M3 rotationII = rotation_at(sc, iI);
+    w.cachedTI = tI;
+    w.tR.origin = mul(rotationII, w.src.origin + shift_at(sc, iI));
+    f3 d = mul(rotationII, w.src.dir);
+    w.tR.dir = (w.mode == 0) ? normalize(d) : d;      /* fragment:261 normalises, fragment:201 does not */
+  }
+  int next = i + 1;
+  if (e2.z == 0.0f) {
+    endWalk = true;
+  } else if (e2.z == 1.0f) {
+    if (!rayCuboid(w.minLen, w.tR, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y))) next += (int)e1.z;
+  } else {
+    f3 a = F3(e0.x, e0.y, e0.z), b = F3(e0.w, e1.x, e1.y), c = F3(e1.z, e1.w, e2.x);
+    if (w.mode == 0) {
+      if (moellerTrumboreCull(a, b, c, w.tR, w.minLen)) { w.shadowed = true; endWalk = true; }
+    } else {
+      f3 suv;
+      if (moellerTrumbore(a, b, c, w.tR, w.minLen, suv)) {
+        w.suv = suv; w.hitTI = tI; w.tri = i;
+        w.minLen = suv.x;
+      }
+    }
+  }
+  w.i = next;
+  return endWalk || next >= (int)sc.n_entries;
+}
+
 /* The two traversals of one bounce in ONE loop: shadowTest (fragment:231-280) on so.shadowRay, then
  * rayTracer (fragment:172-227) on the next ray.  The reference runs them back to back; they are
  * independent (the next direction does not depend on the shadow result), so each lane simply
  * starts its closest-hit walk the moment its own shadow walk ends instead of waiting for the
- * slowest shadow ray of the wave: wave time is max(n_shadow + n_closest) rather than
- * max(n_shadow) + max(n_closest).  Per ray the entries visited, their order and every arithmetic
+ * slowest shadow ray of the wave.  Per ray the entries visited, their order and every arithmetic
  * operation are unchanged. */
 template <bool COUNT>
 FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, const Ray &shadowRay, float shadowLen, const Ray &nextRay,
                         bool &shadowed, Hit &hit, WorkCounters &cnt) {
-  const int size = (int)sc.n_entries;
-  shadowed = false;
-  hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
-  int mode = needShadow ? 0 : 1;                 /* 0 shadow walk, 1 closest walk, 2 done */
-  Ray src = needShadow ? shadowRay : nextRay;
-  Ray tR = src;
-  int cachedTI = 0;
-  float minLen = needShadow ? shadowLen : POW32;
-  int i = 0;
+  WalkState w;
+  walkClearResults(w);
+  if (needShadow) walkStart(w, 0, shadowRay, shadowLen); else walkStart(w, 1, nextRay, POW32);
   if (COUNT) { if (needShadow) cnt.shadow_walks++; cnt.closest_walks++; }
-  while (mode != 2) {
-    bool endWalk = false;
-    float4 e0 = sc.geometry[3 * i], e1 = sc.geometry[3 * i + 1], e2 = sc.geometry[3 * i + 2];
-    if (COUNT) { if (mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
-    int tI = (int)e2.y << 1;
-    if (tI != cachedTI) {
-      int iI = tI + 1;
-      M3 rotationII = rotation_at(sc, iI);
-      cachedTI = tI;
-      tR.origin = mul(rotationII, src.origin + shift_at(sc, iI));
-      f3 d = mul(rotationII, src.dir);
-      tR.dir = (mode == 0) ? normalize(d) : d;      /* fragment:261 normalises, fragment:201 does not */
-    }
-    if (e2.z == 0.0f) {
-      endWalk = true;
-    } else if (e2.z == 1.0f) {
-      if (!rayCuboid(minLen, tR, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y))) i += (int)e1.z;
-    } else {
-      f3 a = F3(e0.x, e0.y, e0.z), b = F3(e0.w, e1.x, e1.y), c = F3(e1.z, e1.w, e2.x);
-      if (mode == 0) {
-        if (moellerTrumboreCull(a, b, c, tR, minLen)) { shadowed = true; endWalk = true; }
-      } else {
-        f3 suv;
-        if (moellerTrumbore(a, b, c, tR, minLen, suv)) {
-          hit.suv = suv; hit.transformId = tI; hit.triangleId = i;
-          minLen = suv.x;
-        }
-      }
-    }
-    i++;
-    if (endWalk || i >= size) {
-      if (mode == 0) {                            /* shadow walk over: start the closest-hit walk */
-        mode = 1; src = nextRay; tR = nextRay; cachedTI = 0; minLen = POW32; i = 0;
-      } else {
-        mode = 2;
-      }
+  while (w.mode != 2) {
+    if (walkStep<COUNT>(sc, w, cnt)) {
+      if (w.mode == 0) walkStart(w, 1, nextRay, POW32); else w.mode = 2;
     }
   }
+  shadowed = w.shadowed;
+  hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri;
 }
 
 /* fragment:445-460 + 580: fold the shadow result into the path. */

@@ -1,0 +1,45 @@
+/* flx_kernel_util.h — small device helpers shared by the kernel files. */
+#ifndef FLX_KERNEL_UTIL_H
+#define FLX_KERNEL_UTIL_H
+
+#include "flx_device.h"
+
+namespace flx {
+
+/* 8x8 pixel tile `tile` (row-major over the context's W x rows image), lane -> pixel. */
+__device__ __forceinline__ void tile8_pixel(const DeviceFrame &fr, uint32_t tile, uint32_t lane, uint32_t &px, uint32_t &k) {
+  const uint32_t tiles_x = (fr.width + 7u) >> 3;
+  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+  px = (tx << 3) + (lane & 7u);
+  k = (ty << 3) + (lane >> 3);
+}
+
+/* Path item -> (pixel, sample).  Items are numbered [8x8 tile][sample][lane]: the 64 items a wave draws
+ * together are one sample of one screen tile. Returns false for lanes outside the frame. */
+__device__ __forceinline__ bool item_pixel(const DeviceFrame &fr, uint32_t item, uint32_t &px, uint32_t &k, uint32_t &s) {
+  const uint32_t S = (uint32_t)fr.samples;
+  const uint32_t l = item & 63u, ts = item >> 6;
+  s = ts % S;
+  tile8_pixel(fr, ts / S, l, px, k);
+  return px < fr.width && k < fr.rows;
+}
+
+/* rank of this lane among the set bits of `mask` below it */
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void flush_counters(const WorkCounters &c, unsigned long long *out) {
+  if (!COUNT) return;
+  uint32_t v[8] = { c.primary_visits, c.closest_visits, c.shadow_visits, c.closest_walks, c.shadow_walks, c.shades, c.primary_hits, c.atlas_texels };
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    unsigned long long x = v[j];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if ((threadIdx.x & 63u) == 0u && x) atomicAdd(out + j, x);
+  }
+}
+
+}  // namespace flx
+#endif

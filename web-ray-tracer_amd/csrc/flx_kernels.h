@@ -18,6 +18,20 @@ void launch_paths(const DeviceScene &sc, const DeviceFrame &fr, const float4 *hi
                   uint32_t *queue, uint32_t blocks, unsigned long long *counters, hipStream_t stream);
 void launch_resolve(const DeviceFrame &fr, const float4 *hits, const float4 *sampleRadiance, const float4 *lastOriginal, float4 *out,
                     hipStream_t stream);
+/* pipeline 3 (flx_wavefront.hip): per bounce a dense shade kernel and a persistent walk kernel; path state in HBM. */
+constexpr int WF_MAX_BOUNCES = 250;
+struct WavefrontBuffers {
+  float4 *rec;                  /* 8 x float4 (128 B) per path item */
+  uint32_t *live[2];            /* live path lists, alternating per bounce */
+  uint32_t *counts;             /* [WF_MAX_BOUNCES + 2] slots used in the live list of bounce b */
+  uint32_t *walkQueue;          /* [WF_MAX_BOUNCES + 2] per-bounce refill cursor of the walk kernel */
+  const float4 *hits;
+  float4 *sampleRadiance, *lastOriginal;
+  unsigned long long *counters; /* or nullptr */
+};
+size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units);
+void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
+                      hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, uint32_t n, hipStream_t stream);
 
 }  // namespace flx

@@ -7,6 +7,7 @@
  * entry loads hit the same cache lines); a workgroup covers 16x16.
  */
 #include "flx_kernels.h"
+#include "flx_kernel_util.h"
 
 namespace flx {
 
@@ -17,18 +18,6 @@ __device__ __forceinline__ void tile_pixel(const DeviceFrame &fr, uint32_t &px, 
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   px = (tx << 4) + ((wave & 1u) << 3) + (lane & 7u);
   k = (ty << 4) + ((wave >> 1) << 3) + (lane >> 3);
-}
-
-template <bool COUNT>
-__device__ __forceinline__ void flush_counters(const WorkCounters &c, unsigned long long *out) {
-  if (!COUNT) return;
-  uint32_t v[8] = { c.primary_visits, c.closest_visits, c.shadow_visits, c.closest_walks, c.shadow_walks, c.shades, c.primary_hits, c.atlas_texels };
-#pragma unroll
-  for (int j = 0; j < 8; j++) {
-    unsigned long long x = v[j];
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-    if ((threadIdx.x & 63u) == 0u && x) atomicAdd(out + j, x);
-  }
 }
 
 /* ---- v1: one thread per pixel, the whole fragment program (fragment:601-646) --------------------- */
@@ -120,13 +109,6 @@ void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *o
  */
 constexpr uint32_t PATH_CHUNK = 256;
 
-__device__ __forceinline__ void tile8_pixel(const DeviceFrame &fr, uint32_t tile, uint32_t lane, uint32_t &px, uint32_t &k) {
-  const uint32_t tiles_x = (fr.width + 7u) >> 3;
-  const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-  px = (tx << 3) + (lane & 7u);
-  k = (ty << 3) + (lane >> 3);
-}
-
 template <bool COUNT>
 __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ hits,
                                                  unsigned long long *__restrict__ counters) {
@@ -147,8 +129,11 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
   flush_counters<COUNT>(cnt, counters);
 }
 
+#ifndef FLX_PATHS_WAVES
+#define FLX_PATHS_WAVES 1
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_paths(DeviceScene sc, DeviceFrame fr, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, DeviceFrame fr, const float4 *__restrict__ hits,
                                                float4 *__restrict__ sampleRadiance, float4 *__restrict__ lastOriginal,
                                                uint32_t *__restrict__ queue, uint32_t total_items,
                                                unsigned long long *__restrict__ counters) {

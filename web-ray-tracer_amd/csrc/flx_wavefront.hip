@@ -1,0 +1,286 @@
+/*
+ * flx_wavefront.hip — wavefront organisation of the path-trace pass for gfx950 (pipeline 3).
+ *
+ * The reference runs lightTrace's bounce loop (fragment:475-596) inside one fragment invocation.
+ * On a wave64 machine that loop has two very different halves: ~2 k instructions of shading that
+ * every lane executes alike, and two skip-list walks whose length varies from a handful of entries
+ * (ray leaves the scene) to hundreds (ray grazes the dragon).  Run per lane in lock step, the walk
+ * half sat at ~30 % lane utilisation (rocprofv3 SQ_THREAD_CYCLES_VALU, profiles/r01_*).  So the loop
+ * is cut at that seam and each half gets the launch shape that suits it:
+ *
+ *   k_wf_shade(b)  one lane per live path: fragment:476-589 (surface fetch, material, RNG, Fresnel
+ *                  choice, light pick, next direction).  Dense list in, every lane busy.
+ *   k_wf_walk(b)   persistent waves: each lane walks its path's shadow ray, then its closest-hit ray
+ *                  (walkStep, one 48-byte entry per trip).  Lanes whose walks have ended park; once a
+ *                  quarter of the wave is parked the wave folds their results (fragment:445-460,580,
+ *                  593-598 and the loop guard :475), compacts the survivors into the next bounce's
+ *                  live list and refills the free lanes from the queue — wave-level ray compaction
+ *                  and restart, so the wave never idles on its longest ray.
+ *
+ * Path state lives in HBM between the kernels as one 128-byte record per (pixel, sample) path (8
+ * float4, written and read whole: one cache line per lane).  Every path does exactly the arithmetic
+ * of the sequential shader, in the same order; only the interleaving between paths differs, and each
+ * path writes its radiance to its own slot, summed in sample order by k_resolve — so the frame is
+ * bit-identical to the per-pixel kernel and to the CPU oracle.
+ */
+#include "flx_kernels.h"
+#include "flx_kernel_util.h"
+
+namespace flx {
+
+constexpr uint32_t WF_INVALID = 0xffffffffu;
+constexpr uint32_t WF_IN_CHUNK = 256;       /* path ids a wave draws from the walk queue per atomic */
+constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves per atomic */
+#ifndef FLX_WF_BATCH
+#define FLX_WF_BATCH 16                     /* parked lanes that trigger a fold + refill */
+#endif
+
+/* record flags (q0.w as int bits) */
+constexpr int RF_DEAD = 1, RF_DONT_FILTER = 2, RF_NEED_SHADOW = 4, RF_SHADOWED_NO_WALK = 8;
+
+/* q0 origin.xyz flags | q1 nextDir.xyz shadowLen | q2 shadowOrigin.xyz baseLuminance  (after the walk: hit s,u,v,tri)
+ * q3 shadowDir.xyz - | q4 litColor.xyz - | q5 finalColor.xyz - | q6 importancyFactor.xyz - | q7 originalColor.xyz - */
+
+__device__ __forceinline__ void finalize_path(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t pathId, f3 finalColor,
+                                              f3 importancy, f3 originalColor) {
+  uint32_t px, k, s;
+  item_pixel(fr, pathId, px, k, s);
+  const size_t P = (size_t)fr.rows * fr.width;
+  const size_t o = (size_t)k * fr.width + px;
+  const f3 r = finalColor + importancy * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]);          /* fragment:598 */
+  wb.sampleRadiance[(size_t)s * P + o] = make_float4(r.x, r.y, r.z, 1.0f);
+  if (s == (uint32_t)fr.samples - 1u) wb.lastOriginal[o] = make_float4(originalColor.x, originalColor.y, originalColor.z, 1.0f);
+}
+
+template <bool COUNT, bool FIRST>
+__global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items) {
+  const uint32_t n = FIRST ? total_items : wb.counts[b];
+  const uint32_t *__restrict__ listIn = wb.live[b & 1];
+  const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
+  WorkCounters cnt = {};
+  for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
+    const uint32_t pathId = FIRST ? j : listIn[j];
+    if (pathId == WF_INVALID) continue;
+    float4 *rec = wb.rec + (size_t)pathId * 8;
+    uint32_t px, k, s;
+    const bool inFrame = item_pixel(fr, pathId, px, k, s);
+    PathState p;
+    PixelState ps;
+    ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
+    ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+    ps.renderOriginalId = ps.renderId;
+    if (FIRST) {
+      bool alive = false;
+      if (inFrame) {
+        const float4 h = wb.hits[(size_t)k * fr.width + px];
+        const int tri = __float_as_int(h.w);
+        if (tri != -1) {
+          p.hit.suv = F3(h.x, h.y, h.z);
+          p.hit.triangleId = tri;
+          p.hit.transformId = (int)sc.geometry[3 * tri + 2].y << 1;
+          p.ray.origin = camera;
+          p.lastHitPoint = camera;
+          p.dontFilter = true;
+          p.importancyFactor = F3(1.0f, 1.0f, 1.0f);
+          ps.originalColor = F3(1.0f, 1.0f, 1.0f);
+          /* loop guard of fragment:475 before the first bounce */
+          alive = fr.max_reflections > 0 && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3;
+          if (!alive) finalize_path(fr, wb, pathId, F3(0.0f, 0.0f, 0.0f), p.importancyFactor, ps.originalColor);
+        }
+      }
+      if (!alive) { rec[0] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD)); continue; }
+    } else {
+      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q6 = rec[6], q7 = rec[7];
+      p.ray.origin = F3(q0.x, q0.y, q0.z);
+      p.lastHitPoint = p.ray.origin;                    /* fragment:595 */
+      p.ray.dir = F3(q1.x, q1.y, q1.z);
+      p.hit.suv = F3(q2.x, q2.y, q2.z);
+      p.hit.triangleId = __float_as_int(q2.w);
+      p.hit.transformId = (int)sc.geometry[3 * p.hit.triangleId + 2].y << 1;
+      p.dontFilter = (__float_as_int(q0.w) & RF_DONT_FILTER) != 0;
+      p.importancyFactor = F3(q6.x, q6.y, q6.z);
+      ps.originalColor = F3(q7.x, q7.y, q7.z);
+    }
+    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+    float viewDepthPerS;
+    const f3 dir0 = primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+    if (FIRST) p.ray.dir = dir0;
+    const float cosSampleN = flx_cos((float)s);
+    ShadeOut so;
+    bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, b, so, cnt);
+    const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0);
+    rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
+    rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
+    rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
+    rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, 0.0f);
+    rec[4] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
+    if (FIRST) rec[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
+    rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
+  }
+  flush_counters<COUNT>(cnt, wb.counters);
+}
+
+enum { L_EMPTY = 0, L_WALKING = 1, L_DONE = 2 };
+
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_wf_walk(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items) {
+  const uint32_t n = (b == 0) ? total_items : wb.counts[b];
+  const uint32_t waveId = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (waveId * 128u >= n && waveId != 0u) return;          /* more waves than work: leave */
+  const uint32_t *__restrict__ listIn = wb.live[b & 1];
+  uint32_t *__restrict__ listOut = wb.live[(b + 1) & 1];
+  uint32_t *__restrict__ queue = wb.walkQueue + b;
+  uint32_t *__restrict__ outAlloc = wb.counts + (b + 1);
+  const uint32_t lane = threadIdx.x & 63u;
+  WorkCounters cnt = {};
+
+  int st = L_EMPTY;
+  uint32_t pathId = 0;
+  int flags = 0;
+  float base = 0.0f;
+  Ray nextRay; nextRay.origin = F3(0.f, 0.f, 0.f); nextRay.dir = nextRay.origin;
+  WalkState w;
+  walkClearResults(w);
+  w.mode = 2;
+  uint32_t chunkNext = 0, chunkEnd = 0;      /* wave-uniform: ids still to hand out */
+  bool itemsLeft = true;
+  uint32_t outBase = 0, outUsed = WF_OUT_CHUNK;   /* wave-uniform: reserved live-list slots; none yet */
+  bool outValid = false;
+
+  for (;;) {
+    const unsigned long long walking = __ballot(st == L_WALKING);
+    const unsigned long long doneMask = __ballot(st == L_DONE);
+    const bool canRefill = itemsLeft || chunkNext != chunkEnd;
+    const uint32_t parked = 64u - (uint32_t)__popcll(walking);
+    if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (doneMask != 0ull || canRefill))) {
+      /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475 ------------ */
+      if (doneMask != 0ull) {
+        bool append = false;
+        if (st == L_DONE) {
+          float4 *rec = wb.rec + (size_t)pathId * 8;
+          const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+          const bool shadowed = (flags & RF_SHADOWED_NO_WALK) || ((flags & RF_NEED_SHADOW) && w.shadowed);
+          const f3 localColor = shadowed ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
+          const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
+          const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
+          bool cont = w.tri != -1;
+          if (cont) cont = (b + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+          if (cont) {
+            rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
+            rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
+            append = true;
+          } else {
+            finalize_path(fr, wb, pathId, finalColor, importancy, originalColor);
+          }
+          st = L_EMPTY;
+        }
+        const unsigned long long am = __ballot(append);
+        if (am != 0ull) {
+          const uint32_t cntA = (uint32_t)__popcll(am);
+          const uint32_t r = lane_rank(am);
+          const uint32_t room = WF_OUT_CHUNK - outUsed;
+          const uint32_t seg1 = cntA < room ? cntA : room;
+          if (append && r < seg1) listOut[outBase + outUsed + r] = pathId;
+          outUsed += seg1;
+          if (cntA > seg1) {
+            uint32_t nb = 0;
+            if (lane == 0) nb = atomicAdd(outAlloc, WF_OUT_CHUNK);
+            nb = __builtin_amdgcn_readfirstlane(nb);
+            outBase = nb; outValid = true;
+            if (append && r >= seg1) listOut[outBase + (r - seg1)] = pathId;
+            outUsed = cntA - seg1;
+          }
+        }
+      }
+      /* ---- refill the free lanes from the walk queue ------------------------------------------------ */
+      for (;;) {
+        const unsigned long long idle = __ballot(st == L_EMPTY);
+        if (idle == 0ull) break;
+        if (chunkNext == chunkEnd) {
+          if (!itemsLeft) break;
+          uint32_t base0 = 0;
+          if (lane == 0) base0 = atomicAdd(queue, WF_IN_CHUNK);
+          base0 = __builtin_amdgcn_readfirstlane(base0);
+          if (base0 >= n) { itemsLeft = false; break; }
+          chunkNext = base0;
+          chunkEnd = (base0 + WF_IN_CHUNK < n) ? base0 + WF_IN_CHUNK : n;
+        }
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        const uint32_t avail = chunkEnd - chunkNext;
+        const uint32_t take = nIdle < avail ? nIdle : avail;
+        const uint32_t r = lane_rank(idle);
+        if (st == L_EMPTY && r < take) {
+          const uint32_t j = chunkNext + r;
+          const uint32_t id = (b == 0) ? j : listIn[j];
+          if (id != WF_INVALID) {
+            const float4 *rec = wb.rec + (size_t)id * 8;
+            const float4 q0 = rec[0];
+            const int fl = __float_as_int(q0.w);
+            if (!(fl & RF_DEAD)) {
+              const float4 q1 = rec[1], q2 = rec[2], q3 = rec[3];
+              pathId = id; flags = fl; base = q2.w;
+              nextRay.origin = F3(q0.x, q0.y, q0.z);
+              nextRay.dir = F3(q1.x, q1.y, q1.z);
+              walkClearResults(w);
+              if (fl & RF_NEED_SHADOW) {
+                Ray sr; sr.origin = F3(q2.x, q2.y, q2.z); sr.dir = F3(q3.x, q3.y, q3.z);
+                walkStart(w, 0, sr, q1.w);
+                if (COUNT) cnt.shadow_walks++;
+              } else {
+                walkStart(w, 1, nextRay, POW32);
+              }
+              if (COUNT) cnt.closest_walks++;
+              st = L_WALKING;
+            }
+          }
+        }
+        chunkNext += take;
+      }
+      if (__ballot(st == L_WALKING) == 0ull) {
+        if (itemsLeft || chunkNext != chunkEnd) continue;
+        break;
+      }
+    }
+    /* ---- one entry for every walking lane ------------------------------------------------------------ */
+    if (st == L_WALKING) {
+      if (walkStep<COUNT>(sc, w, cnt)) {
+        if (w.mode == 0) walkStart(w, 1, nextRay, POW32);
+        else { w.mode = 2; st = L_DONE; }
+      }
+    }
+  }
+  /* pad the unused tail of the reserved live-list chunk so the next bounce can skip it */
+  if (outValid) {
+    for (uint32_t t = outUsed + lane; t < WF_OUT_CHUNK; t += 64u) listOut[outBase + t] = WF_INVALID;
+  }
+  flush_counters<COUNT>(cnt, wb.counters);
+}
+
+void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
+                      hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
+  const uint32_t total = path_item_count(fr);
+  const uint32_t maxBlocks = compute_units * 8u;
+  const int bounces = fr.max_reflections > 0 ? fr.max_reflections : 1;   /* 0 bounces: shade(0) only finalises */
+  for (int b = 0; b < bounces; b++) {
+    uint32_t shadeBlocks = (b == 0) ? (total + 255u) / 256u : maxBlocks * 2u;
+    if (shadeBlocks > maxBlocks * 4u) shadeBlocks = maxBlocks * 4u;
+    if (b == 0) {
+      if (count) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+      else hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+    } else {
+      if (count) hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+      else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+    }
+    if (b == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
+    if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(maxBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+    else hipLaunchKernelGGL(k_wf_walk<false>, dim3(maxBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+    if (b == 0 && walk0_end) (void)hipEventRecord(walk0_end, stream);
+  }
+}
+
+size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units) {
+  return (size_t)path_item_count(fr) + (size_t)WF_OUT_CHUNK * compute_units * 8u * 4u + 1024u;
+}
+
+}  // namespace flx
