@@ -147,6 +147,9 @@ flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
  * functions); used by tests to prove CPU/GPU bit equality.  fn: 0 sin 1 cos 2 tan 3 acos 4 atan2
  * 5 exp 6 pow 7 tanh 8 floor 9 sqrt 10 div. */
 flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, const float *b, float *out, uint32_t n);
+/* Scheduler statistics of the last counted frame (wavefront pipeline): for bounce b = 0..3 (3 = all
+ * later ones) out[2b] = wave-iterations of the walk kernel, out[2b+1] = fold/refill batches. */
+flx_status flx_get_diag(flx_context *ctx, uint64_t out[16]);   /* out[8..12]: bounce-0 walk kernel stamps: fold, refill, step cycles, wave lifetime, waves */
 /* Device name / CU count of the context's GPU. */
 flx_status flx_device_info(flx_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units);
 const char *flx_version(void);

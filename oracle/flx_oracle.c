@@ -216,6 +216,9 @@ static int rayCuboid(float l, Ray ray, v3 minCorner, v3 maxCorner) {
 
 static const Hit NO_HIT = { { 0.0f, 0.0f, 0.0f }, 0, -1 };     /* fragment:81 */
 
+/* analysis hook (tools/visit_histogram.py): when set, every entry fetch is tallied per entry index */
+static uint64_t *g_visit_hist = NULL;
+
 /* fragment:172-227.  mode 0 = rayTracer as written; mode 1 = primary visibility (same walk, the
  * primary triangle rule, strict "<" so the first of equal-depth triangles is kept). */
 static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float viewDepthPerS, uint64_t *visits) {
@@ -227,6 +230,7 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
   for (int i = 0; i < size; i++) {
     const float *e = sc->geometry + (size_t)i * 12;
     (*visits)++;
+    if (g_visit_hist) { _Pragma("omp atomic") g_visit_hist[i]++; }
     int tI = (int)e[9] << 1;
     if (tI != cachedTI) {
       int iI = tI + 1;
@@ -260,6 +264,7 @@ static int shadowTestImpl(const flx_scene_view *sc, Ray ray, float l, uint64_t *
   for (int i = 0; i < size; i++) {
     const float *e = sc->geometry + (size_t)i * 12;
     (*visits)++;
+    if (g_visit_hist) { _Pragma("omp atomic") g_visit_hist[i]++; }
     int tI = (int)e[9] << 1;
     if (tI != cachedTI) {
       int iI = tI + 1;
@@ -670,6 +675,8 @@ void flx_oracle_primary(const flx_scene_view *scene, const flx_frame_params *par
   *transform_id = h.transformId; *triangle_id = h.triangleId;
   dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
 }
+void flx_oracle_set_visit_histogram(uint64_t *hist) { g_visit_hist = hist; }
+
 void flx_oracle_math(int fn, const float *a, const float *b, float *out, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) {
     float x = a[i], y = b ? b[i] : 0.0f, r;

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,6 +29,8 @@ struct flx_context {
   hipDeviceProp_t prop;
   /* resident scene */
   float4 *d_geometry = nullptr, *d_attributes = nullptr, *d_rotation = nullptr, *d_shift = nullptr;
+  float4 *d_walk = nullptr;                      /* threaded hot-first copy of the skip list */
+  uint32_t walk_entries = 0, walk_hot = 0, walk_root = 0, walk_fast_boxes = 0;
   int32_t *d_ids = nullptr;
   float *d_lights = nullptr;
   uchar4 *d_atlas[3] = { nullptr, nullptr, nullptr };
@@ -100,7 +104,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_frame1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_counters, 24 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_wfcounts, 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   *out = ctx;
@@ -114,7 +118,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_rec, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts };
+                   ctx->d_rec, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk };
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -129,6 +133,71 @@ static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t byte
   FLX_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));          /* the caller's buffer is not retained */
   return FLX_OK;
+}
+
+/* Threaded, hot-first copy of the skip list (DeviceScene::walk).  The reference's array is the DFS
+ * pre-order of the AABB tree with a skip count per node (scene.js:224-282); a walk only ever moves to
+ * "the next entry" or "the next entry after the subtree".  Writing those two successors into every
+ * entry makes the storage order free, so the shallow levels — which every ray crosses — go to the
+ * front where the walk kernel keeps them in LDS.  Entry contents, the sequence of entries a given
+ * ray visits and therefore every result are unchanged. */
+static void build_threaded(const float *geometry, uint32_t n, std::vector<float> &out, uint32_t &n_out, uint32_t &n_hot, uint32_t &root) {
+  const uint32_t HOT_MAX = 4096;                 /* upper bound of entries worth ordering by depth */
+  /* live entries: everything a walk can reach = all entries before the first terminator that is reached;
+   * keep every non-terminator entry plus ONE shared terminator. */
+  std::vector<uint32_t> depth(n, 0);
+  {
+    std::vector<uint32_t> stack;                 /* last index of the enclosing subtrees */
+    for (uint32_t i = 0; i < n; i++) {
+      while (!stack.empty() && i > stack.back()) stack.pop_back();
+      depth[i] = (uint32_t)stack.size();
+      const float *e = geometry + (size_t)i * 12;
+      if (e[10] == 1.0f) stack.push_back(i + (uint32_t)e[6]);
+    }
+  }
+  std::vector<uint32_t> order;                   /* original indices of non-terminator entries, hot first */
+  order.reserve(n);
+  for (uint32_t i = 0; i < n; i++) if (geometry[(size_t)i * 12 + 10] != 0.0f) order.push_back(i);
+  /* shallowest HOT_MAX entries first (stable: by depth, then original index), the rest in original order */
+  std::vector<uint32_t> byDepth(order);
+  std::stable_sort(byDepth.begin(), byDepth.end(), [&](uint32_t a, uint32_t b) { return depth[a] < depth[b]; });
+  const uint32_t hot = (uint32_t)std::min<size_t>(HOT_MAX, byDepth.size());
+  std::vector<char> isHot(n, 0);
+  for (uint32_t k = 0; k < hot; k++) isHot[byDepth[k]] = 1;
+  std::vector<uint32_t> newIndex(n, WALK_END);
+  uint32_t next = 0;
+  const uint32_t terminator = next++;            /* threaded index 0: the shared terminator (every full walk ends on it) */
+  for (uint32_t k = 0; k < hot; k++) newIndex[byDepth[k]] = next++;
+  for (uint32_t i : order) if (!isHot[i]) newIndex[i] = next++;
+  n_out = next;
+  n_hot = hot + 1;
+  out.assign((size_t)n_out * 12, 0.0f);
+  auto bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+  auto succ = [&](uint64_t j) -> uint32_t {      /* threaded index of original successor j */
+    if (j >= n) return WALK_END;                 /* loop bound reached: no fetch (fragment:184) */
+    if (geometry[(size_t)j * 12 + 10] == 0.0f) return terminator;
+    return newIndex[j];
+  };
+  root = succ(0);
+  for (uint32_t i : order) {
+    const float *e = geometry + (size_t)i * 12;
+    float *o = out.data() + (size_t)newIndex[i] * 12;
+    const uint32_t type = e[10] == 1.0f ? 1u : 2u;
+    const uint32_t meta = type | ((uint32_t)e[9] << 2);
+    if (type == 1u) {
+      for (int k = 0; k < 6; k++) o[k] = e[k];
+      o[8] = bits(succ((uint64_t)i + 1));
+      o[9] = bits(succ((uint64_t)i + 1 + (uint64_t)e[6]));
+      o[10] = bits(meta);
+      o[11] = bits(i);
+    } else {
+      for (int k = 0; k < 9; k++) o[k] = e[k];
+      o[9] = bits(succ((uint64_t)i + 1));
+      o[10] = bits(meta);
+      o[11] = bits(i);
+    }
+  }
+  /* terminator entry stays all zero (meta type 0) */
 }
 
 extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, const float *attributes, uint32_t n_entries_padded,
@@ -159,6 +228,19 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
   if ((s = upload(ctx, &ctx->d_geometry, geometry, (size_t)n_entries_padded * 48))) return s;
   if ((s = upload(ctx, &ctx->d_attributes, attributes, (size_t)n_entries_padded * 112))) return s;
   if ((s = upload(ctx, &ctx->d_ids, ids, (size_t)n_ids * 4))) return s;
+  {
+    std::vector<float> threaded;
+    build_threaded(geometry, n_entries_padded, threaded, ctx->walk_entries, ctx->walk_hot, ctx->walk_root);
+    if ((s = upload(ctx, &ctx->d_walk, threaded.data(), threaded.size() * sizeof(float)))) return s;
+    /* precondition of the walk kernel's fast box test (flx_device.h: rayCuboidR): bounded, finite AABBs */
+    bool bounded = true;
+    for (uint32_t i = 0; i < n_entries_padded && bounded; i++) {
+      const float *e = geometry + (size_t)i * 12;
+      if (e[10] == 1.0f)
+        for (int k = 0; k < 6; k++) if (!(std::fabs(e[k]) <= 5.764607523034235e17f)) bounded = false;
+    }
+    ctx->walk_fast_boxes = bounded ? 1u : 0u;
+  }
   ctx->n_entries = n_entries_padded;
   ctx->n_ids = n_ids;
   ctx->max_transform = max_transform;
@@ -246,6 +328,7 @@ static flx_status make_frame(flx_context *ctx, const flx_frame_params *p, Device
   sc.rotation = ctx->d_rotation; sc.shift = ctx->d_shift; sc.lights = ctx->d_lights;
   for (int i = 0; i < 3; i++) { sc.atlas[i] = ctx->d_atlas[i]; sc.atlas_w[i] = ctx->atlas_w[i]; sc.atlas_h[i] = ctx->atlas_h[i]; }
   sc.n_entries = ctx->n_entries; sc.n_lights = ctx->n_lights;
+  sc.walk = ctx->d_walk; sc.walk_entries = ctx->walk_entries; sc.walk_hot = ctx->walk_hot; sc.walk_root = ctx->walk_root; sc.walk_fast_boxes = ctx->walk_fast_boxes;
   uint32_t tr, ti, tc;
   tile_normalise(p, tr, ti, tc);
   fr.width = p->width; fr.height = p->height;
@@ -303,7 +386,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     }
   }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
-  if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, 8 * sizeof(unsigned long long), ctx->stream));
+  if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, 24 * sizeof(unsigned long long), ctx->stream));
   if (pipeline == 1) {
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     launch_trace_pixels(sc, fr, d_out, gb, cnt, ctx->stream);
@@ -431,6 +514,14 @@ extern "C" flx_status flx_get_counters(flx_context *ctx, flx_counters *out) {
   unsigned long long host_cnt[8];
   FLX_HIP(ctx, hipMemcpy(host_cnt, ctx->d_counters, sizeof host_cnt, hipMemcpyDeviceToHost));
   memcpy(out, host_cnt, sizeof host_cnt);
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_get_diag(flx_context *ctx, uint64_t out[16]) {
+  if (!ctx || !out) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FLX_HIP(ctx, hipMemcpy(out, ctx->d_counters + 8, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return FLX_OK;
 }
 

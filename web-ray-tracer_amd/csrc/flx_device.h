@@ -76,7 +76,20 @@ struct DeviceScene {
   uint32_t atlas_w[3], atlas_h[3];
   uint32_t n_entries;           /* padded entry count = loop bound (fragment:181-184) */
   uint32_t n_lights;
+  /* Threaded copy of the skip list for the walk kernels (built at upload, flx_api.hip: build_threaded):
+   * same entries, same logical visit order, but every entry names its successors explicitly, so the
+   * array can be stored hot-first (shallow tree levels in front) and its prefix staged in LDS. */
+  const float4 *walk;           /* 3 x float4 per entry, layout below */
+  uint32_t walk_entries;        /* entries in `walk` */
+  uint32_t walk_hot;            /* the first walk_hot entries are the shallowest ones (LDS candidates) */
+  uint32_t walk_root;           /* threaded index of original entry 0 */
+  uint32_t walk_fast_boxes;     /* 1: every AABB coordinate is finite with |x| <= 2^59 (precondition of rayCuboidR's fast path) */
 };
+/* threaded entry:  AABB      e0 = min.xyz max.x | e1 = max.y max.z - - | e2 = bits(nextHit) bits(nextMiss) bits(meta) bits(origIndex)
+ *                  triangle  e0 = a.xyz b.x     | e1 = b.yz c.xy      | e2 = c.z        bits(next)     bits(meta) bits(origIndex)
+ *                  terminator                                           e2 = -          -              bits(meta = 0)
+ * meta = type | transform << 2; successor WALK_END = the loop bound of fragment:184 was reached (no fetch). */
+constexpr uint32_t WALK_END = 0xffffffffu;
 
 /* Per-frame constants (flx_frame_params + what the host derives from it). */
 struct DeviceFrame {
@@ -221,8 +234,14 @@ FLX_DEV bool moellerTrumborePrimary(f3 a, f3 b, f3 c, const Ray &ray, float l, f
 
 /* fragment:161-167 */
 FLX_DEV bool rayCuboid(float l, const Ray &ray, f3 minCorner, f3 maxCorner) {
+#ifdef FLX_EXPERIMENT_FASTDIV   /* timing experiment only: NOT the reference arithmetic */
+  f3 inv = F3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
+  f3 v0 = (minCorner - ray.origin) * inv;
+  f3 v1 = (maxCorner - ray.origin) * inv;
+#else
   f3 v0 = (minCorner - ray.origin) / ray.dir;
   f3 v1 = (maxCorner - ray.origin) / ray.dir;
+#endif
   float tmin = flx_max(flx_max(flx_min(v0.x, v1.x), flx_min(v0.y, v1.y)), flx_min(v0.z, v1.z));
   float tmax = flx_min(flx_min(flx_max(v0.x, v1.x), flx_max(v0.y, v1.y)), flx_max(v0.z, v1.z));
   return tmax >= flx_max(tmin, BIAS) && tmin < l;
@@ -511,12 +530,15 @@ struct WalkState {
   bool shadowed;      /* result of the shadow walk */
   f3 suv;             /* closest hit so far */
   int tri, hitTI;     /* entry index (-1: none) and 2 * transform number of the closest hit */
+  f3 inv;             /* RN(1 / tR.dir), for the threaded walk's box test */
+  bool fastDiv;       /* tR is in the range where divByRecip() is proven exact */
 };
 
 FLX_DEV void walkStart(WalkState &w, int mode, const Ray &ray, float len) {
   w.mode = mode; w.src = ray; w.tR = ray; w.cachedTI = 0; w.minLen = len; w.i = 0;
 }
 FLX_DEV void walkClearResults(WalkState &w) {
+  w.inv = F3(0.0f, 0.0f, 0.0f); w.fastDiv = false;
   w.shadowed = false; w.suv = F3(0.0f, 0.0f, 0.0f); w.tri = -1; w.hitTI = 0;
 }
 
@@ -555,6 +577,184 @@ FLX_DEV bool walkStep(const DeviceScene &sc, WalkState &w, WorkCounters &cnt) {
   }
   w.i = next;
   return endWalk || next >= (int)sc.n_entries;
+}
+
+/* walkStep() split by entry type, for schedulers that want all lanes of a wave to run the SAME test:
+ * the current entry is held in registers (WalkEntry), walkFetch() loads entry w.i and applies the
+ * transform-change rule, walkBox() / walkTri() do the test of fragment:210-223 / :270-276 and set w.i.
+ * Entry order, arithmetic and visit counts per ray are those of walkStep(). */
+struct WalkEntry { float4 e0, e1, e2; };
+
+/* Returns true when the walk ends here (loop bound reached or terminator entry, fragment:184,208). */
+template <bool COUNT>
+FLX_DEV bool walkFetch(const DeviceScene &sc, WalkState &w, WalkEntry &cur, WorkCounters &cnt) {
+  if (w.i >= (int)sc.n_entries) return true;
+  cur.e0 = sc.geometry[3 * w.i]; cur.e1 = sc.geometry[3 * w.i + 1]; cur.e2 = sc.geometry[3 * w.i + 2];
+  if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
+  int tI = (int)cur.e2.y << 1;
+  if (tI != w.cachedTI) {
+    int iI = tI + 1;
+    M3 rotationII = rotation_at(sc, iI);
+    w.cachedTI = tI;
+    w.tR.origin = mul(rotationII, w.src.origin + shift_at(sc, iI));
+    f3 d = mul(rotationII, w.src.dir);
+    w.tR.dir = (w.mode == 0) ? normalize(d) : d;
+  }
+  return cur.e2.z == 0.0f;
+}
+FLX_DEV void walkBox(WalkState &w, const WalkEntry &cur) {
+  int next = w.i + 1;
+  if (!rayCuboid(w.minLen, w.tR, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y))) next += (int)cur.e1.z;
+  w.i = next;
+}
+/* Returns true when the (shadow) walk ends on this triangle. */
+FLX_DEV bool walkTri(WalkState &w, const WalkEntry &cur) {
+  f3 a = F3(cur.e0.x, cur.e0.y, cur.e0.z), b = F3(cur.e0.w, cur.e1.x, cur.e1.y), c = F3(cur.e1.z, cur.e1.w, cur.e2.x);
+  bool ended = false;
+  if (w.mode == 0) {
+    if (moellerTrumboreCull(a, b, c, w.tR, w.minLen)) { w.shadowed = true; ended = true; }
+  } else {
+    f3 suv;
+    if (moellerTrumbore(a, b, c, w.tR, w.minLen, suv)) {
+      w.suv = suv; w.hitTI = (int)cur.e2.y << 1; w.tri = w.i;
+      w.minLen = suv.x;
+    }
+  }
+  w.i = w.i + 1;
+  return ended;
+}
+
+/* ---- the same walk over the threaded copy (DeviceScene::walk) ---------------------------------------
+ * w.i is a threaded index; `lds` holds the first ldsCount entries (3 float4 each) or is null. */
+
+/* a / d from y = RN(1/d) with two FMA corrections (Markstein): q0 = RN(a*y) is within ~2 ulp of a/d; the
+ * first correction q1 = RN(q0 + (a - q0*d)*y) is the rounding of a value within 2^-47 relative of a/d,
+ * hence faithful; with y = RN(1/d) and q1 faithful, q2 = RN(q1 + (a - q1*d)*y) IS RN(a/d) (Markstein's
+ * theorem; the residuals are exact in an FMA).  Preconditions, which keep every intermediate normal:
+ * 2^-60 <= |d| <= 2^60, |a| <= 2^60, and a == 0 or |a| >= 2^-40.  Outside them callers divide.
+ * tools/divtest.c compares it with `/` on 5e8 random and near-midpoint operands: 0 mismatches. */
+FLX_DEV float divByRecip(float a, float d, float y) {
+  float q = a * y;
+  float r = __builtin_fmaf(-q, d, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-q, d, a);
+  return __builtin_fmaf(r, y, q);
+}
+/* tR changed: refresh the reciprocal and decide whether the fast box test may be used for this ray. */
+#ifndef FLX_WF_RECIP_DIV
+#define FLX_WF_RECIP_DIV 0     /* measured on MI355X (dragon frame): the 3 extra divisions per transform change eat the gain; off */
+#endif
+FLX_DEV void walkPrepareRay(const DeviceScene &sc, WalkState &w) {
+#if !FLX_WF_RECIP_DIV
+  (void)sc; (void)w;
+  return;
+#endif
+  const f3 d = w.tR.dir, o = w.tR.origin;
+  w.inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const float LO = 8.673617379884035e-19f, HI = 1.152921504606847e18f, OHI = 5.764607523034235e17f;   /* 2^-60, 2^60, 2^59 */
+  const float ax = flx_abs(d.x), ay = flx_abs(d.y), az = flx_abs(d.z);
+  w.fastDiv = sc.walk_fast_boxes != 0u && ax >= LO && ax <= HI && ay >= LO && ay <= HI && az >= LO && az <= HI &&
+              flx_abs(o.x) <= OHI && flx_abs(o.y) <= OHI && flx_abs(o.z) <= OHI;
+}
+/* rayCuboid (fragment:161-167) with the six quotients taken through divByRecip when its preconditions
+ * hold (same bits as the division, so the same boolean), through `/` otherwise (zero, denormal, huge,
+ * infinite or NaN components: the reference's behaviour there is whatever IEEE division gives). */
+FLX_DEV bool rayCuboidR(float l, const WalkState &w, f3 minCorner, f3 maxCorner) {
+#if !FLX_WF_RECIP_DIV
+  return rayCuboid(l, w.tR, minCorner, maxCorner);
+#endif
+  const f3 o = w.tR.origin, d = w.tR.dir, y = w.inv;
+  const f3 a0 = minCorner - o, a1 = maxCorner - o;
+  /* every |a| is 0 or >= 2^-40:  (bits & 0x7fffffff) - 1 as unsigned is huge for 0 and small for tiny values */
+  uint32_t m = (flx_f2u(a0.x) & 0x7fffffffu) - 1u;
+  uint32_t t;
+  t = (flx_f2u(a0.y) & 0x7fffffffu) - 1u; m = t < m ? t : m;
+  t = (flx_f2u(a0.z) & 0x7fffffffu) - 1u; m = t < m ? t : m;
+  t = (flx_f2u(a1.x) & 0x7fffffffu) - 1u; m = t < m ? t : m;
+  t = (flx_f2u(a1.y) & 0x7fffffffu) - 1u; m = t < m ? t : m;
+  t = (flx_f2u(a1.z) & 0x7fffffffu) - 1u; m = t < m ? t : m;
+  f3 v0, v1;
+  if (w.fastDiv && m >= 0x2b800000u - 1u) {
+    v0 = F3(divByRecip(a0.x, d.x, y.x), divByRecip(a0.y, d.y, y.y), divByRecip(a0.z, d.z, y.z));
+    v1 = F3(divByRecip(a1.x, d.x, y.x), divByRecip(a1.y, d.y, y.y), divByRecip(a1.z, d.z, y.z));
+  } else {
+    v0 = a0 / d;
+    v1 = a1 / d;
+  }
+  float tmin = flx_max(flx_max(flx_min(v0.x, v1.x), flx_min(v0.y, v1.y)), flx_min(v0.z, v1.z));
+  float tmax = flx_min(flx_min(flx_max(v0.x, v1.x), flx_max(v0.y, v1.y)), flx_max(v0.z, v1.z));
+  return tmax >= flx_max(tmin, BIAS) && tmin < l;
+}
+
+template <bool COUNT>
+FLX_DEV bool walkFetchT(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, WalkState &w, WalkEntry &cur, WorkCounters &cnt) {
+  const uint32_t i = (uint32_t)w.i;
+  if (i == WALK_END) return true;
+  if (i < ldsCount) { cur.e0 = lds[3 * i]; cur.e1 = lds[3 * i + 1]; cur.e2 = lds[3 * i + 2]; }
+  else { cur.e0 = sc.walk[3 * (size_t)i]; cur.e1 = sc.walk[3 * (size_t)i + 1]; cur.e2 = sc.walk[3 * (size_t)i + 2]; }
+  if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
+  const int meta = __float_as_int(cur.e2.z);
+  int tI = (meta >> 2) << 1;
+  if (tI != w.cachedTI) {
+    int iI = tI + 1;
+    M3 rotationII = rotation_at(sc, iI);
+    w.cachedTI = tI;
+    w.tR.origin = mul(rotationII, w.src.origin + shift_at(sc, iI));
+    f3 d = mul(rotationII, w.src.dir);
+    w.tR.dir = (w.mode == 0) ? normalize(d) : d;
+    walkPrepareRay(sc, w);
+  }
+  return (meta & 3) == 0;
+}
+FLX_DEV bool walkIsBoxT(const WalkEntry &cur) { return (__float_as_int(cur.e2.z) & 3) == 1; }
+FLX_DEV void walkBoxT(WalkState &w, const WalkEntry &cur) {
+  const bool hit = rayCuboidR(w.minLen, w, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y));
+  w.i = hit ? __float_as_int(cur.e2.x) : __float_as_int(cur.e2.y);
+}
+/* moellerTrumbore (fragment:123-140) and moellerTrumboreCull (fragment:143-158) as ONE straight-line
+ * instruction stream: a wave holds shadow walks and closest-hit walks side by side, and the two
+ * functions share every arithmetic operation (edges, pvec, det, 1/det, u, qvec, v, s) — they differ
+ * only in the predicates.  The shader's early returns have no side effects, so evaluating all of it
+ * and combining the predicates at the end gives the same accept/reject and the same (s,u,v), NaNs
+ * included: two-sided accepts unless (s > l || s <= BIAS), cull accepts only if (s <= l && s > BIAS). */
+FLX_DEV bool moellerTrumboreAny(f3 a, f3 b, f3 c, const Ray &ray, float l, bool cull, f3 &suv) {
+  f3 edge1 = b - a;
+  f3 edge2 = c - a;
+  f3 pvec = cross(ray.dir, edge2);
+  float det = dot(edge1, pvec);
+  float inv_det = 1.0f / det;
+  f3 tvec = ray.origin - a;
+  float u = dot(tvec, pvec) * inv_det;
+  f3 qvec = cross(tvec, edge1);
+  float v = dot(ray.dir, qvec) * inv_det;
+  float uvSum = u + v;
+  float s = dot(edge2, qvec) * inv_det;
+  bool detBad = cull ? (det < BIAS) : (flx_abs(det) < BIAS);
+  bool uBad = (u < BIAS) || (u > 1.0f);
+  bool vBad = (v < BIAS) || (uvSum > 1.0f);
+  bool sOk = cull ? ((s <= l) && (s > BIAS)) : (!(s > l) && !(s <= BIAS));
+  suv = F3(s, u, v);
+  return !detBad && !uBad && !vBad && sOk;
+}
+FLX_DEV bool walkTriT(WalkState &w, const WalkEntry &cur) {
+  f3 a = F3(cur.e0.x, cur.e0.y, cur.e0.z), b = F3(cur.e0.w, cur.e1.x, cur.e1.y), c = F3(cur.e1.z, cur.e1.w, cur.e2.x);
+  f3 suv;
+  const bool cull = w.mode == 0;
+  const bool hit = moellerTrumboreAny(a, b, c, w.tR, w.minLen, cull, suv);
+  bool ended = false;
+  if (hit) {
+    if (cull) { w.shadowed = true; ended = true; }
+    else if (suv.x != 0.0f) {                        /* fragment:217 */
+      w.suv = suv; w.hitTI = (__float_as_int(cur.e2.z) >> 2) << 1; w.tri = __float_as_int(cur.e2.w);
+      w.minLen = suv.x;
+    }
+  }
+  w.i = __float_as_int(cur.e2.y);
+  return ended;
+}
+FLX_DEV void walkStartT(const DeviceScene &sc, WalkState &w, int mode, const Ray &ray, float len) {
+  w.mode = mode; w.src = ray; w.tR = ray; w.cachedTI = 0; w.minLen = len; w.i = (int)sc.walk_root;
+  walkPrepareRay(sc, w);
 }
 
 /* The two traversals of one bounce in ONE loop: shadowTest (fragment:231-280) on so.shadowRay, then

@@ -31,6 +31,24 @@ namespace flx {
 constexpr uint32_t WF_INVALID = 0xffffffffu;
 constexpr uint32_t WF_IN_CHUNK = 256;       /* path ids a wave draws from the walk queue per atomic */
 constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves per atomic */
+#ifndef FLX_WF_WALK_THREADS
+#define FLX_WF_WALK_THREADS 1024
+#endif
+#ifndef FLX_WF_LDS_BYTES
+#define FLX_WF_LDS_BYTES 131072              /* LDS given to the hot prefix of the threaded skip list (of 160 KB per CU) */
+#endif
+#ifndef FLX_WF_INNER
+#define FLX_WF_INNER 4
+#endif
+#ifndef FLX_WF_VOTE
+#define FLX_WF_VOTE 0
+#endif
+#ifndef FLX_WALK_WAVES
+#define FLX_WALK_WAVES 1
+#endif
+#ifndef FLX_WF_ITEMS_PER_LANE
+#define FLX_WF_ITEMS_PER_LANE 8
+#endif
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 16                     /* parked lanes that trigger a fold + refill */
 #endif
@@ -124,16 +142,25 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
 enum { L_EMPTY = 0, L_WALKING = 1, L_DONE = 2 };
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_wf_walk(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items) {
+__global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
+                                                                 uint32_t ldsCount) {
+  /* The shallow levels of the tree — the front of the threaded array — are crossed by every ray
+   * (2 730 entries take 73 % of all entry fetches of the dragon frame, tools/visit_histogram.py), so
+   * each workgroup keeps them in LDS: ds_read_b128 instead of three divergent 16-byte global loads. */
+  extern __shared__ float4 ldsEntries[];
+  for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
+  __syncthreads();
   const uint32_t n = (b == 0) ? total_items : wb.counts[b];
-  const uint32_t waveId = blockIdx.x * 4u + (threadIdx.x >> 6);
-  if (waveId * 128u >= n && waveId != 0u) return;          /* more waves than work: leave */
+  const uint32_t waveId = blockIdx.x * (FLX_WF_WALK_THREADS / 64u) + (threadIdx.x >> 6);
+  if (waveId * (64u * FLX_WF_ITEMS_PER_LANE) >= n && waveId != 0u) return;   /* more waves than work: leave (a wave wants several items per lane, or its tail dominates) */
   const uint32_t *__restrict__ listIn = wb.live[b & 1];
   uint32_t *__restrict__ listOut = wb.live[(b + 1) & 1];
   uint32_t *__restrict__ queue = wb.walkQueue + b;
   uint32_t *__restrict__ outAlloc = wb.counts + (b + 1);
   const uint32_t lane = threadIdx.x & 63u;
   WorkCounters cnt = {};
+  uint32_t diagIters = 0, diagBatches = 0;     /* COUNT builds only: scheduler statistics */
+  long long tFold = 0, tRefill = 0, tInner = 0, tStart = COUNT ? clock64() : 0;
 
   int st = L_EMPTY;
   uint32_t pathId = 0;
@@ -143,6 +170,8 @@ __global__ __launch_bounds__(256) void k_wf_walk(DeviceScene sc, DeviceFrame fr,
   WalkState w;
   walkClearResults(w);
   w.mode = 2;
+  WalkEntry cur;
+  cur.e0 = cur.e1 = cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
   uint32_t chunkNext = 0, chunkEnd = 0;      /* wave-uniform: ids still to hand out */
   bool itemsLeft = true;
   uint32_t outBase = 0, outUsed = WF_OUT_CHUNK;   /* wave-uniform: reserved live-list slots; none yet */
@@ -154,6 +183,8 @@ __global__ __launch_bounds__(256) void k_wf_walk(DeviceScene sc, DeviceFrame fr,
     const bool canRefill = itemsLeft || chunkNext != chunkEnd;
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (doneMask != 0ull || canRefill))) {
+      if (COUNT) diagBatches++;
+      long long t0 = COUNT ? clock64() : 0;
       /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475 ------------ */
       if (doneMask != 0ull) {
         bool append = false;
@@ -193,6 +224,8 @@ __global__ __launch_bounds__(256) void k_wf_walk(DeviceScene sc, DeviceFrame fr,
           }
         }
       }
+      long long t1 = COUNT ? clock64() : 0;
+      if (COUNT) tFold += t1 - t0;
       /* ---- refill the free lanes from the walk queue ------------------------------------------------ */
       for (;;) {
         const unsigned long long idle = __ballot(st == L_EMPTY);
@@ -225,42 +258,91 @@ __global__ __launch_bounds__(256) void k_wf_walk(DeviceScene sc, DeviceFrame fr,
               walkClearResults(w);
               if (fl & RF_NEED_SHADOW) {
                 Ray sr; sr.origin = F3(q2.x, q2.y, q2.z); sr.dir = F3(q3.x, q3.y, q3.z);
-                walkStart(w, 0, sr, q1.w);
+                walkStartT(sc, w, 0, sr, q1.w);
                 if (COUNT) cnt.shadow_walks++;
               } else {
-                walkStart(w, 1, nextRay, POW32);
+                walkStartT(sc, w, 1, nextRay, POW32);
               }
               if (COUNT) cnt.closest_walks++;
               st = L_WALKING;
+              bool ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt);
+              if (ended && w.mode == 0) { walkStartT(sc, w, 1, nextRay, POW32); ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt); }
+              if (ended) { w.mode = 2; st = L_DONE; }
             }
           }
         }
         chunkNext += take;
       }
+      if (COUNT) tRefill += clock64() - t1;
       if (__ballot(st == L_WALKING) == 0ull) {
         if (itemsLeft || chunkNext != chunkEnd) continue;
         break;
       }
     }
-    /* ---- one entry for every walking lane ------------------------------------------------------------ */
-    if (st == L_WALKING) {
-      if (walkStep<COUNT>(sc, w, cnt)) {
-        if (w.mode == 0) walkStart(w, 1, nextRay, POW32);
-        else { w.mode = 2; st = L_DONE; }
+    long long t2 = COUNT ? clock64() : 0;
+    /* ---- FLX_WF_INNER entries for every walking lane, without looking at the scheduler state in between
+     * (the fold / refill decision above costs ballots and scalar work; amortise it) ------------------- */
+#pragma unroll 1
+    for (int it = 0; it < FLX_WF_INNER; it++) {
+      if (COUNT) diagIters++;
+#if FLX_WF_VOTE
+      /* the wave votes and runs the entry type most lanes stand at: box and triangle tests are different
+       * code, run per lane in lock step they serialise */
+      const bool atBox = st == L_WALKING && walkIsBoxT(cur);
+      const bool atTri = st == L_WALKING && !walkIsBoxT(cur);
+      const uint32_t nBox = (uint32_t)__popcll(__ballot(atBox)), nTri = (uint32_t)__popcll(__ballot(atTri));
+      if (nBox + nTri == 0u) break;
+      bool ended = false, stepped = false;
+      if (nBox >= nTri) {
+        if (atBox) { walkBoxT(w, cur); stepped = true; }
+      } else {
+        if (atTri) { ended = walkTriT(w, cur); stepped = true; }
+      }
+      if (stepped) {
+#else
+      if (st == L_WALKING) {
+        bool ended = false;
+        if (walkIsBoxT(cur)) walkBoxT(w, cur); else ended = walkTriT(w, cur);
+#endif
+        if (!ended) ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt);
+        if (ended && w.mode == 0) {                      /* shadow walk over: start the closest-hit walk at entry 0 */
+          walkStartT(sc, w, 1, nextRay, POW32);
+          ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt);
+        }
+        if (ended) { w.mode = 2; st = L_DONE; }
       }
     }
+    if (COUNT) tInner += clock64() - t2;
   }
   /* pad the unused tail of the reserved live-list chunk so the next bounce can skip it */
   if (outValid) {
     for (uint32_t t = outUsed + lane; t < WF_OUT_CHUNK; t += 64u) listOut[outBase + t] = WF_INVALID;
   }
   flush_counters<COUNT>(cnt, wb.counters);
+  if (COUNT && lane == 0) {
+    atomicAdd(wb.counters + 8 + 2 * (b < 4 ? b : 3), (unsigned long long)diagIters); atomicAdd(wb.counters + 9 + 2 * (b < 4 ? b : 3), (unsigned long long)diagBatches);
+    if (b == 0) {   /* in-kernel stamps (diagnostic builds only): shader-clock cycles per phase summed over waves */
+      atomicAdd(wb.counters + 16, (unsigned long long)tFold); atomicAdd(wb.counters + 17, (unsigned long long)tRefill);
+      atomicAdd(wb.counters + 18, (unsigned long long)tInner); atomicAdd(wb.counters + 19, (unsigned long long)(clock64() - tStart)); atomicAdd(wb.counters + 20, 1ull);
+    }
+  }
 }
 
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
                       hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
   const uint32_t total = path_item_count(fr);
   const uint32_t maxBlocks = compute_units * 8u;
+  /* walk kernel: one big workgroup per CU sharing one LDS copy of the tree top */
+  uint32_t ldsCount = (uint32_t)(FLX_WF_LDS_BYTES / 48);
+  if (ldsCount > sc.walk_hot) ldsCount = sc.walk_hot;
+  const uint32_t ldsBytes = ldsCount * 48u;
+  const uint32_t walkBlocks = compute_units * (160u * 1024u / (ldsBytes > 16384u ? ldsBytes : 16384u) > 8u ? 8u : (160u * 1024u / (ldsBytes > 16384u ? ldsBytes : 16384u)));
+  static bool attrSet = false;
+  if (!attrSet) {
+    (void)hipFuncSetAttribute((const void *)k_wf_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_wf_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attrSet = true;
+  }
   const int bounces = fr.max_reflections > 0 ? fr.max_reflections : 1;   /* 0 bounces: shade(0) only finalises */
   for (int b = 0; b < bounces; b++) {
     uint32_t shadeBlocks = (b == 0) ? (total + 255u) / 256u : maxBlocks * 2u;
@@ -273,14 +355,14 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
       else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
     }
     if (b == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
-    if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(maxBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
-    else hipLaunchKernelGGL(k_wf_walk<false>, dim3(maxBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+    if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
+    else hipLaunchKernelGGL(k_wf_walk<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
     if (b == 0 && walk0_end) (void)hipEventRecord(walk0_end, stream);
   }
 }
 
 size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units) {
-  return (size_t)path_item_count(fr) + (size_t)WF_OUT_CHUNK * compute_units * 8u * 4u + 1024u;
+  return (size_t)path_item_count(fr) + (size_t)WF_OUT_CHUNK * compute_units * 8u * (FLX_WF_WALK_THREADS / 64u) + 1024u;
 }
 
 }  // namespace flx

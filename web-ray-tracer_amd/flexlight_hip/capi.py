@@ -12,13 +12,13 @@ import numpy as np
 from .scene_io import Counters, FrameParams, GBuffers, SceneView
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflexlight_hip.so")
+LIB_PATH = os.environ.get("FLX_LIB") or os.path.join(_HERE, "libflexlight_hip.so")   # FLX_LIB: A/B a variant build
 
 EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline",
+    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag",
 ]
 
 
@@ -55,6 +55,7 @@ def _load():
         "flx_device_info": (C.c_int, [vp, C.c_char_p, u32, C.POINTER(u32)]),
         "flx_version": (C.c_char_p, []),
         "flx_set_pipeline": (C.c_int, [vp, C.c_int]),
+        "flx_get_diag": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -163,6 +164,11 @@ class Context:
         cnt = Counters()
         self._check(LIB.flx_get_counters(self._h, C.byref(cnt)), "flx_get_counters")
         return cnt.as_dict()
+
+    def get_diag(self):
+        out = (C.c_uint64 * 16)()
+        self._check(LIB.flx_get_diag(self._h, out), "flx_get_diag")
+        return [int(x) for x in out]
 
     def last_frame_ms(self):
         a, b = C.c_float(), C.c_float()
