@@ -1,6 +1,305 @@
-/* placeholder until the denoise chain (F0-F3) lands */
+/*
+ * flx_oracle_filter.c — CPU oracle of the denoise chain.  TEST INFRASTRUCTURE ONLY (flx_oracle.h).
+ *
+ * Follows shaders/pathtracer_first_filter.glsl:18-123, pathtracer_second_filter.glsl:17-79,
+ * pathtracer_final_filter.glsl:13-71 and the pass schedule of modules/pathtracerWGL2.js:462-550
+ * with firstPasses = secondPasses = 3 (forced at :818-819).  Every render target is RGBA8
+ * (pathtracerWGL2.js:790-799): a write stores floor(clamp(x,0,1)*255 + 0.5), a read returns k/255.
+ *
+ * The schedule as the driver really runs it, frozen for frame 0 (all targets zero):
+ *   pass  program  reads  R/Ip[n]  O[nO]  Id[nId]   writes R/Ip[np]   third output
+ *    0    first          0        0      0                 1          Id[1]
+ *    1    first          1        0      1                 0          Id[0]
+ *    2    first          0        0      0                 1          Id[1]
+ *    3    first          1        0      1                 2          dropped (IdRenderTexture[2] does not exist)
+ *    4    second         2        1*     1                 3          dropped      (* O[1] not yet written: zeros)
+ *    5    second         3        0      1                 2          O[1]
+ *   final                2        1      1                 canvas
+ * Behaviour the GLSL leaves open, pinned here: texelFetch outside the image returns 0; the first
+ * filter's unwritten renderColorIp (read at :123) starts at 0; float->int casts truncate.
+ * Image rows are stored top-down; the shaders' texel coordinates count from the bottom
+ * (gl_FragCoord), so y is flipped when indexing — tap order and the 4-neighbour vote depend on it.
+ */
 #include "flx_oracle.h"
-int flx_oracle_filter(const flx_frame_params *params, const flx_gbuffers *gbuffers, float *out_rgba, int threads) {
-  (void)params; (void)gbuffers; (void)out_rgba; (void)threads;
-  return FLX_ERR_INVALID;
+#include "flx_math.h"
+
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define INV_256 0.00390625f
+
+typedef struct { float x, y, z, w; } v4;
+typedef struct { const uint8_t *p; int W, H; } Tex;      /* RGBA8, rows top-down */
+
+static inline v4 V4(float x, float y, float z, float w) { v4 r = { x, y, z, w }; return r; }
+static inline v4 add4(v4 a, v4 b) { return V4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+static inline v4 scale4(v4 a, float s) { return V4(a.x * s, a.y * s, a.z * s, a.w * s); }
+static inline int eq3(v4 a, v4 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+static inline int eq4(v4 a, v4 b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
+
+/* texelFetch(tex, ivec2(x, y_gl), 0) with zero outside (and for a NULL = never-written texture) */
+static inline v4 fetch(Tex t, int x, int y_gl) {
+  if (!t.p || x < 0 || y_gl < 0 || x >= t.W || y_gl >= t.H) return V4(0.0f, 0.0f, 0.0f, 0.0f);
+  const uint8_t *q = t.p + ((size_t)(t.H - 1 - y_gl) * t.W + x) * 4;
+  return V4((float)q[0] / 255.0f, (float)q[1] / 255.0f, (float)q[2] / 255.0f, (float)q[3] / 255.0f);
+}
+static inline uint8_t quant(float x) {
+  if (!(x > 0.0f)) return 0;               /* NaN and negatives clamp to 0 */
+  if (x >= 1.0f) return 255;
+  return (uint8_t)(x * 255.0f + 0.5f);
+}
+static inline void store(uint8_t *dst, int W, int H, int x, int y_gl, v4 v) {
+  if (!dst) return;
+  uint8_t *q = dst + ((size_t)(H - 1 - y_gl) * W + x) * 4;
+  q[0] = quant(v.x); q[1] = quant(v.y); q[2] = quant(v.z); q[3] = quant(v.w);
+}
+
+static const float STENCIL3_37[37][2] = {
+                              {-3, -1}, {-3, 0}, {-3, 1},
+                    {-2, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-2, 2},
+  {-1, -3}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {-1, 2}, {-1, 3},
+  { 0, -3}, { 0, -2}, { 0, -1}, { 0, 0}, { 0, 1}, { 0, 2}, { 0, 3},
+  { 1, -3}, { 1, -2}, { 1, -1}, { 1, 0}, { 1, 1}, { 1, 2}, { 1, 3},
+                    { 2, -2}, { 2, -1}, { 2, 0}, { 2, 1}, { 2, 2},
+                              { 3, -1}, { 3, 0}, { 3, 1}
+};
+static const int STENCIL1[4][2] = { {-1, 0}, {0, -1}, {0, 1}, {1, 0} };
+
+/* pathtracer_first_filter.glsl:18-123 for texel (x, y_gl) */
+static void first_filter(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, int x, int y, v4 *oColor, v4 *oIp, v4 *oId) {
+  v4 centerColor = fetch(tColor, x, y);
+  v4 centerColorIp = fetch(tIp, x, y);
+  v4 centerOColor = fetch(tOColor, x, y);
+  v4 centerId = fetch(tId, x, y);
+  int centerIdw = (int)(centerId.w * 255.0f);
+  int centerLightNum = centerIdw / 2;
+  int centerShadow = centerIdw % 2;
+  v4 renderId = centerId;
+  v4 renderColorIp = V4(0.0f, 0.0f, 0.0f, 0.0f);
+  v4 centerOId = fetch(tOId, x, y);
+  v4 color = V4(0.0f, 0.0f, 0.0f, 0.0f);
+  float count = 0.0f;
+  if (centerOId.w != 0.0f && centerColorIp.w != 0.0f) {
+    v4 id = centerId;
+    v4 ids[4], oIds[4];
+    float ipws[4];
+    for (int i = 0; i < 4; i++) {
+      ids[i] = fetch(tId, x + STENCIL1[i][0], y + STENCIL1[i][1]);
+      oIds[i] = fetch(tOId, x + STENCIL1[i][0], y + STENCIL1[i][1]);
+      ipws[i] = fetch(tIp, x + STENCIL1[i][0], y + STENCIL1[i][1]).w;
+    }
+    int vote[4] = { 0, 0, 0, 0 };
+    for (int i = 0; i < 4; i++) {
+      if (ipws[i] == 0.0f) {
+        vote[i] = 1;
+        if (eq3(ids[i], id) && eq4(oIds[i], centerOId)) vote[i]++;
+        for (int j = i + 1; j < 4; j++) if (eq3(ids[i], ids[j]) && eq4(oIds[i], oIds[j])) vote[i]++;
+      }
+    }
+    int maxVote = vote[0];
+    int idNumber = 0;
+    for (int i = 1; i < 4; i++) {
+      if (vote[i] >= maxVote) { maxVote = vote[i]; idNumber = i; }
+    }
+    renderId = ids[idNumber];
+    renderColorIp.w = flx_max(1.0f - flx_sign((float)maxVote), 0.0f);
+  }
+  if (centerOColor.w == 0.0f) {
+    color = centerColor;
+    count = 1.0f;
+  } else {
+    for (int i = 0; i < 37; i++) {
+      float k = 1.0f + centerOColor.w;
+      int cx = x + (int)(STENCIL3_37[i][0] * k * k * 3.5f);
+      int cy = y + (int)(STENCIL3_37[i][1] * k * k * 3.5f);
+      v4 id = fetch(tId, cx, cy);
+      v4 originalId = fetch(tOId, cx, cy);
+      int idW = (int)(id.w * 255.0f);
+      int lightNum = idW / 2;
+      int shadow = idW % 2;
+      v4 nextColor = fetch(tColor, cx, cy);
+      v4 nextColorIp = fetch(tIp, cx, cy);
+      if (eq3(centerId, id) && eq4(centerOId, originalId) && (centerLightNum != lightNum || centerShadow == shadow)) {
+        color = add4(color, add4(nextColor, scale4(nextColorIp, 256.0f)));
+        count += 1.0f;
+      }
+    }
+  }
+  float invCount = 1.0f / count;
+  float sg = flx_sign(centerColor.w);
+  float cx_ = color.x * invCount, cy_ = color.y * invCount, cz_ = color.z * invCount;
+  *oColor = V4(sg * flx_mod(cx_, 1.0f), sg * flx_mod(cy_, 1.0f), sg * flx_mod(cz_, 1.0f), sg * centerColor.w);
+  *oIp = V4(sg * (flx_floor(cx_) * INV_256), sg * (flx_floor(cy_) * INV_256), sg * (flx_floor(cz_) * INV_256), sg * renderColorIp.w);
+  *oId = renderId;
+}
+
+static const float STENCIL3_36[36][2] = {
+                              {-3, -1}, {-3, 0}, {-3, 1},
+                    {-2, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-2, 2},
+  {-1, -3}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {-1, 2}, {-1, 3},
+  { 0, -3}, { 0, -2}, { 0, -1},          { 0, 1}, { 0, 2}, { 0, 3},
+  { 1, -3}, { 1, -2}, { 1, -1}, { 1, 0}, { 1, 1}, { 1, 2}, { 1, 3},
+                    { 2, -2}, { 2, -1}, { 2, 0}, { 2, 1}, { 2, 2},
+                              { 3, -1}, { 3, 0}, { 3, 1}
+};
+
+/* pathtracer_second_filter.glsl:17-79 */
+static void second_filter(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, int x, int y, v4 *oColor_, v4 *oIp, v4 *oOrig) {
+  v4 centerColor = fetch(tColor, x, y);
+  v4 centerColorIp = fetch(tIp, x, y);
+  v4 centerOColor = fetch(tOColor, x, y);
+  v4 centerId = fetch(tId, x, y);
+  v4 centerOId = fetch(tOId, x, y);
+  v4 color = add4(centerColor, scale4(V4(centerColorIp.x, centerColorIp.y, centerColorIp.z, 0.0f), 256.0f));
+  v4 oColor = centerOColor;
+  float ipw = centerColorIp.w;
+  float count = 1.0f;
+  float oCount = 1.0f;
+  float scale = 1.0f + 2.0f * flx_tanh(centerOColor.w + centerOId.w * 4.0f);
+  for (int i = 0; i < 36; i++) {
+    int cx = x + (int)(STENCIL3_36[i][0] * scale);
+    int cy = y + (int)(STENCIL3_36[i][1] * scale);
+    v4 id = fetch(tId, cx, cy);
+    v4 nextOId = fetch(tOId, cx, cy);
+    v4 nextColor = fetch(tColor, cx, cy);
+    v4 nextColorIp = fetch(tIp, cx, cy);
+    v4 nextOColor = fetch(tOColor, cx, cy);
+    if (eq3(centerOId, nextOId)) {
+      if (flx_min(centerOId.w, nextOId.w) > 0.1f && (eq4(id, centerId) || flx_max(nextColorIp.w, centerColorIp.w) >= 0.1f)) {
+        color = add4(color, add4(nextColor, scale4(V4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
+        count += 1.0f;
+        ipw += nextColorIp.w;
+        oColor = add4(oColor, nextOColor);
+        oCount += 1.0f;
+      } else if (eq3(id, centerId)) {
+        color = add4(color, add4(nextColor, scale4(V4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
+        count += 1.0f;
+      }
+    }
+  }
+  float invCount = 1.0f / count;
+  float w = centerColor.w;
+  float cx_ = color.x * invCount, cy_ = color.y * invCount, cz_ = color.z * invCount;
+  *oColor_ = V4(w * flx_mod(cx_, 1.0f), w * flx_mod(cy_, 1.0f), w * flx_mod(cz_, 1.0f), w * (color.w * invCount));
+  *oIp = V4(w * (flx_floor(cx_) * INV_256), w * (flx_floor(cy_) * INV_256), w * (flx_floor(cz_) * INV_256), w * ipw);
+  *oOrig = V4((w * oColor.x) / oCount, (w * oColor.y) / oCount, (w * oColor.z) / oCount, (w * oColor.w) / oCount);
+}
+
+/* pathtracer_final_filter.glsl:13-71; returns the canvas colour before its RGBA8 store */
+static v4 final_filter(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, int x, int y, int hdr) {
+  v4 centerColor = fetch(tColor, x, y);
+  v4 centerColorIp = fetch(tIp, x, y);
+  v4 centerOColor = fetch(tOColor, x, y);
+  v4 centerId = fetch(tId, x, y);
+  v4 centerOId = fetch(tOId, x, y);
+  v4 color = V4(0.0f, 0.0f, 0.0f, 0.0f);
+  v4 oColor = V4(0.0f, 0.0f, 0.0f, 0.0f);
+  float count = 0.0f, oCount = 0.0f;
+  float scale = 0.7f + 2.0f * flx_tanh(centerOColor.w + centerOId.w * 4.0f);
+  for (int i = 0; i < 37; i++) {
+    int cx = x + (int)(STENCIL3_37[i][0] * scale);
+    int cy = y + (int)(STENCIL3_37[i][1] * scale);
+    v4 id = fetch(tId, cx, cy);
+    v4 nextOId = fetch(tOId, cx, cy);
+    v4 nextColor = fetch(tColor, cx, cy);
+    v4 nextColorIp = fetch(tIp, cx, cy);
+    v4 nextOColor = fetch(tOColor, cx, cy);
+    int blurTranslucent = flx_max(nextColorIp.w, centerColorIp.w) != 0.0f && flx_min(centerOId.w, nextOId.w) > 0.0f;
+    if (blurTranslucent && eq3(centerOId, nextOId)) {
+      oColor = add4(oColor, nextOColor);
+      oCount += 1.0f;
+    }
+    if ((blurTranslucent || eq3(centerId, id)) && eq3(centerOId, nextOId)) {
+      color = add4(color, add4(nextColor, scale4(nextColorIp, 255.0f)));
+      count += 1.0f;
+    }
+  }
+  if (centerColor.w > 0.0f) {
+    float f[3] = { color.x / count, color.y / count, color.z / count };
+    float m[3];
+    if (oCount == 0.0f) { m[0] = centerOColor.x; m[1] = centerOColor.y; m[2] = centerOColor.z; }
+    else { m[0] = oColor.x / oCount; m[1] = oColor.y / oCount; m[2] = oColor.z / oCount; }
+    for (int c = 0; c < 3; c++) {
+      f[c] = f[c] * m[c];
+      if (hdr == 1) {
+        f[c] = f[c] / (f[c] + 1.0f);
+        const float gamma = 0.8f;
+        f[c] = flx_pow(4.0f * f[c], 1.0f / gamma) / 4.0f * 1.3f;
+      }
+    }
+    return V4(f[0], f[1], f[2], 1.0f);
+  }
+  return V4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+static uint8_t *quantise_plane(const float *src, int W, int H) {
+  uint8_t *dst = (uint8_t *)malloc((size_t)W * H * 4);
+  if (!dst) return NULL;
+  for (size_t i = 0; i < (size_t)W * H * 4; i++) dst[i] = quant(src[i]);
+  return dst;
+}
+
+int flx_oracle_filter(const flx_frame_params *params, const flx_gbuffers *gb, float *out_rgba, int threads) {
+  if (!params || !gb || !out_rgba || !gb->color || !gb->color_ip || !gb->original_color || !gb->id || !gb->original_id) return FLX_ERR_INVALID;
+  const int W = (int)params->width, H = (int)params->height;
+  if (W <= 0 || H <= 0) return FLX_ERR_INVALID;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+  const size_t bytes = (size_t)W * H * 4;
+  /* the path tracer's five RGBA8 targets (slot 0) */
+  uint8_t *R[4] = { quantise_plane(gb->color, W, H), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1) };
+  uint8_t *Ip[4] = { quantise_plane(gb->color_ip, W, H), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1) };
+  uint8_t *O[2] = { quantise_plane(gb->original_color, W, H), (uint8_t *)calloc(bytes, 1) };
+  uint8_t *Id[2] = { quantise_plane(gb->id, W, H), (uint8_t *)calloc(bytes, 1) };
+  uint8_t *OId = quantise_plane(gb->original_id, W, H);
+  int ok = OId != NULL;
+  for (int i = 0; i < 4; i++) ok = ok && R[i] && Ip[i];
+  for (int i = 0; i < 2; i++) ok = ok && O[i] && Id[i];
+  if (ok) {
+    /* modules/pathtracerWGL2.js:462-512 with firstPasses = secondPasses = 3 */
+    int n = 0, nId = 0, nOriginal = 0;
+    for (int i = 0; i < 6; i++) {
+      int np = (i % 2) ^ 1;
+      int npOriginal = ((i - 3) % 2) ^ 1;
+      if (3 <= i) np += 2;
+      uint8_t *third = NULL;                          /* attachment 2 */
+      if (3 <= i - 2) third = O[npOriginal];
+      else if (np < 2) third = Id[np];                /* IdRenderTexture has two elements; [2],[3] do not exist */
+      Tex tColor = { R[n], W, H }, tIp = { Ip[n], W, H }, tOColor = { O[nOriginal], W, H }, tId = { Id[nId], W, H }, tOId = { OId, W, H };
+      const int first = n < 2;                        /* PostProgram[0..1] first filter, [2..3] second */
+      uint8_t *dR = R[np], *dIp = Ip[np];
+#pragma omp parallel for schedule(dynamic, 4)
+      for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+          v4 a, b, c;
+          if (first) first_filter(tColor, tIp, tOColor, tId, tOId, x, y, &a, &b, &c);
+          else second_filter(tColor, tIp, tOColor, tId, tOId, x, y, &a, &b, &c);
+          store(dR, W, H, x, y, a);
+          store(dIp, W, H, x, y, b);
+          store(third, W, H, x, y, c);
+        }
+      }
+      n = np;
+      if (3 <= i) nOriginal = npOriginal; else nId = np;
+    }
+    Tex tColor = { R[2], W, H }, tIp = { Ip[2], W, H }, tOColor = { O[1], W, H }, tId = { Id[1], W, H }, tOId = { OId, W, H };
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = 0; y < H; y++) {
+      for (int x = 0; x < W; x++) {
+        v4 c = final_filter(tColor, tIp, tOColor, tId, tOId, x, y, params->hdr);
+        float *o = out_rgba + ((size_t)(H - 1 - y) * W + x) * 4;
+        o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
+      }
+    }
+  }
+  for (int i = 0; i < 4; i++) { free(R[i]); free(Ip[i]); }
+  for (int i = 0; i < 2; i++) { free(O[i]); free(Id[i]); }
+  free(OId);
+  return ok ? FLX_OK : FLX_ERR_INVALID;
 }

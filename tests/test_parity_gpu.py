@@ -89,3 +89,36 @@ def test_errors_are_reported_not_thrown(hip, scenes):
             fresh.render(sc.frame_params(width=8, height=8))
     finally:
         fresh.close()
+
+
+# ---- filter on: G-buffers (fragment:619-639) and the denoise chain (F0-F3) ------------------------------
+FILTER_CASES = [
+    ("cornell_obj", 320, 180, 4, 3),      # BASELINE config 2 at reduced size
+    ("cornell", 160, 120, 2, 3),          # textured PBR material, translucency flags off
+    ("dragon", 240, 136, 2, 4),           # translucent dragon + sphere: glassFilter / vote branch of the first filter
+    ("theater", 200, 112, 1, 3),
+]
+
+
+@pytest.mark.parametrize("name,w,h,spp,bounces", FILTER_CASES)
+def test_filter_chain_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounces):
+    sc = scenes(name)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=1)
+    hip.update_scene(sc)
+    got, got_cnt, got_gb = hip.render(p, gbuffers=True, counters=True)
+    want, want_cnt, want_gb = oracle.render(sc, p, gbuffers=True)
+    for key in want_gb:
+        rms, mism = assert_parity(got_gb[key], want_gb[key], "%s G-buffer %s" % (name, key))
+        assert mism == 0, "%s G-buffer %s: %d floats differ" % (name, key, mism)
+    rms, mism = assert_parity(got, want, name + " filtered")
+    assert mism == 0, "%s filtered frame: %d of %d floats differ (rms %s)" % (name, mism, got.size, rms)
+    assert got_cnt == want_cnt
+
+
+def test_filter_refuses_tiles(hip, scenes):
+    from flexlight_hip import capi
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=64, height=64, use_filter=1, tile=(8, 0, 2))
+    with pytest.raises(capi.FlexLightHipError, match="tiled"):
+        hip.render(p)

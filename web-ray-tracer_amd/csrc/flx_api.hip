@@ -43,6 +43,8 @@ struct flx_context {
   size_t out_capacity = 0;                       /* pixels */
   float4 *d_gb[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
   size_t gb_capacity = 0;
+  uint32_t *d_planes[13] = {};                   /* the filter chain's RGBA8 render targets */
+  size_t planes_capacity = 0;
   /* v2 pipeline workspace: primary hits, per-(sample,pixel) radiance, last sample's originalColor, item queue */
   float4 *d_hits = nullptr, *d_samples = nullptr, *d_last = nullptr;
   size_t hits_capacity = 0, samples_capacity = 0, last_capacity = 0;
@@ -118,7 +120,9 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_rec, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk };
+                   ctx->d_rec, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
+                   ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
+                   ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -421,6 +425,37 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   return FLX_OK;
 }
 
+/* G-buffer + plane workspace of a filter frame, then trace + chain into d_out. */
+static flx_status run_filter_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, int hdr, float4 *d_out) {
+  if (fr.rows != fr.height) return fail(ctx, FLX_ERR_INVALID, "filter frames cannot be tiled: the denoise taps reach +-42 px (render the whole frame on one context)");
+  const size_t pixels = (size_t)fr.rows * fr.width;
+  flx_status s;
+  if (ctx->gb_capacity < pixels) {
+    for (int i = 0; i < 5; i++) {
+      size_t cap = 0;
+      if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
+      if ((s = ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
+    }
+    ctx->gb_capacity = pixels;
+  }
+  if (ctx->planes_capacity < pixels) {
+    for (int i = 0; i < 13; i++) {
+      if (ctx->d_planes[i]) { FLX_HIP(ctx, hipFree(ctx->d_planes[i])); ctx->d_planes[i] = nullptr; }
+      FLX_HIP(ctx, hipMalloc(&ctx->d_planes[i], pixels * sizeof(uint32_t)));
+    }
+    ctx->planes_capacity = pixels;
+  }
+  GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4] };
+  if ((s = run_frame(ctx, sc, fr, nullptr, gb))) return s;
+  FilterPlanes pl;
+  for (int i = 0; i < 4; i++) { pl.R[i] = ctx->d_planes[i]; pl.Ip[i] = ctx->d_planes[4 + i]; }
+  pl.O[0] = ctx->d_planes[8]; pl.O[1] = ctx->d_planes[9]; pl.Id[0] = ctx->d_planes[10]; pl.Id[1] = ctx->d_planes[11]; pl.OId = ctx->d_planes[12];
+  launch_filter_chain(gb, pl, d_out, (int)fr.width, (int)fr.height, hdr, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_set_pipeline(flx_context *ctx, int pipeline) {
   if (!ctx) return FLX_ERR_INVALID;
   if (pipeline < 0 || pipeline > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_pipeline: 0 auto, 1 per-pixel, 2 persistent paths, 3 wavefront");
@@ -435,7 +470,7 @@ extern "C" flx_status flx_render_device(flx_context *ctx, const flx_frame_params
   DeviceScene sc; DeviceFrame fr;
   flx_status s = make_frame(ctx, params, sc, fr);
   if (s) return s;
-  if (params->use_filter) return fail(ctx, FLX_ERR_INVALID, "flx_render_device: filter chain not available on the device-output path yet");
+  if (params->use_filter) return run_filter_frame(ctx, sc, fr, params->hdr, (float4 *)d_out_rgba);
   GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr };
   return run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
 }
@@ -452,21 +487,14 @@ extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *param
   const size_t pixels = (size_t)fr.rows * fr.width;
   if (pixels == 0) return FLX_OK;
   if ((s = ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
-  GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr };
-  if (params->use_filter) {
-    if (ctx->gb_capacity < pixels) {
-      for (int i = 0; i < 5; i++) {
-        size_t cap = 0;
-        if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
-        if ((s = ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
-      }
-      ctx->gb_capacity = pixels;
-    }
-    gb.color = ctx->d_gb[0]; gb.color_ip = ctx->d_gb[1]; gb.original_color = ctx->d_gb[2]; gb.id = ctx->d_gb[3]; gb.original_id = ctx->d_gb[4];
-  }
   const bool saved = ctx->counters_enabled;
   if (counters) ctx->counters_enabled = true;
-  s = run_frame(ctx, sc, fr, ctx->d_out, gb);
+  if (params->use_filter) {
+    s = run_filter_frame(ctx, sc, fr, params->hdr, ctx->d_out);
+  } else {
+    GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    s = run_frame(ctx, sc, fr, ctx->d_out, gb);
+  }
   ctx->counters_enabled = saved;
   if (s) return s;
   FLX_HIP(ctx, hipMemcpyAsync(out_rgba, ctx->d_out, pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));

@@ -1,0 +1,272 @@
+/*
+ * flx_filter.hip — the denoise chain on gfx950: first / second / final filter kernels.
+ *
+ * What they compute: shaders/pathtracer_first_filter.glsl:18-123, pathtracer_second_filter.glsl:17-79,
+ * pathtracer_final_filter.glsl:13-71, one thread per texel, over RGBA8 planes exactly like the
+ * reference's render targets (modules/pathtracerWGL2.js:790-799): a store keeps
+ * floor(clamp(x,0,1)*255 + 0.5), a fetch returns k/255, a fetch outside the image returns 0.
+ * The pass schedule (which slot feeds which, including the two dropped outputs and the read of a
+ * never-written plane at pass 4) is replayed by flx_api.hip from pathtracerWGL2.js:462-550.
+ *
+ * Memory: the planes are plain uint32 arrays in HBM, 8.3 MB each at 1080p, so the five inputs of a
+ * pass sit in the XCD L2s / Infinity Cache; taps are 4-byte gathers, neighbouring threads hit the
+ * same cache lines.  Threads are mapped 16x16 to keep a workgroup's taps together.
+ */
+#include "flx_kernels.h"
+
+namespace flx {
+
+struct Tex { const uint32_t *p; };       /* RGBA8 plane, rows top-down; null = never written (reads 0) */
+
+__device__ __forceinline__ f4 F4(float x, float y, float z, float w) { f4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+__device__ __forceinline__ f4 add4(f4 a, f4 b) { return F4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ f4 scale4(f4 a, float s) { return F4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ bool eq3(f4 a, f4 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+__device__ __forceinline__ bool eq4(f4 a, f4 b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
+
+__device__ __forceinline__ f4 fetch(Tex t, int W, int H, int x, int y_gl) {
+  if (!t.p || x < 0 || y_gl < 0 || x >= W || y_gl >= H) return F4(0.0f, 0.0f, 0.0f, 0.0f);
+  const uint32_t q = t.p[(size_t)(H - 1 - y_gl) * W + x];
+  return F4((float)(q & 255u) / 255.0f, (float)((q >> 8) & 255u) / 255.0f, (float)((q >> 16) & 255u) / 255.0f, (float)(q >> 24) / 255.0f);
+}
+__device__ __forceinline__ uint32_t quant(float x) {
+  if (!(x > 0.0f)) return 0u;
+  if (x >= 1.0f) return 255u;
+  return (uint32_t)(x * 255.0f + 0.5f);
+}
+__device__ __forceinline__ uint32_t pack(f4 v) { return quant(v.x) | (quant(v.y) << 8) | (quant(v.z) << 16) | (quant(v.w) << 24); }
+
+__device__ const float STENCIL3_37[37][2] = {
+                              {-3, -1}, {-3, 0}, {-3, 1},
+                    {-2, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-2, 2},
+  {-1, -3}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {-1, 2}, {-1, 3},
+  { 0, -3}, { 0, -2}, { 0, -1}, { 0, 0}, { 0, 1}, { 0, 2}, { 0, 3},
+  { 1, -3}, { 1, -2}, { 1, -1}, { 1, 0}, { 1, 1}, { 1, 2}, { 1, 3},
+                    { 2, -2}, { 2, -1}, { 2, 0}, { 2, 1}, { 2, 2},
+                              { 3, -1}, { 3, 0}, { 3, 1}
+};
+__device__ const float STENCIL3_36[36][2] = {
+                              {-3, -1}, {-3, 0}, {-3, 1},
+                    {-2, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-2, 2},
+  {-1, -3}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {-1, 2}, {-1, 3},
+  { 0, -3}, { 0, -2}, { 0, -1},          { 0, 1}, { 0, 2}, { 0, 3},
+  { 1, -3}, { 1, -2}, { 1, -1}, { 1, 0}, { 1, 1}, { 1, 2}, { 1, 3},
+                    { 2, -2}, { 2, -1}, { 2, 0}, { 2, 1}, { 2, 2},
+                              { 3, -1}, { 3, 0}, { 3, 1}
+};
+__device__ const int STENCIL1[4][2] = { {-1, 0}, {0, -1}, {0, 1}, {1, 0} };
+
+__device__ __forceinline__ bool texel_of_thread(int W, int H, int &x, int &y_gl) {
+  const int tiles_x = (W + 15) >> 4;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  x = (tx << 4) + (threadIdx.x & 15);
+  const int row = (ty << 4) + (threadIdx.x >> 4);
+  y_gl = H - 1 - row;
+  return x < W && row < H;
+}
+
+/* float G-buffers of the path-trace pass -> the five RGBA8 targets it renders into */
+__global__ __launch_bounds__(256) void k_quantize5(GBufferPtrs gb, uint32_t *c, uint32_t *ip, uint32_t *oc, uint32_t *id, uint32_t *oid, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float4 v;
+  v = gb.color[i]; c[i] = pack(F4(v.x, v.y, v.z, v.w));
+  v = gb.color_ip[i]; ip[i] = pack(F4(v.x, v.y, v.z, v.w));
+  v = gb.original_color[i]; oc[i] = pack(F4(v.x, v.y, v.z, v.w));
+  v = gb.id[i]; id[i] = pack(F4(v.x, v.y, v.z, v.w));
+  v = gb.original_id[i]; oid[i] = pack(F4(v.x, v.y, v.z, v.w));
+}
+
+/* pathtracer_first_filter.glsl:18-123 */
+__global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, uint32_t *dColor, uint32_t *dIp,
+                                                      uint32_t *dId, int W, int H) {
+  int x, y;
+  if (!texel_of_thread(W, H, x, y)) return;
+  const f4 centerColor = fetch(tColor, W, H, x, y);
+  const f4 centerColorIp = fetch(tIp, W, H, x, y);
+  const f4 centerOColor = fetch(tOColor, W, H, x, y);
+  const f4 centerId = fetch(tId, W, H, x, y);
+  const int centerIdw = (int)(centerId.w * 255.0f);
+  const int centerLightNum = centerIdw / 2;
+  const int centerShadow = centerIdw % 2;
+  f4 renderId = centerId;
+  f4 renderColorIp = F4(0.0f, 0.0f, 0.0f, 0.0f);
+  const f4 centerOId = fetch(tOId, W, H, x, y);
+  f4 color = F4(0.0f, 0.0f, 0.0f, 0.0f);
+  float count = 0.0f;
+  if (centerOId.w != 0.0f && centerColorIp.w != 0.0f) {
+    f4 ids[4], oIds[4];
+    float ipws[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      ids[i] = fetch(tId, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]);
+      oIds[i] = fetch(tOId, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]);
+      ipws[i] = fetch(tIp, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]).w;
+    }
+    int vote[4] = { 0, 0, 0, 0 };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      if (ipws[i] == 0.0f) {
+        vote[i] = 1;
+        if (eq3(ids[i], centerId) && eq4(oIds[i], centerOId)) vote[i]++;
+#pragma unroll
+        for (int j = i + 1; j < 4; j++) if (eq3(ids[i], ids[j]) && eq4(oIds[i], oIds[j])) vote[i]++;
+      }
+    }
+    int maxVote = vote[0];
+    int idNumber = 0;
+#pragma unroll
+    for (int i = 1; i < 4; i++) if (vote[i] >= maxVote) { maxVote = vote[i]; idNumber = i; }
+    renderId = idNumber == 0 ? ids[0] : idNumber == 1 ? ids[1] : idNumber == 2 ? ids[2] : ids[3];
+    renderColorIp.w = flx_max(1.0f - flx_sign((float)maxVote), 0.0f);
+  }
+  if (centerOColor.w == 0.0f) {
+    color = centerColor;
+    count = 1.0f;
+  } else {
+    const float k = 1.0f + centerOColor.w;
+    for (int i = 0; i < 37; i++) {
+      const int cx = x + (int)(STENCIL3_37[i][0] * k * k * 3.5f);
+      const int cy = y + (int)(STENCIL3_37[i][1] * k * k * 3.5f);
+      const f4 id = fetch(tId, W, H, cx, cy);
+      const f4 originalId = fetch(tOId, W, H, cx, cy);
+      const int idW = (int)(id.w * 255.0f);
+      const int lightNum = idW / 2;
+      const int shadow = idW % 2;
+      const f4 nextColor = fetch(tColor, W, H, cx, cy);
+      const f4 nextColorIp = fetch(tIp, W, H, cx, cy);
+      if (eq3(centerId, id) && eq4(centerOId, originalId) && (centerLightNum != lightNum || centerShadow == shadow)) {
+        color = add4(color, add4(nextColor, scale4(nextColorIp, 256.0f)));
+        count += 1.0f;
+      }
+    }
+  }
+  const float invCount = 1.0f / count;
+  const float sg = flx_sign(centerColor.w);
+  const float cx_ = color.x * invCount, cy_ = color.y * invCount, cz_ = color.z * invCount;
+  const size_t o = (size_t)(H - 1 - y) * W + x;
+  dColor[o] = pack(F4(sg * flx_mod(cx_, 1.0f), sg * flx_mod(cy_, 1.0f), sg * flx_mod(cz_, 1.0f), sg * centerColor.w));
+  dIp[o] = pack(F4(sg * (flx_floor(cx_) * INV_256), sg * (flx_floor(cy_) * INV_256), sg * (flx_floor(cz_) * INV_256), sg * renderColorIp.w));
+  if (dId) dId[o] = pack(renderId);
+}
+
+/* pathtracer_second_filter.glsl:17-79 */
+__global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, uint32_t *dColor, uint32_t *dIp,
+                                                       uint32_t *dOrig, int W, int H) {
+  int x, y;
+  if (!texel_of_thread(W, H, x, y)) return;
+  const f4 centerColor = fetch(tColor, W, H, x, y);
+  const f4 centerColorIp = fetch(tIp, W, H, x, y);
+  const f4 centerOColor = fetch(tOColor, W, H, x, y);
+  const f4 centerId = fetch(tId, W, H, x, y);
+  const f4 centerOId = fetch(tOId, W, H, x, y);
+  f4 color = add4(centerColor, scale4(F4(centerColorIp.x, centerColorIp.y, centerColorIp.z, 0.0f), 256.0f));
+  f4 oColor = centerOColor;
+  float ipw = centerColorIp.w;
+  float count = 1.0f, oCount = 1.0f;
+  const float scale = 1.0f + 2.0f * flx_tanh(centerOColor.w + centerOId.w * 4.0f);
+  for (int i = 0; i < 36; i++) {
+    const int cx = x + (int)(STENCIL3_36[i][0] * scale);
+    const int cy = y + (int)(STENCIL3_36[i][1] * scale);
+    const f4 id = fetch(tId, W, H, cx, cy);
+    const f4 nextOId = fetch(tOId, W, H, cx, cy);
+    const f4 nextColor = fetch(tColor, W, H, cx, cy);
+    const f4 nextColorIp = fetch(tIp, W, H, cx, cy);
+    const f4 nextOColor = fetch(tOColor, W, H, cx, cy);
+    if (eq3(centerOId, nextOId)) {
+      if (flx_min(centerOId.w, nextOId.w) > 0.1f && (eq4(id, centerId) || flx_max(nextColorIp.w, centerColorIp.w) >= 0.1f)) {
+        color = add4(color, add4(nextColor, scale4(F4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
+        count += 1.0f;
+        ipw += nextColorIp.w;
+        oColor = add4(oColor, nextOColor);
+        oCount += 1.0f;
+      } else if (eq3(id, centerId)) {
+        color = add4(color, add4(nextColor, scale4(F4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
+        count += 1.0f;
+      }
+    }
+  }
+  const float invCount = 1.0f / count;
+  const float w = centerColor.w;
+  const float cx_ = color.x * invCount, cy_ = color.y * invCount, cz_ = color.z * invCount;
+  const size_t o = (size_t)(H - 1 - y) * W + x;
+  dColor[o] = pack(F4(w * flx_mod(cx_, 1.0f), w * flx_mod(cy_, 1.0f), w * flx_mod(cz_, 1.0f), w * (color.w * invCount)));
+  dIp[o] = pack(F4(w * (flx_floor(cx_) * INV_256), w * (flx_floor(cy_) * INV_256), w * (flx_floor(cz_) * INV_256), w * ipw));
+  if (dOrig) dOrig[o] = pack(F4((w * oColor.x) / oCount, (w * oColor.y) / oCount, (w * oColor.z) / oCount, (w * oColor.w) / oCount));
+}
+
+/* pathtracer_final_filter.glsl:13-71; writes the canvas colour as float4 (before its RGBA8 store) */
+__global__ __launch_bounds__(256) void k_filter_final(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, float4 *out, int W, int H, int hdr) {
+  int x, y;
+  if (!texel_of_thread(W, H, x, y)) return;
+  const f4 centerColor = fetch(tColor, W, H, x, y);
+  const f4 centerColorIp = fetch(tIp, W, H, x, y);
+  const f4 centerOColor = fetch(tOColor, W, H, x, y);
+  const f4 centerId = fetch(tId, W, H, x, y);
+  const f4 centerOId = fetch(tOId, W, H, x, y);
+  f4 color = F4(0.0f, 0.0f, 0.0f, 0.0f), oColor = color;
+  float count = 0.0f, oCount = 0.0f;
+  const float scale = 0.7f + 2.0f * flx_tanh(centerOColor.w + centerOId.w * 4.0f);
+  for (int i = 0; i < 37; i++) {
+    const int cx = x + (int)(STENCIL3_37[i][0] * scale);
+    const int cy = y + (int)(STENCIL3_37[i][1] * scale);
+    const f4 id = fetch(tId, W, H, cx, cy);
+    const f4 nextOId = fetch(tOId, W, H, cx, cy);
+    const f4 nextColor = fetch(tColor, W, H, cx, cy);
+    const f4 nextColorIp = fetch(tIp, W, H, cx, cy);
+    const f4 nextOColor = fetch(tOColor, W, H, cx, cy);
+    const bool blurTranslucent = flx_max(nextColorIp.w, centerColorIp.w) != 0.0f && flx_min(centerOId.w, nextOId.w) > 0.0f;
+    if (blurTranslucent && eq3(centerOId, nextOId)) {
+      oColor = add4(oColor, nextOColor);
+      oCount += 1.0f;
+    }
+    if ((blurTranslucent || eq3(centerId, id)) && eq3(centerOId, nextOId)) {
+      color = add4(color, add4(nextColor, scale4(nextColorIp, 255.0f)));
+      count += 1.0f;
+    }
+  }
+  float4 res = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  if (centerColor.w > 0.0f) {
+    float f[3] = { color.x / count, color.y / count, color.z / count };
+    float m[3];
+    if (oCount == 0.0f) { m[0] = centerOColor.x; m[1] = centerOColor.y; m[2] = centerOColor.z; }
+    else { m[0] = oColor.x / oCount; m[1] = oColor.y / oCount; m[2] = oColor.z / oCount; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+      f[c] = f[c] * m[c];
+      if (hdr == 1) {
+        f[c] = f[c] / (f[c] + 1.0f);
+        const float gamma = 0.8f;
+        f[c] = flx_pow(4.0f * f[c], 1.0f / gamma) / 4.0f * 1.3f;
+      }
+    }
+    res = make_float4(f[0], f[1], f[2], 1.0f);
+  }
+  out[(size_t)(H - 1 - y) * W + x] = res;
+}
+
+/* Replays modules/pathtracerWGL2.js:462-550 (firstPasses = secondPasses = 3).  planes: R[4], Ip[4], O[2], Id[2], OId. */
+void launch_filter_chain(const GBufferPtrs &gb, const FilterPlanes &pl, float4 *out, int W, int H, int hdr, hipStream_t stream) {
+  const size_t n = (size_t)W * H;
+  const dim3 grid(((W + 15) >> 4) * ((H + 15) >> 4)), block(256);
+  hipLaunchKernelGGL(k_quantize5, dim3((uint32_t)((n + 255) / 256)), block, 0, stream, gb, pl.R[0], pl.Ip[0], pl.O[0], pl.Id[0], pl.OId, n);
+  (void)hipMemsetAsync(pl.O[1], 0, n * 4, stream);          /* read at pass 4 before anything wrote it this frame */
+  int cur = 0, nId = 0, nOriginal = 0;
+  for (int i = 0; i < 6; i++) {
+    int np = (i % 2) ^ 1;
+    const int npOriginal = ((i - 3) % 2) ^ 1;
+    if (3 <= i) np += 2;
+    uint32_t *third = nullptr;
+    if (3 <= i - 2) third = pl.O[npOriginal];
+    else if (np < 2) third = pl.Id[np];                       /* IdRenderTexture[2], [3] do not exist: output dropped */
+    Tex tColor = { pl.R[cur] }, tIp = { pl.Ip[cur] }, tOColor = { pl.O[nOriginal] }, tId = { pl.Id[nId] }, tOId = { pl.OId };
+    if (cur < 2) hipLaunchKernelGGL(k_filter_first, grid, block, 0, stream, tColor, tIp, tOColor, tId, tOId, pl.R[np], pl.Ip[np], third, W, H);
+    else hipLaunchKernelGGL(k_filter_second, grid, block, 0, stream, tColor, tIp, tOColor, tId, tOId, pl.R[np], pl.Ip[np], third, W, H);
+    cur = np;
+    if (3 <= i) nOriginal = npOriginal; else nId = np;
+  }
+  Tex tColor = { pl.R[2] }, tIp = { pl.Ip[2] }, tOColor = { pl.O[1] }, tId = { pl.Id[1] }, tOId = { pl.OId };
+  hipLaunchKernelGGL(k_filter_final, grid, block, 0, stream, tColor, tIp, tOColor, tId, tOId, out, W, H, hdr);
+}
+
+}  // namespace flx

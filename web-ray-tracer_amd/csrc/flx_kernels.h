@@ -32,6 +32,10 @@ struct WavefrontBuffers {
 size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units);
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
                       hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
+/* denoise chain (flx_filter.hip): 13 RGBA8 planes = the reference's RenderTexture[0..3], IpRenderTexture[0..3],
+ * OriginalRenderTexture[0..1], IdRenderTexture[0..1], OriginalIdRenderTexture (pathtracerWGL2.js:224-252). */
+struct FilterPlanes { uint32_t *R[4], *Ip[4], *O[2], *Id[2], *OId; };
+void launch_filter_chain(const GBufferPtrs &gb, const FilterPlanes &pl, float4 *out, int W, int H, int hdr, hipStream_t stream);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, uint32_t n, hipStream_t stream);
 
 }  // namespace flx
