@@ -134,16 +134,8 @@ def main():
         dst_index = torch.tensor(dst_row, device="cuda")
         assert sorted(dst_row) == list(range(H))
 
-    host_out = None
-    if use_filter:
-        host_out = np.zeros((rows_local, W, 4), np.float32)
-
     def step():
-        if use_filter:
-            # filter-on frames go through flx_render (host output); the chain runs on the GPU.
-            ctx.render(params)
-            return
-        ctx.render_device(params, local.data_ptr())
+        ctx.render_device(params, local.data_ptr())         # filter-on frames: trace + denoise chain, all on the GPU
         if world > 1:
             dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
             frame.index_copy_(0, dst_index, gathered.view(world * rows_max, W, 4).index_select(0, src_index))
@@ -171,20 +163,14 @@ def main():
     # Dominant-kernel duration, measured live with HIP events on the launch stream, outside the timed
     # region so the event syncs do not perturb it: same frame, K more launches.
     for _ in range(min(args.steps, 10)):
-        if use_filter:
-            ctx.render(params)
-        else:
-            ctx.render_device(params, local.data_ptr())
+        ctx.render_device(params, local.data_ptr())
         frame_ms, trace_ms = ctx.last_frame_ms()
         kernel_ms.append(trace_ms)
     # Work counters of this rank's share of the frame (a counted launch; not timed).
     ctx.set_counters_enabled(True)
-    if use_filter:
-        _, cnt, _ = ctx.render(params, counters=True)
-    else:
-        ctx.render_device(params, local.data_ptr())
-        ctx.sync()
-        cnt = ctx.get_counters()
+    ctx.render_device(params, local.data_ptr())
+    ctx.sync()
+    cnt = ctx.get_counters()
     ctx.set_counters_enabled(False)
     torch.cuda.synchronize()
 
@@ -207,7 +193,7 @@ def main():
                 "rays_per_frame": rays,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_trace_pixels", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_trace_pixels" if use_filter else "k_wf_walk (bounce 0)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": k_ms,
                 "note": "algorithmic bytes = 48 B x entries visited + 160 B x shades + 24 B x lights x shades + 4 B x texels + 16 B x pixels (SURVEY.md 8d); the <=12 MB scene is cache resident, real HBM traffic is far lower",

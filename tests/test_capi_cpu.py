@@ -1,0 +1,76 @@
+"""CPU-side checks of the C ABI: the library loads without a GPU, exports every symbol the header
+declares, and refuses to create a context without a device (no CPU fallback).  No compute calls."""
+import ctypes as C
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "flexlight_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(flx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    from flexlight_hip import capi
+    names = declared_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(capi.LIB, name), "libflexlight_hip.so does not export %s" % name
+    assert sorted(capi.EXPORTS) == [n for n in names if n in capi.EXPORTS]
+    missing = [n for n in names if n not in capi.EXPORTS]
+    assert not missing, "capi.EXPORTS lacks %s" % missing
+
+
+def test_no_cpu_fallback():
+    import torch
+    from flexlight_hip import capi
+    if torch.cuda.is_available():
+        return                      # on a GPU box a context is legitimately created
+    try:
+        capi.Context(0)
+    except capi.FlexLightHipError as e:
+        assert "no HIP device" in str(e) or "failed" in str(e)
+    else:
+        raise AssertionError("a context was created without a GPU")
+
+
+def test_tile_policy_helpers():
+    from flexlight_hip import capi
+    from flexlight_hip.scene_io import FrameParams
+    p = FrameParams()
+    p.width, p.height = 64, 37
+    assert capi.Context.tile_row_count(p) == 37
+    seen = []
+    for idx in range(3):
+        p.tile_rows, p.tile_index, p.tile_count = 8, idx, 3
+        rows = capi.Context.tile_rows(p)
+        assert rows == [y for y in range(37) if (y // 8) % 3 == idx]
+        seen += rows
+    assert sorted(seen) == list(range(37))
+
+
+def test_struct_layouts_match_the_c_compiler(tmp_path):
+    """ctypes mirrors of the header structs against gcc's own sizeof / offsetof (a drift corrupts every call)."""
+    import subprocess
+    from flexlight_hip.scene_io import Counters, FrameParams, GBuffers, SceneView
+    src = tmp_path / "layout.c"
+    src.write_text(r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "flexlight_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu\n", sizeof(flx_frame_params), sizeof(flx_counters), sizeof(flx_gbuffers), sizeof(flx_scene_view));
+  printf("%zu %zu %zu %zu %zu\n", offsetof(flx_frame_params, view_matrix), offsetof(flx_frame_params, ambient),
+         offsetof(flx_frame_params, tile_rows), offsetof(flx_scene_view, atlas), offsetof(flx_scene_view, atlas_h));
+  return 0;
+}
+""")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes, offs = [list(map(int, l.split())) for l in subprocess.check_output([str(exe)]).decode().splitlines()]
+    assert sizes == [C.sizeof(FrameParams), C.sizeof(Counters), C.sizeof(GBuffers), C.sizeof(SceneView)]
+    assert offs == [FrameParams.view_matrix.offset, FrameParams.ambient.offset, FrameParams.tile_rows.offset,
+                    SceneView.atlas.offset, SceneView.atlas_h.offset]

@@ -1,0 +1,41 @@
+"""End to end through the JavaScript path on the GPU: FlexLight facade -> scene graph -> flattening ->
+N-API addon -> libflexlight_hip.so, compared with the same frame through the ctypes binding of the
+fixture arrays and with the CPU oracle.  The cornell scene is built purely through the API (no asset
+files), so this runs on the GPU box."""
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from parity_util import assert_parity
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("filt", [0, 1])
+def test_cornell_through_node_matches_capi_and_oracle(hip, oracle, scenes, tmp_path, filt):
+    node = shutil.which("node")
+    addon = os.path.join(ROOT, "web-ray-tracer_amd", "napi", "flexlight_napi.node")
+    assert node, "node is part of the image"
+    assert os.path.exists(addon), "N-API addon not built (run __graft_entry__.build())"
+    out = tmp_path / "frame.f32"
+    w, h, spp, bounces = 96, 64, 2, 3
+    info = json.loads(subprocess.check_output(
+        [node, os.path.join(ROOT, "tools", "render_scene.js"), "cornell", "--out", str(out), "--width", str(w), "--height", str(h),
+         "--spp", str(spp), "--bounces", str(bounces), "--filter", str(filt), "--assets", "/nonexistent"], timeout=300).decode().splitlines()[-1])
+    got = np.fromfile(out, np.float32).reshape(h, w, 4)
+    sc = scenes("cornell")
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=filt)
+    hip.update_scene(sc)
+    via_capi, cnt, _ = hip.render(p, counters=True)
+    want, want_cnt, _ = oracle.render(sc, p)
+    assert np.array_equal(got, via_capi, equal_nan=True)
+    rms, mism = assert_parity(got, want, "cornell via node")
+    assert mism == 0
+    js_cnt = info["counters"]
+    assert js_cnt["shades"] == want_cnt["shades"] and js_cnt["closestVisits"] == want_cnt["closest_visits"]
+    assert js_cnt["primaryHits"] == want_cnt["primary_hits"]

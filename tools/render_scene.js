@@ -1,0 +1,47 @@
+'use strict';
+/*
+ * Render one BASELINE scene through the whole JavaScript path — FlexLight facade, scene graph, host
+ * flattening, N-API addon, libflexlight_hip.so — and write the float32 radiance to a file.
+ *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --assets DIR]
+ */
+const fs = require('fs');
+const os = require('os');
+const path = require('path');
+const childProcess = require('child_process');
+const ROOT = path.resolve(__dirname, '..');
+const { FlexLight, Transform } = require(path.join(ROOT, 'web-ray-tracer_amd', 'js', 'flexlight.js'));
+const scenes = require(path.join(ROOT, 'web-ray-tracer_amd', 'js', 'scenes', 'index.js'));
+
+const args = process.argv.slice(2);
+const name = args[0];
+const opt = (flag, d) => { const i = args.indexOf(flag); return i >= 0 ? args[i + 1] : d; };
+const assets = opt('--assets', process.env.FLX_REFERENCE || '/root/reference');
+
+function loadImage (rel) {
+  const tmp = path.join(os.tmpdir(), 'flx-img-' + process.pid + '.rgba');
+  const py = 'import sys; from PIL import Image; im = Image.open(sys.argv[1]).convert("RGBA"); open(sys.argv[2], "wb").write(im.tobytes()); print(im.width, im.height)';
+  const dims = childProcess.execFileSync('python3', ['-c', py, path.join(assets, rel), tmp]).toString().trim().split(' ').map(Number);
+  const data = new Uint8Array(fs.readFileSync(tmp));
+  fs.unlinkSync(tmp);
+  return { width: dims[0], height: dims[1], data };
+}
+
+(async () => {
+  const frame = scenes[name].frame;
+  const canvas = { width: Number(opt('--width', frame.width)), height: Number(opt('--height', frame.height)) };
+  Transform.reset();
+  const log = console.log; console.log = () => {};
+  const engine = new FlexLight(canvas, { assetRoot: assets });
+  engine.loadImage = async rel => loadImage(rel);
+  await scenes[name](engine);
+  console.log = log;
+  engine.config.samplesPerRay = Number(opt('--spp', frame.samplesPerRay));
+  engine.config.maxReflections = Number(opt('--bounces', frame.maxReflections));
+  engine.config.filter = Number(opt('--filter', frame.filter ? 1 : 0)) === 1;
+  engine.renderer = 'pathtracer';
+  await engine.renderer.updateScene();
+  const f = engine.renderer.renderFrame({ counters: true });
+  fs.writeFileSync(opt('--out', 'frame.f32'), Buffer.from(f.radiance.buffer));
+  console.log(JSON.stringify({ width: f.width, height: f.height, rows: f.rows, frameMs: f.frameMs, counters: f.counters }));
+  engine.renderer.halt();
+})().catch(e => { console.error(e); process.exit(1); });

@@ -1,0 +1,156 @@
+'use strict';
+/*
+ * PathTracerHIP — the FlexLight renderer object whose frames are traced by libflexlight_hip.so on an
+ * MI355X instead of by WebGL2.  It has the shape FlexLight expects from a renderer
+ * (reference modules/pathtracerWGL2.js:25-78,143,167,191; SURVEY.md §8b): type, public config /
+ * camera / scene, fps, fpsLimit, canvas getter, async render(), halt(), async updateScene(),
+ * async updatePrimaryLightSources() — plus renderFrame(), a synchronous single frame for headless use.
+ * Conventions kept from the reference: config, camera and scene are re-read every frame; lights,
+ * transforms and (when their list changed) atlases are re-derived every frame (pathtracerWGL2.js:
+ * 258-262, 361-365); errors of the frame loop go to console.error, renderFrame() throws.
+ * The "canvas" is any object with width and height; if it has onFrame(frame) the loop calls it.
+ */
+const path = require('path');
+const { Transform } = require('./scene.js');
+const sceneFile = require('./sceneFile.js');
+
+let addon = null;
+function native () {
+  if (!addon) {
+    const file = path.join(__dirname, '..', 'napi', 'flexlight_napi.node');
+    try {
+      addon = require(file);
+    } catch (e) {
+      throw new Error('flexlight_napi.node is not built or cannot load libflexlight_hip.so (' + e.message +
+        '). Build with `python -c "import __graft_entry__ as g; g.build()"`. There is no CPU fallback.');
+    }
+  }
+  return addon;
+}
+
+class PathTracerHIP {
+  constructor (canvas, scene, camera, config, options) {
+    this.type = 'pathtracer';
+    this.config = config;
+    this.camera = camera;
+    this.scene = scene;
+    this.fps = 0;
+    this.fpsLimit = Infinity;
+    this._canvas = canvas;
+    this._device = (options && options.device) || 0;
+    this._tile = (options && options.tile) || null;      // {rows, index, count}: this context's strips of the frame
+    this._ctx = null;
+    this._halt = true;
+    this._atlasLists = [null, null, null];
+    this._haveScene = false;
+    this.lastFrame = null;
+  }
+
+  get canvas () { return this._canvas; }
+
+  _context () {
+    if (!this._ctx) this._ctx = native().createContext(this._device);
+    return this._ctx;
+  }
+
+  halt () {                                               // pathtracerWGL2.js:70-77
+    this._halt = true;
+    if (this._ctx) {
+      try { native().destroyContext(this._ctx); } catch (e) { console.warn('Unable to release the GPU context', e.message); }
+      this._ctx = null;
+      this._haveScene = false;
+      this._atlasLists = [null, null, null];
+    }
+  }
+
+  async updateScene () {                                  // pathtracerWGL2.js:167-189
+    const built = await this.scene.generateArraysFromGraph();
+    native().uploadScene(this._context(), built.geometryBuffer, built.sceneBuffer, built.idBuffer);
+    this._haveScene = true;
+  }
+
+  async updatePrimaryLightSources () {                    // pathtracerWGL2.js:143-165
+    native().uploadLights(this._context(), sceneFile.buildLightArray(this.scene));
+  }
+
+  _updateAtlases () {                                     // pathtracerWGL2.js:106-140: rebuild only when the list object or its members changed
+    const lists = [this.scene.textures, this.scene.pbrTextures, this.scene.translucencyTextures];
+    lists.forEach((list, which) => {
+      const old = this._atlasLists[which];
+      if (old && old.length === list.length && list.every((e, i) => e === old[i])) return;
+      this._atlasLists[which] = list.slice();
+      if (list.length === 0) { native().uploadAtlas(this._context(), which, null, 0, 0); return; }
+      const atlas = sceneFile.buildAtlas(list, this.scene.standardTextureSizes);
+      native().uploadAtlas(this._context(), which, atlas.data, atlas.width, atlas.height);
+    });
+  }
+
+  frameParams () {                                        // pathtracerWGL2.js:307-347
+    const w = this._canvas.width, h = this._canvas.height;
+    const p = {
+      width: w, height: h,
+      camera: [this.camera.x, this.camera.y, this.camera.z],
+      viewMatrix: Array.from(sceneFile.buildViewMatrix(this.camera, w, h)),
+      samples: this.config.samplesPerRay,
+      maxReflections: this.config.maxReflections,
+      minImportancy: this.config.minImportancy,
+      useFilter: this.config.filter ? 1 : 0,
+      isTemporal: 0,                                      // no history pass in this back-end (SURVEY.md §8f N1)
+      hdr: this.config.hdr ? 1 : 0,
+      ambient: [this.scene.ambientLight[0], this.scene.ambientLight[1], this.scene.ambientLight[2]],
+      randomSeed: 0,                                      // pathtracerWGL2.js:347 with temporal off
+      textureWidth: Math.floor(2048 / this.scene.standardTextureSizes[0])
+    };
+    if (this._tile) { p.tileRows = this._tile.rows; p.tileIndex = this._tile.index; p.tileCount = this._tile.count; }
+    return p;
+  }
+
+  /* One frame, synchronously.  Returns {width, height, rows, radiance: Float32Array(rows*width*4), frameMs, traceMs, counters?}. */
+  renderFrame (options) {
+    const ctx = this._context();
+    if (!this._haveScene) {
+      const built = this.scene.generateArraysFromGraph();
+      native().uploadScene(ctx, built.geometryBuffer, built.sceneBuffer, built.idBuffer);
+      this._haveScene = true;
+    }
+    this._updateAtlases();
+    native().uploadLights(ctx, sceneFile.buildLightArray(this.scene));
+    const tr = Transform.buildWGL2Arrays();
+    native().uploadTransforms(ctx, tr[0], tr[1]);
+    const p = this.frameParams();
+    const rows = native().tileRowCount(p);
+    const radiance = new Float32Array(rows * p.width * 4);
+    const info = native().render(ctx, p, radiance, !!(options && options.counters));
+    this.lastFrame = Object.assign({ width: p.width, height: p.height, rows, radiance }, info);
+    return this.lastFrame;
+  }
+
+  async render () {                                       // pathtracerWGL2.js:191-831: start the frame loop
+    if (!this._halt) return;                              // already running (the WebGPU renderer guards the same way)
+    this._halt = false;
+    await this.updateScene();
+    let frames = 0, windowStart = Date.now();
+    const cycle = () => {
+      if (this._halt) return;
+      try {
+        const frame = this.renderFrame();
+        if (typeof this._canvas.onFrame === 'function') this._canvas.onFrame(frame);
+      } catch (e) {
+        console.error(e);
+        this._halt = true;
+        return;
+      }
+      frames++;
+      const now = Date.now();
+      if (now - windowStart >= 500) {                     // pathtracerWGL2.js:293-298
+        this.fps = (1000 * frames / (now - windowStart)).toFixed(0);
+        frames = 0; windowStart = now;
+      }
+      if (this.fpsLimit === Infinity) setImmediate(cycle);
+      else setTimeout(cycle, 1000 / this.fpsLimit);
+    };
+    setImmediate(cycle);
+  }
+}
+
+module.exports = { PathTracerHIP };

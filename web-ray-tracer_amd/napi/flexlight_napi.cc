@@ -1,0 +1,285 @@
+/*
+ * flexlight_napi.cc — thin N-API shim over the C ABI of libflexlight_hip.so (include/flexlight_hip.h).
+ *
+ * One JS function per C entry point, typed arrays in, typed arrays out, no logic: the JavaScript
+ * renderer (js/pathtracerHIP.js) is to this addon what modules/pathtracerWGL2.js is to the WebGL2
+ * context.  A non-zero flx_status becomes a JS exception carrying flx_last_error().  Memory: every
+ * typed array stays owned by JS; the library copies in during the call (napi_get_typedarray_info
+ * gives the backing store, nothing is retained).  Built with plain g++ against /usr/include/node
+ * (no node-gyp, no network): napi/Makefile.
+ */
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+
+#include "flexlight_hip.h"
+
+#define NAPI_OK(env, call)                                                     \
+  do {                                                                         \
+    if ((call) != napi_ok) { napi_throw_error((env), nullptr, "N-API call failed: " #call); return nullptr; } \
+  } while (0)
+
+static napi_value fail(napi_env env, flx_context *ctx, const char *what, flx_status rc) {
+  std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + flx_last_error(ctx);
+  napi_throw_error(env, nullptr, msg.c_str());
+  return nullptr;
+}
+
+static bool get_args(napi_env env, napi_callback_info info, size_t want, napi_value *argv) {
+  size_t argc = want;
+  if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < want) {
+    napi_throw_type_error(env, nullptr, "wrong number of arguments");
+    return false;
+  }
+  return true;
+}
+
+static flx_context *get_ctx(napi_env env, napi_value v) {
+  void *p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a context handle"); return nullptr; }
+  flx_context *ctx = *static_cast<flx_context **>(p);
+  if (!ctx) napi_throw_error(env, nullptr, "context was halted");
+  return ctx;
+}
+
+/* typed array -> pointer + element count; null / undefined -> nullptr, 0 */
+static bool typed(napi_env env, napi_value v, napi_typedarray_type want, void **data, size_t *len) {
+  napi_valuetype t;
+  napi_typeof(env, v, &t);
+  if (t == napi_null || t == napi_undefined) { *data = nullptr; *len = 0; return true; }
+  bool is = false;
+  napi_is_typedarray(env, v, &is);
+  napi_typedarray_type type;
+  if (!is || napi_get_typedarray_info(env, v, &type, len, data, nullptr, nullptr) != napi_ok ||
+      (type != want && !(want == napi_uint8_array && type == napi_uint8_clamped_array))) {
+    napi_throw_type_error(env, nullptr, "expected a typed array of the right element type");
+    return false;
+  }
+  return true;
+}
+
+static bool num(napi_env env, napi_value obj, const char *key, double *out, bool required = true) {
+  napi_value v;
+  bool has = false;
+  napi_has_named_property(env, obj, key, &has);
+  if (!has) {
+    if (required) { napi_throw_type_error(env, nullptr, (std::string("frame params: missing ") + key).c_str()); return false; }
+    return true;
+  }
+  napi_get_named_property(env, obj, key, &v);
+  napi_valuetype t;
+  napi_typeof(env, v, &t);
+  if (t == napi_boolean) { bool b; napi_get_value_bool(env, v, &b); *out = b ? 1.0 : 0.0; return true; }
+  if (napi_get_value_double(env, v, out) != napi_ok) { napi_throw_type_error(env, nullptr, (std::string("frame params: ") + key + " is not a number").c_str()); return false; }
+  return true;
+}
+
+static bool floats(napi_env env, napi_value obj, const char *key, float *dst, size_t n) {
+  napi_value v;
+  if (napi_get_named_property(env, obj, key, &v) != napi_ok) return false;
+  for (size_t i = 0; i < n; i++) {
+    napi_value e; double d;
+    if (napi_get_element(env, v, (uint32_t)i, &e) != napi_ok || napi_get_value_double(env, e, &d) != napi_ok) {
+      napi_throw_type_error(env, nullptr, (std::string("frame params: ") + key + " needs " + std::to_string(n) + " numbers").c_str());
+      return false;
+    }
+    dst[i] = (float)d;
+  }
+  return true;
+}
+
+static void finalize_ctx(napi_env, void *data, void *) {
+  flx_context **slot = static_cast<flx_context **>(data);
+  if (*slot) flx_context_destroy(*slot);
+  delete slot;
+}
+
+/* createContext(device) -> handle */
+static napi_value CreateContext(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  int32_t device = 0;
+  NAPI_OK(env, napi_get_value_int32(env, argv[0], &device));
+  flx_context *ctx = nullptr;
+  flx_status rc = flx_context_create(device, &ctx);
+  if (rc != FLX_OK) return fail(env, nullptr, "flx_context_create", rc);
+  napi_value ext;
+  NAPI_OK(env, napi_create_external(env, new flx_context *(ctx), finalize_ctx, nullptr, &ext));
+  return ext;
+}
+
+/* destroyContext(handle): halt() */
+static napi_value DestroyContext(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  void *p = nullptr;
+  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+    flx_context **slot = static_cast<flx_context **>(p);
+    if (*slot) { flx_context_destroy(*slot); *slot = nullptr; }
+  }
+  return nullptr;
+}
+
+/* uploadScene(handle, geometry Float32Array, attributes Float32Array, ids Int32Array) */
+static napi_value UploadScene(napi_env env, napi_callback_info info) {
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  void *g, *a, *ids; size_t ng, na, nids;
+  if (!typed(env, argv[1], napi_float32_array, &g, &ng) || !typed(env, argv[2], napi_float32_array, &a, &na) ||
+      !typed(env, argv[3], napi_int32_array, &ids, &nids)) return nullptr;
+  if (ng % 12 != 0 || na / 28 != ng / 12 || na % 28 != 0) { napi_throw_range_error(env, nullptr, "geometry needs 12 and attributes 28 floats per entry"); return nullptr; }
+  flx_status rc = flx_scene_upload(ctx, (const float *)g, (const float *)a, (uint32_t)(ng / 12), (const int32_t *)ids, (uint32_t)nids);
+  if (rc != FLX_OK) return fail(env, ctx, "flx_scene_upload", rc);
+  return nullptr;
+}
+
+/* uploadTransforms(handle, rotation Float32Array(24 T), shift Float32Array(8 T)) */
+static napi_value UploadTransforms(napi_env env, napi_callback_info info) {
+  napi_value argv[3];
+  if (!get_args(env, info, 3, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  void *r, *s; size_t nr, ns;
+  if (!typed(env, argv[1], napi_float32_array, &r, &nr) || !typed(env, argv[2], napi_float32_array, &s, &ns)) return nullptr;
+  if (ns % 8 != 0 || nr != ns * 3) { napi_throw_range_error(env, nullptr, "rotation needs 24 and shift 8 floats per transform"); return nullptr; }
+  flx_status rc = flx_transforms_upload(ctx, (const float *)r, (const float *)s, (uint32_t)(ns / 8));
+  if (rc != FLX_OK) return fail(env, ctx, "flx_transforms_upload", rc);
+  return nullptr;
+}
+
+/* uploadLights(handle, lights Float32Array(6 L)) */
+static napi_value UploadLights(napi_env env, napi_callback_info info) {
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  void *l; size_t nl;
+  if (!typed(env, argv[1], napi_float32_array, &l, &nl)) return nullptr;
+  if (nl % 6 != 0) { napi_throw_range_error(env, nullptr, "lights needs 6 floats per light"); return nullptr; }
+  flx_status rc = flx_lights_upload(ctx, (const float *)l, (uint32_t)(nl / 6));
+  if (rc != FLX_OK) return fail(env, ctx, "flx_lights_upload", rc);
+  return nullptr;
+}
+
+/* uploadAtlas(handle, which, rgba Uint8Array | null, width, height) */
+static napi_value UploadAtlas(napi_env env, napi_callback_info info) {
+  napi_value argv[5];
+  if (!get_args(env, info, 5, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  int32_t which; uint32_t w, h;
+  NAPI_OK(env, napi_get_value_int32(env, argv[1], &which));
+  void *px; size_t n;
+  if (!typed(env, argv[2], napi_uint8_array, &px, &n)) return nullptr;
+  NAPI_OK(env, napi_get_value_uint32(env, argv[3], &w));
+  NAPI_OK(env, napi_get_value_uint32(env, argv[4], &h));
+  if (px && n != (size_t)w * h * 4) { napi_throw_range_error(env, nullptr, "atlas needs width*height*4 bytes"); return nullptr; }
+  flx_status rc = flx_atlas_upload(ctx, which, (const uint8_t *)px, w, h);
+  if (rc != FLX_OK) return fail(env, ctx, "flx_atlas_upload", rc);
+  return nullptr;
+}
+
+static bool read_params(napi_env env, napi_value o, flx_frame_params *p) {
+  memset(p, 0, sizeof *p);
+  double d = 0;
+  if (!num(env, o, "width", &d)) return false; p->width = (uint32_t)d;
+  if (!num(env, o, "height", &d)) return false; p->height = (uint32_t)d;
+  if (!floats(env, o, "camera", p->camera, 3) || !floats(env, o, "viewMatrix", p->view_matrix, 9) || !floats(env, o, "ambient", p->ambient, 3)) return false;
+  if (!num(env, o, "samples", &d)) return false; p->samples = (int32_t)d;
+  if (!num(env, o, "maxReflections", &d)) return false; p->max_reflections = (int32_t)d;
+  if (!num(env, o, "minImportancy", &d)) return false; p->min_importancy = (float)d;
+  d = 0; if (!num(env, o, "useFilter", &d, false)) return false; p->use_filter = (int32_t)d;
+  d = 0; if (!num(env, o, "isTemporal", &d, false)) return false; p->is_temporal = (int32_t)d;
+  d = 1; if (!num(env, o, "hdr", &d, false)) return false; p->hdr = (int32_t)d;
+  d = 0; if (!num(env, o, "randomSeed", &d, false)) return false; p->random_seed = (float)d;
+  if (!num(env, o, "textureWidth", &d)) return false; p->texture_width = (int32_t)d;
+  d = 0; if (!num(env, o, "tileRows", &d, false)) return false; p->tile_rows = (uint32_t)d;
+  d = 0; if (!num(env, o, "tileIndex", &d, false)) return false; p->tile_index = (uint32_t)d;
+  d = 0; if (!num(env, o, "tileCount", &d, false)) return false; p->tile_count = (uint32_t)d;
+  return true;
+}
+
+/* tileRowCount(params) -> rows this context renders */
+static napi_value TileRowCount(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_frame_params p;
+  if (!read_params(env, argv[0], &p)) return nullptr;
+  napi_value r;
+  NAPI_OK(env, napi_create_uint32(env, flx_tile_row_count(&p), &r));
+  return r;
+}
+
+/* render(handle, params, out Float32Array(rows*width*4), wantCounters) -> { frameMs, traceMs, counters? } */
+static napi_value Render(napi_env env, napi_callback_info info) {
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  flx_frame_params p;
+  if (!read_params(env, argv[1], &p)) return nullptr;
+  void *out; size_t n;
+  if (!typed(env, argv[2], napi_float32_array, &out, &n)) return nullptr;
+  if (!out || n != (size_t)flx_tile_row_count(&p) * p.width * 4) { napi_throw_range_error(env, nullptr, "out needs rows*width*4 floats"); return nullptr; }
+  bool want = false;
+  napi_get_value_bool(env, argv[3], &want);
+  flx_counters c;
+  flx_status rc = flx_render(ctx, &p, (float *)out, nullptr, want ? &c : nullptr);
+  if (rc != FLX_OK) return fail(env, ctx, "flx_render", rc);
+  float frame_ms = 0.f, trace_ms = 0.f;
+  flx_last_frame_ms(ctx, &frame_ms, &trace_ms);
+  napi_value res, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  napi_create_double(env, frame_ms, &v); napi_set_named_property(env, res, "frameMs", v);
+  napi_create_double(env, trace_ms, &v); napi_set_named_property(env, res, "traceMs", v);
+  if (want) {
+    napi_value co;
+    napi_create_object(env, &co);
+    const char *names[8] = { "primaryVisits", "closestVisits", "shadowVisits", "closestWalks", "shadowWalks", "shades", "primaryHits", "atlasTexels" };
+    const uint64_t vals[8] = { c.primary_visits, c.closest_visits, c.shadow_visits, c.closest_walks, c.shadow_walks, c.shades, c.primary_hits, c.atlas_texels };
+    for (int i = 0; i < 8; i++) { napi_create_double(env, (double)vals[i], &v); napi_set_named_property(env, co, names[i], v); }
+    napi_set_named_property(env, res, "counters", co);
+  }
+  return res;
+}
+
+/* deviceInfo(handle) -> { name, computeUnits } */
+static napi_value DeviceInfo(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  char name[256]; uint32_t cus = 0;
+  flx_device_info(ctx, name, sizeof name, &cus);
+  napi_value res, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, res, "name", v);
+  napi_create_uint32(env, cus, &v); napi_set_named_property(env, res, "computeUnits", v);
+  return res;
+}
+
+static napi_value Version(napi_env env, napi_callback_info) {
+  napi_value v;
+  napi_create_string_utf8(env, flx_version(), NAPI_AUTO_LENGTH, &v);
+  return v;
+}
+
+static napi_value Init(napi_env env, napi_value exports) {
+  const struct { const char *name; napi_callback fn; } fns[] = {
+    { "createContext", CreateContext }, { "destroyContext", DestroyContext }, { "uploadScene", UploadScene },
+    { "uploadTransforms", UploadTransforms }, { "uploadLights", UploadLights }, { "uploadAtlas", UploadAtlas },
+    { "tileRowCount", TileRowCount }, { "render", Render }, { "deviceInfo", DeviceInfo }, { "version", Version },
+  };
+  for (const auto &f : fns) {
+    napi_value fn;
+    if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn) != napi_ok) return nullptr;
+    napi_set_named_property(env, exports, f.name, fn);
+  }
+  return exports;
+}
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)
