@@ -1,0 +1,199 @@
+"""Known-answer tests that pin the CPU oracle (oracle/): hand-computable cases for the intersection
+routines, the RNG and the BRDF, behaviour at NaN / zero-direction edge cases the path relies on
+(SURVEY.md §7 R2), committed whole-frame fixtures, and include/flx_math.h against libm.  CPU only."""
+import ctypes as C
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIAS = 2.0 ** -16
+F3 = C.c_float * 3
+F9 = C.c_float * 9
+
+
+@pytest.fixture(scope="module")
+def lib(oracle):
+    l = oracle.lib()
+    l.flx_oracle_moeller_trumbore.argtypes = [F9, F3, F3, C.c_float, F3]
+    l.flx_oracle_moeller_trumbore_cull.argtypes = [F9, F3, F3, C.c_float]
+    l.flx_oracle_moeller_trumbore_cull.restype = C.c_int
+    l.flx_oracle_ray_cuboid.argtypes = [C.c_float, F3, F3, F3, F3]
+    l.flx_oracle_ray_cuboid.restype = C.c_int
+    l.flx_oracle_noise.argtypes = [C.c_float] * 4 + [C.c_float * 4]
+    l.flx_oracle_forward_trace.argtypes = [F9, F3, C.c_float, F3, F3, F3]
+    l.flx_oracle_math.argtypes = [C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32]
+    return l
+
+
+UNIT_TRI = F9(0, 0, 0, 1, 0, 0, 0, 1, 0)          # a, b, c in the z = 0 plane, normal (e1 x e2) = +z
+
+
+def mt(lib, origin, direction, l=1e9, tri=UNIT_TRI):
+    out = F3()
+    lib.flx_oracle_moeller_trumbore(tri, F3(*origin), F3(*direction), l, out)
+    return tuple(out)
+
+
+def test_moeller_trumbore_known_hit(lib):
+    s, u, v = mt(lib, (0.25, 0.25, 1.0), (0, 0, -1))
+    assert (s, u, v) == (1.0, 0.25, 0.25)
+    # two-sided: from below as well (fragment:128 tests abs(det))
+    assert mt(lib, (0.25, 0.5, -2.0), (0, 0, 1)) == (2.0, 0.25, 0.5)
+
+
+def test_moeller_trumbore_rejections(lib):
+    assert mt(lib, (0.25, 0.25, 1.0), (1, 0, 0)) == (0, 0, 0)              # parallel: |det| < BIAS
+    assert mt(lib, (2.0, 0.25, 1.0), (0, 0, -1)) == (0, 0, 0)             # u > 1
+    assert mt(lib, (0.75, 0.75, 1.0), (0, 0, -1)) == (0, 0, 0)            # u + v > 1
+    assert mt(lib, (0.25, 0.25, 1.0), (0, 0, -1), l=0.5) == (0, 0, 0)     # s > l
+    assert mt(lib, (0.25, 0.25, 1.0), (0, 0, -1), l=1.0)[0] == 1.0        # s == l is kept (ties: later entry wins)
+    assert mt(lib, (0.25, 0.25, -1.0), (0, 0, -1)) == (0, 0, 0)           # behind: s <= BIAS
+    # BIAS-wide cracks along the edges (fragment:132,136): u = BIAS/2 misses, u = 2 BIAS hits
+    assert mt(lib, (BIAS / 2, 0.25, 1.0), (0, 0, -1)) == (0, 0, 0)
+    assert mt(lib, (2 * BIAS, 0.25, 1.0), (0, 0, -1))[0] == 1.0
+
+
+def test_moeller_trumbore_nan_direction_misses(lib):
+    nan = float("nan")
+    # NaN never satisfies the rejections of fragment:128-138 -> the shader returns vec3(NaN...) as a hit;
+    # that is the reference's behaviour and what rayTracer's `intersection.x != 0.0` then accepts.
+    s, u, v = mt(lib, (0.25, 0.25, 1.0), (nan, nan, nan))
+    assert math.isnan(s)
+    # the culling variant ends on (s <= l && s > BIAS), false for NaN
+    assert lib.flx_oracle_moeller_trumbore_cull(UNIT_TRI, F3(0.25, 0.25, 1.0), F3(nan, nan, nan), 1e9) == 0
+
+
+def test_moeller_trumbore_cull_is_one_sided(lib):
+    hit = lambda o, d, l=1e9: lib.flx_oracle_moeller_trumbore_cull(UNIT_TRI, F3(*o), F3(*d), l)
+    # det = e1 . (d x e2) = -d . (e1 x e2): positive only when the ray runs against e1 x e2 = +z
+    assert hit((0.25, 0.25, 1.0), (0, 0, -1)) == 1
+    assert hit((0.25, 0.25, -1.0), (0, 0, 1)) == 0        # det = -1 < BIAS: culled (fragment:149)
+    assert hit((0.25, 0.25, 1.0), (0, 0, -1), l=0.5) == 0
+    assert hit((0.25, 0.25, 1.0), (0, 0, -1), l=1.0) == 1
+
+
+def test_ray_cuboid(lib):
+    box = lambda l, o, d: lib.flx_oracle_ray_cuboid(l, F3(*o), F3(*d), F3(-1, -1, -1), F3(1, 1, 1))
+    assert box(1e9, (0, 0, -5), (0, 0, 1)) == 1
+    assert box(3.9, (0, 0, -5), (0, 0, 1)) == 0           # tmin = 4 is not < l
+    assert box(4.1, (0, 0, -5), (0, 0, 1)) == 1
+    assert box(1e9, (0, 0, 5), (0, 0, 1)) == 0            # behind: tmax < BIAS
+    assert box(1e9, (0, 0, 0), (0, 0, 1)) == 1            # inside
+    assert box(1e9, (3, 0, -5), (0, 0, 1)) == 0           # zero direction components: (+-inf) slabs miss in x
+    # origin exactly on the slab plane x = 1 with d.x = 0: v0.x = -inf, v1.x = 0/0 = NaN; GLSL min/max return their
+    # first argument when the second is NaN, so both the near and the far x-slab are -inf and the box is missed
+    assert box(1e9, (1, 0, -5), (0, 0, 1)) == 0
+    nan = float("nan")
+    assert box(1e9, (0, 0, -5), (nan, nan, nan)) == 0     # NaN direction skips every AABB
+
+
+def test_noise_is_the_pinned_formula(lib):
+    out = (C.c_float * 4)()
+    lib.flx_oracle_noise(0.3, -0.2, 1.5, 0.0, out)
+    f = np.float32
+    d = f(f(0.3) * f(12.9898)) + f(f(-0.2) * f(78.233))
+    for k, expect in zip((53.0, 59.0, 61.0, 67.0), out):
+        arg = f(d + f(f(k) * f(1.5)))
+        sv = np.zeros(1, np.float32)
+        lib.flx_oracle_math(0, np.array([arg], np.float32).ctypes.data_as(C.POINTER(C.c_float)), None,
+                            sv.ctypes.data_as(C.POINTER(C.c_float)), 1)
+        x = f(sv[0] * f(43758.5453))
+        want = f(f(x - np.floor(x)) * f(2.0)) - f(1.0)
+        assert f(expect) == want
+        assert -1.0 <= expect <= 1.0
+    # randomSeed enters as seed + randomSeed * PHI (fragment:120)
+    a, b = (C.c_float * 4)(), (C.c_float * 4)()
+    lib.flx_oracle_noise(0.3, -0.2, 1.5, 2.0, a)
+    lib.flx_oracle_noise(0.3, -0.2, float(np.float32(1.5) + np.float32(2.0) * np.float32(1.61803398874989484820459)), 0.0, b)
+    assert tuple(a) == tuple(b)
+
+
+def test_forward_trace_lambert_limit(lib):
+    """Fully rough dielectric lit head-on: Cook-Torrance by hand (fragment:304-334)."""
+    mat = F9(0.8, 0.6, 0.4, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0)
+    out = F3()
+    lib.flx_oracle_forward_trace(mat, F3(0, 0, 3), 16.0, F3(0, 0, 1), F3(0, 0, 1), out)
+    brightness = 16.0 / (1 + 3) ** 2
+    # N = V = L = H: VdotH = NdotL = NdotH = NdotV = 1, alpha = 1, fresnel(F0, 1) = F0 = albedo
+    D = 1.0 / math.pi                    # alpha^2 / (pi * (1*(1-1)+1)^2)
+    G = 1.0                              # schlickBeckmann(1, 1) = 1 / (0.5 + 0.5)
+    for c, albedo in zip(out, (0.8, 0.6, 0.4)):
+        Ks = albedo
+        want = ((1 - Ks) * albedo / math.pi + Ks * D * G / 4.0) * brightness
+        assert c == pytest.approx(want, rel=2e-6)
+    # light behind the surface contributes nothing (NdotL clamps to 0)
+    lib.flx_oracle_forward_trace(mat, F3(1, 0, -3), 16.0, F3(0, 0, 1), F3(0, 0, 1), out)
+    assert tuple(out) == (0.0, 0.0, 0.0)
+    # exactly opposite light and view: H = normalize(0) = NaN, as in the shader (fragment:310)
+    lib.flx_oracle_forward_trace(mat, F3(0, 0, -3), 16.0, F3(0, 0, 1), F3(0, 0, 1), out)
+    assert all(math.isnan(c) for c in out)
+
+
+def test_flx_math_against_libm(lib):
+    rng = np.random.default_rng(7)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    cases = {0: (rng.uniform(-600, 600, 50000), np.sin), 1: (rng.uniform(-600, 600, 50000), np.cos),
+             3: (rng.uniform(-1, 1, 50000), np.arccos), 5: (rng.uniform(-30, 30, 50000), np.exp), 7: (rng.uniform(-6, 6, 50000), np.tanh)}
+    for fn, (x, ref) in cases.items():
+        x = x.astype(np.float32)
+        got = np.empty_like(x)
+        lib.flx_oracle_math(fn, fp(x), None, fp(got), x.size)
+        want = ref(x.astype(np.float64))
+        ulp = np.spacing(np.abs(want).astype(np.float32)).astype(np.float64)
+        assert np.max(np.abs(got - want) / ulp) <= 0.5000001, fn       # correctly rounded (to double-libm accuracy)
+    specials = np.array([np.inf, -np.inf, np.nan, 2.0 ** 21], np.float32)
+    got = np.empty_like(specials)
+    lib.flx_oracle_math(0, fp(specials), None, fp(got), specials.size)
+    assert np.isnan(got).all()           # sin is pinned to NaN outside |x| <= 2^20
+    one = np.array([1.0000001, 1.0, -1.0, -1.5], np.float32)
+    got = np.empty_like(one)
+    lib.flx_oracle_math(3, fp(one), None, fp(got), one.size)
+    assert list(got) == [0.0, 0.0, np.float32(math.pi), np.float32(math.pi)]   # acos clamps (fragment:516 can exceed 1 by rounding)
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "oracle_*.npz"))))
+def test_oracle_reproduces_committed_frames(oracle, scenes, path):
+    name, size, s, b, f = os.path.basename(path)[len("oracle_"):-len(".npz")].rsplit("_", 4)
+    w, h = map(int, size.split("x"))
+    fix = np.load(path)
+    sc = scenes(name)
+    p = sc.frame_params(width=w, height=h, samples=int(s[1:]), max_reflections=int(b[1:]), use_filter=int(f[1:]))
+    img, cnt, _ = oracle.render(sc, p)
+    assert np.array_equal(img, fix["frame"], equal_nan=True)
+    assert [cnt[k] for k in sorted(cnt)] == list(fix["counters"])
+    single, cnt1, _ = oracle.render(sc, p, threads=1)           # OpenMP row split must not matter
+    assert np.array_equal(single, img, equal_nan=True) and cnt1 == cnt
+
+
+def test_oracle_primary_ray_geometry(oracle, scenes):
+    """Centre pixel of the cornell frame looks down +z from (0,0,-20) and hits the back wall at z = 5."""
+    l = oracle.lib()
+    from flexlight_hip.scene_io import FrameParams, SceneView
+    l.flx_oracle_primary.argtypes = [C.POINTER(SceneView), C.POINTER(FrameParams), C.c_uint32, C.c_uint32, F3, C.POINTER(C.c_int), C.POINTER(C.c_int), F3]
+    sc = scenes("cornell")
+    p = sc.frame_params(width=255, height=255)
+    view = sc.view()
+    suv, d = F3(), F3()
+    tid, tri = C.c_int(), C.c_int()
+    l.flx_oracle_primary(C.byref(view), C.byref(p), 127, 127, suv, C.byref(tid), C.byref(tri), d)
+    assert tuple(d) == (0.0, 0.0, 1.0)
+    assert suv[0] == 25.0 and tid.value == 0
+    g = sc.arrays["geometry"].reshape(-1, 12)[tri.value]
+    assert g[10] == 2 and g[2] == 5 and g[5] == 5 and g[8] == 5      # a triangle of the back plane (z = 5)
+
+
+def test_empty_and_degenerate_inputs(oracle, scenes):
+    sc = scenes("cornell")
+    p = sc.frame_params(width=8, height=8, samples=1, max_reflections=0, use_filter=0)
+    img, cnt, _ = oracle.render(sc, p)                      # zero bounces: ambient only, times originalColor (1,1,1)
+    hit = img[..., 3] == 1
+    assert cnt["shades"] == 0 and cnt["closest_walks"] == 0
+    assert np.allclose(img[hit][:, :3], np.array(sc.meta["ambient"], np.float32))
+    bad = sc.frame_params(width=8, height=8)
+    bad.samples = 0
+    with pytest.raises(RuntimeError):
+        oracle.render(sc, bad)

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Small whole-frame fixtures of the CPU oracle (tests/golden/oracle_*.npz): regression pins for the
+restatement itself.  Re-generate only when the oracle's definition changes on purpose."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+import flx_oracle
+from flexlight_hip.scene_io import Scene
+
+CASES = [("cornell", 64, 64, 1, 1, 0), ("cornell", 64, 48, 2, 3, 1), ("cornell_obj", 96, 54, 4, 3, 1),
+         ("dragon", 96, 54, 2, 4, 0), ("theater", 96, 54, 2, 6, 0)]
+for name, w, h, spp, b, filt in CASES:
+    sc = Scene.golden(name)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=b, use_filter=filt)
+    img, cnt, _ = flx_oracle.render(sc, p)
+    out = os.path.join(ROOT, "tests", "golden", "oracle_%s_%dx%d_s%d_b%d_f%d.npz" % (name, w, h, spp, b, filt))
+    np.savez_compressed(out, frame=img, counters=np.array([cnt[k] for k in sorted(cnt)], np.int64), keys=np.array(sorted(cnt)))
+    print(out, img.shape, cnt)
