@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the rank logic)")
+    ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     import numpy as np
@@ -94,12 +96,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     fixture, config_name = WORKLOADS[args.workload]
     scene = Scene.golden(fixture)
@@ -166,11 +173,18 @@ def main():
         ctx.render_device(params, local.data_ptr())
         frame_ms, trace_ms = ctx.last_frame_ms()
         kernel_ms.append(trace_ms)
-    # Work counters of this rank's share of the frame (a counted launch; not timed).
+    # Work counters of this rank's share of the frame (a counted launch; not timed), and of bounce 0 alone
+    # (the same frame cut after one bounce: identical paths) for the dominant kernel's roofline.
     ctx.set_counters_enabled(True)
     ctx.render_device(params, local.data_ptr())
     ctx.sync()
     cnt = ctx.get_counters()
+    cnt_b0 = None
+    if not use_filter and params.max_reflections > 1:
+        p1 = scene.frame_params(width=args.width, height=args.height, tile=tile, max_reflections=1)
+        ctx.render_device(p1, local.data_ptr())
+        ctx.sync()
+        cnt_b0 = ctx.get_counters()
     ctx.set_counters_enabled(False)
     torch.cuda.synchronize()
 
@@ -181,8 +195,20 @@ def main():
         value = rays / (elapsed / args.steps) / 1e6
         n_lights = scene.arrays["lights"].size // 6
         k_ms = float(np.mean(kernel_ms))
-        bytes_launch = algorithmic_bytes(cnt, n_lights, rows_local * W, use_filter)
+        frame_bytes = algorithmic_bytes(cnt, n_lights, rows_local * W, use_filter)
+        if use_filter or cnt_b0 is None:
+            kernel_name, bytes_launch = "k_trace_pixels", frame_bytes - (244 * rows_local * W if use_filter else 0)
+        else:                      # the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
+            kernel_name, bytes_launch = "k_wf_walk (bounce 0)", 48 * (cnt_b0["closest_visits"] + cnt_b0["shadow_visits"])
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
+        traffic = None
+        try:                       # HBM bytes of that kernel from rocprofv3 PMC passes (profiles/, not measurable from inside bench.py)
+            with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
+                t = json.load(fh)
+            if t["workload"] == args.workload and world == 1 and W == 1920 and H == 1080 and kernel_name == t["kernel"]:
+                traffic = t["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         line = {
             "metric": "Mray/s at 1080p (spp x bounces x pixels / s)", "value": value, "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -193,9 +219,10 @@ def main():
                 "rays_per_frame": rays,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "k_trace_pixels" if use_filter else "k_wf_walk (bounce 0)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": k_ms,
+                "frame_algorithmic_bytes": frame_bytes, "frame_achieved": frame_bytes / (ms_per_step * 1e-3) / 1e9,
                 "note": "algorithmic bytes = 48 B x entries visited + 160 B x shades + 24 B x lights x shades + 4 B x texels + 16 B x pixels (SURVEY.md 8d); the <=12 MB scene is cache resident, real HBM traffic is far lower",
             },
             "counters": cnt,
