@@ -331,7 +331,7 @@ static flx_status make_frame(flx_context *ctx, const flx_frame_params *p, Device
   sc.geometry = ctx->d_geometry; sc.attributes = ctx->d_attributes;
   sc.rotation = ctx->d_rotation; sc.shift = ctx->d_shift; sc.lights = ctx->d_lights;
   for (int i = 0; i < 3; i++) { sc.atlas[i] = ctx->d_atlas[i]; sc.atlas_w[i] = ctx->atlas_w[i]; sc.atlas_h[i] = ctx->atlas_h[i]; }
-  sc.n_entries = ctx->n_entries; sc.n_lights = ctx->n_lights;
+  sc.n_entries = ctx->n_entries; sc.n_lights = ctx->n_lights; sc.n_transforms = ctx->n_transforms;
   sc.walk = ctx->d_walk; sc.walk_entries = ctx->walk_entries; sc.walk_hot = ctx->walk_hot; sc.walk_root = ctx->walk_root; sc.walk_fast_boxes = ctx->walk_fast_boxes;
   uint32_t tr, ti, tc;
   tile_normalise(p, tr, ti, tc);

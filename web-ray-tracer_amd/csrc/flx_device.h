@@ -76,6 +76,7 @@ struct DeviceScene {
   uint32_t atlas_w[3], atlas_h[3];
   uint32_t n_entries;           /* padded entry count = loop bound (fragment:181-184) */
   uint32_t n_lights;
+  uint32_t n_transforms;
   /* Threaded copy of the skip list for the walk kernels (built at upload, flx_api.hip: build_threaded):
    * same entries, same logical visit order, but every entry names its successors explicitly, so the
    * array can be stored hot-first (shallow tree levels in front) and its prefix staged in LDS. */
@@ -755,6 +756,46 @@ FLX_DEV bool walkTriT(WalkState &w, const WalkEntry &cur) {
 FLX_DEV void walkStartT(const DeviceScene &sc, WalkState &w, int mode, const Ray &ray, float len) {
   w.mode = mode; w.src = ray; w.tR = ray; w.cachedTI = 0; w.minLen = len; w.i = (int)sc.walk_root;
   walkPrepareRay(sc, w);
+}
+
+/* ---- threaded walk with the ray pre-transformed into every object space --------------------------
+ * A ray meets a new transform ~3 times per walk (dragon scene); done per lane inside the stepping loop
+ * that is ~100 VALU instructions (two mat3 products, a normalize) executed for ONE lane while 63 wait,
+ * in almost every wave-iteration.  The walk kernel therefore transforms a ray into ALL object spaces
+ * when the walk is set up (a batched point where many lanes set up together, with the matrices read
+ * through scalar loads) and parks the results in LDS; the stepping loop only reloads 2 x 16 bytes.
+ * The arithmetic per (ray, transform) is exactly fragment:197-202 / :257-262. */
+FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, float4 *rays, const Ray &src, bool shadowMode) {
+  for (uint32_t t = 0; t < nTransforms; t++) {
+    const int iI = 2 * (int)t + 1;
+    M3 rotationII = rotation_at(sc, iI);
+    f3 o = mul(rotationII, src.origin + shift_at(sc, iI));
+    f3 d = mul(rotationII, src.dir);
+    if (__ballot(shadowMode) != 0ull) {                   /* skip the normalize when no lane of the wave sets up a shadow walk */
+      f3 dn = normalize(d);
+      if (shadowMode) d = dn;                             /* fragment:261 normalises, fragment:201 does not */
+    }
+    rays[2 * t] = make_float4(o.x, o.y, o.z, 0.0f);
+    rays[2 * t + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+  }
+}
+template <bool COUNT>
+FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float4 *rays, WalkState &w, WalkEntry &cur,
+                        WorkCounters &cnt) {
+  const uint32_t i = (uint32_t)w.i;
+  if (i == WALK_END) return true;
+  if (i < ldsCount) { cur.e0 = lds[3 * i]; cur.e1 = lds[3 * i + 1]; cur.e2 = lds[3 * i + 2]; }
+  else { cur.e0 = sc.walk[3 * (size_t)i]; cur.e1 = sc.walk[3 * (size_t)i + 1]; cur.e2 = sc.walk[3 * (size_t)i + 2]; }
+  if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
+  const int meta = __float_as_int(cur.e2.z);
+  const int tI = (meta >> 2) << 1;
+  if (tI != w.cachedTI) {
+    w.cachedTI = tI;
+    const float4 o = rays[tI], d = rays[tI + 1];          /* slot of transform tI/2 */
+    w.tR.origin = F3(o.x, o.y, o.z);
+    w.tR.dir = F3(d.x, d.y, d.z);
+  }
+  return (meta & 3) == 0;
 }
 
 /* The two traversals of one bounce in ONE loop: shadowTest (fragment:231-280) on so.shadowRay, then

@@ -37,6 +37,12 @@ constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves p
 #ifndef FLX_WF_LDS_BYTES
 #define FLX_WF_LDS_BYTES 131072              /* LDS given to the hot prefix of the threaded skip list (of 160 KB per CU) */
 #endif
+#ifndef FLX_WF_PRETRANSFORM
+#define FLX_WF_PRETRANSFORM 1
+#endif
+#ifndef FLX_WF_LDS_TOTAL
+#define FLX_WF_LDS_TOTAL (156 * 1024)         /* LDS a walk workgroup may use (of 160 KB per CU) */
+#endif
 #ifndef FLX_WF_INNER
 #define FLX_WF_INNER 4
 #endif
@@ -328,19 +334,204 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
   }
 }
 
+/* ---- walk kernel, pre-transformed rays (the default when the scene's transforms fit in LDS) ---------- */
+enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4 };
+
+template <bool COUNT>
+__global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
+                                                                     uint32_t ldsCount, uint32_t nTransforms) {
+  /* LDS: [tree top: ldsCount entries x 48 B][per thread: nTransforms x (origin, dir) float4 pairs] */
+  extern __shared__ float4 ldsAll[];
+  float4 *ldsEntries = ldsAll;
+  float4 *myRays = ldsAll + (size_t)ldsCount * 3u + (size_t)threadIdx.x * nTransforms * 2u;
+  for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
+  __syncthreads();
+  const uint32_t n = (b == 0) ? total_items : wb.counts[b];
+  const uint32_t waveId = blockIdx.x * (FLX_WF_WALK_THREADS / 64u) + (threadIdx.x >> 6);
+  if (waveId * (64u * FLX_WF_ITEMS_PER_LANE) >= n && waveId != 0u) return;
+  const uint32_t *__restrict__ listIn = wb.live[b & 1];
+  uint32_t *__restrict__ listOut = wb.live[(b + 1) & 1];
+  uint32_t *__restrict__ queue = wb.walkQueue + b;
+  uint32_t *__restrict__ outAlloc = wb.counts + (b + 1);
+  const uint32_t lane = threadIdx.x & 63u;
+  WorkCounters cnt = {};
+  uint32_t diagIters = 0, diagBatches = 0;
+  long long tFold = 0, tRefill = 0, tInner = 0, tStart = COUNT ? clock64() : 0;
+
+  int st = P_EMPTY;
+  uint32_t pathId = 0;
+  int flags = 0;
+  float base = 0.0f;
+  Ray nextRay; nextRay.origin = F3(0.f, 0.f, 0.f); nextRay.dir = nextRay.origin;
+  Ray shadowRay = nextRay;
+  float shadowLen = 0.0f;
+  WalkState w;
+  walkClearResults(w);
+  w.src = nextRay; w.tR = nextRay; w.minLen = 0.0f; w.i = 0; w.cachedTI = 0;
+  w.mode = 2;
+  WalkEntry cur;
+  cur.e0 = cur.e1 = cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t chunkNext = 0, chunkEnd = 0;
+  bool itemsLeft = true;
+  uint32_t outBase = 0, outUsed = WF_OUT_CHUNK;
+  bool outValid = false;
+
+  for (;;) {
+    const unsigned long long walking = __ballot(st == P_WALKING);
+    const unsigned long long workMask = __ballot(st == P_DONE || st == P_SWITCH);
+    const bool canRefill = itemsLeft || chunkNext != chunkEnd;
+    const uint32_t parked = 64u - (uint32_t)__popcll(walking);
+    if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || canRefill))) {
+      if (COUNT) diagBatches++;
+      long long t0 = COUNT ? clock64() : 0;
+      /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475 ------------ */
+      if (__ballot(st == P_DONE) != 0ull) {
+        bool append = false;
+        if (st == P_DONE) {
+          float4 *rec = wb.rec + (size_t)pathId * 8;
+          const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+          const bool shadowed = (flags & RF_SHADOWED_NO_WALK) || ((flags & RF_NEED_SHADOW) && w.shadowed);
+          const f3 localColor = shadowed ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
+          const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
+          const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
+          bool cont = w.tri != -1;
+          if (cont) cont = (b + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+          if (cont) {
+            rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
+            rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
+            append = true;
+          } else {
+            finalize_path(fr, wb, pathId, finalColor, importancy, originalColor);
+          }
+          st = P_EMPTY;
+        }
+        const unsigned long long am = __ballot(append);
+        if (am != 0ull) {
+          const uint32_t cntA = (uint32_t)__popcll(am);
+          const uint32_t r = lane_rank(am);
+          const uint32_t room = WF_OUT_CHUNK - outUsed;
+          const uint32_t seg1 = cntA < room ? cntA : room;
+          if (append && r < seg1) listOut[outBase + outUsed + r] = pathId;
+          outUsed += seg1;
+          if (cntA > seg1) {
+            uint32_t nb = 0;
+            if (lane == 0) nb = atomicAdd(outAlloc, WF_OUT_CHUNK);
+            nb = __builtin_amdgcn_readfirstlane(nb);
+            outBase = nb; outValid = true;
+            if (append && r >= seg1) listOut[outBase + (r - seg1)] = pathId;
+            outUsed = cntA - seg1;
+          }
+        }
+      }
+      long long t1 = COUNT ? clock64() : 0;
+      if (COUNT) tFold += t1 - t0;
+      /* ---- refill the free lanes from the walk queue ------------------------------------------------ */
+      for (;;) {
+        const unsigned long long idle = __ballot(st == P_EMPTY);
+        if (idle == 0ull) break;
+        if (chunkNext == chunkEnd) {
+          if (!itemsLeft) break;
+          uint32_t base0 = 0;
+          if (lane == 0) base0 = atomicAdd(queue, WF_IN_CHUNK);
+          base0 = __builtin_amdgcn_readfirstlane(base0);
+          if (base0 >= n) { itemsLeft = false; break; }
+          chunkNext = base0;
+          chunkEnd = (base0 + WF_IN_CHUNK < n) ? base0 + WF_IN_CHUNK : n;
+        }
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        const uint32_t avail = chunkEnd - chunkNext;
+        const uint32_t take = nIdle < avail ? nIdle : avail;
+        const uint32_t r = lane_rank(idle);
+        if (st == P_EMPTY && r < take) {
+          const uint32_t j = chunkNext + r;
+          const uint32_t id = (b == 0) ? j : listIn[j];
+          if (id != WF_INVALID) {
+            const float4 *rec = wb.rec + (size_t)id * 8;
+            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];     /* one cache line, four loads in flight */
+            const int fl = __float_as_int(q0.w);
+            if (!(fl & RF_DEAD)) {
+              pathId = id; flags = fl; base = q2.w;
+              nextRay.origin = F3(q0.x, q0.y, q0.z);
+              nextRay.dir = F3(q1.x, q1.y, q1.z);
+              shadowRay.origin = F3(q2.x, q2.y, q2.z);
+              shadowRay.dir = F3(q3.x, q3.y, q3.z);
+              shadowLen = q1.w;
+              walkClearResults(w);
+              w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
+              if (COUNT) { if (w.mode == 0) cnt.shadow_walks++; cnt.closest_walks++; }
+              st = P_SETUP;
+            }
+          }
+        }
+        chunkNext += take;
+      }
+      /* ---- set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended -------- */
+      if (st == P_SWITCH) { w.mode = 1; st = P_SETUP; }
+      if (__ballot(st == P_SETUP) != 0ull) {
+        if (st == P_SETUP) {
+          const bool shadowMode = w.mode == 0;
+          const Ray src = shadowMode ? shadowRay : nextRay;
+          walkSetupRays(sc, nTransforms, myRays, src, shadowMode);
+          w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
+          st = P_WALKING;
+          if (walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
+        }
+      }
+      if (COUNT) tRefill += clock64() - t1;
+      if (__ballot(st == P_WALKING) == 0ull) {
+        if (itemsLeft || chunkNext != chunkEnd || __ballot(st == P_SWITCH || st == P_DONE) != 0ull) continue;
+        break;
+      }
+    }
+    long long t2 = COUNT ? clock64() : 0;
+    /* ---- FLX_WF_INNER entries for every walking lane ------------------------------------------------- */
+#pragma unroll 1
+    for (int it = 0; it < FLX_WF_INNER; it++) {
+      if (COUNT) diagIters++;
+      if (st == P_WALKING) {
+        bool ended = false;
+        if (walkIsBoxT(cur)) walkBoxT(w, cur); else ended = walkTriT(w, cur);
+        if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
+        if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
+      }
+    }
+    if (COUNT) tInner += clock64() - t2;
+  }
+  if (outValid) {
+    for (uint32_t t = outUsed + lane; t < WF_OUT_CHUNK; t += 64u) listOut[outBase + t] = WF_INVALID;
+  }
+  flush_counters<COUNT>(cnt, wb.counters);
+  if (COUNT && lane == 0) {
+    atomicAdd(wb.counters + 8 + 2 * (b < 4 ? b : 3), (unsigned long long)diagIters); atomicAdd(wb.counters + 9 + 2 * (b < 4 ? b : 3), (unsigned long long)diagBatches);
+    if (b == 0) {
+      atomicAdd(wb.counters + 16, (unsigned long long)tFold); atomicAdd(wb.counters + 17, (unsigned long long)tRefill);
+      atomicAdd(wb.counters + 18, (unsigned long long)tInner); atomicAdd(wb.counters + 19, (unsigned long long)(clock64() - tStart)); atomicAdd(wb.counters + 20, 1ull);
+    }
+  }
+}
+
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
                       hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
   const uint32_t total = path_item_count(fr);
   const uint32_t maxBlocks = compute_units * 8u;
-  /* walk kernel: one big workgroup per CU sharing one LDS copy of the tree top */
-  uint32_t ldsCount = (uint32_t)(FLX_WF_LDS_BYTES / 48);
+  /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
+   * (n_transforms x 32 B each) when they fit, the rest goes to the tree top. */
+  const uint32_t T = sc.n_transforms;
+  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 32u;
+  const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 128u * 1024u;
+  const uint32_t ldsBudget = (uint32_t)FLX_WF_LDS_TOTAL - (pre ? rayBytes : 0u);
+  uint32_t ldsCount = ldsBudget / 48u;
   if (ldsCount > sc.walk_hot) ldsCount = sc.walk_hot;
-  const uint32_t ldsBytes = ldsCount * 48u;
-  const uint32_t walkBlocks = compute_units * (160u * 1024u / (ldsBytes > 16384u ? ldsBytes : 16384u) > 8u ? 8u : (160u * 1024u / (ldsBytes > 16384u ? ldsBytes : 16384u)));
+  const uint32_t ldsBytes = ldsCount * 48u + (pre ? rayBytes : 0u);
+  uint32_t perCu = (160u * 1024u) / (ldsBytes > 20480u ? ldsBytes : 20480u);
+  if (perCu > 8u) perCu = 8u;
+  const uint32_t walkBlocks = compute_units * perCu;
   static bool attrSet = false;
   if (!attrSet) {
     (void)hipFuncSetAttribute((const void *)k_wf_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attrSet = true;
   }
   const int bounces = fr.max_reflections > 0 ? fr.max_reflections : 1;   /* 0 bounces: shade(0) only finalises */
@@ -355,8 +546,13 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
       else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
     }
     if (b == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
-    if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
-    else hipLaunchKernelGGL(k_wf_walk<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
+    if (pre) {
+      if (count) hipLaunchKernelGGL(k_wf_walk_pre<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+      else hipLaunchKernelGGL(k_wf_walk_pre<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+    } else {
+      if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
+      else hipLaunchKernelGGL(k_wf_walk<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
+    }
     if (b == 0 && walk0_end) (void)hipEventRecord(walk0_end, stream);
   }
 }
