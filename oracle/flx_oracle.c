@@ -218,10 +218,19 @@ static const Hit NO_HIT = { { 0.0f, 0.0f, 0.0f }, 0, -1 };     /* fragment:81 */
 
 /* analysis hook (tools/visit_histogram.py): when set, every entry fetch is tallied per entry index */
 static uint64_t *g_visit_hist = NULL;
+/* analysis hook: g_walk_hist[k] counts walks with 2^k <= visits < 2^(k+1) (k < 31), [31] = longest walk */
+static uint64_t *g_walk_hist = NULL;
+static void tally_walk(uint64_t v) {
+  if (!g_walk_hist) return;
+  int k = 0; while ((v >> (k + 1)) && k < 30) k++;
+  _Pragma("omp atomic") g_walk_hist[k]++;
+  _Pragma("omp critical") { if (v > g_walk_hist[31]) g_walk_hist[31] = v; }
+}
 
 /* fragment:172-227.  mode 0 = rayTracer as written; mode 1 = primary visibility (same walk, the
  * primary triangle rule, strict "<" so the first of equal-depth triangles is kept). */
 static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float viewDepthPerS, uint64_t *visits) {
+  const uint64_t visits0 = *visits;
   Ray tR = ray;
   int cachedTI = 0;
   Hit hit = NO_HIT;
@@ -239,7 +248,7 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
       tR.origin = m3mul(rotationII, add3(ray.origin, shift_at(sc, iI)));
       tR.unitDirection = m3mul(rotationII, ray.unitDirection);
     }
-    if (e[10] == 0.0f) return hit;
+    if (e[10] == 0.0f) { if (!mode) tally_walk(*visits - visits0); return hit; }
     if (e[10] == 1.0f) {
       if (!rayCuboid(minLen, tR, V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]))) i += (int)e[6];
     } else {
@@ -252,6 +261,7 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
       }
     }
   }
+  if (!mode) tally_walk(*visits - visits0);
   return hit;
 }
 
@@ -695,6 +705,7 @@ void flx_oracle_primary(const flx_scene_view *scene, const flx_frame_params *par
   dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
 }
 void flx_oracle_set_visit_histogram(uint64_t *hist) { g_visit_hist = hist; }
+void flx_oracle_set_walk_histogram(uint64_t *hist32) { g_walk_hist = hist32; }
 
 void flx_oracle_math(int fn, const float *a, const float *b, float *out, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) {

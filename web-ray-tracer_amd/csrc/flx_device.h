@@ -642,28 +642,36 @@ FLX_DEV float divByRecip(float a, float d, float y) {
   return __builtin_fmaf(r, y, q);
 }
 /* tR changed: refresh the reciprocal and decide whether the fast box test may be used for this ray. */
+/* RN(1/d) per component and whether (d, o) are in the range where divByRecip() is proven exact. */
+FLX_DEV void reciprocalOfDir(const DeviceScene &sc, f3 d, f3 o, f3 &inv, bool &fast) {
+  inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const float LO = 8.673617379884035e-19f, HI = 1.152921504606847e18f, OHI = 5.764607523034235e17f;   /* 2^-60, 2^60, 2^59 */
+  const float ax = flx_abs(d.x), ay = flx_abs(d.y), az = flx_abs(d.z);
+  fast = sc.walk_fast_boxes != 0u && ax >= LO && ax <= HI && ay >= LO && ay <= HI && az >= LO && az <= HI &&
+         flx_abs(o.x) <= OHI && flx_abs(o.y) <= OHI && flx_abs(o.z) <= OHI;
+}
 #ifndef FLX_WF_RECIP_DIV
-#define FLX_WF_RECIP_DIV 0     /* measured on MI355X (dragon frame): the 3 extra divisions per transform change eat the gain; off */
+#define FLX_WF_RECIP_DIV 0     /* k_wf_walk (rays transformed on the fly): the 3 extra divisions per transform change eat the gain; off */
 #endif
 FLX_DEV void walkPrepareRay(const DeviceScene &sc, WalkState &w) {
 #if !FLX_WF_RECIP_DIV
   (void)sc; (void)w;
   return;
 #endif
-  const f3 d = w.tR.dir, o = w.tR.origin;
-  w.inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const float LO = 8.673617379884035e-19f, HI = 1.152921504606847e18f, OHI = 5.764607523034235e17f;   /* 2^-60, 2^60, 2^59 */
-  const float ax = flx_abs(d.x), ay = flx_abs(d.y), az = flx_abs(d.z);
-  w.fastDiv = sc.walk_fast_boxes != 0u && ax >= LO && ax <= HI && ay >= LO && ay <= HI && az >= LO && az <= HI &&
-              flx_abs(o.x) <= OHI && flx_abs(o.y) <= OHI && flx_abs(o.z) <= OHI;
+  reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
 }
 /* rayCuboid (fragment:161-167) with the six quotients taken through divByRecip when its preconditions
  * hold (same bits as the division, so the same boolean), through `/` otherwise (zero, denormal, huge,
  * infinite or NaN components: the reference's behaviour there is whatever IEEE division gives). */
+FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCorner);
 FLX_DEV bool rayCuboidR(float l, const WalkState &w, f3 minCorner, f3 maxCorner) {
 #if !FLX_WF_RECIP_DIV
   return rayCuboid(l, w.tR, minCorner, maxCorner);
+#else
+  return rayCuboidRecip(l, w, minCorner, maxCorner);
 #endif
+}
+FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCorner) {
   const f3 o = w.tR.origin, d = w.tR.dir, y = w.inv;
   const f3 a0 = minCorner - o, a1 = maxCorner - o;
   /* every |a| is 0 or >= 2^-40:  (bits & 0x7fffffff) - 1 as unsigned is huge for 0 and small for tiny values */
@@ -675,6 +683,13 @@ FLX_DEV bool rayCuboidR(float l, const WalkState &w, f3 minCorner, f3 maxCorner)
   t = (flx_f2u(a1.y) & 0x7fffffffu) - 1u; m = t < m ? t : m;
   t = (flx_f2u(a1.z) & 0x7fffffffu) - 1u; m = t < m ? t : m;
   f3 v0, v1;
+#ifdef FLX_DIAG_SLOW
+  { extern __device__ unsigned long long g_diagSlow[4];
+    const bool slow = !(w.fastDiv && m >= 0x2b800000u - 1u);
+    const unsigned long long sm = __ballot(slow);
+    if (sm && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)sm) - 1u) { atomicAdd(&g_diagSlow[0], (unsigned long long)__popcll(sm)); atomicAdd(&g_diagSlow[1], 1ull); if (!w.fastDiv) atomicAdd(&g_diagSlow[2], 1ull); }
+    if ((threadIdx.x & 63u) == 0u || !(__ballot(1) & 1ull)) {} }
+#endif
   if (w.fastDiv && m >= 0x2b800000u - 1u) {
     v0 = F3(divByRecip(a0.x, d.x, y.x), divByRecip(a0.y, d.y, y.y), divByRecip(a0.z, d.z, y.z));
     v1 = F3(divByRecip(a1.x, d.x, y.x), divByRecip(a1.y, d.y, y.y), divByRecip(a1.z, d.z, y.z));
@@ -775,8 +790,11 @@ FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, float4 *
       f3 dn = normalize(d);
       if (shadowMode) d = dn;                             /* fragment:261 normalises, fragment:201 does not */
     }
-    rays[2 * t] = make_float4(o.x, o.y, o.z, 0.0f);
-    rays[2 * t + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+    f3 inv; bool fast;
+    reciprocalOfDir(sc, d, o, inv, fast);
+    rays[3 * t] = make_float4(o.x, o.y, o.z, 0.0f);
+    rays[3 * t + 1] = make_float4(d.x, d.y, d.z, 0.0f);
+    rays[3 * t + 2] = make_float4(inv.x, inv.y, inv.z, fast ? 1.0f : 0.0f);
   }
 }
 template <bool COUNT>
@@ -791,11 +809,43 @@ FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
   const int tI = (meta >> 2) << 1;
   if (tI != w.cachedTI) {
     w.cachedTI = tI;
-    const float4 o = rays[tI], d = rays[tI + 1];          /* slot of transform tI/2 */
+    const int slot = (tI >> 1) * 3;                       /* slot of transform tI/2 */
+    const float4 o = rays[slot], d = rays[slot + 1], y = rays[slot + 2];
     w.tR.origin = F3(o.x, o.y, o.z);
     w.tR.dir = F3(d.x, d.y, d.z);
+    w.inv = F3(y.x, y.y, y.z);
+    w.fastDiv = y.w != 0.0f;
   }
   return (meta & 3) == 0;
+}
+/* Entry fetch split from its use, so the loads of BOTH possible successors can be issued before the
+ * current entry is tested and complete while the test's ~100 VALU instructions run. */
+FLX_DEV void walkLoadEntry(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, uint32_t i, WalkEntry &e) {
+  if (i == WALK_END) { e.e0 = e.e1 = e.e2 = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+  if (i < ldsCount) { e.e0 = lds[3 * i]; e.e1 = lds[3 * i + 1]; e.e2 = lds[3 * i + 2]; }
+  else { e.e0 = sc.walk[3 * (size_t)i]; e.e1 = sc.walk[3 * (size_t)i + 1]; e.e2 = sc.walk[3 * (size_t)i + 2]; }
+}
+/* The rest of walkFetchP once `cur` holds entry w.i: visit count, transform change, terminator test. */
+template <bool COUNT>
+FLX_DEV bool walkArriveP(const float4 *rays, WalkState &w, const WalkEntry &cur, WorkCounters &cnt) {
+  if ((uint32_t)w.i == WALK_END) return true;
+  if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
+  const int meta = __float_as_int(cur.e2.z);
+  const int tI = (meta >> 2) << 1;
+  if (tI != w.cachedTI) {
+    w.cachedTI = tI;
+    const int slot = (tI >> 1) * 3;
+    const float4 o = rays[slot], d = rays[slot + 1], y = rays[slot + 2];
+    w.tR.origin = F3(o.x, o.y, o.z);
+    w.tR.dir = F3(d.x, d.y, d.z);
+    w.inv = F3(y.x, y.y, y.z);
+    w.fastDiv = y.w != 0.0f;
+  }
+  return (meta & 3) == 0;
+}
+FLX_DEV void walkBoxP(WalkState &w, const WalkEntry &cur) {
+  const bool hit = rayCuboidRecip(w.minLen, w, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y));
+  w.i = hit ? __float_as_int(cur.e2.x) : __float_as_int(cur.e2.y);
 }
 
 /* The two traversals of one bounce in ONE loop: shadowTest (fragment:231-280) on so.shadowRay, then

@@ -23,10 +23,15 @@
  * path writes its radiance to its own slot, summed in sample order by k_resolve — so the frame is
  * bit-identical to the per-pixel kernel and to the CPU oracle.
  */
+#include <cstdio>
 #include "flx_kernels.h"
 #include "flx_kernel_util.h"
 
 namespace flx {
+
+#ifdef FLX_DIAG_SLOW
+__device__ unsigned long long g_diagSlow[4];
+#endif
 
 constexpr uint32_t WF_INVALID = 0xffffffffu;
 constexpr uint32_t WF_IN_CHUNK = 256;       /* path ids a wave draws from the walk queue per atomic */
@@ -36,6 +41,9 @@ constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves p
 #endif
 #ifndef FLX_WF_LDS_BYTES
 #define FLX_WF_LDS_BYTES 131072              /* LDS given to the hot prefix of the threaded skip list (of 160 KB per CU) */
+#endif
+#ifndef FLX_WF_PREFETCH
+#define FLX_WF_PREFETCH 0     /* measured: doubling the entry loads costs more than the latency it hides */
 #endif
 #ifndef FLX_WF_PRETRANSFORM
 #define FLX_WF_PRETRANSFORM 1
@@ -53,7 +61,7 @@ constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves p
 #define FLX_WALK_WAVES 1
 #endif
 #ifndef FLX_WF_ITEMS_PER_LANE
-#define FLX_WF_ITEMS_PER_LANE 8
+#define FLX_WF_ITEMS_PER_LANE 4
 #endif
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 16                     /* parked lanes that trigger a fold + refill */
@@ -340,10 +348,10 @@ enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4 };
 template <bool COUNT>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
                                                                      uint32_t ldsCount, uint32_t nTransforms) {
-  /* LDS: [tree top: ldsCount entries x 48 B][per thread: nTransforms x (origin, dir) float4 pairs] */
+  /* LDS: [tree top: ldsCount entries x 48 B][per thread: nTransforms x (origin, dir, 1/dir + fast flag) float4 triples] */
   extern __shared__ float4 ldsAll[];
   float4 *ldsEntries = ldsAll;
-  float4 *myRays = ldsAll + (size_t)ldsCount * 3u + (size_t)threadIdx.x * nTransforms * 2u;
+  float4 *myRays = ldsAll + (size_t)ldsCount * 3u + (size_t)threadIdx.x * nTransforms * 3u;
   for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
   __syncthreads();
   const uint32_t n = (b == 0) ? total_items : wb.counts[b];
@@ -473,6 +481,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
           const Ray src = shadowMode ? shadowRay : nextRay;
           walkSetupRays(sc, nTransforms, myRays, src, shadowMode);
           w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
+          reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);      /* the untransformed ray (cachedTI = 0, fragment:174-175) */
           st = P_WALKING;
           if (walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
         }
@@ -489,9 +498,25 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
     for (int it = 0; it < FLX_WF_INNER; it++) {
       if (COUNT) diagIters++;
       if (st == P_WALKING) {
+#if FLX_WF_PREFETCH
+        /* both successors are named by the entry itself: start their loads now, test the entry meanwhile */
+        const bool isBox = walkIsBoxT(cur);
+        const uint32_t succA = isBox ? (uint32_t)__float_as_int(cur.e2.x) : (uint32_t)__float_as_int(cur.e2.y);   /* box hit / triangle next */
+        const uint32_t succB = (uint32_t)__float_as_int(cur.e2.y);                                              /* box miss */
+        WalkEntry nA, nB;
+        walkLoadEntry(sc, ldsEntries, ldsCount, succA, nA);
+        if (isBox) walkLoadEntry(sc, ldsEntries, ldsCount, succB, nB); else nB = nA;
         bool ended = false;
-        if (walkIsBoxT(cur)) walkBoxT(w, cur); else ended = walkTriT(w, cur);
+        if (isBox) walkBoxP(w, cur); else ended = walkTriT(w, cur);
+        if (!ended) {
+          cur = ((uint32_t)w.i == succA) ? nA : nB;
+          ended = walkArriveP<COUNT>(myRays, w, cur, cnt);
+        }
+#else
+        bool ended = false;
+        if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
         if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
+#endif
         if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
       }
     }
@@ -512,13 +537,16 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
 
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
                       hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
+#ifdef FLX_DIAG_SLOW
+  { unsigned long long h[4]; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diagSlow), sizeof h); fprintf(stderr, "diag slow-box: lanes %llu wave-events %llu notFast %llu\n", h[0], h[1], h[2]); }
+#endif
   const uint32_t total = path_item_count(fr);
   const uint32_t maxBlocks = compute_units * 8u;
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
    * (n_transforms x 32 B each) when they fit, the rest goes to the tree top. */
   const uint32_t T = sc.n_transforms;
-  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 32u;
-  const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 128u * 1024u;
+  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 48u;
+  const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 148u * 1024u;
   const uint32_t ldsBudget = (uint32_t)FLX_WF_LDS_TOTAL - (pre ? rayBytes : 0u);
   uint32_t ldsCount = ldsBudget / 48u;
   if (ldsCount > sc.walk_hot) ldsCount = sc.walk_hot;
