@@ -109,7 +109,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get("FLX_BENCH_FORCE_DIST") == "1"      # rehearse the RCCL code path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -122,7 +123,8 @@ def main():
     full = scene.frame_params(width=args.width, height=args.height)
     use_filter = int(full.use_filter)
     W, H = full.width, full.height
-    tile = (args.tile_rows, rank, world) if world > 1 else (0, 0, 0)
+    multi = world > 1 or force_dist
+    tile = (args.tile_rows, rank, world) if multi else (0, 0, 0)
     params = scene.frame_params(width=args.width, height=args.height, tile=tile)
     if use_filter and world > 1:
         raise SystemExit("filter-on workloads are single-GPU for now (the filter is not pixel-independent, SURVEY.md §8e)")
@@ -134,12 +136,12 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     rows_local = ctx.tile_row_count(params)
-    strips = (H + args.tile_rows - 1) // args.tile_rows if world > 1 else 1
-    rows_max = ((strips + world - 1) // world) * args.tile_rows if world > 1 else H
+    strips = (H + args.tile_rows - 1) // args.tile_rows if multi else 1
+    rows_max = ((strips + world - 1) // world) * args.tile_rows if multi else H
     local = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world, rows_max, W, 4), dtype=torch.float32, device="cuda") if world > 1 else None
-    frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if world > 1 else None
-    if world > 1:
+    gathered = torch.empty((world, rows_max, W, 4), dtype=torch.float32, device="cuda") if multi else None
+    frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if multi else None
+    if multi:
         # image row of every (rank, packed row) slot, -1 for padding
         src_rank, src_row, dst_row = [], [], []
         for r in range(world):
@@ -152,13 +154,13 @@ def main():
 
     def step():
         ctx.render_device(params, local.data_ptr())         # filter-on frames: trace + denoise chain, all on the GPU
-        if world > 1:
+        if multi:
             dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
             frame.index_copy_(0, dst_index, gathered.view(world * rows_max, W, 4).index_select(0, src_index))
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -171,7 +173,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -240,7 +242,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(scene, full)
         print(json.dumps(line), flush=True)
     ctx.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

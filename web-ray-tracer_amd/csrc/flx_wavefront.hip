@@ -42,8 +42,8 @@ constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves p
 #ifndef FLX_WF_LDS_BYTES
 #define FLX_WF_LDS_BYTES 131072              /* LDS given to the hot prefix of the threaded skip list (of 160 KB per CU) */
 #endif
-#ifndef FLX_WF_PREFETCH
-#define FLX_WF_PREFETCH 0     /* measured: doubling the entry loads costs more than the latency it hides */
+#ifndef FLX_WF_TAIL_LANES
+#define FLX_WF_TAIL_LANES 0      /* >0: waves with this few walking lanes (queue dry) prefetch both successors; measured slower (profiles/r01_ab_tail_prefetch.txt), off */
 #endif
 #ifndef FLX_WF_PRETRANSFORM
 #define FLX_WF_PRETRANSFORM 1
@@ -492,31 +492,34 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         break;
       }
     }
+    const bool tailMode = FLX_WF_TAIL_LANES > 0 && !(itemsLeft || chunkNext != chunkEnd) && (uint32_t)__popcll(__ballot(st == P_WALKING)) <= (uint32_t)FLX_WF_TAIL_LANES;
     long long t2 = COUNT ? clock64() : 0;
     /* ---- FLX_WF_INNER entries for every walking lane ------------------------------------------------- */
 #pragma unroll 1
     for (int it = 0; it < FLX_WF_INNER; it++) {
       if (COUNT) diagIters++;
       if (st == P_WALKING) {
-#if FLX_WF_PREFETCH
-        /* both successors are named by the entry itself: start their loads now, test the entry meanwhile */
-        const bool isBox = walkIsBoxT(cur);
-        const uint32_t succA = isBox ? (uint32_t)__float_as_int(cur.e2.x) : (uint32_t)__float_as_int(cur.e2.y);   /* box hit / triangle next */
-        const uint32_t succB = (uint32_t)__float_as_int(cur.e2.y);                                              /* box miss */
-        WalkEntry nA, nB;
-        walkLoadEntry(sc, ldsEntries, ldsCount, succA, nA);
-        if (isBox) walkLoadEntry(sc, ldsEntries, ldsCount, succB, nB); else nB = nA;
         bool ended = false;
-        if (isBox) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-        if (!ended) {
-          cur = ((uint32_t)w.i == succA) ? nA : nB;
-          ended = walkArriveP<COUNT>(myRays, w, cur, cnt);
+        if (tailMode) {
+          /* few lanes left and nothing to refill: the kernel's end is now the longest remaining walk, one
+           * dependent fetch -> test -> fetch chain per entry.  Both successors are named by the entry itself:
+           * start their loads before the test so they complete under it (costs twice the loads — only worth it
+           * here, where the memory pipes are idle). */
+          const bool isBox = walkIsBoxT(cur);
+          const uint32_t succA = isBox ? (uint32_t)__float_as_int(cur.e2.x) : (uint32_t)__float_as_int(cur.e2.y);   /* box hit / triangle next */
+          const uint32_t succB = (uint32_t)__float_as_int(cur.e2.y);                                              /* box miss */
+          WalkEntry nA, nB;
+          walkLoadEntry(sc, ldsEntries, ldsCount, succA, nA);
+          if (isBox) walkLoadEntry(sc, ldsEntries, ldsCount, succB, nB); else nB = nA;
+          if (isBox) walkBoxP(w, cur); else ended = walkTriT(w, cur);
+          if (!ended) {
+            cur = ((uint32_t)w.i == succA) ? nA : nB;
+            ended = walkArriveP<COUNT>(myRays, w, cur, cnt);
+          }
+        } else {
+          if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
+          if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
         }
-#else
-        bool ended = false;
-        if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-        if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
-#endif
         if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
       }
     }
