@@ -149,7 +149,7 @@ flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
 flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, const float *b, float *out, uint32_t n);
 /* Scheduler statistics of the last counted frame (wavefront pipeline): for bounce b = 0..3 (3 = all
  * later ones) out[2b] = wave-iterations of the walk kernel, out[2b+1] = fold/refill batches. */
-flx_status flx_get_diag(flx_context *ctx, uint64_t out[16]);   /* out[8..12]: bounce-0 walk kernel stamps: fold, refill, step cycles, wave lifetime, waves */
+flx_status flx_get_diag(flx_context *ctx, uint64_t out[32]);   /* out[8..12]: bounce-0 walk kernel stamps: fold, refill, step cycles, wave lifetime, waves; out[16+3b..]: per bounce sum / count / max of wave lifetimes */
 /* Device name / CU count of the context's GPU. */
 flx_status flx_device_info(flx_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units);
 const char *flx_version(void);

@@ -24,4 +24,6 @@ for bounces in range(1, sc.meta["frame"]["maxReflections"] + 1):
     if b == 0:
         fold, refill, inner, life, waves = d[8:13]
         print('   bounce-0 walk waves %d: mean lifetime %.0f cycles; share fold %.3f refill %.3f steps %.3f; cycles per wave-iteration %.0f' % (waves, life / max(1, waves), fold / max(1, life), refill / max(1, life), inner / max(1, life), inner / max(1, it)))
+    if b < 4 and d[17 + 3 * b]:
+        print('   wave lifetimes: %d waves, mean %.0f, max %.0f cycles' % (d[17 + 3 * b], d[16 + 3 * b] / d[17 + 3 * b], d[18 + 3 * b]))
     prev = cnt

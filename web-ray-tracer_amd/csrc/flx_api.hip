@@ -106,7 +106,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_frame1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&ctx->d_counters, 24 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_counters, 40 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_wfcounts, 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   *out = ctx;
@@ -390,7 +390,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     }
   }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
-  if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, 24 * sizeof(unsigned long long), ctx->stream));
+  if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, 40 * sizeof(unsigned long long), ctx->stream));
   if (pipeline == 1) {
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     launch_trace_pixels(sc, fr, d_out, gb, cnt, ctx->stream);
@@ -545,11 +545,11 @@ extern "C" flx_status flx_get_counters(flx_context *ctx, flx_counters *out) {
   return FLX_OK;
 }
 
-extern "C" flx_status flx_get_diag(flx_context *ctx, uint64_t out[16]) {
+extern "C" flx_status flx_get_diag(flx_context *ctx, uint64_t out[32]) {
   if (!ctx || !out) return FLX_ERR_INVALID;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  FLX_HIP(ctx, hipMemcpy(out, ctx->d_counters + 8, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  FLX_HIP(ctx, hipMemcpy(out, ctx->d_counters + 8, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return FLX_OK;
 }
 

@@ -42,6 +42,9 @@ constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves p
 #ifndef FLX_WF_LDS_BYTES
 #define FLX_WF_LDS_BYTES 131072              /* LDS given to the hot prefix of the threaded skip list (of 160 KB per CU) */
 #endif
+#ifndef FLX_WF_DRAWS_PER_WAVE
+#define FLX_WF_DRAWS_PER_WAVE 16
+#endif
 #ifndef FLX_WF_TAIL_LANES
 #define FLX_WF_TAIL_LANES 0      /* >0: waves with this few walking lanes (queue dry) prefetch both successors; measured slower (profiles/r01_ab_tail_prefetch.txt), off */
 #endif
@@ -362,6 +365,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   uint32_t *__restrict__ queue = wb.walkQueue + b;
   uint32_t *__restrict__ outAlloc = wb.counts + (b + 1);
   const uint32_t lane = threadIdx.x & 63u;
+  /* ids a wave draws per atomic: large while there is plenty (one atomic per 256 paths), small when the
+   * whole queue is only a few draws per wave — the last draws decide how long the kernel's tail is */
+  const uint32_t nWaves = gridDim.x * (FLX_WF_WALK_THREADS / 64u);
+  uint32_t lastBase = 0;
+  uint32_t inChunk = n / (nWaves * FLX_WF_DRAWS_PER_WAVE);
+  inChunk = inChunk < 64u ? 64u : (inChunk > WF_IN_CHUNK ? WF_IN_CHUNK : inChunk);
   WorkCounters cnt = {};
   uint32_t diagIters = 0, diagBatches = 0;
   long long tFold = 0, tRefill = 0, tInner = 0, tStart = COUNT ? clock64() : 0;
@@ -440,11 +449,15 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         if (chunkNext == chunkEnd) {
           if (!itemsLeft) break;
           uint32_t base0 = 0;
-          if (lane == 0) base0 = atomicAdd(queue, WF_IN_CHUNK);
+          /* guided self-scheduling: draw 1/(2 x waves) of what was left at the last draw, within [64, WF_IN_CHUNK] */
+          uint32_t want = (n - lastBase) / (nWaves * 2u);
+          want = want < 64u ? 64u : (want > inChunk ? inChunk : want);
+          if (lane == 0) base0 = atomicAdd(queue, want);
           base0 = __builtin_amdgcn_readfirstlane(base0);
           if (base0 >= n) { itemsLeft = false; break; }
+          lastBase = base0;
           chunkNext = base0;
-          chunkEnd = (base0 + WF_IN_CHUNK < n) ? base0 + WF_IN_CHUNK : n;
+          chunkEnd = (base0 + want < n) ? base0 + want : n;
         }
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         const uint32_t avail = chunkEnd - chunkNext;
@@ -531,9 +544,13 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   flush_counters<COUNT>(cnt, wb.counters);
   if (COUNT && lane == 0) {
     atomicAdd(wb.counters + 8 + 2 * (b < 4 ? b : 3), (unsigned long long)diagIters); atomicAdd(wb.counters + 9 + 2 * (b < 4 ? b : 3), (unsigned long long)diagBatches);
+    const unsigned long long life = (unsigned long long)(clock64() - tStart);
     if (b == 0) {
       atomicAdd(wb.counters + 16, (unsigned long long)tFold); atomicAdd(wb.counters + 17, (unsigned long long)tRefill);
-      atomicAdd(wb.counters + 18, (unsigned long long)tInner); atomicAdd(wb.counters + 19, (unsigned long long)(clock64() - tStart)); atomicAdd(wb.counters + 20, 1ull);
+      atomicAdd(wb.counters + 18, (unsigned long long)tInner); atomicAdd(wb.counters + 19, life); atomicAdd(wb.counters + 20, 1ull);
+    }
+    if (b < 4) {   /* tail statistics per bounce: sum / count / max of wave lifetimes */
+      atomicAdd(wb.counters + 24 + 3 * b, life); atomicAdd(wb.counters + 25 + 3 * b, 1ull); atomicMax(wb.counters + 26 + 3 * b, life);
     }
   }
 }

@@ -166,7 +166,7 @@ class Context:
         return cnt.as_dict()
 
     def get_diag(self):
-        out = (C.c_uint64 * 16)()
+        out = (C.c_uint64 * 32)()
         self._check(LIB.flx_get_diag(self._h, out), "flx_get_diag")
         return [int(x) for x in out]
 
