@@ -180,6 +180,7 @@ def main():
 
     # Dominant-kernel duration, measured live with HIP events on the launch stream, outside the timed
     # region so the event syncs do not perturb it: same frame, K more launches.
+    ctx.set_wavefront_groups(1)          # one chain, so the bounce-0 walk kernel is ONE launch over the whole share of the frame
     for _ in range(min(args.steps, 10)):
         ctx.render_device(params, local.data_ptr())
         frame_ms, trace_ms = ctx.last_frame_ms()

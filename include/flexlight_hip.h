@@ -141,6 +141,9 @@ flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_ker
  * sample-sequential per-pixel kernel when use_filter needs the cross-sample G-buffer state),
  * 1 = per-pixel kernel, 2 = persistent path kernel.  Results are identical; for A/B timing and tests. */
 flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
+/* Wavefront pipeline: run the bounce loop as 1..4 independent chains of screen-tile ranges on separate HIP
+ * streams (default 2), so that the tail of one chain's persistent walk kernel overlaps the other's work. */
+flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
 
 /* ---- diagnostics --------------------------------------------------------------------------------- */
 /* Evaluate one of include/flx_math.h's routines on the GPU for n inputs (b may be NULL for unary

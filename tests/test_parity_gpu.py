@@ -75,6 +75,23 @@ def test_counters_off_same_image(hip, scenes):
     assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 320, 180, 2, 4), ("cornell", 96, 80, 3, 3), ("theater", 64, 40, 1, 2)])
+def test_wavefront_groups_do_not_change_the_frame(hip, oracle, scenes, name, w, h, spp, bounces):
+    """The bounce loop may run as 1..4 independent chains of tile ranges on separate streams; same bits."""
+    sc = scenes(name)
+    hip.update_scene(sc)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+    want, _, _ = oracle.render(sc, p)
+    try:
+        for groups in (1, 2, 3, 4):
+            hip.set_wavefront_groups(groups)
+            for _ in range(2):                       # twice: buffers and streams are reused across frames
+                got, _, _ = hip.render(p)
+                assert np.array_equal(got, want, equal_nan=True), groups
+    finally:
+        hip.set_wavefront_groups(1)
+
+
 def test_errors_are_reported_not_thrown(hip, scenes):
     from flexlight_hip import capi
     sc = scenes("cornell")

@@ -20,6 +20,11 @@
 
 using namespace flx;
 
+#ifndef FLX_WF_GROUPS
+#define FLX_WF_GROUPS 1      /* measured on MI355X: 2-4 concurrent chains are slower than one (profiles/r01_ab_stream_groups.txt) */
+#endif
+constexpr int WF_MAX_GROUPS = 4;
+
 static thread_local std::string g_create_error;
 
 struct flx_context {
@@ -56,6 +61,9 @@ struct flx_context {
   size_t live_capacity = 0;
   uint32_t *d_wfcounts = nullptr;                /* counts[WF_MAX_BOUNCES+2] then walkQueue[WF_MAX_BOUNCES+2] */
   int pipeline = 0;                              /* 0 auto, 1 per-pixel megakernel, 2 persistent paths, 3 wavefront */
+  int wf_groups = FLX_WF_GROUPS;                 /* wavefront pipeline: independent item groups on separate streams (tails of one overlap the other) */
+  hipStream_t aux_stream[3] = { nullptr, nullptr, nullptr };
+  hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
   unsigned long long *d_counters = nullptr;
   bool counters_enabled = false;
   flx_counters last_counters = {};
@@ -108,7 +116,12 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_counters, 40 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_wfcounts, 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_wfcounts, WF_MAX_GROUPS * 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  for (int i = 0; i < 3; i++) {
+    if ((e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+  }
+  if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
   *out = ctx;
   return FLX_OK;
 }
@@ -125,6 +138,8 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
+  for (int i = 0; i < 3; i++) { if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -380,7 +395,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   if (pipeline == 3) {
     flx_status s;
     if ((s = ensure_pixels(ctx, &ctx->d_rec, &ctx->rec_capacity, (size_t)path_item_count(fr) * 8))) return s;
-    const size_t need = wavefront_live_capacity(fr, cus);
+    const size_t need = wavefront_live_capacity(fr, cus) * WF_MAX_GROUPS;      /* every group gets a slice that could hold the whole frame */
     if (ctx->live_capacity < need) {
       for (int i = 0; i < 2; i++) {
         if (ctx->d_live[i]) { FLX_HIP(ctx, hipFree(ctx->d_live[i])); ctx->d_live[i] = nullptr; }
@@ -408,15 +423,39 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
   } else {
-    FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t), ctx->stream));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t), ctx->stream));
     launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
-    WavefrontBuffers wb;
-    wb.rec = ctx->d_rec; wb.live[0] = ctx->d_live[0]; wb.live[1] = ctx->d_live[1];
-    wb.counts = ctx->d_wfcounts; wb.walkQueue = ctx->d_wfcounts + (WF_MAX_BOUNCES + 2);
-    wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
-    launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->ev_k0, ctx->ev_k1, ctx->stream);
-    FLX_HIP(ctx, hipGetLastError());
+    /* The bounce loop runs as `groups` independent chains (contiguous ranges of screen tiles), group 0 on the
+     * context's stream and the others on auxiliary streams: every persistent walk kernel ends in a tail set by
+     * its longest walk (~0.3 ms), and with two chains that tail overlaps the other chain's next kernel. */
+    const uint32_t total = path_item_count(fr);
+    const uint32_t perTile = (uint32_t)fr.samples * 64u;
+    const uint32_t tiles = total / perTile;
+    int groups = ctx->wf_groups < 1 ? 1 : (ctx->wf_groups > WF_MAX_GROUPS ? WF_MAX_GROUPS : ctx->wf_groups);
+    if ((uint32_t)groups > tiles) groups = 1;
+    if (cnt) groups = 1;                               /* counted frames: one chain, so the scheduler statistics describe whole kernels */
+    const size_t listSlice = ctx->live_capacity / WF_MAX_GROUPS;
+    if (groups > 1) {
+      FLX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+      for (int g = 1; g < groups; g++) FLX_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[g - 1], ctx->ev_fork, 0));
+    }
+    for (int g = 0; g < groups; g++) {
+      const uint32_t t0 = (uint32_t)((uint64_t)tiles * g / groups), t1 = (uint32_t)((uint64_t)tiles * (g + 1) / groups);
+      WavefrontBuffers wb;
+      wb.rec = ctx->d_rec;
+      wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
+      wb.counts = ctx->d_wfcounts + (size_t)g * 2 * (WF_MAX_BOUNCES + 2); wb.walkQueue = wb.counts + (WF_MAX_BOUNCES + 2);
+      wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;
+      wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
+      hipStream_t st = g == 0 ? ctx->stream : ctx->aux_stream[g - 1];
+      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
+      FLX_HIP(ctx, hipGetLastError());
+      if (g > 0) {
+        FLX_HIP(ctx, hipEventRecord(ctx->ev_join[g - 1], st));
+        FLX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[g - 1], 0));
+      }
+    }
     launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
   }
@@ -453,6 +492,13 @@ static flx_status run_filter_frame(flx_context *ctx, const DeviceScene &sc, cons
   launch_filter_chain(gb, pl, d_out, (int)fr.width, (int)fr.height, hdr, ctx->stream);
   FLX_HIP(ctx, hipGetLastError());
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_set_wavefront_groups(flx_context *ctx, int groups) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (groups < 1 || groups > WF_MAX_GROUPS) return fail(ctx, FLX_ERR_INVALID, "flx_set_wavefront_groups: 1..4");
+  ctx->wf_groups = groups;
   return FLX_OK;
 }
 

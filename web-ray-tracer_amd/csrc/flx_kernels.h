@@ -25,6 +25,7 @@ struct WavefrontBuffers {
   uint32_t *live[2];            /* live path lists, alternating per bounce */
   uint32_t *counts;             /* [WF_MAX_BOUNCES + 2] slots used in the live list of bounce b */
   uint32_t *walkQueue;          /* [WF_MAX_BOUNCES + 2] per-bounce refill cursor of the walk kernel */
+  uint32_t item_base, item_count; /* the path items [item_base, item_base + item_count) this group of launches owns */
   const float4 *hits;
   float4 *sampleRadiance, *lastOriginal;
   unsigned long long *counters; /* or nullptr */

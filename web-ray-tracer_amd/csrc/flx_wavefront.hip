@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
   const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
   WorkCounters cnt = {};
   for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
-    const uint32_t pathId = FIRST ? j : listIn[j];
+    const uint32_t pathId = FIRST ? wb.item_base + j : listIn[j];
     if (pathId == WF_INVALID) continue;
     float4 *rec = wb.rec + (size_t)pathId * 8;
     uint32_t px, k, s;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
         const uint32_t r = lane_rank(idle);
         if (st == L_EMPTY && r < take) {
           const uint32_t j = chunkNext + r;
-          const uint32_t id = (b == 0) ? j : listIn[j];
+          const uint32_t id = (b == 0) ? wb.item_base + j : listIn[j];
           if (id != WF_INVALID) {
             const float4 *rec = wb.rec + (size_t)id * 8;
             const float4 q0 = rec[0];
@@ -465,7 +465,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         const uint32_t r = lane_rank(idle);
         if (st == P_EMPTY && r < take) {
           const uint32_t j = chunkNext + r;
-          const uint32_t id = (b == 0) ? j : listIn[j];
+          const uint32_t id = (b == 0) ? wb.item_base + j : listIn[j];
           if (id != WF_INVALID) {
             const float4 *rec = wb.rec + (size_t)id * 8;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];     /* one cache line, four loads in flight */
@@ -560,7 +560,7 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
 #ifdef FLX_DIAG_SLOW
   { unsigned long long h[4]; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diagSlow), sizeof h); fprintf(stderr, "diag slow-box: lanes %llu wave-events %llu notFast %llu\n", h[0], h[1], h[2]); }
 #endif
-  const uint32_t total = path_item_count(fr);
+  const uint32_t total = wb.item_count;                 /* items of this group (all of the frame when there is one group) */
   const uint32_t maxBlocks = compute_units * 8u;
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
    * (n_transforms x 32 B each) when they fit, the rest goes to the tree top. */
