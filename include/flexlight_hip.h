@@ -59,7 +59,7 @@ typedef struct flx_frame_params {
   int32_t max_reflections;      /* config.maxReflections */
   float min_importancy;         /* config.minImportancy */
   int32_t use_filter;           /* config.filter: write the five G-buffers and run the denoise chain */
-  int32_t is_temporal;          /* config.temporal (only the fract/floor split of fragment:626-629; no history pass) */
+  int32_t is_temporal;          /* config.temporal: fract/floor split (fragment:626-629) + the temporal accumulation pass over the context's history */
   int32_t hdr;                  /* config.hdr, final filter tone map */
   float ambient[3];             /* scene.ambientLight */
   float random_seed;            /* 0 unless temporal (pathtracerWGL2.js:347) */
@@ -67,6 +67,7 @@ typedef struct flx_frame_params {
   /* Tile policy (multi-GPU): the frame is cut into strips of tile_rows image rows,
    * strip s belongs to the context with s % tile_count == tile_index.  0/0/0 or x/0/1 = whole frame. */
   uint32_t tile_rows, tile_index, tile_count;
+  int32_t temporal_samples;     /* config.temporalSamples: history depth of the temporal pass (1..16; 0 = 4) */
 } flx_frame_params;
 
 /* Work counters of one frame; identical numbers come out of the CPU oracle for the same frame and
@@ -89,6 +90,7 @@ typedef struct flx_gbuffers {
   float *original_color;        /* renderOriginalColor */
   float *id;                    /* renderId */
   float *original_id;           /* renderOriginalId */
+  float *location_id;           /* renderLocationId (fragment:640-642); may be NULL */
 } flx_gbuffers;
 
 /* ---- life cycle -------------------------------------------------------------------------------- */
@@ -123,6 +125,11 @@ uint32_t flx_tile_row_at(const flx_frame_params *params, uint32_t k);
  * with filter = the final filter's canvas colour.  gbuffers / counters may be NULL. */
 flx_status flx_render(flx_context *ctx, const flx_frame_params *params, float *out_rgba,
                       const flx_gbuffers *gbuffers, flx_counters *counters);
+/* Temporal frames (is_temporal = 1) keep config.temporalSamples frames of history in the context, like the
+ * reference's TempTexture rings (pathtracerWGL2.js:389-402,419-460): every call rotates the ring, traces with
+ * params->random_seed (the caller passes frame % temporalSamples, pathtracerWGL2.js:291,347) and averages the
+ * history where the packed ids match.  flx_temporal_reset forgets the history (a resize does the same). */
+flx_status flx_temporal_reset(flx_context *ctx);
 /* Same, output left in DEVICE memory (d_out_rgba is a device pointer on the context's GPU, e.g. a
  * torch tensor's data_ptr) and enqueued on the context's stream without a host sync: for the
  * multi-GPU gather over RCCL.  Call flx_sync before reading on another stream. */

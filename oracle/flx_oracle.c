@@ -83,6 +83,7 @@ typedef struct {
   v3 originalColor;
   v4 renderId, renderOriginalId;
   v3 ndc;                       /* clipSpace.xy / clipSpace.z of this fragment (z unused) */
+  v3 relativePosition;          /* object-space position of the primary hit (vertex:53-63 interpolated) */
   flx_counters cnt;
 } Frag;
 
@@ -520,7 +521,7 @@ static Hit primary_hit(Frag *f, const PrimarySetup *ps, uint32_t px, uint32_t py
 
 /* fragment:601-646, one pixel.  out* are 4-float slots (any may be NULL). */
 static void fragment_main(Frag *f, const PrimarySetup *ps, uint32_t px, uint32_t py_gl, float *outRgba,
-                          float *gColor, float *gColorIp, float *gOrigColor, float *gId, float *gOrigId) {
+                          float *gColor, float *gColorIp, float *gOrigColor, float *gId, float *gOrigId, float *gLoc) {
   const flx_frame_params *fp = f->fp;
   f->firstRayLength = 1.0f; f->glassFilter = 0.0f; f->originalRMEx = 0.0f; f->originalTPOx = 0.0f;
   f->originalColor = V3(0.0f, 0.0f, 0.0f);
@@ -536,6 +537,7 @@ static void fragment_main(Frag *f, const PrimarySetup *ps, uint32_t px, uint32_t
     if (gOrigColor) memcpy(gOrigColor, zero4, sizeof zero4);
     if (gId) memcpy(gId, zero4, sizeof zero4);
     if (gOrigId) memcpy(gOrigId, zero4, sizeof zero4);
+    if (gLoc) memcpy(gLoc, zero4, sizeof zero4);
     return;
   }
   f->cnt.primary_hits++;
@@ -571,6 +573,13 @@ static void fragment_main(Frag *f, const PrimarySetup *ps, uint32_t px, uint32_t
   }
   if (gId) { gId[0] = f->renderId.x; gId[1] = f->renderId.y; gId[2] = f->renderId.z; gId[3] = f->renderId.w + INV_255; }
   if (gOrigId) { gOrigId[0] = 0.0f; gOrigId[1] = 0.0f; gOrigId[2] = 0.0f; gOrigId[3] = f->originalTPOx + INV_255; }
+  if (gLoc) {                                /* fragment:640-642; relativePosition is in object space, camera in world space, as in the shader */
+    const float *g = f->sc->geometry + (size_t)hit.triangleId * 12;
+    float w0 = 1.0f - hit.suv.y - hit.suv.z;
+    v3 rel = add3(add3(scale3(V3(g[0], g[1], g[2]), w0), scale3(V3(g[3], g[4], g[5]), hit.suv.y)), scale3(V3(g[6], g[7], g[8]), hit.suv.z));
+    float div = 2.0f * distance3(rel, camera);
+    gLoc[0] = flx_mod(rel.x, div) / div; gLoc[1] = flx_mod(rel.y, div) / div; gLoc[2] = flx_mod(rel.z, div) / div; gLoc[3] = INV_255;
+  }
 }
 
 static int check_inputs(const flx_scene_view *sc, const flx_frame_params *fp) {
@@ -590,8 +599,9 @@ static uint32_t tile_rows_total(const flx_frame_params *fp, uint32_t *rows, uint
   return n;
 }
 
-int flx_oracle_render(const flx_scene_view *scene, const flx_frame_params *params, float *out_rgba,
-                      const flx_gbuffers *gb_in, flx_counters *counters, int threads) {
+/* The path-trace pass alone: what the fragment program writes for every pixel (no temporal pass, no filter). */
+int flx_oracle_trace(const flx_scene_view *scene, const flx_frame_params *params, float *out_rgba,
+                     const flx_gbuffers *gb, flx_counters *counters, int threads) {
   if (!check_inputs(scene, params)) return FLX_ERR_INVALID;
   PrimarySetup ps;
   primary_setup(params, &ps);
@@ -599,17 +609,6 @@ int flx_oracle_render(const flx_scene_view *scene, const flx_frame_params *param
   uint32_t *rows = (uint32_t *)malloc(sizeof(uint32_t) * H);
   if (!rows) return FLX_ERR_INVALID;
   uint32_t nrows = tile_rows_total(params, rows, H);
-  /* filter on: the chain needs all five G-buffers of the WHOLE frame (its taps reach +-42 px) */
-  flx_gbuffers own = { NULL, NULL, NULL, NULL, NULL };
-  const flx_gbuffers *gb = gb_in;
-  if (params->use_filter == 1) {
-    if (nrows != H) { free(rows); return FLX_ERR_INVALID; }
-    float **dst[5] = { &own.color, &own.color_ip, &own.original_color, &own.id, &own.original_id };
-    float *given[5] = { gb_in ? gb_in->color : NULL, gb_in ? gb_in->color_ip : NULL, gb_in ? gb_in->original_color : NULL,
-                        gb_in ? gb_in->id : NULL, gb_in ? gb_in->original_id : NULL };
-    for (int i = 0; i < 5; i++) *dst[i] = given[i] ? given[i] : (float *)calloc((size_t)W * H * 4, sizeof(float));
-    gb = &own;
-  }
   flx_counters total;
   memset(&total, 0, sizeof total);
 #ifdef _OPENMP
@@ -631,7 +630,7 @@ int flx_oracle_render(const flx_scene_view *scene, const flx_frame_params *param
         fragment_main(&f, &ps, px, py_gl, out_rgba ? out_rgba + o : NULL,
                       gb && gb->color ? gb->color + o : NULL, gb && gb->color_ip ? gb->color_ip + o : NULL,
                       gb && gb->original_color ? gb->original_color + o : NULL, gb && gb->id ? gb->id + o : NULL,
-                      gb && gb->original_id ? gb->original_id + o : NULL);
+                      gb && gb->original_id ? gb->original_id + o : NULL, gb && gb->location_id ? gb->location_id + o : NULL);
       }
     }
 #pragma omp critical
@@ -643,17 +642,22 @@ int flx_oracle_render(const flx_scene_view *scene, const flx_frame_params *param
     }
   }
   free(rows);
-  int rc = FLX_OK;
-  if (params->use_filter == 1) {
-    if (out_rgba) rc = flx_oracle_filter(params, gb, out_rgba, threads);
-    float *mine[5] = { own.color, own.color_ip, own.original_color, own.id, own.original_id };
-    float *given[5] = { gb_in ? gb_in->color : NULL, gb_in ? gb_in->color_ip : NULL, gb_in ? gb_in->original_color : NULL,
-                        gb_in ? gb_in->id : NULL, gb_in ? gb_in->original_id : NULL };
-    for (int i = 0; i < 5; i++) if (mine[i] != given[i]) free(mine[i]);
-  }
   if (counters) *counters = total;
-  return rc;
+  return FLX_OK;
 }
+
+/* One frame as renderFrame() produces it (pathtracerWGL2.js:375-554): trace, then the temporal pass over an
+ * EMPTY history when is_temporal (= the first frame after a reset; use flx_oracle_render_sequence for more),
+ * then the filter chain when use_filter. */
+int flx_oracle_render(const flx_scene_view *scene, const flx_frame_params *params, float *out_rgba,
+                      const flx_gbuffers *gb_in, flx_counters *counters, int threads) {
+  if (!check_inputs(scene, params)) return FLX_ERR_INVALID;
+  if (params->is_temporal != 1 && params->use_filter != 1) return flx_oracle_trace(scene, params, out_rgba, gb_in, counters, threads);
+  if (flx_tile_rows_of(params) != params->height) return FLX_ERR_INVALID;   /* temporal / filter frames are whole frames */
+  return flx_oracle_render_sequence_impl(scene, params, 1, out_rgba, gb_in, counters, threads);
+}
+
+uint32_t flx_tile_rows_of(const flx_frame_params *params) { return tile_rows_total(params, NULL, 0); }
 
 /* ---- known-answer hooks ---------------------------------------------------------------------------- */
 static Ray mkray(const float o[3], const float d[3]) { Ray r = { V3(o[0], o[1], o[2]), V3(d[0], d[1], d[2]) }; return r; }

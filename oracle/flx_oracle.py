@@ -30,6 +30,8 @@ def lib():
         _LIB.flx_oracle_render.restype = C.c_int
         _LIB.flx_oracle_filter.argtypes = [C.POINTER(FrameParams), C.POINTER(GBuffers), C.POINTER(C.c_float), C.c_int]
         _LIB.flx_oracle_filter.restype = C.c_int
+        _LIB.flx_oracle_render_sequence.argtypes = [C.POINTER(SceneView), C.POINTER(FrameParams), C.c_int, C.POINTER(C.c_float), C.c_int]
+        _LIB.flx_oracle_render_sequence.restype = C.c_int
     return _LIB
 
 
@@ -58,3 +60,13 @@ def render(scene, params, gbuffers=False, threads=0):
     if rc != 0:
         raise RuntimeError("flx_oracle_render failed: %d" % rc)
     return out, cnt.as_dict(), gbs
+
+
+def render_sequence(scene, params, n_frames, threads=0):
+    """Frames 0..n_frames-1 of a temporal run -> [n_frames, H, W, 4] float32 (canvas colour of every frame)."""
+    view = scene.view()
+    out = np.zeros((n_frames, params.height, params.width, 4), np.float32)
+    rc = lib().flx_oracle_render_sequence(C.byref(view), C.byref(params), n_frames, _fp(out), threads)
+    if rc != 0:
+        raise RuntimeError("flx_oracle_render_sequence failed: %d" % rc)
+    return out

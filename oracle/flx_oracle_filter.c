@@ -242,22 +242,13 @@ static uint8_t *quantise_plane(const float *src, int W, int H) {
   return dst;
 }
 
-int flx_oracle_filter(const flx_frame_params *params, const flx_gbuffers *gb, float *out_rgba, int threads) {
-  if (!params || !gb || !out_rgba || !gb->color || !gb->color_ip || !gb->original_color || !gb->id || !gb->original_id) return FLX_ERR_INVALID;
-  const int W = (int)params->width, H = (int)params->height;
-  if (W <= 0 || H <= 0) return FLX_ERR_INVALID;
-#ifdef _OPENMP
-  if (threads > 0) omp_set_num_threads(threads);
-#else
-  (void)threads;
-#endif
+/* The chain on RGBA8 planes (slot 0 of every ring given, rows top-down); planes are consumed (freed). */
+static int filter_chain_u8(int W, int H, int hdr, uint8_t *R0, uint8_t *Ip0, uint8_t *O0, uint8_t *Id0, uint8_t *OId, float *out_rgba) {
   const size_t bytes = (size_t)W * H * 4;
-  /* the path tracer's five RGBA8 targets (slot 0) */
-  uint8_t *R[4] = { quantise_plane(gb->color, W, H), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1) };
-  uint8_t *Ip[4] = { quantise_plane(gb->color_ip, W, H), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1) };
-  uint8_t *O[2] = { quantise_plane(gb->original_color, W, H), (uint8_t *)calloc(bytes, 1) };
-  uint8_t *Id[2] = { quantise_plane(gb->id, W, H), (uint8_t *)calloc(bytes, 1) };
-  uint8_t *OId = quantise_plane(gb->original_id, W, H);
+  uint8_t *R[4] = { R0, (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1) };
+  uint8_t *Ip[4] = { Ip0, (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1), (uint8_t *)calloc(bytes, 1) };
+  uint8_t *O[2] = { O0, (uint8_t *)calloc(bytes, 1) };
+  uint8_t *Id[2] = { Id0, (uint8_t *)calloc(bytes, 1) };
   int ok = OId != NULL;
   for (int i = 0; i < 4; i++) ok = ok && R[i] && Ip[i];
   for (int i = 0; i < 2; i++) ok = ok && O[i] && Id[i];
@@ -292,7 +283,7 @@ int flx_oracle_filter(const flx_frame_params *params, const flx_gbuffers *gb, fl
 #pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < H; y++) {
       for (int x = 0; x < W; x++) {
-        v4 c = final_filter(tColor, tIp, tOColor, tId, tOId, x, y, params->hdr);
+        v4 c = final_filter(tColor, tIp, tOColor, tId, tOId, x, y, hdr);
         float *o = out_rgba + ((size_t)(H - 1 - y) * W + x) * 4;
         o[0] = c.x; o[1] = c.y; o[2] = c.z; o[3] = c.w;
       }
@@ -302,4 +293,125 @@ int flx_oracle_filter(const flx_frame_params *params, const flx_gbuffers *gb, fl
   for (int i = 0; i < 2; i++) { free(O[i]); free(Id[i]); }
   free(OId);
   return ok ? FLX_OK : FLX_ERR_INVALID;
+}
+
+int flx_oracle_filter(const flx_frame_params *params, const flx_gbuffers *gb, float *out_rgba, int threads) {
+  if (!params || !gb || !out_rgba || !gb->color || !gb->color_ip || !gb->original_color || !gb->id || !gb->original_id) return FLX_ERR_INVALID;
+  const int W = (int)params->width, H = (int)params->height;
+  if (W <= 0 || H <= 0) return FLX_ERR_INVALID;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#else
+  (void)threads;
+#endif
+  return filter_chain_u8(W, H, params->hdr, quantise_plane(gb->color, W, H), quantise_plane(gb->color_ip, W, H),
+                         quantise_plane(gb->original_color, W, H), quantise_plane(gb->id, W, H), quantise_plane(gb->original_id, W, H), out_rgba);
+}
+
+/* ---- temporal accumulation (modules/pathtracerWGL2.js:389-402, 419-460, generated GLSL :571-662) -------------
+ * History rings of N = temporalSamples RGBA8 planes: colour, colour integer part, location id, original id;
+ * slot 0 is the frame just traced.  For texel t: the slots 1..N-1 whose location id equals slot 0's add their
+ * colour, those whose original id equals slot 0's add their glass filter.  The generated shader walks the slots in
+ * groups of four with vec4(0) standing in for slots >= N, so a texel whose own id is all zero (an uncovered pixel)
+ * also "matches" those stand-ins: counted, as the shader does. */
+typedef struct { uint8_t **c, **ip, **id, **oid; int n; } History;
+
+static void temporal_pass(const History *h, int W, int H, int hdr, int use_filter, uint8_t *dColor, uint8_t *dIp, float *canvas) {
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < H; y++) {
+    for (int x = 0; x < W; x++) {
+      Tex c0 = { h->c[0], W, H }, ip0 = { h->ip[0], W, H }, id0 = { h->id[0], W, H }, oid0 = { h->oid[0], W, H };
+      v4 id = fetch(id0, x, y), originalId = fetch(oid0, x, y);
+      float counter = 1.0f, glassCounter = 1.0f;
+      v4 cc = fetch(c0, x, y), ci = fetch(ip0, x, y);
+      float centerW = cc.w;
+      float color[3] = { cc.x + ci.x * 256.0f, cc.y + ci.y * 256.0f, cc.z + ci.z * 256.0f };
+      float glassFilter = ci.w;
+      for (int i = 1; i < h->n; i += 4) {
+        v4 cs[4], ips[4], ids[4], oids[4];
+        for (int j = 0; j < 4; j++) {
+          int k = i + j;
+          if (k < h->n) {
+            Tex tc = { h->c[k], W, H }, tip = { h->ip[k], W, H }, tid = { h->id[k], W, H }, toid = { h->oid[k], W, H };
+            cs[j] = fetch(tc, x, y); ips[j] = fetch(tip, x, y); ids[j] = fetch(tid, x, y); oids[j] = fetch(toid, x, y);
+          } else {
+            cs[j] = ips[j] = ids[j] = oids[j] = V4(0.0f, 0.0f, 0.0f, 0.0f);
+          }
+        }
+        for (int j = 0; j < 4; j++) if (eq4(ids[j], id)) {
+          color[0] += cs[j].x + ips[j].x * 256.0f; color[1] += cs[j].y + ips[j].y * 256.0f; color[2] += cs[j].z + ips[j].z * 256.0f;
+          counter += 1.0f;
+        }
+        for (int j = 0; j < 4; j++) if (eq4(oids[j], originalId)) {
+          glassFilter += ips[j].w;
+          glassCounter += 1.0f;
+        }
+      }
+      for (int k = 0; k < 3; k++) color[k] /= counter;
+      glassFilter /= glassCounter;
+      if (use_filter) {
+        store(dColor, W, H, x, y, V4(flx_mod(color[0], 1.0f), flx_mod(color[1], 1.0f), flx_mod(color[2], 1.0f), centerW));
+        store(dIp, W, H, x, y, V4(flx_floor(color[0]) / 256.0f, flx_floor(color[1]) / 256.0f, flx_floor(color[2]) / 256.0f, glassFilter));
+      } else {
+        if (hdr == 1) {
+          for (int k = 0; k < 3; k++) {
+            color[k] = color[k] / (color[k] + 1.0f);
+            const float gamma = 0.8f;
+            color[k] = flx_pow(4.0f * color[k], 1.0f / gamma) / 4.0f * 1.3f;
+          }
+        }
+        float *o = canvas + ((size_t)(H - 1 - y) * W + x) * 4;
+        o[0] = color[0]; o[1] = color[1]; o[2] = color[2]; o[3] = centerW;
+      }
+    }
+  }
+}
+
+int flx_oracle_render_sequence_impl(const flx_scene_view *scene, const flx_frame_params *params, int n_frames, float *out_all,
+                                    const flx_gbuffers *gb_last, flx_counters *counters_last, int threads) {
+  if (!scene || !params || n_frames < 1 || !out_all) return FLX_ERR_INVALID;
+  const int W = (int)params->width, H = (int)params->height;
+  const size_t px = (size_t)W * H, bytes = px * 4;
+  const int temporal = params->is_temporal == 1;
+  int N = params->temporal_samples <= 0 ? 4 : (params->temporal_samples > 16 ? 16 : params->temporal_samples);
+  if (!temporal) N = 1;
+  uint8_t *ring[4][16];
+  for (int r = 0; r < 4; r++) for (int i = 0; i < 16; i++) ring[r][i] = i < N ? (uint8_t *)calloc(bytes, 1) : NULL;
+  float *g[6];
+  for (int i = 0; i < 6; i++) g[i] = (float *)calloc(px * 4, sizeof(float));
+  flx_gbuffers gb = { g[0], g[1], g[2], g[3], g[4], g[5] };
+  int rc = FLX_OK;
+  for (int f = 0; f < n_frames && rc == FLX_OK; f++) {
+    flx_frame_params p = *params;
+    if (temporal) p.random_seed = (float)(f % N);
+    float *canvas = out_all + (size_t)f * px * 4;
+    rc = flx_oracle_trace(scene, &p, NULL, &gb, f == n_frames - 1 ? counters_last : NULL, threads);
+    if (rc != FLX_OK) break;
+    uint8_t *R0 = quantise_plane(g[0], W, H), *Ip0 = quantise_plane(g[1], W, H);
+    if (temporal) {
+      /* rotate the rings (TempTexture.unshift(TempTexture.pop())) and store the new frame in slot 0 */
+      for (int r = 0; r < 4; r++) { uint8_t *last = ring[r][N - 1]; for (int i = N - 1; i > 0; i--) ring[r][i] = ring[r][i - 1]; ring[r][0] = last; }
+      memcpy(ring[0][0], R0, bytes); memcpy(ring[1][0], Ip0, bytes);
+      uint8_t *q = quantise_plane(g[5], W, H); memcpy(ring[2][0], q, bytes); free(q);
+      q = quantise_plane(g[4], W, H); memcpy(ring[3][0], q, bytes); free(q);
+      History h = { ring[0], ring[1], ring[2], ring[3], N };
+      temporal_pass(&h, W, H, p.hdr, p.use_filter == 1, R0, Ip0, canvas);      /* with filter: R0 / Ip0 become RenderTexture[0] / IpRenderTexture[0] */
+    }
+    if (p.use_filter == 1) {
+      rc = filter_chain_u8(W, H, p.hdr, R0, Ip0, quantise_plane(g[2], W, H), quantise_plane(g[3], W, H), quantise_plane(g[4], W, H), canvas);
+    } else {
+      free(R0); free(Ip0);
+    }
+  }
+  if (gb_last) {
+    float *dst[6] = { gb_last->color, gb_last->color_ip, gb_last->original_color, gb_last->id, gb_last->original_id, gb_last->location_id };
+    for (int i = 0; i < 6; i++) if (dst[i]) memcpy(dst[i], g[i], px * 4 * sizeof(float));
+  }
+  for (int i = 0; i < 6; i++) free(g[i]);
+  for (int r = 0; r < 4; r++) for (int i = 0; i < 16; i++) free(ring[r][i]);
+  return rc;
+}
+
+int flx_oracle_render_sequence(const flx_scene_view *scene, const flx_frame_params *params, int n_frames, float *out_all, int threads) {
+  return flx_oracle_render_sequence_impl(scene, params, n_frames, out_all, NULL, NULL, threads);
 }

@@ -46,10 +46,14 @@ struct flx_context {
   /* frame workspace */
   float4 *d_out = nullptr;
   size_t out_capacity = 0;                       /* pixels */
-  float4 *d_gb[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  float4 *d_gb[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   size_t gb_capacity = 0;
   uint32_t *d_planes[13] = {};                   /* the filter chain's RGBA8 render targets */
   size_t planes_capacity = 0;
+  /* temporal history: rings of RGBA8 planes (colour, colour ip, location id, original id), newest at ring_head */
+  uint32_t *d_ring[4][16] = {};
+  int ring_n = 0, ring_head = 0;
+  uint32_t ring_w = 0, ring_h = 0;
   /* v2 pipeline workspace: primary hits, per-(sample,pixel) radiance, last sample's originalColor, item queue */
   float4 *d_hits = nullptr, *d_samples = nullptr, *d_last = nullptr;
   size_t hits_capacity = 0, samples_capacity = 0, last_capacity = 0;
@@ -132,11 +136,12 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
-                   ctx->d_gb[3], ctx->d_gb[4], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
+                   ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
                    ctx->d_rec, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
+  for (auto &ring : ctx->d_ring) for (uint32_t *pl : ring) if (pl) (void)hipFree(pl);
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < 3; i++) { if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -380,9 +385,9 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   /* The G-buffer accumulators of the filter path carry state from sample to sample (fragment:83-89),
    * so filter frames use the sample-sequential kernel; everything else runs the wavefront pipeline. */
   int pipeline = ctx->pipeline;
-  if (pipeline == 0) pipeline = fr.use_filter ? 1 : 3;
+  if (pipeline == 0) pipeline = (fr.use_filter || fr.is_temporal) ? 1 : 3;
   if (pipeline == 3 && fr.max_reflections > WF_MAX_BOUNCES) pipeline = 2;
-  if (pipeline != 1 && fr.use_filter) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the filter G-buffers");
+  if (pipeline != 1 && (fr.use_filter || fr.is_temporal)) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the G-buffers of filter / temporal frames");
   const size_t P = (size_t)fr.rows * fr.width;
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
   if (pipeline != 1) {
@@ -464,13 +469,16 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   return FLX_OK;
 }
 
-/* G-buffer + plane workspace of a filter frame, then trace + chain into d_out. */
-static flx_status run_filter_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, int hdr, float4 *d_out) {
-  if (fr.rows != fr.height) return fail(ctx, FLX_ERR_INVALID, "filter frames cannot be tiled: the denoise taps reach +-42 px (render the whole frame on one context)");
+/* Frames with a post pass (temporal accumulation and / or the denoise chain): trace with the per-pixel kernel
+ * into float G-buffers, store them to RGBA8 planes like the reference's render targets, run the passes. */
+static flx_status run_post_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, const flx_frame_params *p, float4 *d_out) {
+  if (fr.rows != fr.height)
+    return fail(ctx, FLX_ERR_INVALID, "temporal / filter frames cannot be tiled: they read neighbouring pixels and history (render the whole frame on one context)");
   const size_t pixels = (size_t)fr.rows * fr.width;
+  const bool temporal = fr.is_temporal == 1, filter = fr.use_filter == 1;
   flx_status s;
   if (ctx->gb_capacity < pixels) {
-    for (int i = 0; i < 5; i++) {
+    for (int i = 0; i < 6; i++) {
       size_t cap = 0;
       if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
       if ((s = ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
@@ -484,14 +492,58 @@ static flx_status run_filter_frame(flx_context *ctx, const DeviceScene &sc, cons
     }
     ctx->planes_capacity = pixels;
   }
-  GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4] };
-  if ((s = run_frame(ctx, sc, fr, nullptr, gb))) return s;
   FilterPlanes pl;
   for (int i = 0; i < 4; i++) { pl.R[i] = ctx->d_planes[i]; pl.Ip[i] = ctx->d_planes[4 + i]; }
   pl.O[0] = ctx->d_planes[8]; pl.O[1] = ctx->d_planes[9]; pl.Id[0] = ctx->d_planes[10]; pl.Id[1] = ctx->d_planes[11]; pl.OId = ctx->d_planes[12];
-  launch_filter_chain(gb, pl, d_out, (int)fr.width, (int)fr.height, hdr, ctx->stream);
+  int N = 1;
+  if (temporal) {
+    N = p->temporal_samples <= 0 ? 4 : (p->temporal_samples > 16 ? 16 : p->temporal_samples);
+    if (ctx->ring_n != N || ctx->ring_w != fr.width || ctx->ring_h != fr.height) {      /* new size: fresh (zero) history, like a resize */
+      for (auto &ring : ctx->d_ring) for (uint32_t *&plane : ring) if (plane) { FLX_HIP(ctx, hipFree(plane)); plane = nullptr; }
+      for (int r = 0; r < 4; r++) for (int i = 0; i < N; i++) {
+        FLX_HIP(ctx, hipMalloc(&ctx->d_ring[r][i], pixels * sizeof(uint32_t)));
+        FLX_HIP(ctx, hipMemsetAsync(ctx->d_ring[r][i], 0, pixels * sizeof(uint32_t), ctx->stream));
+      }
+      ctx->ring_n = N; ctx->ring_head = 0; ctx->ring_w = fr.width; ctx->ring_h = fr.height;
+    }
+  }
+  GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5] };
+  if ((s = run_frame(ctx, sc, fr, nullptr, gb))) return s;
+  launch_quantize(gb.color, pl.R[0], pixels, ctx->stream);
+  launch_quantize(gb.color_ip, pl.Ip[0], pixels, ctx->stream);
+  if (temporal) {
+    ctx->ring_head = (ctx->ring_head + N - 1) % N;                  /* TempTexture.unshift(TempTexture.pop()) */
+    TemporalRings rings;
+    rings.n = N;
+    for (int k = 0; k < 16; k++) {
+      const int slot = (ctx->ring_head + k) % N;
+      rings.c[k] = k < N ? ctx->d_ring[0][slot] : nullptr; rings.ip[k] = k < N ? ctx->d_ring[1][slot] : nullptr;
+      rings.id[k] = k < N ? ctx->d_ring[2][slot] : nullptr; rings.oid[k] = k < N ? ctx->d_ring[3][slot] : nullptr;
+    }
+    const int h0 = ctx->ring_head;
+    FLX_HIP(ctx, hipMemcpyAsync(ctx->d_ring[0][h0], pl.R[0], pixels * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    FLX_HIP(ctx, hipMemcpyAsync(ctx->d_ring[1][h0], pl.Ip[0], pixels * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    launch_quantize(gb.location_id, ctx->d_ring[2][h0], pixels, ctx->stream);
+    launch_quantize(gb.original_id, ctx->d_ring[3][h0], pixels, ctx->stream);
+    launch_temporal(rings, (int)fr.width, (int)fr.height, p->hdr, filter ? 1 : 0, pl.R[0], pl.Ip[0], d_out, ctx->stream);
+  }
+  if (filter) {
+    launch_quantize(gb.original_color, pl.O[0], pixels, ctx->stream);
+    launch_quantize(gb.id, pl.Id[0], pixels, ctx->stream);
+    launch_quantize(gb.original_id, pl.OId, pixels, ctx->stream);
+    launch_filter_chain(pl, d_out, (int)fr.width, (int)fr.height, p->hdr, ctx->stream);
+  }
   FLX_HIP(ctx, hipGetLastError());
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_temporal_reset(flx_context *ctx) {
+  if (!ctx) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (auto &ring : ctx->d_ring) for (uint32_t *&plane : ring) if (plane) { FLX_HIP(ctx, hipFree(plane)); plane = nullptr; }
+  ctx->ring_n = 0; ctx->ring_head = 0; ctx->ring_w = ctx->ring_h = 0;
   return FLX_OK;
 }
 
@@ -516,8 +568,8 @@ extern "C" flx_status flx_render_device(flx_context *ctx, const flx_frame_params
   DeviceScene sc; DeviceFrame fr;
   flx_status s = make_frame(ctx, params, sc, fr);
   if (s) return s;
-  if (params->use_filter) return run_filter_frame(ctx, sc, fr, params->hdr, (float4 *)d_out_rgba);
-  GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr };
+  if (params->use_filter || params->is_temporal) return run_post_frame(ctx, sc, fr, params, (float4 *)d_out_rgba);
+  GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   return run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
 }
 
@@ -529,24 +581,25 @@ extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *param
   DeviceScene sc; DeviceFrame fr;
   flx_status s = make_frame(ctx, params, sc, fr);
   if (s) return s;
-  if (gbuffers && !params->use_filter) return fail(ctx, FLX_ERR_INVALID, "flx_render: G-buffers are only produced with use_filter = 1");
+  if (gbuffers && !params->use_filter && !params->is_temporal) return fail(ctx, FLX_ERR_INVALID, "flx_render: G-buffers are only produced with use_filter = 1 or is_temporal = 1");
   const size_t pixels = (size_t)fr.rows * fr.width;
   if (pixels == 0) return FLX_OK;
   if ((s = ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
   const bool saved = ctx->counters_enabled;
   if (counters) ctx->counters_enabled = true;
-  if (params->use_filter) {
-    s = run_filter_frame(ctx, sc, fr, params->hdr, ctx->d_out);
+  if (params->use_filter || params->is_temporal) {
+    s = run_post_frame(ctx, sc, fr, params, ctx->d_out);
   } else {
-    GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     s = run_frame(ctx, sc, fr, ctx->d_out, gb);
   }
   ctx->counters_enabled = saved;
   if (s) return s;
   FLX_HIP(ctx, hipMemcpyAsync(out_rgba, ctx->d_out, pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
   if (gbuffers) {
-    float *dst[5] = { gbuffers->color, gbuffers->color_ip, gbuffers->original_color, gbuffers->id, gbuffers->original_id };
-    for (int i = 0; i < 5; i++)
+    float *dst[6] = { gbuffers->color, gbuffers->color_ip, gbuffers->original_color, gbuffers->id, gbuffers->original_id,
+                      gbuffers->location_id };
+    for (int i = 0; i < 6; i++)
       if (dst[i]) FLX_HIP(ctx, hipMemcpyAsync(dst[i], ctx->d_gb[i], pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
   }
   unsigned long long host_cnt[8];

@@ -65,16 +65,68 @@ __device__ __forceinline__ bool texel_of_thread(int W, int H, int &x, int &y_gl)
   return x < W && row < H;
 }
 
-/* float G-buffers of the path-trace pass -> the five RGBA8 targets it renders into */
-__global__ __launch_bounds__(256) void k_quantize5(GBufferPtrs gb, uint32_t *c, uint32_t *ip, uint32_t *oc, uint32_t *id, uint32_t *oid, size_t n) {
+/* a float4 plane of the path-trace pass -> the RGBA8 target it renders into */
+__global__ __launch_bounds__(256) void k_quantize(const float4 *__restrict__ src, uint32_t *__restrict__ dst, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float4 v;
-  v = gb.color[i]; c[i] = pack(F4(v.x, v.y, v.z, v.w));
-  v = gb.color_ip[i]; ip[i] = pack(F4(v.x, v.y, v.z, v.w));
-  v = gb.original_color[i]; oc[i] = pack(F4(v.x, v.y, v.z, v.w));
-  v = gb.id[i]; id[i] = pack(F4(v.x, v.y, v.z, v.w));
-  v = gb.original_id[i]; oid[i] = pack(F4(v.x, v.y, v.z, v.w));
+  const float4 v = src[i];
+  dst[i] = pack(F4(v.x, v.y, v.z, v.w));
+}
+
+/* Temporal accumulation, the shader modules/pathtracerWGL2.js:571-662 generates: average the history slots whose
+ * location id equals the newest frame's; slots are visited in groups of four with vec4(0) standing in for slots >= n
+ * (an all-zero id — an uncovered pixel — "matches" those stand-ins too, as in the shader). */
+__global__ __launch_bounds__(256) void k_temporal(TemporalRings r, int W, int H, int hdr, int use_filter, uint32_t *dColor, uint32_t *dIp, float4 *out) {
+  int x, y;
+  if (!texel_of_thread(W, H, x, y)) return;
+  Tex c0 = { r.c[0] }, ip0 = { r.ip[0] }, id0 = { r.id[0] }, oid0 = { r.oid[0] };
+  const f4 id = fetch(id0, W, H, x, y), originalId = fetch(oid0, W, H, x, y);
+  float counter = 1.0f, glassCounter = 1.0f;
+  const f4 cc = fetch(c0, W, H, x, y), ci = fetch(ip0, W, H, x, y);
+  const float centerW = cc.w;
+  float color[3] = { cc.x + ci.x * 256.0f, cc.y + ci.y * 256.0f, cc.z + ci.z * 256.0f };
+  float glassFilter = ci.w;
+  for (int i = 1; i < r.n; i += 4) {
+    f4 cs[4], ips[4], ids[4], oids[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int k = i + j;
+      if (k < r.n) {
+        Tex tc = { r.c[k] }, tip = { r.ip[k] }, tid = { r.id[k] }, toid = { r.oid[k] };
+        cs[j] = fetch(tc, W, H, x, y); ips[j] = fetch(tip, W, H, x, y); ids[j] = fetch(tid, W, H, x, y); oids[j] = fetch(toid, W, H, x, y);
+      } else {
+        cs[j] = ips[j] = ids[j] = oids[j] = F4(0.0f, 0.0f, 0.0f, 0.0f);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (eq4(ids[j], id)) {
+      color[0] += cs[j].x + ips[j].x * 256.0f; color[1] += cs[j].y + ips[j].y * 256.0f; color[2] += cs[j].z + ips[j].z * 256.0f;
+      counter += 1.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (eq4(oids[j], originalId)) {
+      glassFilter += ips[j].w;
+      glassCounter += 1.0f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) color[k] /= counter;
+  glassFilter /= glassCounter;
+  const size_t o = (size_t)(H - 1 - y) * W + x;
+  if (use_filter) {
+    dColor[o] = pack(F4(flx_mod(color[0], 1.0f), flx_mod(color[1], 1.0f), flx_mod(color[2], 1.0f), centerW));
+    dIp[o] = pack(F4(flx_floor(color[0]) / 256.0f, flx_floor(color[1]) / 256.0f, flx_floor(color[2]) / 256.0f, glassFilter));
+  } else {
+    if (hdr == 1) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        color[k] = color[k] / (color[k] + 1.0f);
+        const float gamma = 0.8f;
+        color[k] = flx_pow(4.0f * color[k], 1.0f / gamma) / 4.0f * 1.3f;
+      }
+    }
+    out[o] = make_float4(color[0], color[1], color[2], centerW);
+  }
 }
 
 /* pathtracer_first_filter.glsl:18-123 */
@@ -246,10 +298,19 @@ __global__ __launch_bounds__(256) void k_filter_final(Tex tColor, Tex tIp, Tex t
 }
 
 /* Replays modules/pathtracerWGL2.js:462-550 (firstPasses = secondPasses = 3).  planes: R[4], Ip[4], O[2], Id[2], OId. */
-void launch_filter_chain(const GBufferPtrs &gb, const FilterPlanes &pl, float4 *out, int W, int H, int hdr, hipStream_t stream) {
+void launch_quantize(const float4 *src, uint32_t *dst, size_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(k_quantize, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
+}
+
+void launch_temporal(const TemporalRings &rings, int W, int H, int hdr, int use_filter, uint32_t *dColor, uint32_t *dIp, float4 *out,
+                     hipStream_t stream) {
+  const dim3 grid(((W + 15) >> 4) * ((H + 15) >> 4)), block(256);
+  hipLaunchKernelGGL(k_temporal, grid, block, 0, stream, rings, W, H, hdr, use_filter, dColor, dIp, out);
+}
+
+void launch_filter_chain(const FilterPlanes &pl, float4 *out, int W, int H, int hdr, hipStream_t stream) {
   const size_t n = (size_t)W * H;
   const dim3 grid(((W + 15) >> 4) * ((H + 15) >> 4)), block(256);
-  hipLaunchKernelGGL(k_quantize5, dim3((uint32_t)((n + 255) / 256)), block, 0, stream, gb, pl.R[0], pl.Ip[0], pl.O[0], pl.Id[0], pl.OId, n);
   (void)hipMemsetAsync(pl.O[1], 0, n * 4, stream);          /* read at pass 4 before anything wrote it this frame */
   int cur = 0, nId = 0, nOriginal = 0;
   for (int i = 0; i < 6; i++) {

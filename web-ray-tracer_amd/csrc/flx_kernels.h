@@ -6,7 +6,7 @@
 
 namespace flx {
 
-struct GBufferPtrs { float4 *color, *color_ip, *original_color, *id, *original_id; };
+struct GBufferPtrs { float4 *color, *color_ip, *original_color, *id, *original_id, *location_id; };
 
 /* counters: 8 x u64 in flx_counters order, or nullptr (no counting code is compiled in). */
 void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *out, const GBufferPtrs &gb,
@@ -36,7 +36,15 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
 /* denoise chain (flx_filter.hip): 13 RGBA8 planes = the reference's RenderTexture[0..3], IpRenderTexture[0..3],
  * OriginalRenderTexture[0..1], IdRenderTexture[0..1], OriginalIdRenderTexture (pathtracerWGL2.js:224-252). */
 struct FilterPlanes { uint32_t *R[4], *Ip[4], *O[2], *Id[2], *OId; };
-void launch_filter_chain(const GBufferPtrs &gb, const FilterPlanes &pl, float4 *out, int W, int H, int hdr, hipStream_t stream);
+/* float4 plane -> RGBA8 plane (a render-target store) */
+void launch_quantize(const float4 *src, uint32_t *dst, size_t n, hipStream_t stream);
+/* the chain over planes whose slot 0 (R[0], Ip[0], O[0], Id[0], OId) holds the frame */
+void launch_filter_chain(const FilterPlanes &pl, float4 *out, int W, int H, int hdr, hipStream_t stream);
+/* temporal accumulation (pathtracerWGL2.js:571-662) over rings of n RGBA8 planes, slot 0 = newest:
+ * without filter -> canvas float4 `out`; with filter -> dColor / dIp (RenderTexture[0] / IpRenderTexture[0]). */
+struct TemporalRings { const uint32_t *c[16], *ip[16], *id[16], *oid[16]; int n; };
+void launch_temporal(const TemporalRings &rings, int W, int H, int hdr, int use_filter, uint32_t *dColor, uint32_t *dIp, float4 *out,
+                     hipStream_t stream);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, uint32_t n, hipStream_t stream);
 
 }  // namespace flx

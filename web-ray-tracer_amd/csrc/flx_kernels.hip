@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFram
     Ray pr; pr.origin = camera; pr.dir = dir0;
     Hit hit0 = rayTracer<true>(sc, pr, viewDepthPerS, cnt.primary_visits);
     const size_t o = (size_t)k * fr.width + px;
-    float4 color = make_float4(0.f, 0.f, 0.f, 0.f), colorIp = color, origColor = color, rid = color, roid = color;
+    float4 color = make_float4(0.f, 0.f, 0.f, 0.f), colorIp = color, origColor = color, rid = color, roid = color, loc = color;
     if (hit0.triangleId != -1) {
       if (COUNT) cnt.primary_hits++;
       f3 finalColor = F3(0.0f, 0.0f, 0.0f);
@@ -77,6 +77,13 @@ __global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFram
       origColor = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, flx_min(ps.originalRMEx, ps.firstRayLength) + INV_255);
       rid = make_float4(ps.renderId.x, ps.renderId.y, ps.renderId.z, ps.renderId.w + INV_255);
       roid = make_float4(0.0f, 0.0f, 0.0f, ps.originalTPOx + INV_255);
+      if (gb.location_id) {                  /* fragment:640-642; relativePosition in object space, camera in world space, as in the shader */
+        const float4 g0 = sc.geometry[3 * hit0.triangleId], g1 = sc.geometry[3 * hit0.triangleId + 1], g2 = sc.geometry[3 * hit0.triangleId + 2];
+        const float w0 = 1.0f - hit0.suv.y - hit0.suv.z;
+        const f3 rel = (F3(g0.x, g0.y, g0.z) * w0 + F3(g0.w, g1.x, g1.y) * hit0.suv.y) + F3(g1.z, g1.w, g2.x) * hit0.suv.z;
+        const float div = 2.0f * distance(rel, camera);
+        loc = make_float4(flx_mod(rel.x, div) / div, flx_mod(rel.y, div) / div, flx_mod(rel.z, div) / div, INV_255);
+      }
     }
     if (out) out[o] = color;
     if (gb.color) gb.color[o] = color;
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFram
     if (gb.original_color) gb.original_color[o] = origColor;
     if (gb.id) gb.id[o] = rid;
     if (gb.original_id) gb.original_id[o] = roid;
+    if (gb.location_id) gb.location_id[o] = loc;
   }
   flush_counters<COUNT>(cnt, counters);
 }

@@ -18,7 +18,7 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups",
+    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset",
 ]
 
 
@@ -57,6 +57,7 @@ def _load():
         "flx_set_pipeline": (C.c_int, [vp, C.c_int]),
         "flx_get_diag": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_set_wavefront_groups": (C.c_int, [vp, C.c_int]),
+        "flx_temporal_reset": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -165,6 +166,9 @@ class Context:
         cnt = Counters()
         self._check(LIB.flx_get_counters(self._h, C.byref(cnt)), "flx_get_counters")
         return cnt.as_dict()
+
+    def temporal_reset(self):
+        self._check(LIB.flx_temporal_reset(self._h), "flx_temporal_reset")
 
     def set_wavefront_groups(self, groups):
         self._check(LIB.flx_set_wavefront_groups(self._h, int(groups)), "flx_set_wavefront_groups")

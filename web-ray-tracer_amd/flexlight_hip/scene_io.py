@@ -51,6 +51,7 @@ class FrameParams(C.Structure):
         ("random_seed", C.c_float),
         ("texture_width", C.c_int32),
         ("tile_rows", C.c_uint32), ("tile_index", C.c_uint32), ("tile_count", C.c_uint32),
+        ("temporal_samples", C.c_int32),
     ]
 
 
@@ -66,7 +67,7 @@ class Counters(C.Structure):
 
 class GBuffers(C.Structure):
     """flx_gbuffers (include/flexlight_hip.h)."""
-    _fields_ = [(n, C.POINTER(C.c_float)) for n in ("color", "color_ip", "original_color", "id", "original_id")]
+    _fields_ = [(n, C.POINTER(C.c_float)) for n in ("color", "color_ip", "original_color", "id", "original_id", "location_id")]
 
 
 def view_matrix(fx, fy, fov, width, height):
@@ -151,4 +152,5 @@ class Scene:
         p.random_seed = 0.0
         p.texture_width = int(self.meta["textureWidth"])
         p.tile_rows, p.tile_index, p.tile_count = tile
+        p.temporal_samples = 4
         return p

@@ -1,7 +1,8 @@
 'use strict';
 // Config of the FlexLight API (reference modules/config.js:3-16), same field names and defaults; the
-// renderer re-reads it every frame.  The HIP renderer has no history pass and no post-AA yet, so
-// `temporal` and `antialiasing` default to off here (the reference's defaults are true / 'fxaa').
+// renderer re-reads it every frame.  The HIP back-end has no post-AA (FXAA/TAA are out of scope), so
+// `antialiasing` defaults to off; `temporal` defaults to off as well so that a single renderFrame()
+// is the plain path-traced frame (the reference's defaults are true / 'fxaa').
 class Config {
   constructor () {
     this.samplesPerRay = 1;

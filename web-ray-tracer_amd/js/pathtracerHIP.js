@@ -43,6 +43,7 @@ class PathTracerHIP {
     this._halt = true;
     this._atlasLists = [null, null, null];
     this._haveScene = false;
+    this._temporalFrame = 0;                             // pathtracerWGL2.js:291,562
     this.lastFrame = null;
   }
 
@@ -95,10 +96,11 @@ class PathTracerHIP {
       maxReflections: this.config.maxReflections,
       minImportancy: this.config.minImportancy,
       useFilter: this.config.filter ? 1 : 0,
-      isTemporal: 0,                                      // no history pass in this back-end (SURVEY.md §8f N1)
+      isTemporal: this.config.temporal ? 1 : 0,
+      temporalSamples: this.config.temporalSamples,
       hdr: this.config.hdr ? 1 : 0,
       ambient: [this.scene.ambientLight[0], this.scene.ambientLight[1], this.scene.ambientLight[2]],
-      randomSeed: 0,                                      // pathtracerWGL2.js:347 with temporal off
+      randomSeed: this.config.temporal ? this._temporalFrame : 0,          // pathtracerWGL2.js:347
       textureWidth: Math.floor(2048 / this.scene.standardTextureSizes[0])
     };
     if (this._tile) { p.tileRows = this._tile.rows; p.tileIndex = this._tile.index; p.tileCount = this._tile.count; }
@@ -121,6 +123,7 @@ class PathTracerHIP {
     const rows = native().tileRowCount(p);
     const radiance = new Float32Array(rows * p.width * 4);
     const info = native().render(ctx, p, radiance, !!(options && options.counters));
+    this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);     // pathtracerWGL2.js:291
     this.lastFrame = Object.assign({ width: p.width, height: p.height, rows, radiance }, info);
     return this.lastFrame;
   }

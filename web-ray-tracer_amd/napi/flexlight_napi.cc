@@ -200,6 +200,7 @@ static bool read_params(napi_env env, napi_value o, flx_frame_params *p) {
   d = 0; if (!num(env, o, "tileRows", &d, false)) return false; p->tile_rows = (uint32_t)d;
   d = 0; if (!num(env, o, "tileIndex", &d, false)) return false; p->tile_index = (uint32_t)d;
   d = 0; if (!num(env, o, "tileCount", &d, false)) return false; p->tile_count = (uint32_t)d;
+  d = 4; if (!num(env, o, "temporalSamples", &d, false)) return false; p->temporal_samples = (int32_t)d;
   return true;
 }
 
@@ -247,6 +248,17 @@ static napi_value Render(napi_env env, napi_callback_info info) {
   return res;
 }
 
+/* temporalReset(handle): forget the temporal history */
+static napi_value TemporalReset(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  flx_status rc = flx_temporal_reset(ctx);
+  if (rc != FLX_OK) return fail(env, ctx, "flx_temporal_reset", rc);
+  return nullptr;
+}
+
 /* deviceInfo(handle) -> { name, computeUnits } */
 static napi_value DeviceInfo(napi_env env, napi_callback_info info) {
   napi_value argv[1];
@@ -272,7 +284,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   const struct { const char *name; napi_callback fn; } fns[] = {
     { "createContext", CreateContext }, { "destroyContext", DestroyContext }, { "uploadScene", UploadScene },
     { "uploadTransforms", UploadTransforms }, { "uploadLights", UploadLights }, { "uploadAtlas", UploadAtlas },
-    { "tileRowCount", TileRowCount }, { "render", Render }, { "deviceInfo", DeviceInfo }, { "version", Version },
+    { "tileRowCount", TileRowCount }, { "render", Render }, { "temporalReset", TemporalReset }, { "deviceInfo", DeviceInfo }, { "version", Version },
   };
   for (const auto &f : fns) {
     napi_value fn;
