@@ -505,7 +505,32 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         break;
       }
     }
-    const bool tailMode = FLX_WF_TAIL_LANES > 0 && !(itemsLeft || chunkNext != chunkEnd) && (uint32_t)__popcll(__ballot(st == P_WALKING)) <= (uint32_t)FLX_WF_TAIL_LANES;
+#if FLX_WF_TAIL_LANES > 0
+    /* Tail: nothing left to draw and only a few lanes still walk.  The kernel's end is now the longest remaining walk,
+     * one dependent fetch -> test -> fetch chain per entry, and the memory pipes are idle: run those lanes in a loop of
+     * their own that starts the loads of BOTH successors (the entry names them) before testing the entry. */
+    if (!(itemsLeft || chunkNext != chunkEnd) && (uint32_t)__popcll(__ballot(st == P_WALKING)) <= (uint32_t)FLX_WF_TAIL_LANES) {
+      while (__ballot(st == P_WALKING) != 0ull) {
+        if (COUNT) diagIters++;
+        if (st == P_WALKING) {
+          const bool isBox = walkIsBoxT(cur);
+          const uint32_t succA = isBox ? (uint32_t)__float_as_int(cur.e2.x) : (uint32_t)__float_as_int(cur.e2.y);   /* box hit / triangle next */
+          const uint32_t succB = (uint32_t)__float_as_int(cur.e2.y);                                              /* box miss */
+          WalkEntry nA, nB;
+          walkLoadEntry(sc, ldsEntries, ldsCount, succA, nA);
+          if (isBox) walkLoadEntry(sc, ldsEntries, ldsCount, succB, nB); else nB = nA;
+          bool ended = false;
+          if (isBox) walkBoxP(w, cur); else ended = walkTriT(w, cur);
+          if (!ended) {
+            cur = ((uint32_t)w.i == succA) ? nA : nB;
+            ended = walkArriveP<COUNT>(myRays, w, cur, cnt);
+          }
+          if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
+        }
+      }
+      continue;
+    }
+#endif
     long long t2 = COUNT ? clock64() : 0;
     /* ---- FLX_WF_INNER entries for every walking lane ------------------------------------------------- */
 #pragma unroll 1
@@ -513,26 +538,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
       if (COUNT) diagIters++;
       if (st == P_WALKING) {
         bool ended = false;
-        if (tailMode) {
-          /* few lanes left and nothing to refill: the kernel's end is now the longest remaining walk, one
-           * dependent fetch -> test -> fetch chain per entry.  Both successors are named by the entry itself:
-           * start their loads before the test so they complete under it (costs twice the loads — only worth it
-           * here, where the memory pipes are idle). */
-          const bool isBox = walkIsBoxT(cur);
-          const uint32_t succA = isBox ? (uint32_t)__float_as_int(cur.e2.x) : (uint32_t)__float_as_int(cur.e2.y);   /* box hit / triangle next */
-          const uint32_t succB = (uint32_t)__float_as_int(cur.e2.y);                                              /* box miss */
-          WalkEntry nA, nB;
-          walkLoadEntry(sc, ldsEntries, ldsCount, succA, nA);
-          if (isBox) walkLoadEntry(sc, ldsEntries, ldsCount, succB, nB); else nB = nA;
-          if (isBox) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-          if (!ended) {
-            cur = ((uint32_t)w.i == succA) ? nA : nB;
-            ended = walkArriveP<COUNT>(myRays, w, cur, cnt);
-          }
-        } else {
-          if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-          if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
-        }
+        if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
+        if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
         if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
       }
     }
