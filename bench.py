@@ -211,7 +211,7 @@ def main():
         if use_filter or cnt_b0 is None:
             kernel_name, bytes_launch = "k_trace_pixels", frame_bytes - (244 * rows_local * W if use_filter else 0)
         else:                      # the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
-            kernel_name, bytes_launch = "k_wf_walk (bounce 0)", 48 * (cnt_b0["closest_visits"] + cnt_b0["shadow_visits"])
+            kernel_name, bytes_launch = "k_wf_walk_pre<false, true> (walk kernel of bounce 0)", 48 * (cnt_b0["closest_visits"] + cnt_b0["shadow_visits"])
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         traffic = None
         try:                       # HBM bytes of that kernel from rocprofv3 PMC passes (profiles/, not measurable from inside bench.py)

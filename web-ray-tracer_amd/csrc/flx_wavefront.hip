@@ -348,7 +348,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
 /* ---- walk kernel, pre-transformed rays (the default when the scene's transforms fit in LDS) ---------- */
 enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4 };
 
-template <bool COUNT>
+/* FIRST = bounce 0 (identity live list); a template parameter so that the dominant launch of a frame is a kernel symbol of
+ * its own in profiler summaries (bench.py's roofline names it). */
+template <bool COUNT, bool FIRST>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
                                                                      uint32_t ldsCount, uint32_t nTransforms) {
   /* LDS: [tree top: ldsCount entries x 48 B][per thread: nTransforms x (origin, dir, 1/dir + fast flag) float4 triples] */
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   float4 *myRays = ldsAll + (size_t)ldsCount * 3u + (size_t)threadIdx.x * nTransforms * 3u;
   for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
   __syncthreads();
-  const uint32_t n = (b == 0) ? total_items : wb.counts[b];
+  const uint32_t n = FIRST ? total_items : wb.counts[b];
   const uint32_t waveId = blockIdx.x * (FLX_WF_WALK_THREADS / 64u) + (threadIdx.x >> 6);
   if (waveId * (64u * FLX_WF_ITEMS_PER_LANE) >= n && waveId != 0u) return;
   const uint32_t *__restrict__ listIn = wb.live[b & 1];
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         const uint32_t r = lane_rank(idle);
         if (st == P_EMPTY && r < take) {
           const uint32_t j = chunkNext + r;
-          const uint32_t id = (b == 0) ? wb.item_base + j : listIn[j];
+          const uint32_t id = FIRST ? wb.item_base + j : listIn[j];
           if (id != WF_INVALID) {
             const float4 *rec = wb.rec + (size_t)id * 8;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];     /* one cache line, four loads in flight */
@@ -585,8 +587,10 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   if (!attrSet) {
     (void)hipFuncSetAttribute((const void *)k_wf_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attrSet = true;
   }
   const int bounces = fr.max_reflections > 0 ? fr.max_reflections : 1;   /* 0 bounces: shade(0) only finalises */
@@ -602,8 +606,13 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
     }
     if (b == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
     if (pre) {
-      if (count) hipLaunchKernelGGL(k_wf_walk_pre<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
-      else hipLaunchKernelGGL(k_wf_walk_pre<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+      if (b == 0) {
+        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+        else hipLaunchKernelGGL((k_wf_walk_pre<false, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+      } else {
+        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+        else hipLaunchKernelGGL((k_wf_walk_pre<false, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+      }
     } else {
       if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
       else hipLaunchKernelGGL(k_wf_walk<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
