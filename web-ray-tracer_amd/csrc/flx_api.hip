@@ -215,7 +215,9 @@ static void build_threaded(const float *geometry, uint32_t n, std::vector<float>
       o[10] = bits(meta);
       o[11] = bits(i);
     } else {
-      for (int k = 0; k < 9; k++) o[k] = e[k];
+      /* vertex a, then the two edges b - a and c - a of fragment:124-125 (the same single-precision subtractions the
+       * shader does per visit, done once here) */
+      for (int k = 0; k < 3; k++) { o[k] = e[k]; o[3 + k] = e[3 + k] - e[k]; o[6 + k] = e[6 + k] - e[k]; }
       o[9] = bits(succ((uint64_t)i + 1));
       o[10] = bits(meta);
       o[11] = bits(i);

@@ -674,31 +674,40 @@ FLX_DEV bool rayCuboidR(float l, const WalkState &w, f3 minCorner, f3 maxCorner)
 FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCorner) {
   const f3 o = w.tR.origin, d = w.tR.dir, y = w.inv;
   const f3 a0 = minCorner - o, a1 = maxCorner - o;
-  /* every |a| is 0 or >= 2^-40:  (bits & 0x7fffffff) - 1 as unsigned is huge for 0 and small for tiny values */
-  uint32_t m = (flx_f2u(a0.x) & 0x7fffffffu) - 1u;
+  /* every |a| is 0 or >= 2^-40.  Exact zeros are common (a ray leaving a flat floor has its origin ON the plane of the
+   * floor's degenerate box) and must stay on the fast path: a float min over |a| that sends zeros to the division path
+   * measured 1.5 % slower on the dragon frame. */
+  uint32_t m = (flx_f2u(a0.x) & 0x7fffffffu) - 1u;                 /* (bits & 0x7fffffff) - 1 as unsigned is huge for 0 and small for tiny values */
   uint32_t t;
   t = (flx_f2u(a0.y) & 0x7fffffffu) - 1u; m = t < m ? t : m;
   t = (flx_f2u(a0.z) & 0x7fffffffu) - 1u; m = t < m ? t : m;
   t = (flx_f2u(a1.x) & 0x7fffffffu) - 1u; m = t < m ? t : m;
   t = (flx_f2u(a1.y) & 0x7fffffffu) - 1u; m = t < m ? t : m;
   t = (flx_f2u(a1.z) & 0x7fffffffu) - 1u; m = t < m ? t : m;
+  const bool aOk = m >= 0x2b800000u - 1u;
   f3 v0, v1;
+  float tmin, tmax;
 #ifdef FLX_DIAG_SLOW
   { extern __device__ unsigned long long g_diagSlow[4];
-    const bool slow = !(w.fastDiv && m >= 0x2b800000u - 1u);
+    const bool slow = !(w.fastDiv && aOk);
     const unsigned long long sm = __ballot(slow);
     if (sm && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)sm) - 1u) { atomicAdd(&g_diagSlow[0], (unsigned long long)__popcll(sm)); atomicAdd(&g_diagSlow[1], 1ull); if (!w.fastDiv) atomicAdd(&g_diagSlow[2], 1ull); }
     if ((threadIdx.x & 63u) == 0u || !(__ballot(1) & 1ull)) {} }
 #endif
-  if (w.fastDiv && m >= 0x2b800000u - 1u) {
+  if (w.fastDiv && aOk) {
     v0 = F3(divByRecip(a0.x, d.x, y.x), divByRecip(a0.y, d.y, y.y), divByRecip(a0.z, d.z, y.z));
     v1 = F3(divByRecip(a1.x, d.x, y.x), divByRecip(a1.y, d.y, y.y), divByRecip(a1.z, d.z, y.z));
-  } else {
-    v0 = a0 / d;
-    v1 = a1 / d;
+    /* all six quotients are finite here, so GLSL min/max ((y < x) ? y : x) and the hardware's v_min/v_max agree except
+     * for the sign of a zero result, which the comparisons below cannot see: one instruction each instead of
+     * compare + select */
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(v0.x, v1.x), __builtin_fminf(v0.y, v1.y)), __builtin_fminf(v0.z, v1.z));
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(v0.x, v1.x), __builtin_fmaxf(v0.y, v1.y)), __builtin_fmaxf(v0.z, v1.z));
+    return tmax >= __builtin_fmaxf(tmin, BIAS) && tmin < l;
   }
-  float tmin = flx_max(flx_max(flx_min(v0.x, v1.x), flx_min(v0.y, v1.y)), flx_min(v0.z, v1.z));
-  float tmax = flx_min(flx_min(flx_max(v0.x, v1.x), flx_max(v0.y, v1.y)), flx_max(v0.z, v1.z));
+  v0 = a0 / d;
+  v1 = a1 / d;
+  tmin = flx_max(flx_max(flx_min(v0.x, v1.x), flx_min(v0.y, v1.y)), flx_min(v0.z, v1.z));
+  tmax = flx_min(flx_min(flx_max(v0.x, v1.x), flx_max(v0.y, v1.y)), flx_max(v0.z, v1.z));
   return tmax >= flx_max(tmin, BIAS) && tmin < l;
 }
 
@@ -730,12 +739,11 @@ FLX_DEV void walkBoxT(WalkState &w, const WalkEntry &cur) {
 /* moellerTrumbore (fragment:123-140) and moellerTrumboreCull (fragment:143-158) as ONE straight-line
  * instruction stream: a wave holds shadow walks and closest-hit walks side by side, and the two
  * functions share every arithmetic operation (edges, pvec, det, 1/det, u, qvec, v, s) — they differ
- * only in the predicates.  The shader's early returns have no side effects, so evaluating all of it
+ * only in the predicates.  edge1 = b - a and edge2 = c - a (fragment:124-125) come precomputed from the threaded
+ * copy (build_threaded).  The shader's early returns have no side effects, so evaluating all of it
  * and combining the predicates at the end gives the same accept/reject and the same (s,u,v), NaNs
  * included: two-sided accepts unless (s > l || s <= BIAS), cull accepts only if (s <= l && s > BIAS). */
-FLX_DEV bool moellerTrumboreAny(f3 a, f3 b, f3 c, const Ray &ray, float l, bool cull, f3 &suv) {
-  f3 edge1 = b - a;
-  f3 edge2 = c - a;
+FLX_DEV bool moellerTrumboreAny(f3 a, f3 edge1, f3 edge2, const Ray &ray, float l, bool cull, f3 &suv) {
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
   float inv_det = 1.0f / det;
@@ -753,10 +761,11 @@ FLX_DEV bool moellerTrumboreAny(f3 a, f3 b, f3 c, const Ray &ray, float l, bool 
   return !detBad && !uBad && !vBad && sOk;
 }
 FLX_DEV bool walkTriT(WalkState &w, const WalkEntry &cur) {
-  f3 a = F3(cur.e0.x, cur.e0.y, cur.e0.z), b = F3(cur.e0.w, cur.e1.x, cur.e1.y), c = F3(cur.e1.z, cur.e1.w, cur.e2.x);
+  /* the threaded copy stores a triangle as (a, b - a, c - a) */
+  f3 a = F3(cur.e0.x, cur.e0.y, cur.e0.z), edge1 = F3(cur.e0.w, cur.e1.x, cur.e1.y), edge2 = F3(cur.e1.z, cur.e1.w, cur.e2.x);
   f3 suv;
   const bool cull = w.mode == 0;
-  const bool hit = moellerTrumboreAny(a, b, c, w.tR, w.minLen, cull, suv);
+  const bool hit = moellerTrumboreAny(a, edge1, edge2, w.tR, w.minLen, cull, suv);
   bool ended = false;
   if (hit) {
     if (cull) { w.shadowed = true; ended = true; }

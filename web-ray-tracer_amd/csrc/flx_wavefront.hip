@@ -66,6 +66,12 @@ constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves p
 #ifndef FLX_WF_ITEMS_PER_LANE
 #define FLX_WF_ITEMS_PER_LANE 4
 #endif
+#ifndef FLX_WF_BOX_RUN
+#define FLX_WF_BOX_RUN 0                    /* >0: k_wf_walk_pre steps in type-homogeneous sub-steps (N box steps, then FLX_WF_TRI_RUN triangle steps) */
+#endif
+#ifndef FLX_WF_TRI_RUN
+#define FLX_WF_TRI_RUN 1
+#endif
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 16                     /* parked lanes that trigger a fold + refill */
 #endif
@@ -538,12 +544,32 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
 #pragma unroll 1
     for (int it = 0; it < FLX_WF_INNER; it++) {
       if (COUNT) diagIters++;
+#if FLX_WF_BOX_RUN > 0
+      /* type-homogeneous sub-steps: FLX_WF_BOX_RUN box-only steps, then one triangle-only step; a lane at the other
+       * type of entry idles for that sub-step instead of making the whole wave run both tests every trip */
+#pragma unroll
+      for (int k = 0; k < FLX_WF_BOX_RUN; k++) {
+        if (st == P_WALKING && walkIsBoxT(cur)) {
+          walkBoxP(w, cur);
+          if (walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = (w.mode == 0) ? P_SWITCH : P_DONE;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < FLX_WF_TRI_RUN; k++) {
+        if (st == P_WALKING && !walkIsBoxT(cur)) {
+          bool ended = walkTriT(w, cur);
+          if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
+          if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
+        }
+      }
+#else
       if (st == P_WALKING) {
         bool ended = false;
         if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
         if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
         if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
       }
+#endif
     }
     if (COUNT) tInner += clock64() - t2;
   }
