@@ -221,6 +221,18 @@ static const Hit NO_HIT = { { 0.0f, 0.0f, 0.0f }, 0, -1 };     /* fragment:81 */
 static uint64_t *g_visit_hist = NULL;
 /* analysis hook: g_walk_hist[k] counts walks with 2^k <= visits < 2^(k+1) (k < 31), [31] = longest walk */
 static uint64_t *g_walk_hist = NULL;
+/* analysis hook (tools/walk_sim.py, single-threaded runs only): byte trace of every bounce walk — an 8-byte header
+ * {0xF0 | kind (0 shadow, 1 closest), bounce, sample, 0, px lo, px hi, py lo, py hi}, one byte per entry visited
+ * (its type: 0 terminator, 1 box, 2 triangle), then 0xFF */
+static uint8_t *g_trace = NULL;
+static size_t g_trace_cap = 0, g_trace_len = 0;
+static uint32_t g_trace_px = 0, g_trace_py = 0, g_trace_sample = 0, g_trace_bounce = 0;
+static void trace_byte(uint8_t b) { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = b; }
+static void trace_begin(int kind) {
+  if (!g_trace) return;
+  trace_byte((uint8_t)(0xF0 | kind)); trace_byte((uint8_t)g_trace_bounce); trace_byte((uint8_t)g_trace_sample); trace_byte(0);
+  trace_byte((uint8_t)(g_trace_px & 255u)); trace_byte((uint8_t)(g_trace_px >> 8)); trace_byte((uint8_t)(g_trace_py & 255u)); trace_byte((uint8_t)(g_trace_py >> 8));
+}
 static void tally_walk(uint64_t v) {
   if (!g_walk_hist) return;
   int k = 0; while ((v >> (k + 1)) && k < 30) k++;
@@ -237,10 +249,12 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
   Hit hit = NO_HIT;
   float minLen = POW32;
   int size = (int)sc->n_entries_padded;
+  if (!mode) trace_begin(1);
   for (int i = 0; i < size; i++) {
     const float *e = sc->geometry + (size_t)i * 12;
     (*visits)++;
     if (g_visit_hist) { _Pragma("omp atomic") g_visit_hist[i]++; }
+    if (!mode) trace_byte((uint8_t)e[10]);
     int tI = (int)e[9] << 1;
     if (tI != cachedTI) {
       int iI = tI + 1;
@@ -249,7 +263,7 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
       tR.origin = m3mul(rotationII, add3(ray.origin, shift_at(sc, iI)));
       tR.unitDirection = m3mul(rotationII, ray.unitDirection);
     }
-    if (e[10] == 0.0f) { if (!mode) tally_walk(*visits - visits0); return hit; }
+    if (e[10] == 0.0f) { if (!mode) { tally_walk(*visits - visits0); trace_byte(0xFF); } return hit; }
     if (e[10] == 1.0f) {
       if (!rayCuboid(minLen, tR, V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]))) i += (int)e[6];
     } else {
@@ -262,7 +276,7 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
       }
     }
   }
-  if (!mode) tally_walk(*visits - visits0);
+  if (!mode) { tally_walk(*visits - visits0); trace_byte(0xFF); }
   return hit;
 }
 
@@ -272,10 +286,12 @@ static int shadowTestImpl(const flx_scene_view *sc, Ray ray, float l, uint64_t *
   int cachedTI = 0;
   float minLen = l;
   int size = (int)sc->n_entries_padded;
+  trace_begin(0);
   for (int i = 0; i < size; i++) {
     const float *e = sc->geometry + (size_t)i * 12;
     (*visits)++;
     if (g_visit_hist) { _Pragma("omp atomic") g_visit_hist[i]++; }
+    trace_byte((uint8_t)e[10]);
     int tI = (int)e[9] << 1;
     if (tI != cachedTI) {
       int iI = tI + 1;
@@ -284,13 +300,14 @@ static int shadowTestImpl(const flx_scene_view *sc, Ray ray, float l, uint64_t *
       tR.origin = m3mul(rotationII, add3(ray.origin, shift_at(sc, iI)));
       tR.unitDirection = normalize3(m3mul(rotationII, ray.unitDirection));
     }
-    if (e[10] == 0.0f) return 0;
+    if (e[10] == 0.0f) { trace_byte(0xFF); return 0; }
     if (e[10] == 1.0f) {
       if (!rayCuboid(minLen, tR, V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]))) i += (int)e[6];
     } else {
-      if (moellerTrumboreCull(V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]), V3(e[6], e[7], e[8]), tR, minLen)) return 1;
+      if (moellerTrumboreCull(V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]), V3(e[6], e[7], e[8]), tR, minLen)) { trace_byte(0xFF); return 1; }
     }
   }
+  trace_byte(0xFF);
   return 0;
 }
 
@@ -407,6 +424,7 @@ static v3 lightTrace(Frag *f, Hit hit, v3 dir0, v3 camera, float cosSampleN, int
   v3 lastHitPoint = camera;
   for (int i = 0; i < bounces && length3(mul3(importancyFactor, f->originalColor)) >= fp->min_importancy * SQRT3; i++) {
     float fi = (float)i;
+    g_trace_bounce = (uint32_t)i;
     f->cnt.shades++;
     m3 rTI = rotation_at(sc, hit.transformId);
     v3 sTI = shift_at(sc, hit.transformId);
@@ -543,7 +561,9 @@ static void fragment_main(Frag *f, const PrimarySetup *ps, uint32_t px, uint32_t
   f->cnt.primary_hits++;
   v3 camera = V3(fp->camera[0], fp->camera[1], fp->camera[2]);
   v3 finalColor = V3(0.0f, 0.0f, 0.0f);
+  g_trace_px = px; g_trace_py = py_gl;
   for (int i = 0; i < fp->samples; i++) {
+    g_trace_sample = (uint32_t)i;
     float cosSampleN = flx_cos((float)i);
     finalColor = add3(finalColor, lightTrace(f, hit, dir0, camera, cosSampleN, fp->max_reflections));
   }
@@ -710,6 +730,8 @@ void flx_oracle_primary(const flx_scene_view *scene, const flx_frame_params *par
 }
 void flx_oracle_set_visit_histogram(uint64_t *hist) { g_visit_hist = hist; }
 void flx_oracle_set_walk_histogram(uint64_t *hist32) { g_walk_hist = hist32; }
+void flx_oracle_set_trace(uint8_t *buf, size_t cap) { g_trace = buf; g_trace_cap = cap; g_trace_len = 0; }
+size_t flx_oracle_trace_length(void) { return g_trace_len; }
 
 void flx_oracle_math(int fn, const float *a, const float *b, float *out, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) {
