@@ -223,7 +223,7 @@ static uint64_t *g_visit_hist = NULL;
 static uint64_t *g_walk_hist = NULL;
 /* analysis hook (tools/walk_sim.py, single-threaded runs only): byte trace of every bounce walk — an 8-byte header
  * {0xF0 | kind (0 shadow, 1 closest), bounce, sample, 0, px lo, px hi, py lo, py hi}, one byte per entry visited
- * (its type: 0 terminator, 1 box, 2 triangle), then 0xFF */
+ * (its type: 0 terminator, 1 box, 2 triangle; | 0x10 when the entry's transform differs from the cached one), then 0xFF */
 static uint8_t *g_trace = NULL;
 static size_t g_trace_cap = 0, g_trace_len = 0;
 static uint32_t g_trace_px = 0, g_trace_py = 0, g_trace_sample = 0, g_trace_bounce = 0;
@@ -254,8 +254,8 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
     const float *e = sc->geometry + (size_t)i * 12;
     (*visits)++;
     if (g_visit_hist) { _Pragma("omp atomic") g_visit_hist[i]++; }
-    if (!mode) trace_byte((uint8_t)e[10]);
     int tI = (int)e[9] << 1;
+    if (!mode) trace_byte((uint8_t)((int)e[10] | (tI != cachedTI ? 0x10 : 0)));
     if (tI != cachedTI) {
       int iI = tI + 1;
       m3 rotationII = rotation_at(sc, iI);
@@ -291,8 +291,8 @@ static int shadowTestImpl(const flx_scene_view *sc, Ray ray, float l, uint64_t *
     const float *e = sc->geometry + (size_t)i * 12;
     (*visits)++;
     if (g_visit_hist) { _Pragma("omp atomic") g_visit_hist[i]++; }
-    trace_byte((uint8_t)e[10]);
     int tI = (int)e[9] << 1;
+    trace_byte((uint8_t)((int)e[10] | (tI != cachedTI ? 0x10 : 0)));
     if (tI != cachedTI) {
       int iI = tI + 1;
       m3 rotationII = rotation_at(sc, iI);

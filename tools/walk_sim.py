@@ -66,15 +66,75 @@ def parse(trace, p):
 
 
 def lane_sequences(items):
-    """one op sequence per path: shadow walk, a SWITCH marker (3), closest walk"""
+    """one op sequence per path: shadow walk, a SWITCH marker (3), closest walk (entry kinds only, for sim_current / sim_slots)"""
     seqs = []
     for _, sh, cl in items:
         parts = []
         if sh is not None:
-            parts += [sh, np.array([3], np.uint8)]
-        parts.append(cl if cl is not None else np.zeros(0, np.uint8))
+            parts += [sh & 15, np.array([3], np.uint8)]
+        parts.append(cl & 15 if cl is not None else np.zeros(0, np.uint8))
         seqs.append(np.concatenate(parts))
     return seqs
+
+
+K_BOX, K_TRI, K_XF, K_NEW = 0, 1, 2, 3
+
+
+def op_sequences(items):
+    """per path, the tests the queue schedulers run: NEW (refill + ray set-up), then per walk its box / triangle tests with an
+    XFORM before every entry whose transform differs from the cached one, NEW again between the shadow and the closest walk"""
+    seqs = []
+    for _, sh, cl in items:
+        ops = [K_NEW]
+        for walk in (sh, cl):
+            if walk is None:
+                continue
+            if len(ops) > 1:
+                ops.append(K_NEW)
+            for byte in walk.tolist():
+                kind = byte & 15
+                if kind == 0:
+                    continue                      # the terminator is handled when its link is routed
+                if byte & 0x10:
+                    ops.append(K_XF)
+                ops.append(K_BOX if kind == 1 else K_TRI)
+        seqs.append(ops)
+    return seqs
+
+
+def sim_local_queues(seqs, walks=128, overhead=55, costs=(64, 85, 110, 300), min_tri=0):
+    """one wave owning `walks` walks in LDS, four wave-local queues; each trip runs ONE kind of test on up to 64 queued walks"""
+    n = len(seqs)
+    nxt = 0
+    queues = [[], [], [], []]
+    pos = {}
+    live = 0
+    cost = 0
+    visits = 0
+    trips = [0, 0, 0, 0]
+    lanes = [0, 0, 0, 0]
+    # a NEW op both retires a path and starts the next one in the same slot: model the slot pool by seeding `walks` paths
+    for _ in range(min(walks, n)):
+        pos[nxt] = 0; queues[K_NEW].append(nxt); nxt += 1
+    while any(queues):
+        sizes = [len(q) for q in queues]
+        k = max(range(4), key=lambda q: sizes[q])
+        if min_tri and k == K_TRI and sizes[K_TRI] < min_tri and sizes[K_BOX] > 0:
+            k = K_BOX
+        batch, queues[k] = queues[k][:64], queues[k][64:]
+        cost += costs[k] + overhead
+        trips[k] += 1; lanes[k] += len(batch)
+        for w in batch:
+            if k in (K_BOX, K_TRI): visits += 1
+            pos[w] += 1
+            ops = seqs[w]
+            if pos[w] >= len(ops):
+                del pos[w]
+                if nxt < n:                       # the fold of this path is the NEW op of the next one
+                    pos[nxt] = 0; queues[K_NEW].append(nxt); nxt += 1
+            else:
+                queues[ops[pos[w]]].append(w)
+    return cost, visits, trips, lanes
 
 
 def sim_current(seqs, inner=4, batch=16, box_run=0):
@@ -176,20 +236,25 @@ def main():
     trace, p = record(name, strips)
     bounces = parse(trace, p)
     for b, items in enumerate(bounces):
-        seqs = lane_sequences(items)
         limit = int(os.environ.get("SIM_PATHS", "20000"))
-        mid = max(0, len(seqs) // 2 - limit // 2)
-        seqs = seqs[mid:mid + limit]                      # the middle of the sampled strips: dragon, not sky
+        mid = max(0, len(items) // 2 - limit // 2)
+        items = items[mid:mid + limit]                     # the middle of the sampled strips: dragon, not sky
+        seqs = lane_sequences(items)
         ops = np.concatenate(seqs)
         nb, nt = int((ops == 1).sum()), int((ops == 2).sum() + (ops == 0).sum())
-        print("bounce %d: %d paths, %d visits (box %.2f tri %.2f)" % (b, len(seqs), nb + nt, nb / (nb + nt), nt / (nb + nt)))
-        ideal = (nb * (C_BOX + 45) + nt * (C_TRI + 45)) / 64.0
+        qs = op_sequences(items)
+        nx = sum(o.count(K_XF) for o in qs)
+        print("bounce %d: %d paths, %d visits (box %.2f tri %.2f), %.1f transform changes per path" % (b, len(seqs), nb + nt, nb / (nb + nt), nt / (nb + nt), nx / len(qs)))
+        ideal = (nb * (C_BOX + 55) + nt * (C_TRI + 55)) / 64.0
         c0, v0 = sim_current(seqs)
-        print("   current            : %7.1f slots / visit   (lane utilisation %.2f)" % (c0 / v0, v0 / (c0 / (C_SCHED + C_BOX + C_TRI + C_FETCH)) / 64))
-        for W in (2, 3, 4):
-            c, v = sim_slots(seqs, W)
-            print("   %d walks per lane   : %7.1f slots / visit" % (W, c / v))
-        print("   perfect regrouping : %7.1f slots / visit" % (ideal / (nb + nt)))
+        print("   one walk per lane (k_wf_walk_pre)     : %5.2f slots / visit" % (c0 / v0))
+        for walks in (128, 256, 1280):
+            c, v, trips, lanes = sim_local_queues(qs, walks)
+            fill = " ".join("%s %.0f" % (nm, lanes[k] / max(1, trips[k])) for k, nm in enumerate(("box", "tri", "xf", "new")))
+            print("   queues over %4d walks                 : %5.2f slots / visit   (mean batch: %s)" % (walks, c / v, fill))
+        c, v, trips, lanes = sim_local_queues(qs, 128, min_tri=40)
+        print("   queues over  128 walks, tri >= 40      : %5.2f slots / visit" % (c / v))
+        print("   perfect regrouping, no set-up ops      : %5.2f slots / visit" % (ideal / (nb + nt)))
 
 
 if __name__ == "__main__":

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -36,6 +37,7 @@ struct flx_context {
   float4 *d_geometry = nullptr, *d_attributes = nullptr, *d_rotation = nullptr, *d_shift = nullptr;
   float4 *d_walk = nullptr;                      /* threaded hot-first copy of the skip list */
   uint32_t walk_entries = 0, walk_hot = 0, walk_root = 0, walk_fast_boxes = 0;
+  int walk_scheduler = 0;
   int32_t *d_ids = nullptr;
   float *d_lights = nullptr;
   uchar4 *d_atlas[3] = { nullptr, nullptr, nullptr };
@@ -105,6 +107,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if (device < 0 || device >= n) { g_create_error = "flx_context_create: device index out of range"; return FLX_ERR_INVALID; }
   flx_context *ctx = new flx_context();
   ctx->device = device;
+  if (const char *ws = getenv("FLX_WALK_SCHEDULER")) ctx->walk_scheduler = atoi(ws);
   auto bail = [&](const char *what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
     delete ctx;
@@ -197,12 +200,15 @@ static void build_threaded(const float *geometry, uint32_t n, std::vector<float>
   n_hot = hot + 1;
   out.assign((size_t)n_out * 12, 0.0f);
   auto bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
-  auto succ = [&](uint64_t j) -> uint32_t {      /* threaded index of original successor j */
+  /* link to original successor j from an entry with transform number `fromT` (flx_device.h: LINK_*) */
+  auto succ = [&](uint64_t j, uint32_t fromT) -> uint32_t {
     if (j >= n) return WALK_END;                 /* loop bound reached: no fetch (fragment:184) */
-    if (geometry[(size_t)j * 12 + 10] == 0.0f) return terminator;
-    return newIndex[j];
+    const float *e = geometry + (size_t)j * 12;
+    if (e[10] == 0.0f) return terminator;        /* kind 0; a terminator's transform is never used */
+    const uint32_t kind = e[10] == 1.0f ? 1u : 2u;
+    return newIndex[j] | kind << LINK_KIND_SHIFT | ((uint32_t)e[9] != fromT ? LINK_XFORM : 0u);
   };
-  root = succ(0);
+  root = succ(0, 0);                             /* a walk starts with the untransformed ray (cachedTI = 0, fragment:174) */
   for (uint32_t i : order) {
     const float *e = geometry + (size_t)i * 12;
     float *o = out.data() + (size_t)newIndex[i] * 12;
@@ -210,15 +216,15 @@ static void build_threaded(const float *geometry, uint32_t n, std::vector<float>
     const uint32_t meta = type | ((uint32_t)e[9] << 2);
     if (type == 1u) {
       for (int k = 0; k < 6; k++) o[k] = e[k];
-      o[8] = bits(succ((uint64_t)i + 1));
-      o[9] = bits(succ((uint64_t)i + 1 + (uint64_t)e[6]));
+      o[8] = bits(succ((uint64_t)i + 1, (uint32_t)e[9]));
+      o[9] = bits(succ((uint64_t)i + 1 + (uint64_t)e[6], (uint32_t)e[9]));
       o[10] = bits(meta);
       o[11] = bits(i);
     } else {
       /* vertex a, then the two edges b - a and c - a of fragment:124-125 (the same single-precision subtractions the
        * shader does per visit, done once here) */
       for (int k = 0; k < 3; k++) { o[k] = e[k]; o[3 + k] = e[3 + k] - e[k]; o[6 + k] = e[6 + k] - e[k]; }
-      o[9] = bits(succ((uint64_t)i + 1));
+      o[9] = bits(succ((uint64_t)i + 1, (uint32_t)e[9]));
       o[10] = bits(meta);
       o[11] = bits(i);
     }
@@ -231,6 +237,7 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
   if (!ctx) return FLX_ERR_INVALID;
   if (!geometry || !attributes || n_entries_padded == 0) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: empty scene");
   if (n_ids && !ids) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: ids is NULL");
+  if (n_entries_padded > LINK_INDEX) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: more than 2^28 - 1 entries");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   ctx->have_scene = false;
   /* Validate the skip list on the host: a skip that leaves the array would make the walk read out of
@@ -456,7 +463,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
       wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;
       wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
       hipStream_t st = g == 0 ? ctx->stream : ctx->aux_stream[g - 1];
-      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
+      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->walk_scheduler, g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
       FLX_HIP(ctx, hipGetLastError());
       if (g > 0) {
         FLX_HIP(ctx, hipEventRecord(ctx->ev_join[g - 1], st));

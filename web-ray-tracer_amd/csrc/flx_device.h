@@ -91,6 +91,13 @@ struct DeviceScene {
  *                  terminator                                           e2 = -          -              bits(meta = 0)
  * meta = type | transform << 2; successor WALK_END = the loop bound of fragment:184 was reached (no fetch). */
 constexpr uint32_t WALK_END = 0xffffffffu;
+/* A successor link = threaded index | kind of the entry it names << 28 | (that entry's transform differs from this
+ * entry's) << 30.  Kinds: 0 terminator, 1 box, 2 triangle, 3 = WALK_END.  The queue scheduler (flx_walkq.hip) routes a
+ * walk to its next test from the link alone, without fetching the entry. */
+constexpr uint32_t LINK_INDEX = 0x0fffffffu, LINK_XFORM = 0x40000000u;
+constexpr int LINK_KIND_SHIFT = 28;
+FLX_DEV uint32_t linkIndex(uint32_t link) { return link & LINK_INDEX; }
+FLX_DEV uint32_t linkKind(uint32_t link) { return (link >> LINK_KIND_SHIFT) & 3u; }
 
 /* Per-frame constants (flx_frame_params + what the host derives from it). */
 struct DeviceFrame {
@@ -713,8 +720,8 @@ FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCor
 
 template <bool COUNT>
 FLX_DEV bool walkFetchT(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, WalkState &w, WalkEntry &cur, WorkCounters &cnt) {
-  const uint32_t i = (uint32_t)w.i;
-  if (i == WALK_END) return true;
+  if ((uint32_t)w.i == WALK_END) return true;
+  const uint32_t i = linkIndex((uint32_t)w.i);
   if (i < ldsCount) { cur.e0 = lds[3 * i]; cur.e1 = lds[3 * i + 1]; cur.e2 = lds[3 * i + 2]; }
   else { cur.e0 = sc.walk[3 * (size_t)i]; cur.e1 = sc.walk[3 * (size_t)i + 1]; cur.e2 = sc.walk[3 * (size_t)i + 2]; }
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
@@ -809,8 +816,8 @@ FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, float4 *
 template <bool COUNT>
 FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float4 *rays, WalkState &w, WalkEntry &cur,
                         WorkCounters &cnt) {
-  const uint32_t i = (uint32_t)w.i;
-  if (i == WALK_END) return true;
+  if ((uint32_t)w.i == WALK_END) return true;
+  const uint32_t i = linkIndex((uint32_t)w.i);
   if (i < ldsCount) { cur.e0 = lds[3 * i]; cur.e1 = lds[3 * i + 1]; cur.e2 = lds[3 * i + 2]; }
   else { cur.e0 = sc.walk[3 * (size_t)i]; cur.e1 = sc.walk[3 * (size_t)i + 1]; cur.e2 = sc.walk[3 * (size_t)i + 2]; }
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
@@ -831,6 +838,7 @@ FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
  * current entry is tested and complete while the test's ~100 VALU instructions run. */
 FLX_DEV void walkLoadEntry(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, uint32_t i, WalkEntry &e) {
   if (i == WALK_END) { e.e0 = e.e1 = e.e2 = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+  i = linkIndex(i);
   if (i < ldsCount) { e.e0 = lds[3 * i]; e.e1 = lds[3 * i + 1]; e.e2 = lds[3 * i + 2]; }
   else { e.e0 = sc.walk[3 * (size_t)i]; e.e1 = sc.walk[3 * (size_t)i + 1]; e.e2 = sc.walk[3 * (size_t)i + 2]; }
 }

@@ -31,8 +31,9 @@ struct WavefrontBuffers {
   unsigned long long *counters; /* or nullptr */
 };
 size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units);
+/* walk_scheduler: 0 = one walk per lane (k_wf_walk_pre / k_wf_walk), 1 = workgroup-wide test queues (flx_walkq.hip) */
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
-                      hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
+                      int walk_scheduler, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
 /* denoise chain (flx_filter.hip): 13 RGBA8 planes = the reference's RenderTexture[0..3], IpRenderTexture[0..3],
  * OriginalRenderTexture[0..1], IdRenderTexture[0..1], OriginalIdRenderTexture (pathtracerWGL2.js:224-252). */
 struct FilterPlanes { uint32_t *R[4], *Ip[4], *O[2], *Id[2], *OId; };

@@ -26,6 +26,7 @@
 #include <cstdio>
 #include "flx_kernels.h"
 #include "flx_kernel_util.h"
+#include "flx_wavefront_common.h"
 
 namespace flx {
 
@@ -33,9 +34,6 @@ namespace flx {
 __device__ unsigned long long g_diagSlow[4];
 #endif
 
-constexpr uint32_t WF_INVALID = 0xffffffffu;
-constexpr uint32_t WF_IN_CHUNK = 256;       /* path ids a wave draws from the walk queue per atomic */
-constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves per atomic */
 #ifndef FLX_WF_WALK_THREADS
 #define FLX_WF_WALK_THREADS 1024
 #endif
@@ -75,23 +73,6 @@ constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves p
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 16                     /* parked lanes that trigger a fold + refill */
 #endif
-
-/* record flags (q0.w as int bits) */
-constexpr int RF_DEAD = 1, RF_DONT_FILTER = 2, RF_NEED_SHADOW = 4, RF_SHADOWED_NO_WALK = 8;
-
-/* q0 origin.xyz flags | q1 nextDir.xyz shadowLen | q2 shadowOrigin.xyz baseLuminance  (after the walk: hit s,u,v,tri)
- * q3 shadowDir.xyz - | q4 litColor.xyz - | q5 finalColor.xyz - | q6 importancyFactor.xyz - | q7 originalColor.xyz - */
-
-__device__ __forceinline__ void finalize_path(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t pathId, f3 finalColor,
-                                              f3 importancy, f3 originalColor) {
-  uint32_t px, k, s;
-  item_pixel(fr, pathId, px, k, s);
-  const size_t P = (size_t)fr.rows * fr.width;
-  const size_t o = (size_t)k * fr.width + px;
-  const f3 r = finalColor + importancy * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]);          /* fragment:598 */
-  wb.sampleRadiance[(size_t)s * P + o] = make_float4(r.x, r.y, r.z, 1.0f);
-  if (s == (uint32_t)fr.samples - 1u) wb.lastOriginal[o] = make_float4(originalColor.x, originalColor.y, originalColor.z, 1.0f);
-}
 
 template <bool COUNT, bool FIRST>
 __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items) {
@@ -591,7 +572,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
 }
 
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
-                      hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
+                      int walk_scheduler, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
 #ifdef FLX_DIAG_SLOW
   { unsigned long long h[4]; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diagSlow), sizeof h); fprintf(stderr, "diag slow-box: lanes %llu wave-events %llu notFast %llu\n", h[0], h[1], h[2]); }
 #endif
@@ -631,7 +612,9 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
       else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
     }
     if (b == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
-    if (pre) {
+    if (walk_scheduler == 1) {
+      launch_walk_queue(sc, fr, wb, compute_units, count, b, total, stream);
+    } else if (pre) {
       if (b == 0) {
         if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
         else hipLaunchKernelGGL((k_wf_walk_pre<false, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);

@@ -1,0 +1,35 @@
+/* Shared by the wavefront pipeline's kernels (flx_wavefront.hip, flx_walkq.hip): path-record flags, list constants,
+ * the store of a finished path's radiance. */
+#pragma once
+#include "flx_kernels.h"
+#include "flx_kernel_util.h"
+
+namespace flx {
+
+constexpr uint32_t WF_INVALID = 0xffffffffu;
+constexpr uint32_t WF_IN_CHUNK = 256;       /* path ids a wave draws from the walk queue per atomic */
+constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves per atomic */
+
+/* record flags (q0.w as int bits) */
+constexpr int RF_DEAD = 1, RF_DONT_FILTER = 2, RF_NEED_SHADOW = 4, RF_SHADOWED_NO_WALK = 8;
+
+/* q0 origin.xyz flags | q1 nextDir.xyz shadowLen | q2 shadowOrigin.xyz baseLuminance  (after the walk: hit s,u,v,tri)
+ * q3 shadowDir.xyz - | q4 litColor.xyz - | q5 finalColor.xyz - | q6 importancyFactor.xyz - | q7 originalColor.xyz - */
+
+__device__ __forceinline__ void finalize_path(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t pathId, f3 finalColor,
+                                              f3 importancy, f3 originalColor) {
+  uint32_t px, k, s;
+  item_pixel(fr, pathId, px, k, s);
+  const size_t P = (size_t)fr.rows * fr.width;
+  const size_t o = (size_t)k * fr.width + px;
+  const f3 r = finalColor + importancy * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]);          /* fragment:598 */
+  wb.sampleRadiance[(size_t)s * P + o] = make_float4(r.x, r.y, r.z, 1.0f);
+  if (s == (uint32_t)fr.samples - 1u) wb.lastOriginal[o] = make_float4(originalColor.x, originalColor.y, originalColor.z, 1.0f);
+}
+
+
+/* flx_walkq.hip */
+void launch_walk_queue(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count, int b,
+                       uint32_t total, hipStream_t stream);
+
+}  // namespace flx
