@@ -23,7 +23,7 @@ for bounces in range(1, sc.meta["frame"]["maxReflections"] + 1):
              delta["shadow_visits"] / max(1, delta["shadow_walks"]), it, visits / max(1, it * 64), ba))
     if b == 0:
         fold, refill, inner, life, waves = d[8:13]
-        print('   bounce-0 walk waves %d: mean lifetime %.0f cycles; share fold %.3f refill %.3f steps %.3f; cycles per wave-iteration %.0f' % (waves, life / max(1, waves), fold / max(1, life), refill / max(1, life), inner / max(1, life), inner / max(1, it)))
+        print('   bounce-0 walk waves %d: mean lifetime %.0f cycles; share fold %.3f refill %.3f (record loads %.3f) steps %.3f; cycles per wave-iteration %.0f' % (waves, life / max(1, waves), fold / max(1, life), refill / max(1, life), d[13] / max(1, life), inner / max(1, life), inner / max(1, it)))
     if b < 4 and d[17 + 3 * b]:
         print('   wave lifetimes: %d waves, mean %.0f, max %.0f cycles' % (d[17 + 3 * b], d[16 + 3 * b] / d[17 + 3 * b], d[18 + 3 * b]))
     prev = cnt

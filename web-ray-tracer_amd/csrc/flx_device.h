@@ -796,11 +796,13 @@ FLX_DEV void walkStartT(const DeviceScene &sc, WalkState &w, int mode, const Ray
  * when the walk is set up (a batched point where many lanes set up together, with the matrices read
  * through scalar loads) and parks the results in LDS; the stepping loop only reloads 2 x 16 bytes.
  * The arithmetic per (ray, transform) is exactly fragment:197-202 / :257-262. */
-FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, float4 *rays, const Ray &src, bool shadowMode) {
+FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, const float4 *xf, float4 *rays, const Ray &src, bool shadowMode) {
   for (uint32_t t = 0; t < nTransforms; t++) {
-    const int iI = 2 * (int)t + 1;
-    M3 rotationII = rotation_at(sc, iI);
-    f3 o = mul(rotationII, src.origin + shift_at(sc, iI));
+    /* xf: the inverse rotation (3 columns) and inverse shift of every transform, staged in LDS by the kernel: the same
+     * address for all lanes (a broadcast read) instead of four global loads per transform in the middle of the set-up */
+    const float4 c0 = xf[4 * t], c1 = xf[4 * t + 1], c2 = xf[4 * t + 2], sh = xf[4 * t + 3];
+    M3 rotationII; rotationII.c0 = F3(c0.x, c0.y, c0.z); rotationII.c1 = F3(c1.x, c1.y, c1.z); rotationII.c2 = F3(c2.x, c2.y, c2.z);
+    f3 o = mul(rotationII, src.origin + F3(sh.x, sh.y, sh.z));
     f3 d = mul(rotationII, src.dir);
     if (__ballot(shadowMode) != 0ull) {                   /* skip the normalize when no lane of the wave sets up a shadow walk */
       f3 dn = normalize(d);

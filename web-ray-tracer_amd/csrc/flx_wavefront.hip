@@ -71,7 +71,7 @@ __device__ unsigned long long g_diagSlow[4];
 #define FLX_WF_TRI_RUN 1
 #endif
 #ifndef FLX_WF_BATCH
-#define FLX_WF_BATCH 16                     /* parked lanes that trigger a fold + refill */
+#define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
 #endif
 
 template <bool COUNT, bool FIRST>
@@ -340,11 +340,17 @@ enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4 };
 template <bool COUNT, bool FIRST>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
                                                                      uint32_t ldsCount, uint32_t nTransforms) {
-  /* LDS: [tree top: ldsCount entries x 48 B][per thread: nTransforms x (origin, dir, 1/dir + fast flag) float4 triples] */
+  /* LDS: [tree top: ldsCount entries x 48 B][per thread: nTransforms x (origin, dir, 1/dir + fast flag) float4 triples]
+   *      [nTransforms x (inverse rotation columns, inverse shift) float4 quadruples] */
   extern __shared__ float4 ldsAll[];
   float4 *ldsEntries = ldsAll;
   float4 *myRays = ldsAll + (size_t)ldsCount * 3u + (size_t)threadIdx.x * nTransforms * 3u;
+  float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u + (size_t)FLX_WF_WALK_THREADS * nTransforms * 3u;
   for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
+  for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
+    const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
+    ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
+  }
   __syncthreads();
   const uint32_t n = FIRST ? total_items : wb.counts[b];
   const uint32_t waveId = blockIdx.x * (FLX_WF_WALK_THREADS / 64u) + (threadIdx.x >> 6);
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   inChunk = inChunk < 64u ? 64u : (inChunk > WF_IN_CHUNK ? WF_IN_CHUNK : inChunk);
   WorkCounters cnt = {};
   uint32_t diagIters = 0, diagBatches = 0;
-  long long tFold = 0, tRefill = 0, tInner = 0, tStart = COUNT ? clock64() : 0;
+  long long tFold = 0, tRefill = 0, tInner = 0, tLoad = 0, tStart = COUNT ? clock64() : 0;
 
   int st = P_EMPTY;
   uint32_t pathId = 0;
@@ -476,12 +482,13 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         chunkNext += take;
       }
       /* ---- set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended -------- */
+      if (COUNT) { const long long tl = clock64(); tLoad += tl - t1; }
       if (st == P_SWITCH) { w.mode = 1; st = P_SETUP; }
       if (__ballot(st == P_SETUP) != 0ull) {
         if (st == P_SETUP) {
           const bool shadowMode = w.mode == 0;
           const Ray src = shadowMode ? shadowRay : nextRay;
-          walkSetupRays(sc, nTransforms, myRays, src, shadowMode);
+          walkSetupRays(sc, nTransforms, ldsXf, myRays, src, shadowMode);
           w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
           reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);      /* the untransformed ray (cachedTI = 0, fragment:174-175) */
           st = P_WALKING;
@@ -564,6 +571,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
     if (b == 0) {
       atomicAdd(wb.counters + 16, (unsigned long long)tFold); atomicAdd(wb.counters + 17, (unsigned long long)tRefill);
       atomicAdd(wb.counters + 18, (unsigned long long)tInner); atomicAdd(wb.counters + 19, life); atomicAdd(wb.counters + 20, 1ull);
+      atomicAdd(wb.counters + 21, (unsigned long long)tLoad);
     }
     if (b < 4) {   /* tail statistics per bounce: sum / count / max of wave lifetimes */
       atomicAdd(wb.counters + 24 + 3 * b, life); atomicAdd(wb.counters + 25 + 3 * b, 1ull); atomicMax(wb.counters + 26 + 3 * b, life);
@@ -581,7 +589,7 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
    * (n_transforms x 32 B each) when they fit, the rest goes to the tree top. */
   const uint32_t T = sc.n_transforms;
-  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 48u;
+  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 48u + T * 64u;      /* per-thread rays + the staged inverse transforms */
   const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 148u * 1024u;
   const uint32_t ldsBudget = (uint32_t)FLX_WF_LDS_TOTAL - (pre ? rayBytes : 0u);
   uint32_t ldsCount = ldsBudget / 48u;
