@@ -62,6 +62,7 @@ struct flx_context {
   uint32_t *d_queue = nullptr;
   /* pipeline 3 (wavefront) workspace */
   float4 *d_rec = nullptr;
+  float4 *d_tail_pool = nullptr;                 /* per walk workgroup: WF_TAIL_POOL_F4 float4 */
   size_t rec_capacity = 0;                       /* float4 units */
   uint32_t *d_live[2] = { nullptr, nullptr };
   size_t live_capacity = 0;
@@ -140,7 +141,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_rec, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
+                   ctx->d_rec, ctx->d_tail_pool, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -438,6 +439,8 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     FLX_HIP(ctx, hipGetLastError());
   } else {
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t), ctx->stream));
+    if (!ctx->d_tail_pool)       /* scratch of the walk kernel's tail consolidation: one slice per chain and possible walk workgroup */
+      FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
     launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     /* The bounce loop runs as `groups` independent chains (contiguous ranges of screen tiles), group 0 on the
@@ -458,6 +461,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
       const uint32_t t0 = (uint32_t)((uint64_t)tiles * g / groups), t1 = (uint32_t)((uint64_t)tiles * (g + 1) / groups);
       WavefrontBuffers wb;
       wb.rec = ctx->d_rec;
+      wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 2 * (WF_MAX_BOUNCES + 2); wb.walkQueue = wb.counts + (WF_MAX_BOUNCES + 2);
       wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;

@@ -29,7 +29,9 @@ struct WavefrontBuffers {
   const float4 *hits;
   float4 *sampleRadiance, *lastOriginal;
   unsigned long long *counters; /* or nullptr */
+  float4 *tailPool;             /* WF_TAIL_POOL_F4 float4 per walk workgroup: scratch of the tail consolidation */
 };
+constexpr size_t WF_TAIL_POOL_F4 = 1024 * 8;
 size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units);
 /* walk_scheduler: 0 = one walk per lane (k_wf_walk_pre / k_wf_walk), 1 = workgroup-wide test queues (flx_walkq.hip) */
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,

@@ -43,9 +43,6 @@ __device__ unsigned long long g_diagSlow[4];
 #ifndef FLX_WF_DRAWS_PER_WAVE
 #define FLX_WF_DRAWS_PER_WAVE 16
 #endif
-#ifndef FLX_WF_TAIL_LANES
-#define FLX_WF_TAIL_LANES 0      /* >0: waves with this few walking lanes (queue dry) prefetch both successors; measured slower (profiles/r01_ab_tail_prefetch.txt), off */
-#endif
 #ifndef FLX_WF_PRETRANSFORM
 #define FLX_WF_PRETRANSFORM 1
 #endif
@@ -64,12 +61,13 @@ __device__ unsigned long long g_diagSlow[4];
 #ifndef FLX_WF_ITEMS_PER_LANE
 #define FLX_WF_ITEMS_PER_LANE 4
 #endif
-#ifndef FLX_WF_BOX_RUN
-#define FLX_WF_BOX_RUN 0                    /* >0: k_wf_walk_pre steps in type-homogeneous sub-steps (N box steps, then FLX_WF_TRI_RUN triangle steps) */
+#ifndef FLX_WF_CONSOLIDATE
+#define FLX_WF_CONSOLIDATE 1                /* k_wf_walk_pre: merge the walks of thinning waves once the queue is dry */
 #endif
-#ifndef FLX_WF_TRI_RUN
-#define FLX_WF_TRI_RUN 1
+#ifndef FLX_WF_TAIL_TRIPS
+#define FLX_WF_TAIL_TRIPS 8                 /* trips of the scheduler loop between two consolidation rounds */
 #endif
+enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_ROUND = 4 };   /* LDS words of the tail consolidation */
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
 #endif
@@ -344,17 +342,23 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
    *      [nTransforms x (inverse rotation columns, inverse shift) float4 quadruples] */
   extern __shared__ float4 ldsAll[];
   float4 *ldsEntries = ldsAll;
-  float4 *myRays = ldsAll + (size_t)ldsCount * 3u + (size_t)threadIdx.x * nTransforms * 3u;
-  float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u + (size_t)FLX_WF_WALK_THREADS * nTransforms * 3u;
+  float4 *raysBase = ldsAll + (size_t)ldsCount * 3u;
+  float4 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 3u;      /* follows a walk when it moves to another lane (tail consolidation) */
+  float4 *ldsXf = raysBase + (size_t)FLX_WF_WALK_THREADS * nTransforms * 3u;
+  uint32_t *tailCtl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);       /* 16 words, see TC_* */
   for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
   for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
     const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
     ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
   }
-  __syncthreads();
   const uint32_t n = FIRST ? total_items : wb.counts[b];
   const uint32_t waveId = blockIdx.x * (FLX_WF_WALK_THREADS / 64u) + (threadIdx.x >> 6);
-  if (waveId * (64u * FLX_WF_ITEMS_PER_LANE) >= n && waveId != 0u) return;
+  const bool surplus = waveId * (64u * FLX_WF_ITEMS_PER_LANE) >= n && waveId != 0u;       /* more waves than work */
+  if (threadIdx.x < 16u) tailCtl[threadIdx.x] = 0u;
+  __syncthreads();
+  if (!surplus && (threadIdx.x & 63u) == 0u) atomicAdd(&tailCtl[TC_LIVE], 1u);
+  __syncthreads();
+  if (surplus) return;
   const uint32_t *__restrict__ listIn = wb.live[b & 1];
   uint32_t *__restrict__ listOut = wb.live[(b + 1) & 1];
   uint32_t *__restrict__ queue = wb.walkQueue + b;
@@ -387,8 +391,91 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   bool itemsLeft = true;
   uint32_t outBase = 0, outUsed = WF_OUT_CHUNK;
   bool outValid = false;
+  bool tailMode = false, tailSynced = false;
+  uint32_t tailTrips = 0, tailRound = 0;
+  float4 *pool = wb.tailPool + (size_t)blockIdx.x * FLX_WF_WALK_THREADS * 8u;
 
   for (;;) {
+#if FLX_WF_CONSOLIDATE
+    /* ---- tail consolidation --------------------------------------------------------------------------------
+     * Once the walk queue is dry a wave only loses lanes, and a SIMD that hosts four quarter-full waves spends four
+     * times the issue slots of one full wave on the same walks: the end of the kernel — set by its longest walk — runs
+     * at a fraction of the machine's speed.  So when every live wave of the workgroup has found the queue dry, the
+     * waves meet every FLX_WF_TAIL_TRIPS trips: if the walks in flight fit in fewer waves, all of them are written to a
+     * scratch pool (128 bytes of registers each; the pre-transformed rays stay where they are in LDS and the walk
+     * keeps pointing at them), the waves take them back 64 at a time, and the waves left without a walk exit.  A walk
+     * only changes lane: its state, entry order and arithmetic are untouched. */
+    if (!tailMode && !(itemsLeft || chunkNext != chunkEnd)) {
+      tailMode = true;
+      if (lane == 0) atomicAdd(&tailCtl[TC_TAIL], 1u);
+    }
+    if (tailMode) {
+      if (!tailSynced) {
+        uint32_t a = 0, l = 1;
+        if (lane == 0) { a = __hip_atomic_load(&tailCtl[TC_TAIL], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); l = __hip_atomic_load(&tailCtl[TC_LIVE], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+        a = __builtin_amdgcn_readfirstlane(a); l = __builtin_amdgcn_readfirstlane(l);
+        if (a == l) { tailSynced = true; tailTrips = FLX_WF_TAIL_TRIPS; }
+      }
+      if (tailSynced && ++tailTrips >= (uint32_t)FLX_WF_TAIL_TRIPS) {
+        tailTrips = 0;
+        const uint32_t par = (tailRound++ & 1u) * 2u;
+        const unsigned long long mine = __ballot(st != P_EMPTY);
+        const uint32_t myCount = (uint32_t)__popcll(mine);
+        if (lane == 0) { atomicAdd(&tailCtl[TC_ROUND + par], myCount); atomicAdd(&tailCtl[TC_ROUND + par + 1u], 1u); }
+        __syncthreads();
+        uint32_t total = 0, waves = 0;
+        if (lane == 0) {
+          total = __hip_atomic_load(&tailCtl[TC_ROUND + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          waves = __hip_atomic_load(&tailCtl[TC_ROUND + par + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&tailCtl[TC_ROUND + (par ^ 2u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      /* the next round's tallies */
+          __hip_atomic_store(&tailCtl[TC_ROUND + (par ^ 2u) + 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        total = __builtin_amdgcn_readfirstlane(total); waves = __builtin_amdgcn_readfirstlane(waves);
+        if (waves > 1u && total <= 64u * (waves - 1u)) {
+          /* export */
+          uint32_t pos0 = 0;
+          if (lane == 0 && myCount) pos0 = atomicAdd(&tailCtl[TC_POOL], myCount);
+          pos0 = __builtin_amdgcn_readfirstlane(pos0);
+          if (st != P_EMPTY) {
+            float4 *r = pool + (size_t)(pos0 + lane_rank(mine)) * 8u;
+            const int packed = st | (w.mode << 4) | ((w.fastDiv ? 1 : 0) << 8) | ((w.shadowed ? 1 : 0) << 9);
+            r[0] = make_float4(__int_as_float((int)pathId), __int_as_float(flags), base, __int_as_float(packed));
+            r[1] = make_float4(nextRay.origin.x, nextRay.origin.y, nextRay.origin.z, nextRay.dir.x);
+            r[2] = make_float4(nextRay.dir.y, nextRay.dir.z, w.minLen, __int_as_float(w.i));
+            r[3] = make_float4(w.tR.origin.x, w.tR.origin.y, w.tR.origin.z, w.tR.dir.x);
+            r[4] = make_float4(w.tR.dir.y, w.tR.dir.z, w.inv.x, w.inv.y);
+            r[5] = make_float4(w.inv.z, w.suv.x, w.suv.y, w.suv.z);
+            r[6] = make_float4(__int_as_float(w.cachedTI), __int_as_float(w.tri), __int_as_float(w.hitTI), __int_as_float((int)(myRays - raysBase)));
+            st = P_EMPTY;
+          }
+          __syncthreads();
+          /* import: 64 walks per claim; waves that find the pool taken up leave through the loop's normal exit */
+          uint32_t at = 0;
+          if (lane == 0) at = atomicAdd(&tailCtl[TC_TAKE], 64u);
+          at = __builtin_amdgcn_readfirstlane(at);
+          if (at + lane < total) {
+            const float4 *r = pool + (size_t)(at + lane) * 8u;
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
+            pathId = (uint32_t)__float_as_int(r0.x); flags = __float_as_int(r0.y); base = r0.z;
+            const int packed = __float_as_int(r0.w);
+            st = packed & 15; w.mode = (packed >> 4) & 15; w.fastDiv = ((packed >> 8) & 1) != 0; w.shadowed = ((packed >> 9) & 1) != 0;
+            nextRay.origin = F3(r1.x, r1.y, r1.z); nextRay.dir = F3(r1.w, r2.x, r2.y);
+            w.minLen = r2.z; w.i = __float_as_int(r2.w);
+            w.tR.origin = F3(r3.x, r3.y, r3.z); w.tR.dir = F3(r3.w, r4.x, r4.y); w.inv = F3(r4.z, r4.w, r5.x);
+            w.suv = F3(r5.y, r5.z, r5.w);
+            w.cachedTI = __float_as_int(r6.x); w.tri = __float_as_int(r6.y); w.hitTI = __float_as_int(r6.z);
+            myRays = raysBase + __float_as_int(r6.w);
+            if (st == P_WALKING) walkLoadEntry(sc, ldsEntries, ldsCount, (uint32_t)w.i, cur);       /* the entry the walk was about to test */
+          }
+          __syncthreads();
+          if (lane == 0) {
+            __hip_atomic_store(&tailCtl[TC_POOL], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(&tailCtl[TC_TAKE], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+        }
+      }
+    }
+#endif
     const unsigned long long walking = __ballot(st == P_WALKING);
     const unsigned long long workMask = __ballot(st == P_DONE || st == P_SWITCH);
     const bool canRefill = itemsLeft || chunkNext != chunkEnd;
@@ -501,66 +588,23 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         break;
       }
     }
-#if FLX_WF_TAIL_LANES > 0
-    /* Tail: nothing left to draw and only a few lanes still walk.  The kernel's end is now the longest remaining walk,
-     * one dependent fetch -> test -> fetch chain per entry, and the memory pipes are idle: run those lanes in a loop of
-     * their own that starts the loads of BOTH successors (the entry names them) before testing the entry. */
-    if (!(itemsLeft || chunkNext != chunkEnd) && (uint32_t)__popcll(__ballot(st == P_WALKING)) <= (uint32_t)FLX_WF_TAIL_LANES) {
-      while (__ballot(st == P_WALKING) != 0ull) {
-        if (COUNT) diagIters++;
-        if (st == P_WALKING) {
-          const bool isBox = walkIsBoxT(cur);
-          const uint32_t succA = isBox ? (uint32_t)__float_as_int(cur.e2.x) : (uint32_t)__float_as_int(cur.e2.y);   /* box hit / triangle next */
-          const uint32_t succB = (uint32_t)__float_as_int(cur.e2.y);                                              /* box miss */
-          WalkEntry nA, nB;
-          walkLoadEntry(sc, ldsEntries, ldsCount, succA, nA);
-          if (isBox) walkLoadEntry(sc, ldsEntries, ldsCount, succB, nB); else nB = nA;
-          bool ended = false;
-          if (isBox) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-          if (!ended) {
-            cur = ((uint32_t)w.i == succA) ? nA : nB;
-            ended = walkArriveP<COUNT>(myRays, w, cur, cnt);
-          }
-          if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
-        }
-      }
-      continue;
-    }
-#endif
     long long t2 = COUNT ? clock64() : 0;
     /* ---- FLX_WF_INNER entries for every walking lane ------------------------------------------------- */
 #pragma unroll 1
     for (int it = 0; it < FLX_WF_INNER; it++) {
       if (COUNT) diagIters++;
-#if FLX_WF_BOX_RUN > 0
-      /* type-homogeneous sub-steps: FLX_WF_BOX_RUN box-only steps, then one triangle-only step; a lane at the other
-       * type of entry idles for that sub-step instead of making the whole wave run both tests every trip */
-#pragma unroll
-      for (int k = 0; k < FLX_WF_BOX_RUN; k++) {
-        if (st == P_WALKING && walkIsBoxT(cur)) {
-          walkBoxP(w, cur);
-          if (walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = (w.mode == 0) ? P_SWITCH : P_DONE;
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < FLX_WF_TRI_RUN; k++) {
-        if (st == P_WALKING && !walkIsBoxT(cur)) {
-          bool ended = walkTriT(w, cur);
-          if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
-          if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
-        }
-      }
-#else
       if (st == P_WALKING) {
         bool ended = false;
         if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
         if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
         if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
       }
-#endif
     }
     if (COUNT) tInner += clock64() - t2;
   }
+#if FLX_WF_CONSOLIDATE
+  if (lane == 0) { atomicSub(&tailCtl[TC_LIVE], 1u); if (tailMode) atomicSub(&tailCtl[TC_TAIL], 1u); }
+#endif
   if (outValid) {
     for (uint32_t t = outUsed + lane; t < WF_OUT_CHUNK; t += 64u) listOut[outBase + t] = WF_INVALID;
   }
@@ -589,7 +633,7 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
    * (n_transforms x 32 B each) when they fit, the rest goes to the tree top. */
   const uint32_t T = sc.n_transforms;
-  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 48u + T * 64u;      /* per-thread rays + the staged inverse transforms */
+  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 48u + T * 64u + 64u;      /* per-thread rays + the staged inverse transforms + tailCtl */
   const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 148u * 1024u;
   const uint32_t ldsBudget = (uint32_t)FLX_WF_LDS_TOTAL - (pre ? rayBytes : 0u);
   uint32_t ldsCount = ldsBudget / 48u;
