@@ -26,4 +26,5 @@ for bounces in range(1, sc.meta["frame"]["maxReflections"] + 1):
         print('   bounce-0 walk waves %d: mean lifetime %.0f cycles; share fold %.3f refill %.3f (record loads %.3f) steps %.3f; cycles per wave-iteration %.0f' % (waves, life / max(1, waves), fold / max(1, life), refill / max(1, life), d[13] / max(1, life), inner / max(1, life), inner / max(1, it)))
     if b < 4 and d[17 + 3 * b]:
         print('   wave lifetimes: %d waves, mean %.0f, max %.0f cycles' % (d[17 + 3 * b], d[16 + 3 * b] / d[17 + 3 * b], d[18 + 3 * b]))
+    print('   tail rounds (wave-rounds) %d, consolidating %d, walks moved %d, waves summed %d' % (d[28], d[29], d[30], d[31]))
     prev = cnt

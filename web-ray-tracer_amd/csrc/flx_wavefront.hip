@@ -431,7 +431,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
           __hip_atomic_store(&tailCtl[TC_ROUND + (par ^ 2u) + 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         total = __builtin_amdgcn_readfirstlane(total); waves = __builtin_amdgcn_readfirstlane(waves);
+        if (COUNT && lane == 0) { atomicAdd(wb.counters + 36, 1ull); atomicAdd(wb.counters + 39, (unsigned long long)waves); }
         if (waves > 1u && total <= 64u * (waves - 1u)) {
+          if (COUNT && lane == 0) { atomicAdd(wb.counters + 37, 1ull); atomicAdd(wb.counters + 38, (unsigned long long)myCount); }
           /* export */
           uint32_t pos0 = 0;
           if (lane == 0 && myCount) pos0 = atomicAdd(&tailCtl[TC_POOL], myCount);
