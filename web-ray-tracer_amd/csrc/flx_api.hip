@@ -25,6 +25,7 @@ using namespace flx;
 #define FLX_WF_GROUPS 1      /* measured on MI355X: 2-4 concurrent chains are slower than one (profiles/r01_ab_stream_groups.txt) */
 #endif
 constexpr int WF_MAX_GROUPS = 4;
+constexpr uint32_t WF_STRAG_MAX = 512;         /* most walks a walk workgroup can suspend */
 
 static thread_local std::string g_create_error;
 
@@ -63,10 +64,12 @@ struct flx_context {
   /* pipeline 3 (wavefront) workspace */
   float4 *d_rec = nullptr;
   float4 *d_tail_pool = nullptr;                 /* per walk workgroup: WF_TAIL_POOL_F4 float4 */
+  float4 *d_strag = nullptr;                     /* per chain 2 x (walk workgroups x WF_STRAG_MAX) suspended walks */
+  uint32_t walk_suspend = 0;                     /* walks a walk workgroup may leave to the next round (0 = off) */
   size_t rec_capacity = 0;                       /* float4 units */
   uint32_t *d_live[2] = { nullptr, nullptr };
   size_t live_capacity = 0;
-  uint32_t *d_wfcounts = nullptr;                /* counts[WF_MAX_BOUNCES+2] then walkQueue[WF_MAX_BOUNCES+2] */
+  uint32_t *d_wfcounts = nullptr;                /* per chain: counts, walkQueue, stragCount, [WF_MAX_ROUNDS + 2] each */
   int pipeline = 0;                              /* 0 auto, 1 per-pixel megakernel, 2 persistent paths, 3 wavefront */
   int wf_groups = FLX_WF_GROUPS;                 /* wavefront pipeline: independent item groups on separate streams (tails of one overlap the other) */
   hipStream_t aux_stream[3] = { nullptr, nullptr, nullptr };
@@ -109,6 +112,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   flx_context *ctx = new flx_context();
   ctx->device = device;
   if (const char *ws = getenv("FLX_WALK_SCHEDULER")) ctx->walk_scheduler = atoi(ws);
+  if (const char *ws = getenv("FLX_WALK_SUSPEND")) ctx->walk_suspend = (uint32_t)atoi(ws);
   auto bail = [&](const char *what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
     delete ctx;
@@ -124,7 +128,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_counters, 40 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_wfcounts, WF_MAX_GROUPS * 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_wfcounts, WF_MAX_GROUPS * 3 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   for (int i = 0; i < 3; i++) {
     if ((e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -141,7 +145,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_rec, ctx->d_tail_pool, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
+                   ctx->d_rec, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -438,9 +442,11 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
   } else {
-    FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 2 * (WF_MAX_BOUNCES + 2) * sizeof(uint32_t), ctx->stream));
-    if (!ctx->d_tail_pool)       /* scratch of the walk kernel's tail consolidation: one slice per chain and possible walk workgroup */
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 3 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t), ctx->stream));
+    if (!ctx->d_tail_pool) {     /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
       FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
+      FLX_HIP(ctx, hipMalloc(&ctx->d_strag, (size_t)WF_MAX_GROUPS * 2 * cus * 8u * WF_STRAG_MAX * WF_STRAG_F4 * sizeof(float4)));
+    }
     launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     /* The bounce loop runs as `groups` independent chains (contiguous ranges of screen tiles), group 0 on the
@@ -463,11 +469,12 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
       wb.rec = ctx->d_rec;
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
-      wb.counts = ctx->d_wfcounts + (size_t)g * 2 * (WF_MAX_BOUNCES + 2); wb.walkQueue = wb.counts + (WF_MAX_BOUNCES + 2);
+      wb.counts = ctx->d_wfcounts + (size_t)g * 3 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
+      for (int k = 0; k < 2; k++) wb.strag[k] = ctx->d_strag + ((size_t)g * 2 + k) * cus * 8u * WF_STRAG_MAX * WF_STRAG_F4;
       wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;
       wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
       hipStream_t st = g == 0 ? ctx->stream : ctx->aux_stream[g - 1];
-      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->walk_scheduler, g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
+      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend > WF_STRAG_MAX ? WF_STRAG_MAX : ctx->walk_suspend, g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
       FLX_HIP(ctx, hipGetLastError());
       if (g > 0) {
         FLX_HIP(ctx, hipEventRecord(ctx->ev_join[g - 1], st));

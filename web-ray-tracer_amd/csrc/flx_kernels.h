@@ -23,19 +23,24 @@ constexpr int WF_MAX_BOUNCES = 250;
 struct WavefrontBuffers {
   float4 *rec;                  /* 8 x float4 (128 B) per path item */
   uint32_t *live[2];            /* live path lists, alternating per bounce */
-  uint32_t *counts;             /* [WF_MAX_BOUNCES + 2] slots used in the live list of bounce b */
-  uint32_t *walkQueue;          /* [WF_MAX_BOUNCES + 2] per-bounce refill cursor of the walk kernel */
+  uint32_t *counts;             /* [WF_MAX_ROUNDS + 2] slots used in the live list of round r */
+  uint32_t *walkQueue;          /* [WF_MAX_ROUNDS + 2] per-round refill cursor of the walk kernel */
   uint32_t item_base, item_count; /* the path items [item_base, item_base + item_count) this group of launches owns */
   const float4 *hits;
   float4 *sampleRadiance, *lastOriginal;
   unsigned long long *counters; /* or nullptr */
   float4 *tailPool;             /* WF_TAIL_POOL_F4 float4 per walk workgroup: scratch of the tail consolidation */
+  float4 *strag[2];             /* walks suspended by the walk kernel of round r (slot r & 1), WF_STRAG_F4 float4 each */
+  uint32_t *stragCount;         /* [WF_MAX_ROUNDS + 2] walks suspended in round r */
 };
 constexpr size_t WF_TAIL_POOL_F4 = 1024 * 8;
+constexpr uint32_t WF_STRAG_F4 = 5;
+constexpr int WF_MAX_ROUNDS = 2 * WF_MAX_BOUNCES;    /* regular rounds + the rounds that drain suspended walks */
 size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units);
 /* walk_scheduler: 0 = one walk per lane (k_wf_walk_pre / k_wf_walk), 1 = workgroup-wide test queues (flx_walkq.hip) */
+/* suspend_max: walks a walk workgroup may hand over to the next round instead of finishing them (0 = never) */
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
-                      int walk_scheduler, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
+                      int walk_scheduler, uint32_t suspend_max, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
 /* denoise chain (flx_filter.hip): 13 RGBA8 planes = the reference's RenderTexture[0..3], IpRenderTexture[0..3],
  * OriginalRenderTexture[0..1], IdRenderTexture[0..1], OriginalIdRenderTexture (pathtracerWGL2.js:224-252). */
 struct FilterPlanes { uint32_t *R[4], *Ip[4], *O[2], *Id[2], *OId; };

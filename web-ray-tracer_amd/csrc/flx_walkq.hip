@@ -153,7 +153,7 @@ __global__ __launch_bounds__(FLX_WQ_THREADS) void k_wf_walk_queue(DeviceScene sc
   uint32_t *__restrict__ listOut = wb.live[(b + 1) & 1];
   uint32_t *__restrict__ queue = wb.walkQueue + b;
   uint32_t *__restrict__ outAlloc = wb.counts + (b + 1);
-  uint32_t *errWord = wb.walkQueue + (WF_MAX_BOUNCES + 1);
+  uint32_t *errWord = wb.walkQueue + (WF_MAX_ROUNDS + 1);
   WorkCounters cnt = {};
   uint32_t outBase = 0, outUsed = WF_OUT_CHUNK;
   bool outValid = false;
@@ -305,7 +305,8 @@ __global__ __launch_bounds__(FLX_WQ_THREADS) void k_wf_walk_queue(DeviceScene sc
         if (foldMe) {
           const float4 r1 = slot[1];
           float4 *rec = wb.rec + (size_t)pathId * 8;
-          const float4 q2 = rec[2], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+          const float4 q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+          const int pathBounce = __float_as_int(q3.w);
           const int rf = (int)(flags >> SF_RF_SHIFT);
           const float base = q2.w;
           const bool shadowed = (rf & RF_SHADOWED_NO_WALK) || ((rf & RF_NEED_SHADOW) && (flags & SF_SHADOWED));
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(FLX_WQ_THREADS) void k_wf_walk_queue(DeviceScene sc
           const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
           const int tri = __float_as_int(r1.w);
           bool cont = tri != -1;
-          if (cont) cont = (b + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+          if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
           if (cont) {
             rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
             rec[2] = make_float4(r1.x, r1.y, r1.z, r1.w);

@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
     const bool inFrame = item_pixel(fr, pathId, px, k, s);
     PathState p;
     PixelState ps;
+    int pb = 0;
     ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
     ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
     ps.renderOriginalId = ps.renderId;
@@ -110,7 +111,8 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
       }
       if (!alive) { rec[0] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD)); continue; }
     } else {
-      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q6 = rec[6], q7 = rec[7];
+      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q6 = rec[6], q7 = rec[7];
+      pb = __float_as_int(q3.w) + 1;                      /* the bounce this path is at (its record carries the last one shaded) */
       p.ray.origin = F3(q0.x, q0.y, q0.z);
       p.lastHitPoint = p.ray.origin;                    /* fragment:595 */
       p.ray.dir = F3(q1.x, q1.y, q1.z);
@@ -127,12 +129,12 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
     if (FIRST) p.ray.dir = dir0;
     const float cosSampleN = flx_cos((float)s);
     ShadeOut so;
-    bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, b, so, cnt);
+    bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, pb, so, cnt);
     const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0);
     rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
     rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
     rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
-    rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, 0.0f);
+    rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, __int_as_float(pb));
     rec[4] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
     if (FIRST) rec[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
@@ -167,6 +169,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
   int st = L_EMPTY;
   uint32_t pathId = 0;
   int flags = 0;
+  int pathBounce = 0;                      /* the bounce the lane's path is at (its record carries it) */
   float base = 0.0f;
   Ray nextRay; nextRay.origin = F3(0.f, 0.f, 0.f); nextRay.dir = nextRay.origin;
   WalkState w;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
           const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
           const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
           bool cont = w.tri != -1;
-          if (cont) cont = (b + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+          if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
           if (cont) {
             rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
             rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
             const int fl = __float_as_int(q0.w);
             if (!(fl & RF_DEAD)) {
               const float4 q1 = rec[1], q2 = rec[2], q3 = rec[3];
-              pathId = id; flags = fl; base = q2.w;
+              pathId = id; flags = fl; base = q2.w; pathBounce = __float_as_int(q3.w);
               nextRay.origin = F3(q0.x, q0.y, q0.z);
               nextRay.dir = F3(q1.x, q1.y, q1.z);
               walkClearResults(w);
@@ -331,13 +334,21 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
 }
 
 /* ---- walk kernel, pre-transformed rays (the default when the scene's transforms fit in LDS) ---------- */
-enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4 };
+enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4, P_RESUME = 5 };
 
 /* FIRST = bounce 0 (identity live list); a template parameter so that the dominant launch of a frame is a kernel symbol of
  * its own in profiler summaries (bench.py's roofline names it). */
 template <bool COUNT, bool FIRST>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
-                                                                     uint32_t ldsCount, uint32_t nTransforms) {
+                                                                     uint32_t ldsCount, uint32_t nTransforms, uint32_t suspendMax) {
+  /* b is the ROUND of the bounce loop.  Without suspension round b walks bounce b of every path.  With it (suspendMax > 0) a
+   * workgroup that has found the queue dry and is down to suspendMax walks writes them to the straggler list and ends, and
+   * the walk kernel of the next round takes them up first: the kernel no longer waits for its longest walk, the paths held
+   * up run one round behind the others (every path's record carries its own bounce index). */
+  const uint32_t nStrag = (b > 0) ? wb.stragCount[b - 1] : 0u;
+  const uint32_t nList = FIRST ? total_items : wb.counts[b];
+  const uint32_t n = nStrag + nList;                       /* queue positions: stragglers first, then the live list */
+  if (n == 0u) return;
   /* LDS: [tree top: ldsCount entries x 48 B][per thread: nTransforms x (origin, dir, 1/dir + fast flag) float4 triples]
    *      [nTransforms x (inverse rotation columns, inverse shift) float4 quadruples] */
   extern __shared__ float4 ldsAll[];
@@ -351,7 +362,6 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
     const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
     ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
   }
-  const uint32_t n = FIRST ? total_items : wb.counts[b];
   const uint32_t waveId = blockIdx.x * (FLX_WF_WALK_THREADS / 64u) + (threadIdx.x >> 6);
   const bool surplus = waveId * (64u * FLX_WF_ITEMS_PER_LANE) >= n && waveId != 0u;       /* more waves than work */
   if (threadIdx.x < 16u) tailCtl[threadIdx.x] = 0u;
@@ -363,6 +373,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   uint32_t *__restrict__ listOut = wb.live[(b + 1) & 1];
   uint32_t *__restrict__ queue = wb.walkQueue + b;
   uint32_t *__restrict__ outAlloc = wb.counts + (b + 1);
+  const float4 *__restrict__ stragIn = wb.strag[(b + 1) & 1];
+  float4 *__restrict__ stragOut = wb.strag[b & 1];
   const uint32_t lane = threadIdx.x & 63u;
   /* ids a wave draws per atomic: large while there is plenty (one atomic per 256 paths), small when the
    * whole queue is only a few draws per wave — the last draws decide how long the kernel's tail is */
@@ -377,6 +389,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   int st = P_EMPTY;
   uint32_t pathId = 0;
   int flags = 0;
+  int pathBounce = 0;                      /* the bounce the lane's path is at (its record carries it) */
   float base = 0.0f;
   Ray nextRay; nextRay.origin = F3(0.f, 0.f, 0.f); nextRay.dir = nextRay.origin;
   Ray shadowRay = nextRay;
@@ -391,8 +404,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   bool itemsLeft = true;
   uint32_t outBase = 0, outUsed = WF_OUT_CHUNK;
   bool outValid = false;
-  bool tailMode = false, tailSynced = false;
+  bool tailMode = false, tailSynced = false, suspendNow = false;
   uint32_t tailTrips = 0, tailRound = 0;
+  int resumeSt = P_EMPTY;
   float4 *pool = wb.tailPool + (size_t)blockIdx.x * FLX_WF_WALK_THREADS * 8u;
 
   for (;;) {
@@ -432,7 +446,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         }
         total = __builtin_amdgcn_readfirstlane(total); waves = __builtin_amdgcn_readfirstlane(waves);
         if (COUNT && lane == 0) { atomicAdd(wb.counters + 36, 1ull); atomicAdd(wb.counters + 39, (unsigned long long)waves); }
-        if (waves > 1u && total <= 64u * (waves - 1u)) {
+        if (total <= suspendMax) {
+          suspendNow = true;                                   /* every wave of the workgroup reads the same total */
+        } else if (waves > 1u && total <= 64u * (waves - 1u)) {
           if (COUNT && lane == 0) { atomicAdd(wb.counters + 37, 1ull); atomicAdd(wb.counters + 38, (unsigned long long)myCount); }
           /* export */
           uint32_t pos0 = 0;
@@ -440,7 +456,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
           pos0 = __builtin_amdgcn_readfirstlane(pos0);
           if (st != P_EMPTY) {
             float4 *r = pool + (size_t)(pos0 + lane_rank(mine)) * 8u;
-            const int packed = st | (w.mode << 4) | ((w.fastDiv ? 1 : 0) << 8) | ((w.shadowed ? 1 : 0) << 9);
+            const int packed = st | (w.mode << 4) | ((w.fastDiv ? 1 : 0) << 8) | ((w.shadowed ? 1 : 0) << 9) | (pathBounce << 16);
             r[0] = make_float4(__int_as_float((int)pathId), __int_as_float(flags), base, __int_as_float(packed));
             r[1] = make_float4(nextRay.origin.x, nextRay.origin.y, nextRay.origin.z, nextRay.dir.x);
             r[2] = make_float4(nextRay.dir.y, nextRay.dir.z, w.minLen, __int_as_float(w.i));
@@ -460,7 +476,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
             const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
             pathId = (uint32_t)__float_as_int(r0.x); flags = __float_as_int(r0.y); base = r0.z;
             const int packed = __float_as_int(r0.w);
-            st = packed & 15; w.mode = (packed >> 4) & 15; w.fastDiv = ((packed >> 8) & 1) != 0; w.shadowed = ((packed >> 9) & 1) != 0;
+            st = packed & 15; w.mode = (packed >> 4) & 15; w.fastDiv = ((packed >> 8) & 1) != 0; w.shadowed = ((packed >> 9) & 1) != 0; pathBounce = (packed >> 16) & 0xffff;
             nextRay.origin = F3(r1.x, r1.y, r1.z); nextRay.dir = F3(r1.w, r2.x, r2.y);
             w.minLen = r2.z; w.i = __float_as_int(r2.w);
             w.tR.origin = F3(r3.x, r3.y, r3.z); w.tR.dir = F3(r3.w, r4.x, r4.y); w.inv = F3(r4.z, r4.w, r5.x);
@@ -482,7 +498,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
     const unsigned long long workMask = __ballot(st == P_DONE || st == P_SWITCH);
     const bool canRefill = itemsLeft || chunkNext != chunkEnd;
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
-    if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || canRefill))) {
+    if (suspendNow || walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || canRefill))) {
       if (COUNT) diagBatches++;
       long long t0 = COUNT ? clock64() : 0;
       /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475 ------------ */
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
           const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
           const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
           bool cont = w.tri != -1;
-          if (cont) cont = (b + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+          if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
           if (cont) {
             rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
             rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
@@ -526,6 +542,27 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
       }
       long long t1 = COUNT ? clock64() : 0;
       if (COUNT) tFold += t1 - t0;
+      if (suspendNow) {
+        /* ---- suspend: the walks still in flight go to the straggler list (the lane's registers; rays and flags are
+         * re-read from the path record when the walk is taken up again) --------------------------------------- */
+        const bool keep = st == P_WALKING || st == P_SWITCH;
+        const unsigned long long km = __ballot(keep);
+        if (km != 0ull) {
+          uint32_t pos0 = 0;
+          if (lane == 0) pos0 = atomicAdd(wb.stragCount + b, (uint32_t)__popcll(km));
+          pos0 = __builtin_amdgcn_readfirstlane(pos0);
+          if (keep) {
+            float4 *r = stragOut + (size_t)(pos0 + lane_rank(km)) * WF_STRAG_F4;
+            const int packed = st | (w.mode << 4) | ((w.fastDiv ? 1 : 0) << 8) | ((w.shadowed ? 1 : 0) << 9);
+            r[0] = make_float4(__int_as_float((int)pathId), __int_as_float(packed), w.minLen, __int_as_float(w.i));
+            r[1] = make_float4(w.tR.origin.x, w.tR.origin.y, w.tR.origin.z, w.tR.dir.x);
+            r[2] = make_float4(w.tR.dir.y, w.tR.dir.z, w.inv.x, w.inv.y);
+            r[3] = make_float4(w.inv.z, w.suv.x, w.suv.y, w.suv.z);
+            r[4] = make_float4(__int_as_float(w.cachedTI), __int_as_float(w.tri), __int_as_float(w.hitTI), 0.0f);
+          }
+        }
+        break;
+      }
       /* ---- refill the free lanes from the walk queue ------------------------------------------------ */
       for (;;) {
         const unsigned long long idle = __ballot(st == P_EMPTY);
@@ -549,22 +586,35 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         const uint32_t r = lane_rank(idle);
         if (st == P_EMPTY && r < take) {
           const uint32_t j = chunkNext + r;
-          const uint32_t id = FIRST ? wb.item_base + j : listIn[j];
+          const bool resume = j < nStrag;                      /* a walk the previous round's kernel suspended */
+          float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0, s4 = s0;
+          if (resume) { const float4 *sr = stragIn + (size_t)j * WF_STRAG_F4; s0 = sr[0]; s1 = sr[1]; s2 = sr[2]; s3 = sr[3]; s4 = sr[4]; }
+          const uint32_t id = resume ? (uint32_t)__float_as_int(s0.x) : (FIRST ? wb.item_base + (j - nStrag) : listIn[j - nStrag]);
           if (id != WF_INVALID) {
             const float4 *rec = wb.rec + (size_t)id * 8;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];     /* one cache line, four loads in flight */
             const int fl = __float_as_int(q0.w);
             if (!(fl & RF_DEAD)) {
-              pathId = id; flags = fl; base = q2.w;
+              pathId = id; flags = fl; base = q2.w; pathBounce = __float_as_int(q3.w);
               nextRay.origin = F3(q0.x, q0.y, q0.z);
               nextRay.dir = F3(q1.x, q1.y, q1.z);
               shadowRay.origin = F3(q2.x, q2.y, q2.z);
               shadowRay.dir = F3(q3.x, q3.y, q3.z);
               shadowLen = q1.w;
-              walkClearResults(w);
-              w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
-              if (COUNT) { if (w.mode == 0) cnt.shadow_walks++; cnt.closest_walks++; }
-              st = P_SETUP;
+              if (resume) {
+                const int packed = __float_as_int(s0.y);
+                resumeSt = packed & 15; w.mode = (packed >> 4) & 15; w.fastDiv = ((packed >> 8) & 1) != 0; w.shadowed = ((packed >> 9) & 1) != 0;
+                w.minLen = s0.z; w.i = __float_as_int(s0.w);
+                w.tR.origin = F3(s1.x, s1.y, s1.z); w.tR.dir = F3(s1.w, s2.x, s2.y); w.inv = F3(s2.z, s2.w, s3.x);
+                w.suv = F3(s3.y, s3.z, s3.w);
+                w.cachedTI = __float_as_int(s4.x); w.tri = __float_as_int(s4.y); w.hitTI = __float_as_int(s4.z);
+                st = (resumeSt == P_SWITCH) ? P_SWITCH : P_RESUME;      /* a shadow walk that had ended goes straight to the closest-hit set-up */
+              } else {
+                walkClearResults(w);
+                w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
+                if (COUNT) { if (w.mode == 0) cnt.shadow_walks++; cnt.closest_walks++; }
+                st = P_SETUP;
+              }
             }
           }
         }
@@ -573,15 +623,22 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
       /* ---- set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended -------- */
       if (COUNT) { const long long tl = clock64(); tLoad += tl - t1; }
       if (st == P_SWITCH) { w.mode = 1; st = P_SETUP; }
-      if (__ballot(st == P_SETUP) != 0ull) {
-        if (st == P_SETUP) {
+      if (__ballot(st == P_SETUP || st == P_RESUME) != 0ull) {
+        if (st == P_SETUP || st == P_RESUME) {
           const bool shadowMode = w.mode == 0;
           const Ray src = shadowMode ? shadowRay : nextRay;
           walkSetupRays(sc, nTransforms, ldsXf, myRays, src, shadowMode);
-          w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
-          reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);      /* the untransformed ray (cachedTI = 0, fragment:174-175) */
-          st = P_WALKING;
-          if (walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
+          if (st == P_SETUP) {
+            w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
+            reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);      /* the untransformed ray (cachedTI = 0, fragment:174-175) */
+            st = P_WALKING;
+            if (walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
+          } else {
+            /* a suspended walk: its registers came back from the straggler list, the rays in LDS are recomputed (the same
+             * arithmetic on the same record), the entry it was about to test is fetched again (not a new visit) */
+            st = P_WALKING;
+            walkLoadEntry(sc, ldsEntries, ldsCount, (uint32_t)w.i, cur);
+          }
         }
       }
       if (COUNT) tRefill += clock64() - t1;
@@ -626,14 +683,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
 }
 
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
-                      int walk_scheduler, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
+                      int walk_scheduler, uint32_t suspend_max, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
 #ifdef FLX_DIAG_SLOW
   { unsigned long long h[4]; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diagSlow), sizeof h); fprintf(stderr, "diag slow-box: lanes %llu wave-events %llu notFast %llu\n", h[0], h[1], h[2]); }
 #endif
   const uint32_t total = wb.item_count;                 /* items of this group (all of the frame when there is one group) */
   const uint32_t maxBlocks = compute_units * 8u;
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
-   * (n_transforms x 32 B each) when they fit, the rest goes to the tree top. */
+   * (n_transforms x 48 B each) when they fit, the rest goes to the tree top. */
   const uint32_t T = sc.n_transforms;
   const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 48u + T * 64u + 64u;      /* per-thread rays + the staged inverse transforms + tailCtl */
   const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 148u * 1024u;
@@ -655,32 +712,38 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
     attrSet = true;
   }
   const int bounces = fr.max_reflections > 0 ? fr.max_reflections : 1;   /* 0 bounces: shade(0) only finalises */
-  for (int b = 0; b < bounces; b++) {
-    uint32_t shadeBlocks = (b == 0) ? (total + 255u) / 256u : maxBlocks * 2u;
+  /* Suspension needs the kernel that can take a walk up again (k_wf_walk_pre), at least two bounces to gain anything, and
+   * as many extra rounds as a path can be held up: one per regular round.  The extra rounds find their lists empty
+   * almost always and return at once. */
+  const bool suspend = suspend_max > 0u && pre && walk_scheduler == 0 && bounces >= 2 && FLX_WF_CONSOLIDATE;
+  const int rounds = suspend ? 2 * bounces : bounces;
+  for (int r = 0; r < rounds; r++) {
+    uint32_t shadeBlocks = (r == 0) ? (total + 255u) / 256u : maxBlocks * 2u;
     if (shadeBlocks > maxBlocks * 4u) shadeBlocks = maxBlocks * 4u;
-    if (b == 0) {
-      if (count) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
-      else hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+    if (r == 0) {
+      if (count) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r, total);
+      else hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r, total);
     } else {
-      if (count) hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
-      else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, b, total);
+      if (count) hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r, total);
+      else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r, total);
     }
-    if (b == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
+    if (r == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
+    const uint32_t smax = (suspend && r < bounces) ? suspend_max : 0u;
     if (walk_scheduler == 1) {
-      launch_walk_queue(sc, fr, wb, compute_units, count, b, total, stream);
+      launch_walk_queue(sc, fr, wb, compute_units, count, r, total, stream);
     } else if (pre) {
-      if (b == 0) {
-        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
-        else hipLaunchKernelGGL((k_wf_walk_pre<false, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+      if (r == 0) {
+        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax);
+        else hipLaunchKernelGGL((k_wf_walk_pre<false, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax);
       } else {
-        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
-        else hipLaunchKernelGGL((k_wf_walk_pre<false, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount, T);
+        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax);
+        else hipLaunchKernelGGL((k_wf_walk_pre<false, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax);
       }
     } else {
-      if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
-      else hipLaunchKernelGGL(k_wf_walk<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, b, total, ldsCount);
+      if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount);
+      else hipLaunchKernelGGL(k_wf_walk<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount);
     }
-    if (b == 0 && walk0_end) (void)hipEventRecord(walk0_end, stream);
+    if (r == 0 && walk0_end) (void)hipEventRecord(walk0_end, stream);
   }
 }
 

@@ -14,7 +14,7 @@ constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves p
 constexpr int RF_DEAD = 1, RF_DONT_FILTER = 2, RF_NEED_SHADOW = 4, RF_SHADOWED_NO_WALK = 8;
 
 /* q0 origin.xyz flags | q1 nextDir.xyz shadowLen | q2 shadowOrigin.xyz baseLuminance  (after the walk: hit s,u,v,tri)
- * q3 shadowDir.xyz - | q4 litColor.xyz - | q5 finalColor.xyz - | q6 importancyFactor.xyz - | q7 originalColor.xyz - */
+ * q3 shadowDir.xyz bounce | q4 litColor.xyz - | q5 finalColor.xyz - | q6 importancyFactor.xyz - | q7 originalColor.xyz - */
 
 __device__ __forceinline__ void finalize_path(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t pathId, f3 finalColor,
                                               f3 importancy, f3 originalColor) {
