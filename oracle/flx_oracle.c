@@ -228,6 +228,10 @@ static uint8_t *g_trace = NULL;
 static size_t g_trace_cap = 0, g_trace_len = 0;
 static uint32_t g_trace_px = 0, g_trace_py = 0, g_trace_sample = 0, g_trace_bounce = 0;
 static void trace_byte(uint8_t b) { if (g_trace && g_trace_len < g_trace_cap) g_trace[g_trace_len++] = b; }
+/* second analysis hook: the entry INDEX of every bounce-walk visit as uint32, 0xFFFFFFFF after each walk */
+static uint32_t *g_itrace = NULL;
+static size_t g_itrace_cap = 0, g_itrace_len = 0;
+static void itrace(uint32_t v) { if (g_itrace && g_itrace_len < g_itrace_cap) g_itrace[g_itrace_len++] = v; }
 static void trace_begin(int kind) {
   if (!g_trace) return;
   trace_byte((uint8_t)(0xF0 | kind)); trace_byte((uint8_t)g_trace_bounce); trace_byte((uint8_t)g_trace_sample); trace_byte(0);
@@ -255,7 +259,7 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
     (*visits)++;
     if (g_visit_hist) { _Pragma("omp atomic") g_visit_hist[i]++; }
     int tI = (int)e[9] << 1;
-    if (!mode) trace_byte((uint8_t)((int)e[10] | (tI != cachedTI ? 0x10 : 0)));
+    if (!mode) { trace_byte((uint8_t)((int)e[10] | (tI != cachedTI ? 0x10 : 0))); itrace((uint32_t)i); }
     if (tI != cachedTI) {
       int iI = tI + 1;
       m3 rotationII = rotation_at(sc, iI);
@@ -263,7 +267,7 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
       tR.origin = m3mul(rotationII, add3(ray.origin, shift_at(sc, iI)));
       tR.unitDirection = m3mul(rotationII, ray.unitDirection);
     }
-    if (e[10] == 0.0f) { if (!mode) { tally_walk(*visits - visits0); trace_byte(0xFF); } return hit; }
+    if (e[10] == 0.0f) { if (!mode) { tally_walk(*visits - visits0); trace_byte(0xFF); itrace(0xFFFFFFFFu); } return hit; }
     if (e[10] == 1.0f) {
       if (!rayCuboid(minLen, tR, V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]))) i += (int)e[6];
     } else {
@@ -276,7 +280,7 @@ static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float view
       }
     }
   }
-  if (!mode) { tally_walk(*visits - visits0); trace_byte(0xFF); }
+  if (!mode) { tally_walk(*visits - visits0); trace_byte(0xFF); itrace(0xFFFFFFFFu); }
   return hit;
 }
 
@@ -292,7 +296,7 @@ static int shadowTestImpl(const flx_scene_view *sc, Ray ray, float l, uint64_t *
     (*visits)++;
     if (g_visit_hist) { _Pragma("omp atomic") g_visit_hist[i]++; }
     int tI = (int)e[9] << 1;
-    trace_byte((uint8_t)((int)e[10] | (tI != cachedTI ? 0x10 : 0)));
+    trace_byte((uint8_t)((int)e[10] | (tI != cachedTI ? 0x10 : 0))); itrace((uint32_t)i);
     if (tI != cachedTI) {
       int iI = tI + 1;
       m3 rotationII = rotation_at(sc, iI);
@@ -300,14 +304,14 @@ static int shadowTestImpl(const flx_scene_view *sc, Ray ray, float l, uint64_t *
       tR.origin = m3mul(rotationII, add3(ray.origin, shift_at(sc, iI)));
       tR.unitDirection = normalize3(m3mul(rotationII, ray.unitDirection));
     }
-    if (e[10] == 0.0f) { trace_byte(0xFF); return 0; }
+    if (e[10] == 0.0f) { trace_byte(0xFF); itrace(0xFFFFFFFFu); return 0; }
     if (e[10] == 1.0f) {
       if (!rayCuboid(minLen, tR, V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]))) i += (int)e[6];
     } else {
-      if (moellerTrumboreCull(V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]), V3(e[6], e[7], e[8]), tR, minLen)) { trace_byte(0xFF); return 1; }
+      if (moellerTrumboreCull(V3(e[0], e[1], e[2]), V3(e[3], e[4], e[5]), V3(e[6], e[7], e[8]), tR, minLen)) { trace_byte(0xFF); itrace(0xFFFFFFFFu); return 1; }
     }
   }
-  trace_byte(0xFF);
+  trace_byte(0xFF); itrace(0xFFFFFFFFu);
   return 0;
 }
 
@@ -732,6 +736,8 @@ void flx_oracle_set_visit_histogram(uint64_t *hist) { g_visit_hist = hist; }
 void flx_oracle_set_walk_histogram(uint64_t *hist32) { g_walk_hist = hist32; }
 void flx_oracle_set_trace(uint8_t *buf, size_t cap) { g_trace = buf; g_trace_cap = cap; g_trace_len = 0; }
 size_t flx_oracle_trace_length(void) { return g_trace_len; }
+void flx_oracle_set_index_trace(uint32_t *buf, size_t cap) { g_itrace = buf; g_itrace_cap = cap; g_itrace_len = 0; }
+size_t flx_oracle_index_trace_length(void) { return g_itrace_len; }
 
 void flx_oracle_math(int fn, const float *a, const float *b, float *out, uint32_t n) {
   for (uint32_t i = 0; i < n; i++) {

@@ -1,0 +1,13 @@
+#!/usr/bin/env python3
+"""Render one rank's share (1/N of the frame) a few times; meant to run under rocprofv3 --kernel-trace."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+from flexlight_hip import capi
+from flexlight_hip.scene_io import Scene
+sc = Scene.golden("dragon")
+ctx = capi.Context(0)
+ctx.update_scene(sc)
+p = sc.frame_params(use_filter=0)
+p.tile_rows, p.tile_count, p.tile_index = 8, int(sys.argv[1]), 0
+for _ in range(4): ctx.render(p)

@@ -128,7 +128,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_counters, 40 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMalloc(&ctx->d_wfcounts, WF_MAX_GROUPS * 3 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&ctx->d_wfcounts, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   for (int i = 0; i < 3; i++) {
     if ((e = hipStreamCreateWithFlags(&ctx->aux_stream[i], hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
@@ -442,7 +442,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
   } else {
-    FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 3 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t), ctx->stream));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t), ctx->stream));
     if (!ctx->d_tail_pool) {     /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
       FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
       FLX_HIP(ctx, hipMalloc(&ctx->d_strag, (size_t)WF_MAX_GROUPS * 2 * cus * 8u * WF_STRAG_MAX * WF_STRAG_F4 * sizeof(float4)));
@@ -469,7 +469,8 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
       wb.rec = ctx->d_rec;
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
-      wb.counts = ctx->d_wfcounts + (size_t)g * 3 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
+      wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
+      wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
       for (int k = 0; k < 2; k++) wb.strag[k] = ctx->d_strag + ((size_t)g * 2 + k) * cus * 8u * WF_STRAG_MAX * WF_STRAG_F4;
       wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;
       wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;

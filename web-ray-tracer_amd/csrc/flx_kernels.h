@@ -32,12 +32,14 @@ struct WavefrontBuffers {
   float4 *tailPool;             /* WF_TAIL_POOL_F4 float4 per walk workgroup: scratch of the tail consolidation */
   float4 *strag[2];             /* walks suspended by the walk kernel of round r (slot r & 1), WF_STRAG_F4 float4 each */
   uint32_t *stragCount;         /* [WF_MAX_ROUNDS + 2] walks suspended in round r */
+  uint32_t *coopQueue;          /* [WF_MAX_ROUNDS + 2] cursor of the cooperative finisher over round r's suspended walks */
 };
 constexpr size_t WF_TAIL_POOL_F4 = 1024 * 8;
 constexpr uint32_t WF_STRAG_F4 = 5;
 constexpr int WF_MAX_ROUNDS = 2 * WF_MAX_BOUNCES;    /* regular rounds + the rounds that drain suspended walks */
 size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units);
-/* walk_scheduler: 0 = one walk per lane (k_wf_walk_pre / k_wf_walk), 1 = workgroup-wide test queues (flx_walkq.hip) */
+/* walk_scheduler: bit 0: 0 = one walk per lane (k_wf_walk_pre / k_wf_walk), 1 = workgroup-wide test queues (flx_walkq.hip);
+ * bit 1: suspended walks are finished by k_wf_walk_coop (a wave per walk) instead of being carried to the next round */
 /* suspend_max: walks a walk workgroup may hand over to the next round instead of finishing them (0 = never) */
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
                       int walk_scheduler, uint32_t suspend_max, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);

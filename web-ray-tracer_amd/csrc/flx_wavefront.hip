@@ -334,18 +334,18 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
 }
 
 /* ---- walk kernel, pre-transformed rays (the default when the scene's transforms fit in LDS) ---------- */
-enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4, P_RESUME = 5 };
 
 /* FIRST = bounce 0 (identity live list); a template parameter so that the dominant launch of a frame is a kernel symbol of
  * its own in profiler summaries (bench.py's roofline names it). */
 template <bool COUNT, bool FIRST>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
-                                                                     uint32_t ldsCount, uint32_t nTransforms, uint32_t suspendMax) {
+                                                                     uint32_t ldsCount, uint32_t nTransforms, uint32_t suspendMax, uint32_t resumePrev) {
   /* b is the ROUND of the bounce loop.  Without suspension round b walks bounce b of every path.  With it (suspendMax > 0) a
    * workgroup that has found the queue dry and is down to suspendMax walks writes them to the straggler list and ends, and
    * the walk kernel of the next round takes them up first: the kernel no longer waits for its longest walk, the paths held
-   * up run one round behind the others (every path's record carries its own bounce index). */
-  const uint32_t nStrag = (b > 0) ? wb.stragCount[b - 1] : 0u;
+   * up run one round behind the others (every path's record carries its own bounce index) — or, with the cooperative
+   * finisher (flx_walkcoop.hip, resumePrev == 0), are completed right after this kernel, a wave per walk. */
+  const uint32_t nStrag = (resumePrev && b > 0) ? wb.stragCount[b - 1] : 0u;     /* with the cooperative finisher nothing is carried over */
   const uint32_t nList = FIRST ? total_items : wb.counts[b];
   const uint32_t n = nStrag + nList;                       /* queue positions: stragglers first, then the live list */
   if (n == 0u) return;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   inChunk = inChunk < 64u ? 64u : (inChunk > WF_IN_CHUNK ? WF_IN_CHUNK : inChunk);
   WorkCounters cnt = {};
   uint32_t diagIters = 0, diagBatches = 0;
-  long long tFold = 0, tRefill = 0, tInner = 0, tLoad = 0, tStart = COUNT ? clock64() : 0;
+  long long tFold = 0, tRefill = 0, tInner = 0, tLoad = 0, tTail = 0, tStart = COUNT ? clock64() : 0;
 
   int st = P_EMPTY;
   uint32_t pathId = 0;
@@ -411,6 +411,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
 
   for (;;) {
 #if FLX_WF_CONSOLIDATE
+    const long long tTail0 = COUNT ? clock64() : 0;
     /* ---- tail consolidation --------------------------------------------------------------------------------
      * Once the walk queue is dry a wave only loses lanes, and a SIMD that hosts four quarter-full waves spends four
      * times the issue slots of one full wave on the same walks: the end of the kernel — set by its longest walk — runs
@@ -445,11 +446,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
           __hip_atomic_store(&tailCtl[TC_ROUND + (par ^ 2u) + 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         total = __builtin_amdgcn_readfirstlane(total); waves = __builtin_amdgcn_readfirstlane(waves);
-        if (COUNT && lane == 0) { atomicAdd(wb.counters + 36, 1ull); atomicAdd(wb.counters + 39, (unsigned long long)waves); }
         if (total <= suspendMax) {
           suspendNow = true;                                   /* every wave of the workgroup reads the same total */
         } else if (waves > 1u && total <= 64u * (waves - 1u)) {
-          if (COUNT && lane == 0) { atomicAdd(wb.counters + 37, 1ull); atomicAdd(wb.counters + 38, (unsigned long long)myCount); }
           /* export */
           uint32_t pos0 = 0;
           if (lane == 0 && myCount) pos0 = atomicAdd(&tailCtl[TC_POOL], myCount);
@@ -493,6 +492,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
         }
       }
     }
+    if (COUNT) tTail += clock64() - tTail0;
 #endif
     const unsigned long long walking = __ballot(st == P_WALKING);
     const unsigned long long workMask = __ballot(st == P_DONE || st == P_SWITCH);
@@ -547,6 +547,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
          * re-read from the path record when the walk is taken up again) --------------------------------------- */
         const bool keep = st == P_WALKING || st == P_SWITCH;
         const unsigned long long km = __ballot(keep);
+        if (COUNT && lane == 0) {
+          atomicAdd(wb.counters + 37, 1ull); atomicAdd(wb.counters + 38, (unsigned long long)__popcll(km));
+          atomicMax(wb.counters + 39, (unsigned long long)(clock64() - tStart)); atomicAdd(wb.counters + 36, (unsigned long long)(clock64() - tStart));
+        }
         if (km != 0ull) {
           uint32_t pos0 = 0;
           if (lane == 0) pos0 = atomicAdd(wb.stragCount + b, (uint32_t)__popcll(km));
@@ -674,7 +678,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
     if (b == 0) {
       atomicAdd(wb.counters + 16, (unsigned long long)tFold); atomicAdd(wb.counters + 17, (unsigned long long)tRefill);
       atomicAdd(wb.counters + 18, (unsigned long long)tInner); atomicAdd(wb.counters + 19, life); atomicAdd(wb.counters + 20, 1ull);
-      atomicAdd(wb.counters + 21, (unsigned long long)tLoad);
+      atomicAdd(wb.counters + 21, (unsigned long long)tLoad); atomicAdd(wb.counters + 22, (unsigned long long)tTail);
     }
     if (b < 4) {   /* tail statistics per bounce: sum / count / max of wave lifetimes */
       atomicAdd(wb.counters + 24 + 3 * b, life); atomicAdd(wb.counters + 25 + 3 * b, 1ull); atomicMax(wb.counters + 26 + 3 * b, life);
@@ -715,8 +719,10 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   /* Suspension needs the kernel that can take a walk up again (k_wf_walk_pre), at least two bounces to gain anything, and
    * as many extra rounds as a path can be held up: one per regular round.  The extra rounds find their lists empty
    * almost always and return at once. */
-  const bool suspend = suspend_max > 0u && pre && walk_scheduler == 0 && bounces >= 2 && FLX_WF_CONSOLIDATE;
-  const int rounds = suspend ? 2 * bounces : bounces;
+  const bool finisher = (walk_scheduler & 2) != 0;          /* suspended walks go to k_wf_walk_coop instead of the next round */
+  const bool lanes = (walk_scheduler & 1) == 0;             /* one walk per lane (not the queue scheduler) */
+  const bool suspend = suspend_max > 0u && pre && lanes && (bounces >= 2 || finisher) && FLX_WF_CONSOLIDATE;
+  const int rounds = (suspend && !finisher) ? 2 * bounces : bounces;
   for (int r = 0; r < rounds; r++) {
     uint32_t shadeBlocks = (r == 0) ? (total + 255u) / 256u : maxBlocks * 2u;
     if (shadeBlocks > maxBlocks * 4u) shadeBlocks = maxBlocks * 4u;
@@ -729,21 +735,22 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
     }
     if (r == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
     const uint32_t smax = (suspend && r < bounces) ? suspend_max : 0u;
-    if (walk_scheduler == 1) {
+    if (!lanes) {
       launch_walk_queue(sc, fr, wb, compute_units, count, r, total, stream);
     } else if (pre) {
       if (r == 0) {
-        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax);
-        else hipLaunchKernelGGL((k_wf_walk_pre<false, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax);
+        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax, finisher ? 0u : 1u);
+        else hipLaunchKernelGGL((k_wf_walk_pre<false, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax, finisher ? 0u : 1u);
       } else {
-        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax);
-        else hipLaunchKernelGGL((k_wf_walk_pre<false, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax);
+        if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax, finisher ? 0u : 1u);
+        else hipLaunchKernelGGL((k_wf_walk_pre<false, false>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax, finisher ? 0u : 1u);
       }
     } else {
       if (count) hipLaunchKernelGGL(k_wf_walk<true>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount);
       else hipLaunchKernelGGL(k_wf_walk<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount);
     }
     if (r == 0 && walk0_end) (void)hipEventRecord(walk0_end, stream);
+    if (suspend && finisher) launch_walk_coop(sc, fr, wb, compute_units, count, r, stream);
   }
 }
 

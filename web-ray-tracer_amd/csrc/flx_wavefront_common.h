@@ -10,6 +10,9 @@ constexpr uint32_t WF_INVALID = 0xffffffffu;
 constexpr uint32_t WF_IN_CHUNK = 256;       /* path ids a wave draws from the walk queue per atomic */
 constexpr uint32_t WF_OUT_CHUNK = 256;      /* live-list slots a wave reserves per atomic */
 
+/* states of a lane of the walk kernel (and of a suspended walk in the straggler list) */
+enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4, P_RESUME = 5 };
+
 /* record flags (q0.w as int bits) */
 constexpr int RF_DEAD = 1, RF_DONT_FILTER = 2, RF_NEED_SHADOW = 4, RF_SHADOWED_NO_WALK = 8;
 
@@ -28,6 +31,9 @@ __device__ __forceinline__ void finalize_path(const DeviceFrame &fr, const Wavef
 }
 
 
+/* flx_walkcoop.hip */
+void launch_walk_coop(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count, int b,
+                      hipStream_t stream);
 /* flx_walkq.hip */
 void launch_walk_queue(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count, int b,
                        uint32_t total, hipStream_t stream);
