@@ -793,10 +793,10 @@ FLX_DEV void walkStartT(const DeviceScene &sc, WalkState &w, int mode, const Ray
  * A ray meets a new transform ~3 times per walk (dragon scene); done per lane inside the stepping loop
  * that is ~100 VALU instructions (two mat3 products, a normalize) executed for ONE lane while 63 wait,
  * in almost every wave-iteration.  The walk kernel therefore transforms a ray into ALL object spaces
- * when the walk is set up (a batched point where many lanes set up together, with the matrices read
- * through scalar loads) and parks the results in LDS; the stepping loop only reloads 2 x 16 bytes.
+ * when the walk is set up (a batched point where many lanes set up together) and parks the results in LDS,
+ * 40 bytes per transform; the stepping loop only reloads those.
  * The arithmetic per (ray, transform) is exactly fragment:197-202 / :257-262. */
-FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, const float4 *xf, float4 *rays, const Ray &src, bool shadowMode) {
+FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, const float4 *xf, float2 *rays, const Ray &src, bool shadowMode) {
   for (uint32_t t = 0; t < nTransforms; t++) {
     /* xf: the inverse rotation (3 columns) and inverse shift of every transform, staged in LDS by the kernel: the same
      * address for all lanes (a broadcast read) instead of four global loads per transform in the middle of the set-up */
@@ -810,13 +810,24 @@ FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, const fl
     }
     f3 inv; bool fast;
     reciprocalOfDir(sc, d, o, inv, fast);
-    rays[3 * t] = make_float4(o.x, o.y, o.z, 0.0f);
-    rays[3 * t + 1] = make_float4(d.x, d.y, d.z, 0.0f);
-    rays[3 * t + 2] = make_float4(inv.x, inv.y, inv.z, fast ? 1.0f : 0.0f);
+    /* 40 bytes per transform: five float2 (origin, dir, 1/dir, fast flag) */
+    rays[5 * t] = make_float2(o.x, o.y);
+    rays[5 * t + 1] = make_float2(o.z, d.x);
+    rays[5 * t + 2] = make_float2(d.y, d.z);
+    rays[5 * t + 3] = make_float2(inv.x, inv.y);
+    rays[5 * t + 4] = make_float2(inv.z, fast ? 1.0f : 0.0f);
   }
 }
+/* the walk's ray in the object space of transform t, from the lane's pre-transformed set */
+FLX_DEV void walkLoadRay(const float2 *rays, int t, WalkState &w) {
+  const float2 a = rays[5 * t], b = rays[5 * t + 1], c = rays[5 * t + 2], d = rays[5 * t + 3], e = rays[5 * t + 4];
+  w.tR.origin = F3(a.x, a.y, b.x);
+  w.tR.dir = F3(b.y, c.x, c.y);
+  w.inv = F3(d.x, d.y, e.x);
+  w.fastDiv = e.y != 0.0f;
+}
 template <bool COUNT>
-FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float4 *rays, WalkState &w, WalkEntry &cur,
+FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float2 *rays, WalkState &w, WalkEntry &cur,
                         WorkCounters &cnt) {
   if ((uint32_t)w.i == WALK_END) return true;
   const uint32_t i = linkIndex((uint32_t)w.i);
@@ -827,12 +838,7 @@ FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
   const int tI = (meta >> 2) << 1;
   if (tI != w.cachedTI) {
     w.cachedTI = tI;
-    const int slot = (tI >> 1) * 3;                       /* slot of transform tI/2 */
-    const float4 o = rays[slot], d = rays[slot + 1], y = rays[slot + 2];
-    w.tR.origin = F3(o.x, o.y, o.z);
-    w.tR.dir = F3(d.x, d.y, d.z);
-    w.inv = F3(y.x, y.y, y.z);
-    w.fastDiv = y.w != 0.0f;
+    walkLoadRay(rays, tI >> 1, w);
   }
   return (meta & 3) == 0;
 }
@@ -846,19 +852,14 @@ FLX_DEV void walkLoadEntry(const DeviceScene &sc, const float4 *lds, uint32_t ld
 }
 /* The rest of walkFetchP once `cur` holds entry w.i: visit count, transform change, terminator test. */
 template <bool COUNT>
-FLX_DEV bool walkArriveP(const float4 *rays, WalkState &w, const WalkEntry &cur, WorkCounters &cnt) {
+FLX_DEV bool walkArriveP(const float2 *rays, WalkState &w, const WalkEntry &cur, WorkCounters &cnt) {
   if ((uint32_t)w.i == WALK_END) return true;
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
   const int meta = __float_as_int(cur.e2.z);
   const int tI = (meta >> 2) << 1;
   if (tI != w.cachedTI) {
     w.cachedTI = tI;
-    const int slot = (tI >> 1) * 3;
-    const float4 o = rays[slot], d = rays[slot + 1], y = rays[slot + 2];
-    w.tR.origin = F3(o.x, o.y, o.z);
-    w.tR.dir = F3(d.x, d.y, d.z);
-    w.inv = F3(y.x, y.y, y.z);
-    w.fastDiv = y.w != 0.0f;
+    walkLoadRay(rays, tI >> 1, w);
   }
   return (meta & 3) == 0;
 }

@@ -68,6 +68,9 @@ __device__ unsigned long long g_diagSlow[4];
 #define FLX_WF_TAIL_TRIPS 8                 /* trips of the scheduler loop between two consolidation rounds */
 #endif
 enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_ROUND = 4 };   /* LDS words of the tail consolidation */
+#ifndef FLX_WF_WAVES_PER_EU
+#define FLX_WF_WAVES_PER_EU 4               /* occupancy the register allocation of k_wf_walk_pre must allow */
+#endif
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
 #endif
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
 /* FIRST = bounce 0 (identity live list); a template parameter so that the dominant launch of a frame is a kernel symbol of
  * its own in profiler summaries (bench.py's roofline names it). */
 template <bool COUNT, bool FIRST>
-__global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
+__global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_walk_pre(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
                                                                      uint32_t ldsCount, uint32_t nTransforms, uint32_t suspendMax, uint32_t resumePrev) {
   /* b is the ROUND of the bounce loop.  Without suspension round b walks bounce b of every path.  With it (suspendMax > 0) a
    * workgroup that has found the queue dry and is down to suspendMax walks writes them to the straggler list and ends, and
@@ -349,14 +352,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk_pre(DeviceScene
   const uint32_t nList = FIRST ? total_items : wb.counts[b];
   const uint32_t n = nStrag + nList;                       /* queue positions: stragglers first, then the live list */
   if (n == 0u) return;
-  /* LDS: [tree top: ldsCount entries x 48 B][per thread: nTransforms x (origin, dir, 1/dir + fast flag) float4 triples]
-   *      [nTransforms x (inverse rotation columns, inverse shift) float4 quadruples] */
+  /* LDS: [tree top: ldsCount entries x 48 B][nTransforms x (inverse rotation columns, inverse shift) float4 quadruples]
+   *      [tailCtl: 16 words][per thread: nTransforms x 40 B (origin, dir, 1/dir, fast flag)] */
   extern __shared__ float4 ldsAll[];
   float4 *ldsEntries = ldsAll;
-  float4 *raysBase = ldsAll + (size_t)ldsCount * 3u;
-  float4 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 3u;      /* follows a walk when it moves to another lane (tail consolidation) */
-  float4 *ldsXf = raysBase + (size_t)FLX_WF_WALK_THREADS * nTransforms * 3u;
+  float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u;
   uint32_t *tailCtl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);       /* 16 words, see TC_* */
+  float2 *raysBase = (float2 *)(tailCtl + 16);
+  float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;      /* follows a walk when it moves to another lane (tail consolidation) */
   for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
   for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
     const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
@@ -696,8 +699,8 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
    * (n_transforms x 48 B each) when they fit, the rest goes to the tree top. */
   const uint32_t T = sc.n_transforms;
-  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 48u + T * 64u + 64u;      /* per-thread rays + the staged inverse transforms + tailCtl */
-  const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 148u * 1024u;
+  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 40u + T * 64u + 64u;      /* per-thread rays + the staged inverse transforms + tailCtl */
+  const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 148u * 1024u && rayBytes <= (uint32_t)FLX_WF_LDS_TOTAL;
   const uint32_t ldsBudget = (uint32_t)FLX_WF_LDS_TOTAL - (pre ? rayBytes : 0u);
   uint32_t ldsCount = ldsBudget / 48u;
   if (ldsCount > sc.walk_hot) ldsCount = sc.walk_hot;
