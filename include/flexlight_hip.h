@@ -151,6 +151,18 @@ flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
 /* Wavefront pipeline: run the bounce loop as 1..4 independent chains of screen-tile ranges on separate HIP
  * streams (default 2), so that the tail of one chain's persistent walk kernel overlaps the other's work. */
 flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
+/* Wavefront pipeline: how the bounce walks are scheduled.  Every mode walks every ray through the same entries with the
+ * same arithmetic (frames and work counters are identical); they differ in speed and exist for A/B measurements
+ * (profiles/r01_ab_tail_schedulers.txt).
+ *   scheduler      FLX_WALK_LANES (default): one walk per lane, lanes refilled as walks end (k_wf_walk_pre)
+ *                  FLX_WALK_QUEUES: walk states in LDS, waves take 64 walks that need the same test (flx_walkq.hip)
+ *                  FLX_WALK_LANES_FINISHER: as FLX_WALK_LANES, suspended walks are finished a wave per walk (flx_walkcoop.hip)
+ *   suspend_walks  FLX_WALK_LANES*: a walk workgroup that has found the queue dry and is down to this many walks hands
+ *                  them over (to the next round's walk kernel, or to the finisher) instead of finishing them; 0 = never */
+#define FLX_WALK_LANES 0
+#define FLX_WALK_QUEUES 1
+#define FLX_WALK_LANES_FINISHER 2
+flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, uint32_t suspend_walks);
 
 /* ---- diagnostics --------------------------------------------------------------------------------- */
 /* Evaluate one of include/flx_math.h's routines on the GPU for n inputs (b may be NULL for unary

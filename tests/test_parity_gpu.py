@@ -92,6 +92,37 @@ def test_wavefront_groups_do_not_change_the_frame(hip, oracle, scenes, name, w, 
         hip.set_wavefront_groups(1)
 
 
+@pytest.mark.parametrize("scheduler,suspend", [(0, 128), (0, 16), (1, 0), (2, 16), (2, 128), (0, 0)])
+@pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 480, 270, 2, 4), ("cornell_obj", 128, 96, 2, 5), ("theater", 96, 64, 1, 1)])
+def test_walk_schedulers_do_not_change_the_frame(hip, oracle, scenes, name, w, h, spp, bounces, scheduler, suspend):
+    """Queue scheduler, suspension to the next round, cooperative finisher: other orders of the same work — same bits, same
+    work counters (every ray visits the same entries)."""
+    sc = scenes(name)
+    hip.update_scene(sc)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+    key = (name, w, h, spp, bounces)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle.render(sc, p)[:2]
+    want, want_cnt = _ORACLE_CACHE[key]
+    try:
+        hip.set_walk_scheduler(scheduler, suspend)
+        for _ in range(2):
+            got, cnt, _ = hip.render(p, counters=True)
+            assert np.array_equal(got, want, equal_nan=True)
+            assert cnt == want_cnt
+        got, _, _ = hip.render(p)
+        assert np.array_equal(got, want, equal_nan=True)
+    finally:
+        hip.set_walk_scheduler(0, 0)
+
+
+def test_walk_scheduler_arguments(hip):
+    from flexlight_hip import capi
+    for args in ((3, 0), (-1, 0), (0, 513), (1, 8)):
+        with pytest.raises(capi.FlexLightHipError):
+            hip.set_walk_scheduler(*args)
+
+
 def test_errors_are_reported_not_thrown(hip, scenes):
     from flexlight_hip import capi
     sc = scenes("cornell")

@@ -3,13 +3,13 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
-os.environ.setdefault("FLX_WALK_SCHEDULER", "1")
 from flexlight_hip import capi
 from flexlight_hip.scene_io import Scene
 name = sys.argv[1] if len(sys.argv) > 1 else "dragon"
 sc = Scene.golden(name)
 ctx = capi.Context(0)
 ctx.update_scene(sc)
+ctx.set_walk_scheduler(1)
 p = sc.frame_params(max_reflections=1, use_filter=0)
 _, cnt, _ = ctx.render(p, counters=True)
 d = ctx.get_diag()

@@ -111,8 +111,6 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if (device < 0 || device >= n) { g_create_error = "flx_context_create: device index out of range"; return FLX_ERR_INVALID; }
   flx_context *ctx = new flx_context();
   ctx->device = device;
-  if (const char *ws = getenv("FLX_WALK_SCHEDULER")) ctx->walk_scheduler = atoi(ws);
-  if (const char *ws = getenv("FLX_WALK_SUSPEND")) ctx->walk_suspend = (uint32_t)atoi(ws);
   auto bail = [&](const char *what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
     delete ctx;
@@ -475,7 +473,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
       wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;
       wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
       hipStream_t st = g == 0 ? ctx->stream : ctx->aux_stream[g - 1];
-      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend > WF_STRAG_MAX ? WF_STRAG_MAX : ctx->walk_suspend, g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
+      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend, g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
       FLX_HIP(ctx, hipGetLastError());
       if (g > 0) {
         FLX_HIP(ctx, hipEventRecord(ctx->ev_join[g - 1], st));
@@ -572,6 +570,16 @@ extern "C" flx_status flx_set_wavefront_groups(flx_context *ctx, int groups) {
   if (!ctx) return FLX_ERR_INVALID;
   if (groups < 1 || groups > WF_MAX_GROUPS) return fail(ctx, FLX_ERR_INVALID, "flx_set_wavefront_groups: 1..4");
   ctx->wf_groups = groups;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, uint32_t suspend_walks) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (scheduler < FLX_WALK_LANES || scheduler > FLX_WALK_LANES_FINISHER) return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: scheduler 0 lanes, 1 queues, 2 lanes + finisher");
+  if (suspend_walks > WF_STRAG_MAX) return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: suspend_walks 0..512");
+  if (scheduler == FLX_WALK_QUEUES && suspend_walks != 0u) return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: the queue scheduler does not suspend walks");
+  ctx->walk_scheduler = scheduler;
+  ctx->walk_suspend = suspend_walks;
   return FLX_OK;
 }
 

@@ -18,7 +18,7 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset",
+    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler",
 ]
 
 
@@ -58,6 +58,7 @@ def _load():
         "flx_get_diag": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_set_wavefront_groups": (C.c_int, [vp, C.c_int]),
         "flx_temporal_reset": (C.c_int, [vp]),
+        "flx_set_walk_scheduler": (C.c_int, [vp, C.c_int, C.c_uint32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -172,6 +173,10 @@ class Context:
 
     def set_wavefront_groups(self, groups):
         self._check(LIB.flx_set_wavefront_groups(self._h, int(groups)), "flx_set_wavefront_groups")
+
+    def set_walk_scheduler(self, scheduler, suspend_walks=0):
+        """0 one walk per lane (default), 1 LDS test queues, 2 lanes + cooperative finisher; identical results"""
+        self._check(LIB.flx_set_walk_scheduler(self._h, int(scheduler), int(suspend_walks)), "flx_set_walk_scheduler")
 
     def get_diag(self):
         out = (C.c_uint64 * 32)()
