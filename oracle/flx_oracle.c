@@ -428,7 +428,7 @@ static v3 lightTrace(Frag *f, Hit hit, v3 dir0, v3 camera, float cosSampleN, int
   v3 lastHitPoint = camera;
   for (int i = 0; i < bounces && length3(mul3(importancyFactor, f->originalColor)) >= fp->min_importancy * SQRT3; i++) {
     float fi = (float)i;
-    g_trace_bounce = (uint32_t)i;
+    if (g_trace) g_trace_bounce = (uint32_t)i;          /* analysis hook only: never written by the threads of a normal render */
     f->cnt.shades++;
     m3 rTI = rotation_at(sc, hit.transformId);
     v3 sTI = shift_at(sc, hit.transformId);
@@ -565,9 +565,9 @@ static void fragment_main(Frag *f, const PrimarySetup *ps, uint32_t px, uint32_t
   f->cnt.primary_hits++;
   v3 camera = V3(fp->camera[0], fp->camera[1], fp->camera[2]);
   v3 finalColor = V3(0.0f, 0.0f, 0.0f);
-  g_trace_px = px; g_trace_py = py_gl;
+  if (g_trace) { g_trace_px = px; g_trace_py = py_gl; }
   for (int i = 0; i < fp->samples; i++) {
-    g_trace_sample = (uint32_t)i;
+    if (g_trace) g_trace_sample = (uint32_t)i;
     float cosSampleN = flx_cos((float)i);
     finalColor = add3(finalColor, lightTrace(f, hit, dir0, camera, cosSampleN, fp->max_reflections));
   }
