@@ -74,6 +74,9 @@ FLX_HD float flx_fract(float x) { return x - flx_floor(x); }
 FLX_HD float flx_mod(float x, float y) { return x - y * flx_floor(x / y); }
 
 FLX_HD double flx_floord(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_floor(x);                               /* v_floor_f64: floor is exact, so this is the value computed below */
+#endif
   uint64_t u = flx_d2u(x);
   int e = (int)((u >> 52) & 0x7ffu) - 1023;
   if (e >= 52) return x;
@@ -114,6 +117,22 @@ FLX_HD double flx_kcos(double r) {
   p = p * z + -0.5;
   return 1.0 + z * p;
 }
+/* flx_ksin(r) or flx_kcos(r) — the same values bit for bit — through ONE Horner chain whose coefficients are selected:
+ * a GPU lane pays for one polynomial instead of both branches of the quadrant test.  The sine chain is one step
+ * shorter; it starts from 0, and 0 * z + c == c exactly. */
+FLX_HD double flx_ksincos(double r, int use_cos) {
+  double z = r * r;
+  double p = use_cos ? 4.7794773323873852974e-14 : 0.0;
+  p = p * z + (use_cos ? -1.1470745597729724714e-11 : -7.6471637318198164759e-13);
+  p = p * z + (use_cos ? 2.0876756987868098979e-09 : 1.6059043836821614599e-10);
+  p = p * z + (use_cos ? -2.7557319223985890653e-07 : -2.5052108385441718775e-08);
+  p = p * z + (use_cos ? 2.4801587301587301587e-05 : 2.7557319223985890653e-06);
+  p = p * z + (use_cos ? -1.3888888888888888889e-03 : -1.9841269841269841270e-04);
+  p = p * z + (use_cos ? 4.1666666666666666667e-02 : 8.3333333333333333333e-03);
+  p = p * z + (use_cos ? -0.5 : -1.6666666666666666667e-01);
+  double t = z * p;
+  return use_cos ? (1.0 + t) : (r + r * t);
+}
 /* Returns quadrant (0..3) and reduced argument; *ok = 0 for NaN/Inf/|x| > 2^20 (result NaN). */
 FLX_HD int flx_rem_pio2(float x, double *r, int *ok) {
   const double INV_PIO2 = 0.63661977236758134308;
@@ -129,14 +148,14 @@ FLX_HD int flx_rem_pio2(float x, double *r, int *ok) {
 FLX_HD float flx_sin(float x) {
   double r; int ok; int q = flx_rem_pio2(x, &r, &ok);
   if (!ok) return flx_nanf();
-  double v = (q & 1) ? flx_kcos(r) : flx_ksin(r);
+  double v = flx_ksincos(r, q & 1);
   if (q & 2) v = -v;
   return (float)v;
 }
 FLX_HD float flx_cos(float x) {
   double r; int ok; int q = flx_rem_pio2(x, &r, &ok);
   if (!ok) return flx_nanf();
-  double v = (q & 1) ? flx_ksin(r) : flx_kcos(r);
+  double v = flx_ksincos(r, (q & 1) ^ 1);
   if ((q + 1) & 2) v = -v;
   return (float)v;
 }
