@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
 
 HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X FP32 vector (non-matrix) peak, MI355X_MICROARCH.md
 
 WORKLOADS = {
     # name: (scene fixture, BASELINE.json config it is)
@@ -236,6 +237,10 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_launch, "kernel_ms": k_ms,
                 "frame_algorithmic_bytes": frame_bytes, "frame_achieved": frame_bytes / (ms_per_step * 1e-3) / 1e9,
                 "note": "algorithmic bytes = 48 B x entries visited + 160 B x shades + 24 B x lights x shades + 4 B x texels + 16 B x pixels (SURVEY.md 8d); the <=12 MB scene is cache resident, real HBM traffic is far lower",
+                # SURVEY.md 8d's secondary figure: ~30 flop per entry visited against the FP32 vector peak (the binding limits are
+                # per-lane latency and VALU issue under divergence)
+                "secondary": {"bound": "valu_fp32", "achieved": 30.0 * bytes_launch / 48.0 / (k_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS,
+                              "unit": "TFLOP/s", "frac": 30.0 * bytes_launch / 48.0 / (k_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS},
             },
             "counters": cnt,
         }

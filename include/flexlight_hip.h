@@ -144,6 +144,18 @@ flx_status flx_get_counters(flx_context *ctx, flx_counters *out);
  * (trace) kernel alone; milliseconds. */
 flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_kernel_ms);
 
+/* Filter frames on several GPUs.  The path-trace pass is per pixel and shards by row strips like a frame
+ * without filter; the denoise chain reads up to ~194 rows around a pixel and runs on the whole frame.  So every rank
+ *   1. flx_render_planes_device: traces its strips (params->tile_*, use_filter = 1, is_temporal = 0) and stores the
+ *      reference's five render targets — RenderTexture, IpRenderTexture, OriginalRenderTexture, IdRenderTexture,
+ *      OriginalIdRenderTexture (pathtracerWGL2.js:224-252) — as the RGBA8 they are, rows packed like a tiled frame:
+ *      d_planes = uint32[5][rows of this rank][width];
+ *   2. all-gathers the planes (5 x 8.3 MB at 1080p) and puts the rows in image order (flx_tile_row_at);
+ *   3. flx_filter_planes_device: runs the chain (pathtracerWGL2.js:462-550) over uint32[5][height][width] into
+ *      float4[height][width] — bit-identical to flx_render_device of the whole frame on one context. */
+flx_status flx_render_planes_device(flx_context *ctx, const flx_frame_params *params, void *d_planes);
+flx_status flx_filter_planes_device(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba);
+
 /* Kernel organisation of the path-trace pass: 0 = automatic (persistent path kernel; the
  * sample-sequential per-pixel kernel when use_filter needs the cross-sample G-buffer state),
  * 1 = per-pixel kernel, 2 = persistent path kernel.  Results are identical; for A/B timing and tests. */

@@ -172,6 +172,48 @@ def test_filter_refuses_tiles(hip, scenes):
         hip.render(p)
 
 
+@pytest.mark.parametrize("name,w,h,spp,bounces,ranks", [("cornell_obj", 160, 96, 2, 3, 3), ("dragon", 192, 120, 1, 3, 4), ("theater", 96, 72, 1, 2, 2)])
+def test_filter_frame_from_strips_of_several_ranks(hip, scenes, name, w, h, spp, bounces, ranks):
+    """SURVEY 8e with the filter on: every rank traces its strips into the five RGBA8 render targets, the planes are gathered
+    into image order, the chain runs on the whole frame — the same bits as the whole frame on one context."""
+    import torch
+    sc = scenes(name)
+    hip.update_scene(sc)
+    full = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=1)
+    want, _, _ = hip.render(full)
+    planes = torch.zeros((5, h, w), dtype=torch.int32, device="cuda")
+    seen = 0
+    for r in range(ranks):
+        p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=1, tile=(8, r, ranks))
+        rows = torch.as_tensor(np.asarray(hip.tile_rows(p), dtype=np.int64), device="cuda")
+        part = torch.zeros((5, rows.numel(), w), dtype=torch.int32, device="cuda")
+        hip.render_planes_device(p, part.data_ptr())
+        hip.sync()
+        planes[:, rows, :] = part
+        seen += rows.numel()
+    assert seen == h
+    out = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    hip.filter_planes_device(full, planes.data_ptr(), out.data_ptr())
+    hip.sync()
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want, equal_nan=True)
+
+
+def test_render_planes_arguments(hip, scenes):
+    from flexlight_hip import capi
+    import torch
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    buf = torch.zeros((5, 64, 64), dtype=torch.int32, device="cuda")
+    with pytest.raises(capi.FlexLightHipError, match="use_filter"):
+        hip.render_planes_device(sc.frame_params(width=64, height=64, use_filter=0), buf.data_ptr())
+    p = sc.frame_params(width=64, height=64, use_filter=1)
+    p.is_temporal = 1
+    with pytest.raises(capi.FlexLightHipError, match="is_temporal"):
+        hip.render_planes_device(p, buf.data_ptr())
+
+
 # ---- temporal accumulation (SURVEY §8f N1): history rings in the context, frame f traced with seed f % N ---------
 @pytest.mark.parametrize("name,w,h,spp,bounces,filt,frames,n", [
     ("cornell", 96, 72, 1, 3, 0, 6, 4),          # more frames than history slots: the ring wraps

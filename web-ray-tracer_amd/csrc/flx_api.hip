@@ -602,6 +602,72 @@ extern "C" flx_status flx_render_device(flx_context *ctx, const flx_frame_params
   return run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
 }
 
+/* ---- filter frames across GPUs: the trace is per pixel and shards by row strips, the denoise chain is not ---- */
+static flx_status ensure_post_buffers(flx_context *ctx, size_t pixels, bool gbuffers, bool planes) {
+  flx_status s;
+  if (gbuffers && ctx->gb_capacity < pixels) {
+    for (int i = 0; i < 6; i++) {
+      size_t cap = 0;
+      if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
+      if ((s = ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
+    }
+    ctx->gb_capacity = pixels;
+  }
+  if (planes && ctx->planes_capacity < pixels) {
+    for (int i = 0; i < 13; i++) {
+      if (ctx->d_planes[i]) { FLX_HIP(ctx, hipFree(ctx->d_planes[i])); ctx->d_planes[i] = nullptr; }
+      FLX_HIP(ctx, hipMalloc(&ctx->d_planes[i], pixels * sizeof(uint32_t)));
+    }
+    ctx->planes_capacity = pixels;
+  }
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_render_planes_device(flx_context *ctx, const flx_frame_params *params, void *d_planes) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!d_planes) return fail(ctx, FLX_ERR_INVALID, "flx_render_planes_device: output pointer is NULL");
+  if (!params || params->use_filter != 1 || params->is_temporal != 0)
+    return fail(ctx, FLX_ERR_INVALID, "flx_render_planes_device: needs use_filter = 1 and is_temporal = 0 (history is per context)");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceScene sc; DeviceFrame fr;
+  flx_status s = make_frame(ctx, params, sc, fr);
+  if (s) return s;
+  const size_t pixels = (size_t)fr.rows * fr.width;
+  if (pixels == 0) return FLX_OK;
+  if ((s = ensure_post_buffers(ctx, pixels, true, false))) return s;
+  GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5] };
+  if ((s = run_frame(ctx, sc, fr, nullptr, gb))) return s;
+  /* the reference's five render targets, stored as it stores them (RGBA8), strips packed like the radiance of a tiled frame */
+  uint32_t *out = (uint32_t *)d_planes;
+  const float4 *src[5] = { gb.color, gb.color_ip, gb.original_color, gb.id, gb.original_id };
+  for (int k = 0; k < 5; k++) launch_quantize(src[k], out + (size_t)k * pixels, pixels, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_filter_planes_device(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!d_planes || !d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_filter_planes_device: NULL pointer");
+  if (!params || params->width == 0 || params->height == 0) return fail(ctx, FLX_ERR_INVALID, "flx_filter_planes_device: empty frame");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t pixels = (size_t)params->width * params->height;
+  flx_status s;
+  if ((s = ensure_post_buffers(ctx, pixels, false, true))) return s;
+  FilterPlanes pl;
+  for (int i = 0; i < 4; i++) { pl.R[i] = ctx->d_planes[i]; pl.Ip[i] = ctx->d_planes[4 + i]; }
+  pl.O[0] = ctx->d_planes[8]; pl.O[1] = ctx->d_planes[9]; pl.Id[0] = ctx->d_planes[10]; pl.Id[1] = ctx->d_planes[11]; pl.OId = ctx->d_planes[12];
+  const uint32_t *in = (const uint32_t *)d_planes;
+  uint32_t *dst[5] = { pl.R[0], pl.Ip[0], pl.O[0], pl.Id[0], pl.OId };
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
+  for (int k = 0; k < 5; k++) FLX_HIP(ctx, hipMemcpyAsync(dst[k], in + (size_t)k * pixels, pixels * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  launch_filter_chain(pl, (float4 *)d_out_rgba, (int)params->width, (int)params->height, params->hdr, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  ctx->timed = true;
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *params, float *out_rgba, const flx_gbuffers *gbuffers,
                                  flx_counters *counters) {
   if (!ctx) return FLX_ERR_INVALID;

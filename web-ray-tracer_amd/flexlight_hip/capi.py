@@ -18,7 +18,7 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler",
+    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_planes_device", "flx_filter_planes_device",
 ]
 
 
@@ -59,6 +59,8 @@ def _load():
         "flx_set_wavefront_groups": (C.c_int, [vp, C.c_int]),
         "flx_temporal_reset": (C.c_int, [vp]),
         "flx_set_walk_scheduler": (C.c_int, [vp, C.c_int, C.c_uint32]),
+        "flx_render_planes_device": (C.c_int, [vp, C.c_void_p, C.c_void_p]),
+        "flx_filter_planes_device": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -173,6 +175,14 @@ class Context:
 
     def set_wavefront_groups(self, groups):
         self._check(LIB.flx_set_wavefront_groups(self._h, int(groups)), "flx_set_wavefront_groups")
+
+    def render_planes_device(self, params, device_ptr):
+        """this rank's strips of a filter frame -> uint32[5][rows][width] RGBA8 render targets in device memory"""
+        self._check(LIB.flx_render_planes_device(self._h, C.byref(params), C.c_void_p(device_ptr)), "flx_render_planes_device")
+
+    def filter_planes_device(self, params, planes_ptr, out_ptr):
+        """uint32[5][height][width] render targets of the whole frame -> float4[height][width] through the denoise chain"""
+        self._check(LIB.flx_filter_planes_device(self._h, C.byref(params), C.c_void_p(planes_ptr), C.c_void_p(out_ptr)), "flx_filter_planes_device")
 
     def set_walk_scheduler(self, scheduler, suspend_walks=0):
         """0 one walk per lane (default), 1 LDS test queues, 2 lanes + cooperative finisher; identical results"""
