@@ -127,8 +127,7 @@ def main():
     multi = world > 1 or force_dist
     tile = (args.tile_rows, rank, world) if multi else (0, 0, 0)
     params = scene.frame_params(width=args.width, height=args.height, tile=tile)
-    if use_filter and world > 1:
-        raise SystemExit("filter-on workloads are single-GPU for now (the filter is not pixel-independent, SURVEY.md §8e)")
+    filter_multi = bool(use_filter) and multi          # strips -> RGBA8 render targets -> gather -> whole-frame chain
 
     ctx = capi.Context(local_rank)
     ctx.update_scene(scene)
@@ -153,7 +152,25 @@ def main():
         dst_index = torch.tensor(dst_row, device="cuda")
         assert sorted(dst_row) == list(range(H))
 
+    if filter_multi:
+        planes_local = torch.zeros((5, rows_max, W), dtype=torch.int32, device="cuda")
+        planes_all = torch.empty((world, 5, rows_max, W), dtype=torch.int32, device="cuda")
+        planes = torch.empty((5, H, W), dtype=torch.int32, device="cuda")
+        if rows_local != rows_max:            # the C ABI packs [5][rows_local][W]; ranks with a strip less use a view of that shape
+            planes_tight = torch.zeros((5, rows_local, W), dtype=torch.int32, device="cuda")
+
     def step():
+        if filter_multi:
+            if rows_local == rows_max:
+                ctx.render_planes_device(params, planes_local.data_ptr())
+            else:
+                ctx.render_planes_device(params, planes_tight.data_ptr())
+                planes_local[:, :rows_local, :] = planes_tight
+            dist.all_gather_into_tensor(planes_all.view(-1), planes_local.view(-1))
+            sel = planes_all.permute(1, 0, 2, 3).reshape(5, world * rows_max, W).index_select(1, src_index)
+            planes.index_copy_(1, dst_index, sel)
+            ctx.filter_planes_device(full, planes.data_ptr(), frame.data_ptr())      # every rank ends up with the frame
+            return
         ctx.render_device(params, local.data_ptr())         # filter-on frames: trace + denoise chain, all on the GPU
         if multi:
             dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
@@ -181,15 +198,21 @@ def main():
 
     # Dominant-kernel duration, measured live with HIP events on the launch stream, outside the timed
     # region so the event syncs do not perturb it: same frame, K more launches.
+    def trace_share():                   # this rank's share of the trace, without gather / chain
+        if filter_multi:
+            ctx.render_planes_device(params, (planes_local if rows_local == rows_max else planes_tight).data_ptr())
+        else:
+            ctx.render_device(params, local.data_ptr())
+
     ctx.set_wavefront_groups(1)          # one chain, so the bounce-0 walk kernel is ONE launch over the whole share of the frame
     for _ in range(min(args.steps, 10)):
-        ctx.render_device(params, local.data_ptr())
+        trace_share()
         frame_ms, trace_ms = ctx.last_frame_ms()
         kernel_ms.append(trace_ms)
     # Work counters of this rank's share of the frame (a counted launch; not timed), and of bounce 0 alone
     # (the same frame cut after one bounce: identical paths) for the dominant kernel's roofline.
     ctx.set_counters_enabled(True)
-    ctx.render_device(params, local.data_ptr())
+    trace_share()
     ctx.sync()
     cnt = ctx.get_counters()
     cnt_b0 = None
