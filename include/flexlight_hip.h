@@ -17,6 +17,7 @@
 #ifndef FLEXLIGHT_HIP_H
 #define FLEXLIGHT_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -175,6 +176,33 @@ flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
 #define FLX_WALK_QUEUES 1
 #define FLX_WALK_LANES_FINISHER 2
 flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, uint32_t suspend_walks);
+
+/* ---- native scene import (host only, needs no GPU and no context) ---------------------------------
+ * One imported object: Scene.importMtl + Scene.importObj of the reference (modules/scene.js:330-487) including the
+ * generateBVH (:62-154) it ends with, the Object3D operations an application applies to the result (:774-839), and its
+ * block of generateArraysFromGraph (:190-316).  The arrays equal what the JavaScript host layer produces for the same
+ * object, bit for bit; a scene's flattening splices the block in (skip counts are relative, ids are entry indices
+ * relative to the block's first entry). */
+typedef struct flx_mesh flx_mesh;
+flx_status flx_mesh_import_obj(const char *obj_text, size_t obj_len, const char *mtl_text /* or NULL */, size_t mtl_len, flx_mesh **out);
+void flx_mesh_destroy(flx_mesh *mesh);
+uint32_t flx_mesh_entry_count(const flx_mesh *mesh);          /* AABB nodes + triangles */
+uint32_t flx_mesh_triangle_count(const flx_mesh *mesh);
+flx_status flx_mesh_set_transform(flx_mesh *mesh, uint32_t transform_number);
+flx_status flx_mesh_move(flx_mesh *mesh, double x, double y, double z);
+flx_status flx_mesh_scale(flx_mesh *mesh, double s);
+#define FLX_MESH_COLOR 0          /* 3 values, 0..255 */
+#define FLX_MESH_ROUGHNESS 1
+#define FLX_MESH_METALLICITY 2
+#define FLX_MESH_EMISSIVENESS 3
+#define FLX_MESH_TRANSLUCENCY 4
+#define FLX_MESH_IOR 5
+#define FLX_MESH_TEXTURE_NUMS 6   /* 3 values: albedo, pbr, translucency texture numbers (-1 = none) */
+flx_status flx_mesh_set_material(flx_mesh *mesh, int field, const double *values);
+/* Scene.updateBoundings of the object (scene.js:157-187): [xmin, xmax, ymin, ymax, zmin, zmax], nodes widened by 100 * 2^-16 */
+flx_status flx_mesh_bounding(flx_mesh *mesh, double box[6]);
+/* geometry: 12 floats per entry, attributes: 28 floats per entry, ids: one entry index per triangle, minmax: the block's box */
+flx_status flx_mesh_flatten(const flx_mesh *mesh, float *geometry, float *attributes, int32_t *ids, float minmax[6]);
 
 /* ---- diagnostics --------------------------------------------------------------------------------- */
 /* Evaluate one of include/flx_math.h's routines on the GPU for n inputs (b may be NULL for unary

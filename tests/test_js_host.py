@@ -18,8 +18,9 @@ pytestmark = pytest.mark.skipif(NODE is None, reason="node is not installed")
 needs_assets = pytest.mark.skipif(not os.path.isdir(os.path.join(REFERENCE, "objects")), reason="OBJ/JPEG assets not mounted")
 
 
-def host_arrays(scene):
-    out = subprocess.check_output([NODE, os.path.join(ROOT, "tools", "host_arrays.js"), scene, "--assets", REFERENCE], timeout=300)
+def host_arrays(scene, native=False):
+    cmd = [NODE, os.path.join(ROOT, "tools", "host_arrays.js"), scene, "--assets", REFERENCE] + (["--native"] if native else [])
+    out = subprocess.check_output(cmd, timeout=300)
     return json.loads(out.decode().strip().splitlines()[-1])
 
 
@@ -28,8 +29,8 @@ def golden(scene):
         return json.load(fh)
 
 
-def check(scene):
-    got, want = host_arrays(scene), golden(scene)
+def check(scene, native=False):
+    got, want = host_arrays(scene, native), golden(scene)
     for key in ("textureLength", "bufferLength", "entriesPadded", "transforms"):
         assert got[key] == want[key], key
     for key, digest in want["sha256"].items():
@@ -44,6 +45,14 @@ def test_cornell_arrays_equal_reference():
 @pytest.mark.parametrize("scene", ["cornell_obj", "dragon", "theater"])
 def test_imported_scene_arrays_equal_reference(scene):
     check(scene)                           # OBJ/MTL import + BVH builder + transforms
+
+
+@needs_assets
+@pytest.mark.parametrize("scene", ["cornell_obj", "dragon"])
+def test_native_import_arrays_equal_reference(scene):
+    """OBJ / MTL parsing, BVH build and flattening in native code (flx_mesh_* through the N-API addon),
+    spliced into the JavaScript scene: the whole scene still hashes to what the reference's own scene.js emits."""
+    check(scene, native=True)
 
 
 def test_golden_scene_file_matches_its_hashes():
@@ -78,7 +87,8 @@ def test_napi_addon_loads_and_exports():
         pytest.skip("addon not built (run __graft_entry__.build())")
     js = "const a = require('%s'); console.log(JSON.stringify({keys: Object.keys(a), version: a.version()}));" % addon
     out = json.loads(subprocess.check_output([NODE, "-e", js]).decode())
-    for name in ("createContext", "destroyContext", "uploadScene", "uploadTransforms", "uploadLights", "uploadAtlas", "tileRowCount", "render"):
+    for name in ("createContext", "destroyContext", "uploadScene", "uploadTransforms", "uploadLights", "uploadAtlas", "tileRowCount", "render",
+                 "meshImport", "meshCounts", "meshSetTransform", "meshMove", "meshScale", "meshSetMaterial", "meshBounding", "meshFlatten"):
         assert name in out["keys"]
     assert "flexlight-hip" in out["version"]
 

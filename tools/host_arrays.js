@@ -3,7 +3,7 @@
  * Build one of the BASELINE scenes with THIS repo's JavaScript host layer (web-ray-tracer_amd/js) and
  * print the sha256 of every array it would hand to the GPU, as JSON — tests/test_js_host.py compares
  * them with tests/golden/ref_<scene>.json, the hashes of what the reference's own scene.js emits.
- *   node tools/host_arrays.js <scene> [--assets DIR] [--save FILE.flxs.gz]
+ *   node tools/host_arrays.js <scene> [--assets DIR] [--save FILE.flxs.gz] [--native]   (--native: OBJ import / BVH / flatten through flx_mesh_*)
  * Asset files (OBJ/MTL/JPEG) are read from --assets (default: $FLX_REFERENCE or /root/reference).
  */
 const fs = require('fs');
@@ -38,13 +38,15 @@ function loadImage (rel) {           // decode with PIL: Node 12 has no JPEG dec
   if (!scenes[name]) { console.error('unknown scene ' + name + '; one of ' + Object.keys(scenes).join(', ')); process.exit(2); }
   Transform.reset();
   const log = console.log; console.log = () => {}; const warn = console.warn; console.warn = () => {};
-  const engine = { scene: new Scene({ assetRoot: assets }), camera: new Camera(), loadImage: async rel => loadImage(rel) };
+  const engine = { scene: new Scene({ assetRoot: assets }), camera: new Camera(), loadImage: async rel => loadImage(rel), nativeImport: args.includes('--native') };
+  const t0 = Date.now();
   await scenes[name](engine);
   const built = engine.scene.generateArraysFromGraph();
+  const buildMs = Date.now() - t0;
   const transforms = Transform.buildWGL2Arrays();
   console.log = log; console.warn = warn;
   const s = sceneFile.assemble(name, engine, built, transforms, scenes[name].frame, { producer: 'web-ray-tracer_amd/js host via tools/host_arrays.js' });
-  const out = { name, textureLength: built.textureLength, bufferLength: built.bufferLength, entriesPadded: s.meta.entriesPadded, transforms: s.meta.transforms, sha256: {} };
+  const out = { name, textureLength: built.textureLength, bufferLength: built.bufferLength, entriesPadded: s.meta.entriesPadded, transforms: s.meta.transforms, buildMs, native: engine.nativeImport, sha256: {} };
   ['geometry', 'attributes', 'ids', 'rotation', 'shift', 'lights', 'atlasAlbedo', 'atlasPbr', 'atlasTpo', 'viewMatrix'].forEach(k => { out.sha256[k] = sha256(s.arrays[k]); });
   const save = opt('--save');
   if (save) require(path.join(JS, 'flxs.js')).write(save, s.meta, s.arrays);

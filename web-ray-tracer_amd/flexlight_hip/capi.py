@@ -19,6 +19,8 @@ EXPORTS = [
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
     "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_planes_device", "flx_filter_planes_device",
+    "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
+    "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten",
 ]
 
 
@@ -61,6 +63,16 @@ def _load():
         "flx_set_walk_scheduler": (C.c_int, [vp, C.c_int, C.c_uint32]),
         "flx_render_planes_device": (C.c_int, [vp, C.c_void_p, C.c_void_p]),
         "flx_filter_planes_device": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "flx_mesh_import_obj": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(vp)]),
+        "flx_mesh_destroy": (None, [vp]),
+        "flx_mesh_entry_count": (C.c_uint32, [vp]),
+        "flx_mesh_triangle_count": (C.c_uint32, [vp]),
+        "flx_mesh_set_transform": (C.c_int, [vp, C.c_uint32]),
+        "flx_mesh_move": (C.c_int, [vp, C.c_double, C.c_double, C.c_double]),
+        "flx_mesh_scale": (C.c_int, [vp, C.c_double]),
+        "flx_mesh_set_material": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
+        "flx_mesh_bounding": (C.c_int, [vp, C.POINTER(C.c_double)]),
+        "flx_mesh_flatten": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -214,3 +226,61 @@ class Context:
 
 def version():
     return LIB.flx_version().decode()
+
+
+class Mesh:
+    """One imported OBJ (+ MTL) in native code: SURVEY 8f N2, include/flexlight_hip.h flx_mesh_*.  Needs no GPU."""
+    FIELDS = {"color": 0, "roughness": 1, "metallicity": 2, "emissiveness": 3, "translucency": 4, "ior": 5, "texture_nums": 6}
+
+    def __init__(self, obj_text, mtl_text=None):
+        obj = obj_text.encode() if isinstance(obj_text, str) else obj_text
+        mtl = (mtl_text.encode() if isinstance(mtl_text, str) else mtl_text) if mtl_text is not None else None
+        h = C.c_void_p()
+        rc = LIB.flx_mesh_import_obj(obj, len(obj), mtl, len(mtl) if mtl else 0, C.byref(h))
+        if rc != 0:
+            raise FlexLightHipError("flx_mesh_import_obj failed (%d)" % rc)
+        self._h = h
+
+    def close(self):
+        if self._h:
+            LIB.flx_mesh_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def entries(self):
+        return int(LIB.flx_mesh_entry_count(self._h))
+
+    @property
+    def triangles(self):
+        return int(LIB.flx_mesh_triangle_count(self._h))
+
+    def set_transform(self, number):
+        LIB.flx_mesh_set_transform(self._h, int(number))
+
+    def move(self, x, y, z):
+        LIB.flx_mesh_move(self._h, float(x), float(y), float(z))
+
+    def scale(self, s):
+        LIB.flx_mesh_scale(self._h, float(s))
+
+    def set_material(self, field, values):
+        vals = (C.c_double * 3)(*([float(values)] * 3 if np.isscalar(values) else [float(v) for v in values]))
+        if LIB.flx_mesh_set_material(self._h, self.FIELDS[field], vals) != 0:
+            raise FlexLightHipError("flx_mesh_set_material: unknown field")
+
+    def bounding(self):
+        box = (C.c_double * 6)()
+        LIB.flx_mesh_bounding(self._h, box)
+        return [float(v) for v in box]
+
+    def flatten(self):
+        """-> geometry [entries, 12] f32, attributes [entries, 28] f32, ids [triangles] i32, minmax [6] f32"""
+        g = np.zeros((self.entries, 12), np.float32)
+        a = np.zeros((self.entries, 28), np.float32)
+        ids = np.zeros(self.triangles, np.int32)
+        box = (C.c_float * 6)()
+        if LIB.flx_mesh_flatten(self._h, g.ctypes.data, a.ctypes.data, ids.ctypes.data, box) != 0:
+            raise FlexLightHipError("flx_mesh_flatten failed")
+        return g, a, ids, np.array(list(box), np.float32)

@@ -232,6 +232,52 @@ class Cuboid extends Object3D {                            // scene.js:903-921; 
   }
 }
 
+/* ---- an imported object that lives in native code (SURVEY 8f N2: flx_mesh_* of libflexlight_hip.so through the N-API addon) ----
+ * Same surface as the Bounding tree importObj returns — transform / material setters, move, scale — and the same arrays at
+ * flattening time, bit for bit; parsing, BVH build and flattening of a 45 k-triangle OBJ take tens of milliseconds instead
+ * of seconds. */
+const MESH_FIELD = { color: 0, albedo: 0, roughness: 1, metallicity: 2, emissiveness: 3, translucency: 4, ior: 5, textureNums: 6 };
+class NativeMesh {
+  constructor (addon, handle) {
+    this.nativeMesh = true;
+    this.indexable = false;
+    this._addon = addon;
+    this._handle = handle;
+    this._transform = undefined;
+    this.relativePosition = [0, 0, 0];
+    const c = addon.meshCounts(handle);
+    this.entries = c.entries;
+    this.triangles = c.triangles;
+  }
+
+  get transformNum () { return this._transform ? this._transform.number : 0; }
+  get transform () { return this._transform; }
+  set transform (t) { this._transform = t; this._addon.meshSetTransform(this._handle, t ? t.number : 0); }
+  move (x, y, z) { this.relativePosition = [x, y, z]; this._addon.meshMove(this._handle, x, y, z); }
+  scale (s) { this._addon.meshScale(this._handle, s); }
+  get bounding () { return this._addon.meshBounding(this._handle); }
+  set bounding (b) { /* recomputed on demand */ }
+  /* the block of generateArraysFromGraph: entries [at, at + entries), ids relative to `at` */
+  flattenInto (geometryBuffer, sceneBuffer, idBuffer, at, tri) {
+    const g = geometryBuffer.subarray(at * ENTRY, (at + this.entries) * ENTRY);
+    const a = sceneBuffer.subarray(at * ATTR, (at + this.entries) * ATTR);
+    const ids = idBuffer.subarray(tri, tri + this.triangles);
+    const box = this._addon.meshFlatten(this._handle, g, a, ids);
+    if (at !== 0) for (let i = 0; i < ids.length; i++) ids[i] += at;
+    return box;
+  }
+}
+Object.keys(MESH_FIELD).forEach(name => {
+  Object.defineProperty(NativeMesh.prototype, name, {
+    set (v) {
+      const vals = new Float64Array(3);
+      if (typeof v === 'number') vals[0] = v; else for (let i = 0; i < 3; i++) vals[i] = v[i];
+      this._addon.meshSetMaterial(this._handle, MESH_FIELD[name], vals);
+    },
+    configurable: true
+  });
+});
+
 /* ---- images: what the browser keeps in <img>/<canvas>, here {width, height, data: RGBA bytes} -------- */
 function imageFromRGBA (array, width, height) {             // scene.js:22-39 (values clamp + round like Uint8ClampedArray)
   return { width, height, data: new Uint8Array(new Uint8ClampedArray(array).buffer) };
@@ -278,6 +324,7 @@ class Scene {
   updateBoundings (obj) {
     if (obj === undefined) obj = this.queue;
     let box = new Array(6);
+    if (obj.nativeMesh) return obj.bounding;
     if (isGroup(obj)) {
       if (obj.length === 0 && !obj.blockError) {
         console.error('problematic object structure', 'isArray:', Array.isArray(obj), 'indexable:', obj.indexable, 'object:', obj);
@@ -370,6 +417,7 @@ class Scene {
     if (root === undefined) root = this.queue;
     let entries = 0, triangles = 0;
     const measure = item => {
+      if (item.nativeMesh) { entries += item.entries; triangles += item.triangles; return; }
       if (isGroup(item)) {
         if (item.length === 0) return;
         entries++;
@@ -386,6 +434,11 @@ class Scene {
     const idBuffer = new Int32Array(triangles);
     let at = 0, tri = 0;
     const emit = item => {
+      if (item.nativeMesh) {
+        const box = item.flattenInto(geometryBuffer, sceneBuffer, idBuffer, at, tri);
+        at += item.entries; tri += item.triangles;
+        return box;
+      }
       if (isGroup(item)) {
         if (item.length === 0) return [];
         const self = at++;
@@ -474,6 +527,19 @@ class Scene {
     return items;
   }
 
+  /* importObj in native code: the OBJ (and optionally the MTL) text goes to flx_mesh_import_obj, the result is a NativeMesh */
+  async importObjNative (file, mtlFile) {
+    const addon = Scene.loadAddon();
+    const objText = await this.readText(file);
+    const mtlText = mtlFile ? await this.readText(mtlFile) : null;
+    return new NativeMesh(addon, addon.meshImport(objText, mtlText));
+  }
+
+  static loadAddon () {
+    if (!Scene._addon) Scene._addon = require(path.join(__dirname, '..', 'napi', 'flexlight_napi.node'));
+    return Scene._addon;
+  }
+
   /* scene.js:438-487: Ka -> colour*255, Ke -> emissiveness = 4*max and colour = 255*Ke/max, Ns/1000 -> metallicity, Ni -> ior */
   async importMtl (file) {
     const materials = [];
@@ -496,4 +562,4 @@ class Scene {
   }
 }
 
-module.exports = { Scene, Transform, Primitive, Triangle, Plane, Object3D, Cuboid, Bounding };
+module.exports = { Scene, Transform, Primitive, Triangle, Plane, Object3D, Cuboid, Bounding, NativeMesh };

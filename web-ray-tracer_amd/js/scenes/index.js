@@ -61,8 +61,9 @@ async function cornellObj (engine) {
   scene.primaryLightSources[0].intensity = 50000;
   scene.primaryLightSources[0].variation = 0;
   scene.ambientLight = [0.01, 0.01, 0.01];
-  const mtl = await scene.importMtl('objects/cornell.mtl');
-  const obj = await scene.importObj('objects/cornell.obj', mtl);
+  // engine.nativeImport: OBJ/MTL parsing, BVH build and flattening in native code (flx_mesh_*), same arrays
+  const obj = engine.nativeImport ? await scene.importObjNative('objects/cornell.obj', 'objects/cornell.mtl')
+    : await scene.importObj('objects/cornell.obj', await scene.importMtl('objects/cornell.mtl'));
   obj.move(5, 0, -5);
   scene.queue.push(obj);
 }
@@ -83,7 +84,8 @@ async function dragon (engine) {
   const dragonTransform = scene.Transform();
   dragonTransform.move(15, 0, 15);
   dragonTransform.scale(0.5);
-  const obj = await scene.importObj('objects/dragon_lp.obj');
+  const load = file => (engine.nativeImport ? scene.importObjNative(file) : scene.importObj(file));
+  const obj = await load('objects/dragon_lp.obj');
   obj.transform = dragonTransform;
   obj.roughness = 0;
   obj.metallicity = 1;
@@ -94,13 +96,13 @@ async function dragon (engine) {
   const monkeTransform = scene.Transform();
   monkeTransform.move(5, 1, 12);
   monkeTransform.scale(2);
-  const monke = await scene.importObj('objects/monke_smooth.obj');
+  const monke = await load('objects/monke_smooth.obj');
   monke.transform = monkeTransform;
   monke.roughness = 0.1;
   monke.metallicity = 1;
   monke.color = [255, 200, 100];
   scene.queue.push(monke);
-  const sphere = await scene.importObj('objects/sphere.obj');
+  const sphere = await load('objects/sphere.obj');
   sphere.scale(4);
   sphere.move(15, 3, 0);
   sphere.metallicity = 1;

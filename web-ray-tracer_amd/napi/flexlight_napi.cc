@@ -274,6 +274,127 @@ static napi_value DeviceInfo(napi_env env, napi_callback_info info) {
   return res;
 }
 
+/* ---- native scene import (flx_mesh_*): meshImport(objText, mtlText | null) -> handle; the Object3D operations; counts; flatten -- */
+static void mesh_finalize(napi_env, void *data, void *) {
+  flx_mesh **box = static_cast<flx_mesh **>(data);
+  if (*box) flx_mesh_destroy(*box);
+  delete box;
+}
+static flx_mesh *get_mesh(napi_env env, napi_value v) {
+  void *p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p || !*static_cast<flx_mesh **>(p)) { napi_throw_type_error(env, nullptr, "expected a mesh handle"); return nullptr; }
+  return *static_cast<flx_mesh **>(p);
+}
+static bool get_text(napi_env env, napi_value v, std::string &out, bool &present) {
+  napi_valuetype t;
+  napi_typeof(env, v, &t);
+  present = !(t == napi_null || t == napi_undefined);
+  if (!present) return true;
+  size_t len = 0;
+  if (napi_get_value_string_utf8(env, v, nullptr, 0, &len) != napi_ok) { napi_throw_type_error(env, nullptr, "expected a string"); return false; }
+  out.resize(len + 1);
+  napi_get_value_string_utf8(env, v, &out[0], len + 1, &len);
+  out.resize(len);
+  return true;
+}
+static napi_value MeshImport(napi_env env, napi_callback_info info) {
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
+  std::string obj, mtl; bool hasObj = false, hasMtl = false;
+  if (!get_text(env, argv[0], obj, hasObj) || !get_text(env, argv[1], mtl, hasMtl)) return nullptr;
+  if (!hasObj) { napi_throw_type_error(env, nullptr, "meshImport: OBJ text expected"); return nullptr; }
+  flx_mesh *m = nullptr;
+  if (flx_mesh_import_obj(obj.data(), obj.size(), hasMtl ? mtl.data() : nullptr, mtl.size(), &m) != FLX_OK) { napi_throw_error(env, nullptr, "flx_mesh_import_obj failed"); return nullptr; }
+  flx_mesh **box = new flx_mesh *(m);
+  napi_value ext;
+  NAPI_OK(env, napi_create_external(env, box, mesh_finalize, nullptr, &ext));
+  return ext;
+}
+static napi_value MeshCounts(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_mesh *m = get_mesh(env, argv[0]);
+  if (!m) return nullptr;
+  napi_value res, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  napi_create_uint32(env, flx_mesh_entry_count(m), &v); napi_set_named_property(env, res, "entries", v);
+  napi_create_uint32(env, flx_mesh_triangle_count(m), &v); napi_set_named_property(env, res, "triangles", v);
+  return res;
+}
+static napi_value MeshSetTransform(napi_env env, napi_callback_info info) {
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
+  flx_mesh *m = get_mesh(env, argv[0]);
+  if (!m) return nullptr;
+  uint32_t n = 0;
+  NAPI_OK(env, napi_get_value_uint32(env, argv[1], &n));
+  flx_mesh_set_transform(m, n);
+  return nullptr;
+}
+static napi_value MeshMove(napi_env env, napi_callback_info info) {
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  flx_mesh *m = get_mesh(env, argv[0]);
+  if (!m) return nullptr;
+  double d[3];
+  for (int i = 0; i < 3; i++) NAPI_OK(env, napi_get_value_double(env, argv[1 + i], &d[i]));
+  flx_mesh_move(m, d[0], d[1], d[2]);
+  return nullptr;
+}
+static napi_value MeshScale(napi_env env, napi_callback_info info) {
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
+  flx_mesh *m = get_mesh(env, argv[0]);
+  if (!m) return nullptr;
+  double s = 1;
+  NAPI_OK(env, napi_get_value_double(env, argv[1], &s));
+  flx_mesh_scale(m, s);
+  return nullptr;
+}
+/* meshSetMaterial(handle, field, Float64Array values) */
+static napi_value MeshSetMaterial(napi_env env, napi_callback_info info) {
+  napi_value argv[3];
+  if (!get_args(env, info, 3, argv)) return nullptr;
+  flx_mesh *m = get_mesh(env, argv[0]);
+  if (!m) return nullptr;
+  int32_t field = 0;
+  NAPI_OK(env, napi_get_value_int32(env, argv[1], &field));
+  void *vals = nullptr; size_t n = 0;
+  if (!typed(env, argv[2], napi_float64_array, &vals, &n)) return nullptr;
+  if (n < 3) { napi_throw_type_error(env, nullptr, "meshSetMaterial: Float64Array(3) expected"); return nullptr; }
+  if (flx_mesh_set_material(m, field, static_cast<const double *>(vals)) != FLX_OK) { napi_throw_error(env, nullptr, "flx_mesh_set_material: unknown field"); return nullptr; }
+  return nullptr;
+}
+static napi_value MeshBounding(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_mesh *m = get_mesh(env, argv[0]);
+  if (!m) return nullptr;
+  double box[6];
+  flx_mesh_bounding(m, box);
+  napi_value res;
+  NAPI_OK(env, napi_create_array_with_length(env, 6, &res));
+  for (uint32_t i = 0; i < 6; i++) { napi_value v; napi_create_double(env, box[i], &v); napi_set_element(env, res, i, v); }
+  return res;
+}
+/* meshFlatten(handle, Float32Array geometry[12 * entries], Float32Array attributes[28 * entries], Int32Array ids[triangles]) -> [min xyz, max xyz] */
+static napi_value MeshFlatten(napi_env env, napi_callback_info info) {
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  flx_mesh *m = get_mesh(env, argv[0]);
+  if (!m) return nullptr;
+  void *g = nullptr, *a = nullptr, *ids = nullptr; size_t ng = 0, na = 0, ni = 0;
+  if (!typed(env, argv[1], napi_float32_array, &g, &ng) || !typed(env, argv[2], napi_float32_array, &a, &na) || !typed(env, argv[3], napi_int32_array, &ids, &ni)) return nullptr;
+  const size_t e = flx_mesh_entry_count(m), t = flx_mesh_triangle_count(m);
+  if (ng < 12 * e || na < 28 * e || ni < t) { napi_throw_range_error(env, nullptr, "meshFlatten: arrays too small"); return nullptr; }
+  float box[6] = { 0, 0, 0, 0, 0, 0 };
+  if (flx_mesh_flatten(m, static_cast<float *>(g), static_cast<float *>(a), static_cast<int32_t *>(ids), box) != FLX_OK) { napi_throw_error(env, nullptr, "flx_mesh_flatten failed"); return nullptr; }
+  napi_value res;
+  NAPI_OK(env, napi_create_array_with_length(env, 6, &res));
+  for (uint32_t i = 0; i < 6; i++) { napi_value v; napi_create_double(env, box[i], &v); napi_set_element(env, res, i, v); }
+  return res;
+}
+
 static napi_value Version(napi_env env, napi_callback_info) {
   napi_value v;
   napi_create_string_utf8(env, flx_version(), NAPI_AUTO_LENGTH, &v);
@@ -285,6 +406,8 @@ static napi_value Init(napi_env env, napi_value exports) {
     { "createContext", CreateContext }, { "destroyContext", DestroyContext }, { "uploadScene", UploadScene },
     { "uploadTransforms", UploadTransforms }, { "uploadLights", UploadLights }, { "uploadAtlas", UploadAtlas },
     { "tileRowCount", TileRowCount }, { "render", Render }, { "temporalReset", TemporalReset }, { "deviceInfo", DeviceInfo }, { "version", Version },
+    { "meshImport", MeshImport }, { "meshCounts", MeshCounts }, { "meshSetTransform", MeshSetTransform }, { "meshMove", MeshMove },
+    { "meshScale", MeshScale }, { "meshSetMaterial", MeshSetMaterial }, { "meshFlatten", MeshFlatten }, { "meshBounding", MeshBounding },
   };
   for (const auto &f : fns) {
     napi_value fn;
