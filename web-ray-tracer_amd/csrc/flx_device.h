@@ -221,9 +221,12 @@ FLX_DEV bool moellerTrumboreCull(f3 a, f3 b, f3 c, const Ray &ray, float l) {
 }
 
 /* Primary-visibility triangle rule: front faces only, inclusive edges, near plane. */
+FLX_DEV bool moellerTrumborePrimaryE(f3 a, f3 edge1, f3 edge2, const Ray &ray, float l, float viewDepthPerS, f3 &suv);
 FLX_DEV bool moellerTrumborePrimary(f3 a, f3 b, f3 c, const Ray &ray, float l, float viewDepthPerS, f3 &suv) {
-  f3 edge1 = b - a;
-  f3 edge2 = c - a;
+  return moellerTrumborePrimaryE(a, b - a, c - a, ray, l, viewDepthPerS, suv);
+}
+/* the same with the edges b - a, c - a given (the threaded copy stores them) */
+FLX_DEV bool moellerTrumborePrimaryE(f3 a, f3 edge1, f3 edge2, const Ray &ray, float l, float viewDepthPerS, f3 &suv) {
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
   if (!(det < 0.0f)) return false;
@@ -716,6 +719,45 @@ FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCor
   tmin = flx_max(flx_max(flx_min(v0.x, v1.x), flx_min(v0.y, v1.y)), flx_min(v0.z, v1.z));
   tmax = flx_min(flx_min(flx_max(v0.x, v1.x), flx_max(v0.y, v1.y)), flx_max(v0.z, v1.z));
   return tmax >= flx_max(tmin, BIAS) && tmin < l;
+}
+
+/* Primary visibility (rayTracer<true>) over the threaded copy: explicit successors, stored edges, the box test through the
+ * exact reciprocal division.  The entries a ray visits, their order, the arithmetic of every test and the visit count are
+ * those of rayTracer<true>; a pixel's ray changes object space a few times per walk, so that is done in place. */
+FLX_DEV Hit primaryWalkT(const DeviceScene &sc, const Ray &ray, float viewDepthPerS, uint32_t &visits) {
+  Hit hit; hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
+  WalkState w;
+  w.tR = ray; w.minLen = POW32;
+  reciprocalOfDir(sc, ray.dir, ray.origin, w.inv, w.fastDiv);
+  int cachedTI = 0;
+  uint32_t link = sc.walk_root;
+  while (link != WALK_END) {
+    const size_t i = (size_t)linkIndex(link) * 3u;
+    const float4 e0 = sc.walk[i], e1 = sc.walk[i + 1], e2 = sc.walk[i + 2];
+    visits++;
+    const int meta = __float_as_int(e2.z);
+    if ((meta & 3) == 0) break;                           /* terminator (its fetch counts, fragment:208) */
+    const int tI = (meta >> 2) << 1;
+    if (tI != cachedTI) {
+      const int iI = tI + 1;
+      const M3 rotationII = rotation_at(sc, iI);
+      cachedTI = tI;
+      w.tR.origin = mul(rotationII, ray.origin + shift_at(sc, iI));
+      w.tR.dir = mul(rotationII, ray.dir);
+      reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
+    }
+    if ((meta & 3) == 1) {
+      link = (uint32_t)__float_as_int(rayCuboidRecip(w.minLen, w, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y)) ? e2.x : e2.y);
+    } else {
+      f3 suv;
+      if (moellerTrumborePrimaryE(F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y), F3(e1.z, e1.w, e2.x), w.tR, w.minLen, viewDepthPerS, suv)) {
+        hit.suv = suv; hit.transformId = tI; hit.triangleId = __float_as_int(e2.w);
+        w.minLen = suv.x;
+      }
+      link = (uint32_t)__float_as_int(e2.y);
+    }
+  }
+  return hit;
 }
 
 template <bool COUNT>

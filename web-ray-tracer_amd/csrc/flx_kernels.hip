@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
     Ray pr;
     pr.dir = primary_dir(fr, px, py_gl, nx, ny, viewDepthPerS);
     pr.origin = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
-    Hit h = rayTracer<true>(sc, pr, viewDepthPerS, cnt.primary_visits);
+    Hit h = primaryWalkT(sc, pr, viewDepthPerS, cnt.primary_visits);
     if (COUNT && h.triangleId != -1) cnt.primary_hits++;
     hits[(size_t)k * fr.width + px] = make_float4(h.suv.x, h.suv.y, h.suv.z, __int_as_float(h.triangleId));
   }
