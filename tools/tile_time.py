@@ -8,6 +8,8 @@ from flexlight_hip.scene_io import Scene
 sc = Scene.golden("dragon")
 ctx = capi.Context(0)
 ctx.update_scene(sc)
+if os.environ.get("FLX_PIPELINE"):
+    ctx.set_pipeline(int(os.environ["FLX_PIPELINE"]))
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
     p = sc.frame_params(use_filter=0)
     p.tile_rows, p.tile_count, p.tile_index = 8, n, 0

@@ -442,21 +442,31 @@ FLX_DEV void reservoirPick(const DeviceScene &sc, const DeviceFrame &fr, PixelSt
 /* One iteration of lightTrace's bounce loop up to its two traversals (fragment:476-589): surface
  * fetch, material, RNG, Fresnel choice, filter bookkeeping, light pick, next direction.  On return
  * p.ray is the next ray to walk with rayTracer (fragment:591) and `so` describes the shadow ray. */
+/* What a bounce's shading knows about the surface it landed on before any random number is drawn (fragment:476-533): the
+ * same for every sample of a pixel at bounce 0, where all samples share the primary hit — k_wf_shade0 computes it once per
+ * pixel (it holds the three acos / tan of the normal deviation, the attribute fetch and the material). */
+struct SurfaceCtx {
+  f3 origin;                 /* the hit point: the new ray origin */
+  f3 dir;                    /* normalize(hit point - last hit point) */
+  f3 smoothNormal;           /* facing the ray */
+  float signDir, geometryOffset, BRDF, roughnessBRDF;
+  f3 F0;
+  Material material;
+};
+
 template <bool COUNT>
-FLX_DEV void bounceShade(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, PathState &p, f3 camera, float cosSampleN, int i,
-                         ShadeOut &so, WorkCounters &cnt) {
-  float fi = (float)i;
+FLX_DEV void shadeSurface(const DeviceScene &sc, const DeviceFrame &fr, const Hit &hit, const Ray &ray, f3 lastHitPoint, SurfaceCtx &sf,
+                          WorkCounters &cnt) {
   if (COUNT) cnt.shades++;
-  Hit hit = p.hit;
   M3 rTI = rotation_at(sc, hit.transformId);
   f3 sTI = shift_at(sc, hit.transformId);
-  p.ray.origin = p.ray.dir * hit.suv.x + p.ray.origin;
+  sf.origin = ray.dir * hit.suv.x + ray.origin;
   f3 uvw = F3(1.0f - hit.suv.y - hit.suv.z, hit.suv.y, hit.suv.z);
   float4 g0 = sc.geometry[3 * hit.triangleId], g1 = sc.geometry[3 * hit.triangleId + 1], g2 = sc.geometry[3 * hit.triangleId + 2];
   f3 t0v = mul(rTI, F3(g0.x, g0.y, g0.z));
   f3 t1v = mul(rTI, F3(g0.w, g1.x, g1.y));
   f3 t2v = mul(rTI, F3(g1.z, g1.w, g2.x));
-  f3 offsetRayTarget = p.ray.origin - sTI;
+  f3 offsetRayTarget = sf.origin - sTI;
   f3 geometryNormal = normalize(cross(t0v - t1v, t0v - t2v));
   f3 diffs = F3(distance(offsetRayTarget, t0v), distance(offsetRayTarget, t1v), distance(offsetRayTarget, t2v));
   const float4 *at = sc.attributes + 7 * (size_t)hit.triangleId;
@@ -471,28 +481,37 @@ FLX_DEV void bounceShade(const DeviceScene &sc, const DeviceFrame &fr, PixelStat
                  flx_acos(flx_abs(dot(geometryNormal, n2))));
   f3 angleTan = F3(flx_clamp(flx_tan(angles.x), 0.0f, 1.0f), flx_clamp(flx_tan(angles.y), 0.0f, 1.0f),
                    flx_clamp(flx_tan(angles.z), 0.0f, 1.0f));
-  float geometryOffset = dot(diffs * angleTan, uvw);
+  sf.geometryOffset = dot(diffs * angleTan, uvw);
   /* uv0 = a2.yz, uv1 = (a2.w, a3.x), uv2 = a3.yz */
   float bu = (a2.y * uvw.x + a2.w * uvw.y) + a3.y * uvw.z;
   float bv = (a2.z * uvw.x + a3.x * uvw.y) + a3.z * uvw.z;
-  Material material;
-  material.albedo = fetchTexVal<COUNT>(sc, fr, 0, bu, bv, a3.w, F3(a4.z, a4.w, a5.x), cnt);
-  material.rme = fetchTexVal<COUNT>(sc, fr, 1, bu, bv, a4.x, F3(a5.y, a5.z, a5.w), cnt);
-  material.tpo = fetchTexVal<COUNT>(sc, fr, 2, bu, bv, a4.y, F3(a6.x, a6.y, a6.z), cnt);
+  sf.material.albedo = fetchTexVal<COUNT>(sc, fr, 0, bu, bv, a3.w, F3(a4.z, a4.w, a5.x), cnt);
+  sf.material.rme = fetchTexVal<COUNT>(sc, fr, 1, bu, bv, a4.x, F3(a5.y, a5.z, a5.w), cnt);
+  sf.material.tpo = fetchTexVal<COUNT>(sc, fr, 2, bu, bv, a4.y, F3(a6.x, a6.y, a6.z), cnt);
 
-  p.ray.dir = normalize(p.ray.origin - p.lastHitPoint);
-  float signDir = flx_sign(dot(p.ray.dir, smoothNormal));
-  smoothNormal = smoothNormal * (-signDir);
+  sf.dir = normalize(sf.origin - lastHitPoint);
+  sf.signDir = flx_sign(dot(sf.dir, smoothNormal));
+  sf.smoothNormal = smoothNormal * (-sf.signDir);
+  sf.BRDF = flx_mix(1.0f, flx_abs(dot(sf.smoothNormal, sf.dir)), sf.material.rme.y);
+  sf.roughnessBRDF = sf.material.rme.x * sf.BRDF;
+  sf.F0 = sf.material.albedo * sf.BRDF;
+}
 
+/* The rest of the bounce (fragment:535-589): the random vector of this (pixel, sample, bounce), Fresnel choice, filter
+ * bookkeeping, light pick, next direction. */
+FLX_DEV void shadeSample(const DeviceScene &sc, const DeviceFrame &fr, const SurfaceCtx &sf, PixelState &ps, PathState &p, f3 camera, float cosSampleN,
+                         int i, ShadeOut &so) {
+  const float fi = (float)i;
+  const Material &material = sf.material;
+  const f3 smoothNormal = sf.smoothNormal;
+  p.ray.origin = sf.origin;
+  p.ray.dir = sf.dir;
   f4 randomVec = noise(fr.random_seed, ps.ndc_x, ps.ndc_y, fi + cosSampleN);
   f3 randomSpheareVec = normalize(smoothNormal + normalize(F3(randomVec.x, randomVec.y, randomVec.z)));
-  float BRDF = flx_mix(1.0f, flx_abs(dot(smoothNormal, p.ray.dir)), material.rme.y);
-  float roughnessBRDF = material.rme.x * BRDF;
-  f3 roughNormal = normalize(mix(smoothNormal, randomSpheareVec, roughnessBRDF));
+  f3 roughNormal = normalize(mix(smoothNormal, randomSpheareVec, sf.roughnessBRDF));
   f3 H = normalize(roughNormal - p.ray.dir);
   float VdotH = flx_max(dot(-p.ray.dir, H), 0.0f);
-  f3 F0 = material.albedo * BRDF;
-  f3 f = fresnel(F0, VdotH);
+  f3 f = fresnel(sf.F0, VdotH);
   float fresnelReflect = flx_max(f.x, flx_max(f.y, f.z));
   bool isSolid = material.tpo.x * fresnelReflect <= flx_abs(randomVec.w);
 
@@ -519,13 +538,21 @@ FLX_DEV void bounceShade(const DeviceScene &sc, const DeviceFrame &fr, PixelStat
   }
 
   if (i == 1) ps.firstRayLength = flx_min(length(p.ray.origin - p.lastHitPoint) / length(p.lastHitPoint - camera), ps.firstRayLength);
-  reservoirPick(sc, fr, ps, material, p.ray, randomVec, roughNormal * (-signDir), smoothNormal * (-signDir), geometryOffset, p.dontFilter, i, so);
+  reservoirPick(sc, fr, ps, material, p.ray, randomVec, roughNormal * (-sf.signDir), smoothNormal * (-sf.signDir), sf.geometryOffset, p.dontFilter, i, so);
   if (isSolid) {
-    p.ray.dir = normalize(mix(reflect(p.ray.dir, smoothNormal), randomSpheareVec, roughnessBRDF));
+    p.ray.dir = normalize(mix(reflect(p.ray.dir, smoothNormal), randomSpheareVec, sf.roughnessBRDF));
   } else {
-    float eta = flx_mix(1.0f / material.tpo.z, material.tpo.z, flx_max(signDir, 0.0f));
-    p.ray.dir = normalize(mix(refract(p.ray.dir, smoothNormal, eta), randomSpheareVec, roughnessBRDF));
+    float eta = flx_mix(1.0f / material.tpo.z, material.tpo.z, flx_max(sf.signDir, 0.0f));
+    p.ray.dir = normalize(mix(refract(p.ray.dir, smoothNormal, eta), randomSpheareVec, sf.roughnessBRDF));
   }
+}
+
+template <bool COUNT>
+FLX_DEV void bounceShade(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, PathState &p, f3 camera, float cosSampleN, int i,
+                         ShadeOut &so, WorkCounters &cnt) {
+  SurfaceCtx sf;
+  shadeSurface<COUNT>(sc, fr, p.hit, p.ray, p.lastHitPoint, sf, cnt);
+  shadeSample(sc, fr, sf, ps, p, camera, cosSampleN, i, so);
 }
 
 /* State of one skip-list walk, advanced one entry per walkStep(): the loop bodies of rayTracer

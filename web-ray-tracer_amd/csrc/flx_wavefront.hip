@@ -75,61 +75,112 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_ROUND = 4 };   /* 
 #define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
 #endif
 
-template <bool COUNT, bool FIRST>
-__global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items) {
-  const uint32_t n = FIRST ? total_items : wb.counts[b];
+/* Bounce 0: one lane per PIXEL.  All samples of a pixel share the primary hit (fragment:606-613), so everything the shading
+ * knows before it draws a random number — triangle and attribute fetch, normals, the acos / tan of the normal deviation,
+ * material (shadeSurface) — is computed once and the per-sample rest (shadeSample) runs `samples` times.  Every path gets the
+ * record the per-path kernel would have written, bit for bit. */
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
+  const uint32_t S = (uint32_t)fr.samples;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lane = t & 63u;
+  const uint32_t tileLocal = t >> 6;
+  if (tileLocal * S * 64u >= total_items) return;
+  const uint32_t tile = wb.item_base / (S * 64u) + tileLocal;
+  const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
+  WorkCounters cnt = {};
+  uint32_t px, k;
+  tile8_pixel(fr, tile, lane, px, k);
+  const bool inFrame = px < fr.width && k < fr.rows;
+  int tri = -1;
+  float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (inFrame) { h = wb.hits[(size_t)k * fr.width + px]; tri = __float_as_int(h.w); }
+  /* loop guard of fragment:475 before the first bounce (importancy and originalColor are 1) */
+  const bool alive = tri != -1 && fr.max_reflections > 0 && length(F3(1.0f, 1.0f, 1.0f) * F3(1.0f, 1.0f, 1.0f)) >= fr.min_importancy * SQRT3;
+  SurfaceCtx sf;
+  float ndcX = 0.0f, ndcY = 0.0f;
+  Hit hit; hit.suv = F3(h.x, h.y, h.z); hit.triangleId = tri; hit.transformId = 0;
+  if (alive) {
+    hit.transformId = (int)sc.geometry[3 * tri + 2].y << 1;
+    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+    float viewDepthPerS;
+    Ray pr;
+    pr.origin = camera;
+    pr.dir = primary_dir(fr, px, py_gl, ndcX, ndcY, viewDepthPerS);
+    const WorkCounters before = cnt;
+    shadeSurface<COUNT>(sc, fr, hit, pr, camera, sf, cnt);
+    if (COUNT) {                                            /* the per-path kernel counts these once per path */
+      cnt.shades = before.shades + (cnt.shades - before.shades) * S;
+      cnt.atlas_texels = before.atlas_texels + (cnt.atlas_texels - before.atlas_texels) * S;
+    }
+  }
+  for (uint32_t s = 0; s < S; s++) {
+    const uint32_t pathId = ((tile * S + s) << 6) | lane;
+    float4 *rec = wb.rec + (size_t)pathId * 8;
+    if (!alive) {
+      if (tri != -1) finalize_path(fr, wb, pathId, F3(0.0f, 0.0f, 0.0f), F3(1.0f, 1.0f, 1.0f), F3(1.0f, 1.0f, 1.0f));
+      rec[0] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD));
+      continue;
+    }
+    PathState p;
+    PixelState ps;
+    ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
+    ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+    ps.renderOriginalId = ps.renderId;
+    ps.ndc_x = ndcX; ps.ndc_y = ndcY;
+    ps.originalColor = F3(1.0f, 1.0f, 1.0f);
+    p.hit = hit;
+    p.lastHitPoint = camera;
+    p.dontFilter = true;
+    p.importancyFactor = F3(1.0f, 1.0f, 1.0f);
+    const float cosSampleN = flx_cos((float)s);
+    ShadeOut so;
+    shadeSample(sc, fr, sf, ps, p, camera, cosSampleN, 0, so);
+    const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0);
+    rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
+    rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
+    rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
+    rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, __int_as_float(0));
+    rec[4] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
+    rec[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
+    rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
+  }
+  flush_counters<COUNT>(cnt, wb.counters);
+}
+
+/* Later rounds: one lane per live path. */
+template <bool COUNT>
+__global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b) {
+  const uint32_t n = wb.counts[b];
   const uint32_t *__restrict__ listIn = wb.live[b & 1];
   const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
   WorkCounters cnt = {};
   for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
-    const uint32_t pathId = FIRST ? wb.item_base + j : listIn[j];
+    const uint32_t pathId = listIn[j];
     if (pathId == WF_INVALID) continue;
     float4 *rec = wb.rec + (size_t)pathId * 8;
     uint32_t px, k, s;
-    const bool inFrame = item_pixel(fr, pathId, px, k, s);
+    item_pixel(fr, pathId, px, k, s);
     PathState p;
     PixelState ps;
-    int pb = 0;
     ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
     ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
     ps.renderOriginalId = ps.renderId;
-    if (FIRST) {
-      bool alive = false;
-      if (inFrame) {
-        const float4 h = wb.hits[(size_t)k * fr.width + px];
-        const int tri = __float_as_int(h.w);
-        if (tri != -1) {
-          p.hit.suv = F3(h.x, h.y, h.z);
-          p.hit.triangleId = tri;
-          p.hit.transformId = (int)sc.geometry[3 * tri + 2].y << 1;
-          p.ray.origin = camera;
-          p.lastHitPoint = camera;
-          p.dontFilter = true;
-          p.importancyFactor = F3(1.0f, 1.0f, 1.0f);
-          ps.originalColor = F3(1.0f, 1.0f, 1.0f);
-          /* loop guard of fragment:475 before the first bounce */
-          alive = fr.max_reflections > 0 && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3;
-          if (!alive) finalize_path(fr, wb, pathId, F3(0.0f, 0.0f, 0.0f), p.importancyFactor, ps.originalColor);
-        }
-      }
-      if (!alive) { rec[0] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD)); continue; }
-    } else {
-      const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q6 = rec[6], q7 = rec[7];
-      pb = __float_as_int(q3.w) + 1;                      /* the bounce this path is at (its record carries the last one shaded) */
-      p.ray.origin = F3(q0.x, q0.y, q0.z);
-      p.lastHitPoint = p.ray.origin;                    /* fragment:595 */
-      p.ray.dir = F3(q1.x, q1.y, q1.z);
-      p.hit.suv = F3(q2.x, q2.y, q2.z);
-      p.hit.triangleId = __float_as_int(q2.w);
-      p.hit.transformId = (int)sc.geometry[3 * p.hit.triangleId + 2].y << 1;
-      p.dontFilter = (__float_as_int(q0.w) & RF_DONT_FILTER) != 0;
-      p.importancyFactor = F3(q6.x, q6.y, q6.z);
-      ps.originalColor = F3(q7.x, q7.y, q7.z);
-    }
+    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q6 = rec[6], q7 = rec[7];
+    const int pb = __float_as_int(q3.w) + 1;            /* the bounce this path is at (its record carries the last one shaded) */
+    p.ray.origin = F3(q0.x, q0.y, q0.z);
+    p.lastHitPoint = p.ray.origin;                      /* fragment:595 */
+    p.ray.dir = F3(q1.x, q1.y, q1.z);
+    p.hit.suv = F3(q2.x, q2.y, q2.z);
+    p.hit.triangleId = __float_as_int(q2.w);
+    p.hit.transformId = (int)sc.geometry[3 * p.hit.triangleId + 2].y << 1;
+    p.dontFilter = (__float_as_int(q0.w) & RF_DONT_FILTER) != 0;
+    p.importancyFactor = F3(q6.x, q6.y, q6.z);
+    ps.originalColor = F3(q7.x, q7.y, q7.z);
     const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
     float viewDepthPerS;
-    const f3 dir0 = primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
-    if (FIRST) p.ray.dir = dir0;
+    (void)primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
     const float cosSampleN = flx_cos((float)s);
     ShadeOut so;
     bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, pb, so, cnt);
@@ -139,7 +190,6 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
     rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
     rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, __int_as_float(pb));
     rec[4] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
-    if (FIRST) rec[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
     rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
   }
@@ -727,14 +777,15 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   const bool suspend = suspend_max > 0u && pre && lanes && (bounces >= 2 || finisher) && FLX_WF_CONSOLIDATE;
   const int rounds = (suspend && !finisher) ? 2 * bounces : bounces;
   for (int r = 0; r < rounds; r++) {
-    uint32_t shadeBlocks = (r == 0) ? (total + 255u) / 256u : maxBlocks * 2u;
-    if (shadeBlocks > maxBlocks * 4u) shadeBlocks = maxBlocks * 4u;
     if (r == 0) {
-      if (count) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r, total);
-      else hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r, total);
+      const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);        /* 64 per screen tile */
+      const uint32_t shadeBlocks = (pixels + 255u) / 256u;
+      if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
+      else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
     } else {
-      if (count) hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r, total);
-      else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r, total);
+      const uint32_t shadeBlocks = maxBlocks * 2u;
+      if (count) hipLaunchKernelGGL(k_wf_shade<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r);
+      else hipLaunchKernelGGL(k_wf_shade<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r);
     }
     if (r == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
     const uint32_t smax = (suspend && r < bounces) ? suspend_max : 0u;
