@@ -204,6 +204,11 @@ flx_status flx_mesh_bounding(flx_mesh *mesh, double box[6]);
 /* geometry: 12 floats per entry, attributes: 28 floats per entry, ids: one entry index per triangle, minmax: the block's box */
 flx_status flx_mesh_flatten(const flx_mesh *mesh, float *geometry, float *attributes, int32_t *ids, float minmax[6]);
 
+/* the per-frame transform arrays in native code — Transform.buildWGL2Arrays (scene.js:500-521) with the
+ * reference's Moore-Penrose inverse (math.js:56-101).  matrices: 9 doubles per transform, row major, = scale x rotation;
+ * positions: 3 per transform; out: rotation 24 floats and shift 8 floats per transform, ready for flx_transforms_upload. */
+flx_status flx_transforms_pack(uint32_t n_transforms, const double *matrices, const double *positions, float *rotation, float *shift);
+
 /* ---- diagnostics --------------------------------------------------------------------------------- */
 /* Evaluate one of include/flx_math.h's routines on the GPU for n inputs (b may be NULL for unary
  * functions); used by tests to prove CPU/GPU bit equality.  fn: 0 sin 1 cos 2 tan 3 acos 4 atan2

@@ -51,7 +51,8 @@ def test_imported_scene_arrays_equal_reference(scene):
 @pytest.mark.parametrize("scene", ["cornell_obj", "dragon"])
 def test_native_import_arrays_equal_reference(scene):
     """OBJ / MTL parsing, BVH build and flattening in native code (flx_mesh_* through the N-API addon),
-    spliced into the JavaScript scene: the whole scene still hashes to what the reference's own scene.js emits."""
+    spliced into the JavaScript scene, and N3: the transform arrays from flx_transforms_pack — the whole scene still hashes to
+    what the reference's own scene.js emits."""
     check(scene, native=True)
 
 
@@ -88,7 +89,7 @@ def test_napi_addon_loads_and_exports():
     js = "const a = require('%s'); console.log(JSON.stringify({keys: Object.keys(a), version: a.version()}));" % addon
     out = json.loads(subprocess.check_output([NODE, "-e", js]).decode())
     for name in ("createContext", "destroyContext", "uploadScene", "uploadTransforms", "uploadLights", "uploadAtlas", "tileRowCount", "render",
-                 "meshImport", "meshCounts", "meshSetTransform", "meshMove", "meshScale", "meshSetMaterial", "meshBounding", "meshFlatten"):
+                 "meshImport", "meshCounts", "meshSetTransform", "meshMove", "meshScale", "meshSetMaterial", "meshBounding", "meshFlatten", "packTransforms"):
         assert name in out["keys"]
     assert "flexlight-hip" in out["version"]
 

@@ -152,3 +152,38 @@ def test_equals_the_javascript_host_layer_on_a_random_soup(capi, tmp_path):
     assert hashlib.sha256(g.tobytes()).hexdigest() == out["g"]
     assert hashlib.sha256(a.tobytes()).hexdigest() == out["a"]
     assert hashlib.sha256(ids.tobytes()).hexdigest() == out["ids"]
+
+
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_transform_arrays_equal_the_javascript_host_layer(capi):
+    """flx_transforms_pack against Transform.buildWGL2Arrays of js/scene.js (itself pinned to the reference's
+    arrays by the scene goldens) on rotations and non-unit scales (a singular matrix sends the reference's inverse into an
+    endless recursion; the native one returns NaNs)."""
+    js = """
+      const path = require('path');
+      const { Transform } = require(path.join(%r, 'web-ray-tracer_amd', 'js', 'scene.js'));
+      Transform.reset();
+      let seed = 12345;
+      const rnd = () => { seed = (seed * 1103515245 + 12345) %% 2147483648; return seed / 2147483648; };
+      for (let i = 0; i < 40; i++) {
+        const t = new Transform();
+        if (i %% 3 === 0) t.rotateSpherical(rnd() * 6 - 3, rnd() * 3 - 1.5);
+        else { const a = [rnd() - 0.5, rnd() - 0.5, rnd() - 0.5]; const l = Math.hypot(a[0], a[1], a[2]); t.rotateAxis(a.map(v => v / l), rnd() * 6.28); }
+        t.scale([0.5, 2, 1, 1.3, 100, 0.05][i %% 6]);      // (1e-3 already sends the reference-style inverse into its endless recursion)
+        t.move(rnd() * 40 - 20, rnd() * 40 - 20, rnd() * 40 - 20);
+      }
+      const arr = Transform.buildWGL2Arrays();
+      const mats = [], pos = [];
+      for (let t = 0; t < Transform.count; t++) { const tr = Transform.transformList[t]; tr.matrix.forEach(r => r.forEach(v => mats.push(v))); tr.position.forEach(v => pos.push(v)); }
+      console.log(JSON.stringify({ mats, pos, rotation: Array.from(new Uint32Array(arr[0].buffer)), shift: Array.from(new Uint32Array(arr[1].buffer)) }));
+    """ % ROOT
+    out = json.loads(subprocess.check_output([NODE, "-e", js], timeout=60).decode().strip().splitlines()[-1])
+    mats = np.array(out["mats"], np.float64).reshape(-1, 3, 3)
+    pos = np.array(out["pos"], np.float64).reshape(-1, 3)
+    rot, sh = capi.transforms_pack(mats, pos)
+    want_rot = np.array(out["rotation"], np.uint32).reshape(-1, 24)
+    want_sh = np.array(out["shift"], np.uint32).reshape(-1, 8)
+    nan = np.isnan(want_rot.view(np.float32))
+    assert np.array_equal(np.isnan(rot), nan)
+    assert np.array_equal(rot.view(np.uint32)[~nan], want_rot[~nan])
+    assert np.array_equal(sh.view(np.uint32), want_sh)

@@ -43,7 +43,7 @@ function loadImage (rel) {           // decode with PIL: Node 12 has no JPEG dec
   await scenes[name](engine);
   const built = engine.scene.generateArraysFromGraph();
   const buildMs = Date.now() - t0;
-  const transforms = Transform.buildWGL2Arrays();
+  const transforms = engine.nativeImport ? Transform.buildWGL2ArraysNative(Scene.loadAddon()) : Transform.buildWGL2Arrays();
   console.log = log; console.warn = warn;
   const s = sceneFile.assemble(name, engine, built, transforms, scenes[name].frame, { producer: 'web-ray-tracer_amd/js host via tools/host_arrays.js' });
   const out = { name, textureLength: built.textureLength, bufferLength: built.bufferLength, entriesPadded: s.meta.entriesPadded, transforms: s.meta.transforms, buildMs, native: engine.nativeImport, sha256: {} };

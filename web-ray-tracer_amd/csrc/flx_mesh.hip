@@ -339,6 +339,77 @@ void emit(const flx_mesh &m, const Node &n, float *geometry, float *attributes, 
 
 }  // namespace
 
+/* ---- the per-frame transform arrays (Transform.buildWGL2Arrays, scene.js:500-521) in native code -------------
+ * The inverse is the reference's Moore-Penrose inverse through a Gram-Schmidt QR of A^T A with its `stabilize` snapping
+ * (math.js:56-101); every operation in the order the JavaScript does it, so the arrays are the same floats. */
+namespace {
+typedef std::vector<std::vector<double>> Mat;
+std::vector<double> scaleVec(const std::vector<double> &v, double s) { std::vector<double> r(v.size()); for (size_t i = 0; i < v.size(); i++) r[i] = snap(v[i] * s); return r; }
+std::vector<double> addVec(const std::vector<double> &a, const std::vector<double> &b) { std::vector<double> r(a.size()); for (size_t i = 0; i < a.size(); i++) r[i] = a[i] + b[i]; return r; }
+double dotN(const std::vector<double> &a, const std::vector<double> &b) {              /* math.js:41: snapped products, summed from 0, snapped */
+  double p = 0.0;
+  for (size_t i = 0; i < a.size(); i++) p = p + snap(a[i] * b[i]);
+  return snap(p);
+}
+std::vector<double> unitN(const std::vector<double> &a) {                                /* math.js:49-54 */
+  double q = 0.0;
+  for (double c : a) q = q + c * c;
+  const double len = snap(std::sqrt(q));
+  std::vector<double> r(a.size());
+  for (size_t i = 0; i < a.size(); i++) r[i] = (snap(len) < EPS) ? 0.0 : snap(a[i] / len);
+  return r;
+}
+Mat transposeM(const Mat &A) { Mat T(A[0].size(), std::vector<double>(A.size())); for (size_t i = 0; i < A.size(); i++) for (size_t j = 0; j < A[0].size(); j++) T[j][i] = A[i][j]; return T; }
+Mat matMul(const Mat &A, const Mat &B) {                                                /* math.js:15-19 */
+  const Mat BT = transposeM(B);
+  Mat R(A.size(), std::vector<double>(BT.size()));
+  for (size_t i = 0; i < A.size(); i++) for (size_t j = 0; j < BT.size(); j++) R[i][j] = dotN(A[i], BT[j]);
+  return R;
+}
+Mat gramSchmidt(const Mat &A) {                                                         /* math.js:62-71, over the rows */
+  Mat B;
+  for (const auto &row : A) {
+    std::vector<double> proj(A[0].size(), 0.0);
+    for (const auto &c : B) proj = addVec(proj, scaleVec(c, dotN(c, row) / dotN(c, c)));
+    B.push_back(addVec(row, scaleVec(proj, -1.0)));
+  }
+  return B;
+}
+Mat pseudoInverse(const Mat &A, int depth = 0) {                                        /* math.js:78-101 */
+  const Mat AT = transposeM(A);
+  const Mat M = matMul(AT, A);
+  Mat QT = gramSchmidt(transposeM(M));
+  for (auto &r : QT) r = unitN(r);
+  const Mat R = matMul(QT, M);
+  const size_t n = R.size();
+  Mat Rinv(n);
+  for (size_t ii = n; ii-- > 0;) {
+    Rinv[ii].assign(n, 0.0); Rinv[ii][ii] = 1.0;
+    for (size_t j = n; j-- > ii + 1;) Rinv[ii] = addVec(Rinv[ii], scaleVec(Rinv[j], -R[ii][j] / R[j][j]));
+  }
+  for (size_t i = 0; i < n; i++) Rinv[i] = scaleVec(Rinv[i], 1.0 / R[i][i]);
+  if (Rinv[0][0] != Rinv[0][0] && depth == 0) return transposeM(pseudoInverse(AT, 1));
+  return matMul(matMul(Rinv, QT), AT);                /* transpose(Q) = QT */
+}
+}  // namespace
+
+extern "C" flx_status flx_transforms_pack(uint32_t n_transforms, const double *matrices, const double *positions, float *rotation, float *shift) {
+  if (!matrices || !positions || !rotation || !shift) return FLX_ERR_INVALID;
+  for (uint32_t t = 0; t < n_transforms; t++) {
+    Mat m(3, std::vector<double>(3));
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) m[(size_t)r][(size_t)c] = matrices[(size_t)t * 9 + (size_t)r * 3 + (size_t)c];
+    const Mat inv = pseudoInverse(m);
+    float *rot = rotation + (size_t)t * 24, *sh = shift + (size_t)t * 8;
+    std::memset(rot, 0, 24 * sizeof(float)); std::memset(sh, 0, 8 * sizeof(float));
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) {            /* JS rows land in GLSL columns (scene.js:510-517) */
+      rot[4 * r + c] = (float)m[(size_t)r][(size_t)c];
+      rot[12 + 4 * r + c] = (float)inv[(size_t)r][(size_t)c];
+    }
+    for (int k = 0; k < 3; k++) { sh[k] = (float)positions[(size_t)t * 3 + (size_t)k]; sh[4 + k] = (float)snap(positions[(size_t)t * 3 + (size_t)k] * -1.0); }
+  }
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_mesh_import_obj(const char *obj_text, size_t obj_len, const char *mtl_text, size_t mtl_len, flx_mesh **out) {
   if (!obj_text || !out) return FLX_ERR_INVALID;
   std::unique_ptr<flx_mesh> m(new flx_mesh());

@@ -20,7 +20,7 @@ EXPORTS = [
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
     "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
-    "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten",
+    "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack",
 ]
 
 
@@ -73,6 +73,7 @@ def _load():
         "flx_mesh_set_material": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double)]),
         "flx_mesh_bounding": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "flx_mesh_flatten": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+        "flx_transforms_pack": (C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -284,3 +285,14 @@ class Mesh:
         if LIB.flx_mesh_flatten(self._h, g.ctypes.data, a.ctypes.data, ids.ctypes.data, box) != 0:
             raise FlexLightHipError("flx_mesh_flatten failed")
         return g, a, ids, np.array(list(box), np.float32)
+
+
+def transforms_pack(matrices, positions):
+    """[T, 3, 3] scale x rotation matrices, [T, 3] positions (float64) -> rotation [T, 24] f32, shift [T, 8] f32"""
+    m = np.ascontiguousarray(matrices, np.float64).reshape(-1, 9)
+    p = np.ascontiguousarray(positions, np.float64).reshape(-1, 3)
+    rot = np.zeros((m.shape[0], 24), np.float32)
+    sh = np.zeros((m.shape[0], 8), np.float32)
+    if LIB.flx_transforms_pack(m.shape[0], m.ctypes.data, p.ctypes.data, rot.ctypes.data, sh.ctypes.data) != 0:
+        raise FlexLightHipError("flx_transforms_pack failed")
+    return rot, sh

@@ -74,6 +74,21 @@ class Transform {
     return [rotation, shift];
   }
 
+  /* buildWGL2Arrays in native code (flx_transforms_pack through the N-API addon; SURVEY 8f N3): the same arrays */
+  static buildWGL2ArraysNative (addon) {
+    const T = Transform.count;
+    const matrices = new Float64Array(9 * T), positions = new Float64Array(3 * T);
+    for (let t = 0; t < T; t++) {
+      const tr = Transform.transformList[t];
+      const m = tr.matrix;
+      for (let r = 0; r < 3; r++) matrices.set(m[r], t * 9 + r * 3);
+      positions.set(tr.position, t * 3);
+    }
+    const rotation = new Float32Array(24 * T), shift = new Float32Array(8 * T);
+    addon.packTransforms(matrices, positions, rotation, shift);
+    return [rotation, shift];
+  }
+
   /* Forget every transform but the identity at number 0 (a fresh page load in the browser). */
   static reset () {
     Transform.used = [];

@@ -395,6 +395,21 @@ static napi_value MeshFlatten(napi_env env, napi_callback_info info) {
   return res;
 }
 
+/* packTransforms(Float64Array matrices[9 T], Float64Array positions[3 T], Float32Array rotation[24 T], Float32Array shift[8 T]) */
+static napi_value PackTransforms(napi_env env, napi_callback_info info) {
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  void *m = nullptr, *p = nullptr, *r = nullptr, *s = nullptr; size_t nm = 0, np = 0, nr = 0, ns = 0;
+  if (!typed(env, argv[0], napi_float64_array, &m, &nm) || !typed(env, argv[1], napi_float64_array, &p, &np) ||
+      !typed(env, argv[2], napi_float32_array, &r, &nr) || !typed(env, argv[3], napi_float32_array, &s, &ns)) return nullptr;
+  const size_t T = nm / 9;
+  if (nm != 9 * T || np < 3 * T || nr < 24 * T || ns < 8 * T) { napi_throw_range_error(env, nullptr, "packTransforms: array sizes do not agree"); return nullptr; }
+  if (flx_transforms_pack((uint32_t)T, static_cast<const double *>(m), static_cast<const double *>(p), static_cast<float *>(r), static_cast<float *>(s)) != FLX_OK) {
+    napi_throw_error(env, nullptr, "flx_transforms_pack failed"); return nullptr;
+  }
+  return nullptr;
+}
+
 static napi_value Version(napi_env env, napi_callback_info) {
   napi_value v;
   napi_create_string_utf8(env, flx_version(), NAPI_AUTO_LENGTH, &v);
@@ -407,7 +422,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     { "uploadTransforms", UploadTransforms }, { "uploadLights", UploadLights }, { "uploadAtlas", UploadAtlas },
     { "tileRowCount", TileRowCount }, { "render", Render }, { "temporalReset", TemporalReset }, { "deviceInfo", DeviceInfo }, { "version", Version },
     { "meshImport", MeshImport }, { "meshCounts", MeshCounts }, { "meshSetTransform", MeshSetTransform }, { "meshMove", MeshMove },
-    { "meshScale", MeshScale }, { "meshSetMaterial", MeshSetMaterial }, { "meshFlatten", MeshFlatten }, { "meshBounding", MeshBounding },
+    { "meshScale", MeshScale }, { "meshSetMaterial", MeshSetMaterial }, { "meshFlatten", MeshFlatten }, { "meshBounding", MeshBounding }, { "packTransforms", PackTransforms },
   };
   for (const auto &f : fns) {
     napi_value fn;
