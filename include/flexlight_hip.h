@@ -157,6 +157,18 @@ flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_ker
 flx_status flx_render_planes_device(flx_context *ctx, const flx_frame_params *params, void *d_planes);
 flx_status flx_filter_planes_device(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba);
 
+/* Anti-aliasing post passes: config.antialiasing = 'fxaa' | 'taa' of the reference (modules/fxaa.js:7-137,
+ * modules/taa.js:11-59).  Both read the RGBA8 texture the renderer drew into — the frame is stored as the reference stores it,
+ * floor(clamp(x) * 255 + 0.5) — and return the float the shader writes to the canvas, rows top-down like every frame here.
+ * TAA keeps the last nine frames in the context (zero textures before that; reset by a change of size or flx_taa_reset); the
+ * sub-pixel camera jitter of taa.js:120-127 is the caller's (js/pathtracerHIP.js).  *_device take device pointers and run on the
+ * context's stream; the others copy in and out and wait. */
+flx_status flx_fxaa_device(flx_context *ctx, uint32_t width, uint32_t height, const void *d_in_rgba, void *d_out_rgba);
+flx_status flx_taa_device(flx_context *ctx, uint32_t width, uint32_t height, const void *d_in_rgba, void *d_out_rgba);
+flx_status flx_fxaa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba);
+flx_status flx_taa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba);
+flx_status flx_taa_reset(flx_context *ctx);
+
 /* Kernel organisation of the path-trace pass: 0 = automatic (persistent path kernel; the
  * sample-sequential per-pixel kernel when use_filter needs the cross-sample G-buffer state),
  * 1 = per-pixel kernel, 2 = persistent path kernel.  Results are identical; for A/B timing and tests. */

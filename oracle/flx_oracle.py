@@ -70,3 +70,24 @@ def render_sequence(scene, params, n_frames, threads=0):
     if rc != 0:
         raise RuntimeError("flx_oracle_render_sequence failed: %d" % rc)
     return out
+
+
+def fxaa(frame):
+    """the reference's FXAA pass over a [H, W, 4] float32 frame"""
+    a = np.ascontiguousarray(frame, np.float32)
+    out = np.empty_like(a)
+    rc = lib().flx_oracle_fxaa(a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0], out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("flx_oracle_fxaa failed: %d" % rc)
+    return out
+
+
+def taa(frames_newest_first):
+    """the reference's TAA pass over up to nine [H, W, 4] float32 frames, newest first"""
+    fs = [np.ascontiguousarray(f, np.float32) for f in frames_newest_first[:9]]
+    out = np.empty_like(fs[0])
+    ptrs = (C.c_void_p * len(fs))(*[f.ctypes.data for f in fs])
+    rc = lib().flx_oracle_taa(ptrs, len(fs), fs[0].shape[1], fs[0].shape[0], out.ctypes.data_as(C.c_void_p))
+    if rc != 0:
+        raise RuntimeError("flx_oracle_taa failed: %d" % rc)
+    return out

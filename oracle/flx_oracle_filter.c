@@ -415,3 +415,111 @@ int flx_oracle_render_sequence_impl(const flx_scene_view *scene, const flx_frame
 int flx_oracle_render_sequence(const flx_scene_view *scene, const flx_frame_params *params, int n_frames, float *out_all, int threads) {
   return flx_oracle_render_sequence_impl(scene, params, n_frames, out_all, NULL, NULL, threads);
 }
+
+/* ---- anti-aliasing post passes: modules/fxaa.js:7-137, modules/taa.js:11-59 ---------------------------------
+ * Both read the RGBA8 texture the renderer drew into (the frame, stored floor(clamp(x) * 255 + 0.5)) and write the canvas;
+ * the value kept here is the float the shader outputs.  Texels outside the image read as zero. */
+static inline float fxaa_luma(v4 c) { return (c.y * (0.587f / 0.299f) + c.x) * c.w; }                 /* fxaa.js:27-29 */
+static inline v4 mix4(v4 a, v4 b, float t) { return V4(flx_mix(a.x, b.x, t), flx_mix(a.y, b.y, t), flx_mix(a.z, b.z, t), flx_mix(a.w, b.w, t)); }
+
+static void fxaa_texel(Tex t, int px, int py, float *out) {
+#define FETCH(dx, dy) fetch(t, px + (dx), py + (dy))
+#define LUMA(dx, dy) fxaa_luma(FETCH(dx, dy))
+  const v4 original = FETCH(0, 0);
+  float luma[3][3];                                         /* luma[j][i] = tex_luma(i - 1, j - 1): fxaa.js:75-79 */
+  for (int j = 0; j < 3; j++) for (int i = 0; i < 3; i++) luma[j][i] = LUMA(i - 1, j - 1);
+  const float edge_vert = flx_abs((0.25f * luma[0][0]) + (-0.5f * luma[0][1]) + (0.25f * luma[0][2])) +
+                          flx_abs((0.50f * luma[1][0]) + (-1.0f * luma[1][1]) + (0.50f * luma[1][2])) +
+                          flx_abs((0.25f * luma[2][0]) + (-0.5f * luma[2][1]) + (0.25f * luma[2][2]));
+  const float edge_horz = flx_abs((0.25f * luma[0][0]) + (-0.5f * luma[1][0]) + (0.25f * luma[2][0])) +
+                          flx_abs((0.50f * luma[0][1]) + (-1.0f * luma[1][1]) + (0.50f * luma[2][1])) +
+                          flx_abs((0.25f * luma[0][2]) + (-0.5f * luma[1][2]) + (0.25f * luma[2][2]));
+  const int horz_span = edge_horz >= edge_vert;
+  const int sx = horz_span ? 1 : 0, sy = horz_span ? 0 : 1;
+  /* fxaa_contrast / fxaa_is_low_contrast (fxaa.js:37-50) at (0, 0) */
+  {
+    const float c = LUMA(0, 0), n = LUMA(0, -1), w = LUMA(-1, 0), s = LUMA(0, 1), e = LUMA(1, 0);
+    const float lo = flx_min(c, flx_min(flx_min(n, w), flx_min(s, e))), hi = flx_max(c, flx_max(flx_max(n, w), flx_max(s, e)));
+    const float range = hi - lo;
+    if (range < flx_max(1.0f / 32.0f, hi * 1.0f / 2.0f)) { out[0] = original.x; out[1] = original.y; out[2] = original.z; out[3] = original.w; return; }
+  }
+  int nx = -sx, ny = -sy, qx = sx, qy = sy;
+  v4 color = original;
+  float pixel_count = 1.0f;
+  int done_n = 0, done_p = 0;
+  const float luma_mcn = flx_max(flx_max(flx_abs(luma[0][1] - luma[1][1]), flx_abs(luma[1][2] - luma[1][1])),
+                                 flx_max(flx_abs(luma[2][1] - luma[1][1]), flx_abs(luma[1][0] - luma[1][1])));
+  const float gradient = flx_abs(luma_mcn - luma[1][1]);
+  for (int i = 0; i < 6; i++) {
+    int x, y;
+    if (!done_n) { x = nx; y = ny; }
+    else if (!done_p) { x = qx; y = qy; }
+    else break;
+    /* blur_3x3 (fxaa.js:52-58): rows y-1, y, y+1, each x-1, x, x+1, summed left to right, times 1/9 */
+    v4 sum = FETCH(x - 1, y - 1);
+    sum = add4(sum, FETCH(x, y - 1)); sum = add4(sum, FETCH(x + 1, y - 1));
+    sum = add4(sum, FETCH(x - 1, y)); sum = add4(sum, FETCH(x, y)); sum = add4(sum, FETCH(x + 1, y));
+    sum = add4(sum, FETCH(x - 1, y + 1)); sum = add4(sum, FETCH(x, y + 1)); sum = add4(sum, FETCH(x + 1, y + 1));
+    const v4 blur = scale4(sum, 1.0f / 9.0f);
+    const int done = flx_abs(fxaa_luma(blur) - luma_mcn) >= gradient;
+    /* fxaa_sub_pixel_aliasing (fxaa.js:60-70) at (x, y) */
+    const float c = LUMA(x, y), n = LUMA(x, y - 1), w = LUMA(x - 1, y), s = LUMA(x, y + 1), e = LUMA(x + 1, y);
+    const float luma_l = 0.25f * (((n + w) + e) + s);
+    const float range_l = flx_abs(luma_l - c);
+    const float lo = flx_min(c, flx_min(flx_min(n, w), flx_min(s, e))), hi = flx_max(c, flx_max(flx_max(n, w), flx_max(s, e)));
+    const float range = hi - lo;
+    float blend = flx_max(0.0f, (range_l / range) - 0.0f) * 1.0f;
+    blend = flx_min(7.0f / 8.0f, blend);
+    color = add4(color, mix4(FETCH(x, y), blur, blend));
+    pixel_count += 1.0f;
+    if (!done_n) { done_n = done; nx -= sx; ny -= sy; }
+    else { done_p = done; qx += sx; qy += sy; }
+  }
+  out[0] = color.x / pixel_count; out[1] = color.y / pixel_count; out[2] = color.z / pixel_count; out[3] = color.w / pixel_count;
+#undef FETCH
+#undef LUMA
+}
+
+/* in / out: float RGBA frames, rows top-down */
+int flx_oracle_fxaa(const float *in_rgba, uint32_t width, uint32_t height, float *out_rgba) {
+  if (!in_rgba || !out_rgba || width == 0 || height == 0) return FLX_ERR_INVALID;
+  const int W = (int)width, H = (int)height;
+  uint8_t *q = quantise_plane(in_rgba, W, H);
+  if (!q) return FLX_ERR_DEVICE;
+  Tex t = { q, W, H };
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) fxaa_texel(t, x, y, out_rgba + ((size_t)(H - 1 - y) * W + x) * 4);
+  free(q);
+  return FLX_OK;
+}
+
+/* TAA over `n_frames` float frames (rows top-down), newest first — the state of the reference's ring after that many
+ * renderFrame() calls; missing history (n_frames < 9) reads as the zero-initialised textures (taa.js:99-117). */
+int flx_oracle_taa(const float *const *frames_newest_first, int n_frames, uint32_t width, uint32_t height, float *out_rgba) {
+  if (!frames_newest_first || n_frames < 1 || !out_rgba || width == 0 || height == 0) return FLX_ERR_INVALID;
+  const int W = (int)width, H = (int)height;
+  uint8_t *q[9];
+  for (int i = 0; i < 9; i++) q[i] = (i < n_frames && frames_newest_first[i]) ? quantise_plane(frames_newest_first[i], W, H) : NULL;
+  Tex t[9];
+  for (int i = 0; i < 9; i++) { t[i].p = q[i]; t[i].W = W; t[i].H = H; }
+#pragma omp parallel for schedule(static)
+  for (int y = 0; y < H; y++)
+    for (int x = 0; x < W; x++) {
+      v4 lo = V4(1.0f, 1.0f, 1.0f, 1.0f), hi = V4(0.0f, 0.0f, 0.0f, 0.0f);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {       /* length(vec2(i-1, j-1)) <= sqrt 2: nothing is skipped (taa.js:43) */
+        const v4 p = fetch(t[0], x + (i - 1), y + (j - 1));
+        lo = V4(flx_min(lo.x, p.x), flx_min(lo.y, p.y), flx_min(lo.z, p.z), flx_min(lo.w, p.w));
+        hi = V4(flx_max(hi.x, p.x), flx_max(hi.y, p.y), flx_max(hi.z, p.z), flx_max(hi.w, p.w));
+      }
+      v4 o = fetch(t[0], x, y);
+      for (int k = 1; k < 9; k++) {
+        const v4 c = fetch(t[k], x, y);
+        o = add4(o, V4(flx_min(flx_max(c.x, lo.x), hi.x), flx_min(flx_max(c.y, lo.y), hi.y), flx_min(flx_max(c.z, lo.z), hi.z), flx_min(flx_max(c.w, lo.w), hi.w)));
+      }
+      float *dst = out_rgba + ((size_t)(H - 1 - y) * W + x) * 4;
+      dst[0] = o.x / 9.0f; dst[1] = o.y / 9.0f; dst[2] = o.z / 9.0f; dst[3] = o.w / 9.0f;
+    }
+  for (int i = 0; i < 9; i++) free(q[i]);
+  return FLX_OK;
+}

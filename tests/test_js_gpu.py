@@ -39,3 +39,23 @@ def test_cornell_through_node_matches_capi_and_oracle(hip, oracle, scenes, tmp_p
     js_cnt = info["counters"]
     assert js_cnt["shades"] == want_cnt["shades"] and js_cnt["closestVisits"] == want_cnt["closest_visits"]
     assert js_cnt["primaryHits"] == want_cnt["primary_hits"]
+
+
+def test_antialiasing_through_node(hip, oracle, scenes, tmp_path):
+    """config.antialiasing = 'fxaa' in the JavaScript renderer = the FXAA pass over the frame it renders (SURVEY 8f N4);
+    'taa' jitters the camera, so only its plumbing is checked here (the pass itself: tests/test_postfx_gpu.py)."""
+    node = shutil.which("node")
+    w, h, spp, bounces = 96, 64, 2, 3
+    base = [node, os.path.join(ROOT, "tools", "render_scene.js"), "cornell", "--width", str(w), "--height", str(h), "--spp", str(spp),
+            "--bounces", str(bounces), "--filter", "0", "--assets", "/nonexistent"]
+    out = tmp_path / "fxaa.f32"
+    subprocess.check_output(base + ["--out", str(out), "--aa", "fxaa"], timeout=300)
+    got = np.fromfile(out, np.float32).reshape(h, w, 4)
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    plain, _, _ = hip.render(sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0))
+    assert np.array_equal(got.view(np.uint32), oracle.fxaa(plain).view(np.uint32))
+    out = tmp_path / "taa.f32"
+    subprocess.check_output(base + ["--out", str(out), "--aa", "taa", "--frames", "3"], timeout=300)
+    taa = np.fromfile(out, np.float32).reshape(h, w, 4)
+    assert np.isfinite(taa).all() and taa.max() > 0 and not np.array_equal(taa, plain)

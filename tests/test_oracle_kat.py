@@ -197,3 +197,18 @@ def test_empty_and_degenerate_inputs(oracle, scenes):
     bad.samples = 0
     with pytest.raises(RuntimeError):
         oracle.render(sc, bad)
+
+
+def test_fxaa_and_taa_known_answers(oracle):
+    """N4 oracle pins: a flat frame passes through FXAA unchanged (low contrast everywhere away from the zero border); TAA of
+    nine equal frames returns the frame in the interior, and so does TAA of one frame: the eight zero textures are clamped
+    to the 3x3 neighbourhood's [min, max] before they are averaged in."""
+    flat = np.full((16, 20, 4), 0.5, np.float32)
+    q = np.float32(128) / np.float32(255)                   # 0.5 stored as RGBA8 and read back
+    out = oracle.fxaa(flat)
+    assert np.all(out[2:-2, 2:-2] == q)
+    t9 = oracle.taa([flat] * 9)
+    assert np.allclose(t9[1:-1, 1:-1], q, atol=1e-6)
+    t1 = oracle.taa([flat])
+    assert np.allclose(t1[1:-1, 1:-1], q, atol=1e-6)
+    assert np.allclose(t1[0, 0], q / 9, atol=1e-6)            # at the border the neighbourhood's minimum is the zero outside

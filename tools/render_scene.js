@@ -2,7 +2,7 @@
 /*
  * Render one BASELINE scene through the whole JavaScript path — FlexLight facade, scene graph, host
  * flattening, N-API addon, libflexlight_hip.so — and write the float32 radiance to a file.
- *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --assets DIR]
+ *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --aa fxaa|taa --frames N --assets DIR]
  */
 const fs = require('fs');
 const os = require('os');
@@ -38,9 +38,12 @@ function loadImage (rel) {
   engine.config.samplesPerRay = Number(opt('--spp', frame.samplesPerRay));
   engine.config.maxReflections = Number(opt('--bounces', frame.maxReflections));
   engine.config.filter = Number(opt('--filter', frame.filter ? 1 : 0)) === 1;
+  engine.config.antialiasing = opt('--aa', undefined);               // 'fxaa' | 'taa'
   engine.renderer = 'pathtracer';
   await engine.renderer.updateScene();
-  const f = engine.renderer.renderFrame({ counters: true });
+  const frames = Number(opt('--frames', 1));                          // the last of `frames` frames is written (TAA keeps history)
+  let f;
+  for (let k = 0; k < frames; k++) f = engine.renderer.renderFrame({ counters: true });
   fs.writeFileSync(opt('--out', 'frame.f32'), Buffer.from(f.radiance.buffer));
   console.log(JSON.stringify({ width: f.width, height: f.height, rows: f.rows, frameMs: f.frameMs, counters: f.counters }));
   engine.renderer.halt();

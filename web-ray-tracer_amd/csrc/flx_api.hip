@@ -64,6 +64,12 @@ struct flx_context {
   /* pipeline 3 (wavefront) workspace */
   float4 *d_rec = nullptr;
   float4 *d_tail_pool = nullptr;                 /* per walk workgroup: WF_TAIL_POOL_F4 float4 */
+  uint32_t *d_aa[10] = {};                       /* RGBA8 planes of the anti-aliasing passes: [0..8] the TAA ring, [9] FXAA's input */
+  size_t aa_capacity = 0;
+  uint32_t aa_w = 0, aa_h = 0;
+  int taa_head = 0, taa_filled = 0;
+  float4 *d_aa_io[2] = {};                       /* staging for the host-pointer variants */
+  size_t aa_io_capacity = 0;
   float4 *d_strag = nullptr;                     /* per chain 2 x (walk workgroups x WF_STRAG_MAX) suspended walks */
   uint32_t walk_suspend = 0;                     /* walks a walk workgroup may leave to the next round (0 = off) */
   size_t rec_capacity = 0;                       /* float4 units */
@@ -148,6 +154,8 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
   for (auto &ring : ctx->d_ring) for (uint32_t *pl : ring) if (pl) (void)hipFree(pl);
+  for (uint32_t *pl : ctx->d_aa) if (pl) (void)hipFree(pl);
+  for (float4 *b : ctx->d_aa_io) if (b) (void)hipFree(b);
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < 3; i++) { if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
@@ -572,6 +580,77 @@ extern "C" flx_status flx_set_wavefront_groups(flx_context *ctx, int groups) {
   ctx->wf_groups = groups;
   return FLX_OK;
 }
+
+/* ---- anti-aliasing post passes ---- */
+static flx_status aa_prepare(flx_context *ctx, uint32_t w, uint32_t h) {
+  if (w == 0 || h == 0) return fail(ctx, FLX_ERR_INVALID, "anti-aliasing pass: empty frame");
+  const size_t pixels = (size_t)w * h;
+  if (ctx->aa_capacity < pixels) {
+    for (auto &pl : ctx->d_aa) { if (pl) { FLX_HIP(ctx, hipFree(pl)); pl = nullptr; } FLX_HIP(ctx, hipMalloc(&pl, pixels * sizeof(uint32_t))); }
+    ctx->aa_capacity = pixels;
+    ctx->aa_w = 0;
+  }
+  if (ctx->aa_w != w || ctx->aa_h != h) {            /* new size: the ring starts from zero textures, like buildTexture() */
+    ctx->aa_w = w; ctx->aa_h = h; ctx->taa_head = 0; ctx->taa_filled = 0;
+  }
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_fxaa_device(flx_context *ctx, uint32_t width, uint32_t height, const void *d_in_rgba, void *d_out_rgba) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!d_in_rgba || !d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_fxaa_device: NULL pointer");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  flx_status s = aa_prepare(ctx, width, height);
+  if (s) return s;
+  launch_quantize((const float4 *)d_in_rgba, ctx->d_aa[9], (size_t)width * height, ctx->stream);      /* the texture the renderer drew into */
+  launch_fxaa(ctx->d_aa[9], (float4 *)d_out_rgba, (int)width, (int)height, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_taa_device(flx_context *ctx, uint32_t width, uint32_t height, const void *d_in_rgba, void *d_out_rgba) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!d_in_rgba || !d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_taa_device: NULL pointer");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  flx_status s = aa_prepare(ctx, width, height);
+  if (s) return s;
+  /* textures.unshift(textureIn); textureIn = textures.pop() (taa.js:100-102): the oldest plane takes the new frame */
+  ctx->taa_head = (ctx->taa_head + 8) % 9;
+  if (ctx->taa_filled < 9) ctx->taa_filled++;
+  launch_quantize((const float4 *)d_in_rgba, ctx->d_aa[ctx->taa_head], (size_t)width * height, ctx->stream);
+  const uint32_t *planes[9];
+  for (int k = 0; k < 9; k++) planes[k] = k < ctx->taa_filled ? ctx->d_aa[(ctx->taa_head + k) % 9] : nullptr;
+  launch_taa(planes, (float4 *)d_out_rgba, (int)width, (int)height, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_taa_reset(flx_context *ctx) {
+  if (!ctx) return FLX_ERR_INVALID;
+  ctx->taa_head = 0; ctx->taa_filled = 0;
+  return FLX_OK;
+}
+
+/* host-pointer variants: in / out are width * height * 4 floats */
+static flx_status aa_host(flx_context *ctx, int which, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!in_rgba || !out_rgba) return fail(ctx, FLX_ERR_INVALID, "anti-aliasing pass: NULL pointer");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t pixels = (size_t)width * height;
+  if (pixels == 0) return fail(ctx, FLX_ERR_INVALID, "anti-aliasing pass: empty frame");
+  if (ctx->aa_io_capacity < pixels) {
+    for (auto &b : ctx->d_aa_io) { if (b) { FLX_HIP(ctx, hipFree(b)); b = nullptr; } FLX_HIP(ctx, hipMalloc(&b, pixels * sizeof(float4))); }
+    ctx->aa_io_capacity = pixels;
+  }
+  FLX_HIP(ctx, hipMemcpyAsync(ctx->d_aa_io[0], in_rgba, pixels * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  flx_status s = which == 0 ? flx_fxaa_device(ctx, width, height, ctx->d_aa_io[0], ctx->d_aa_io[1]) : flx_taa_device(ctx, width, height, ctx->d_aa_io[0], ctx->d_aa_io[1]);
+  if (s) return s;
+  FLX_HIP(ctx, hipMemcpyAsync(out_rgba, ctx->d_aa_io[1], pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FLX_OK;
+}
+extern "C" flx_status flx_fxaa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba) { return aa_host(ctx, 0, width, height, in_rgba, out_rgba); }
+extern "C" flx_status flx_taa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba) { return aa_host(ctx, 1, width, height, in_rgba, out_rgba); }
 
 extern "C" flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, uint32_t suspend_walks) {
   if (!ctx) return FLX_ERR_INVALID;

@@ -298,6 +298,109 @@ __global__ __launch_bounds__(256) void k_filter_final(Tex tColor, Tex tIp, Tex t
 }
 
 /* Replays modules/pathtracerWGL2.js:462-550 (firstPasses = secondPasses = 3).  planes: R[4], Ip[4], O[2], Id[2], OId. */
+/* ---- anti-aliasing post passes: modules/fxaa.js:7-137, modules/taa.js:11-59 — one thread per texel over the RGBA8
+ * texture the renderer drew into; the float the shader outputs is kept ---- */
+__device__ __forceinline__ float fxaa_luma(f4 c) { return (c.y * (0.587f / 0.299f) + c.x) * c.w; }
+__device__ __forceinline__ f4 mix4(f4 a, f4 b, float t) { return F4(flx_mix(a.x, b.x, t), flx_mix(a.y, b.y, t), flx_mix(a.z, b.z, t), flx_mix(a.w, b.w, t)); }
+
+__global__ __launch_bounds__(256) void k_fxaa(Tex t, int W, int H, float4 *__restrict__ out) {
+  int px, py;
+  if (!texel_of_thread(W, H, px, py)) return;
+#define FETCH(dx, dy) fetch(t, W, H, px + (dx), py + (dy))
+#define LUMA(dx, dy) fxaa_luma(FETCH(dx, dy))
+  float4 *dst = out + (size_t)(H - 1 - py) * W + px;
+  const f4 original = FETCH(0, 0);
+  float luma[3][3];
+#pragma unroll
+  for (int j = 0; j < 3; j++)
+#pragma unroll
+    for (int i = 0; i < 3; i++) luma[j][i] = LUMA(i - 1, j - 1);
+  const float edge_vert = flx_abs((0.25f * luma[0][0]) + (-0.5f * luma[0][1]) + (0.25f * luma[0][2])) +
+                          flx_abs((0.50f * luma[1][0]) + (-1.0f * luma[1][1]) + (0.50f * luma[1][2])) +
+                          flx_abs((0.25f * luma[2][0]) + (-0.5f * luma[2][1]) + (0.25f * luma[2][2]));
+  const float edge_horz = flx_abs((0.25f * luma[0][0]) + (-0.5f * luma[1][0]) + (0.25f * luma[2][0])) +
+                          flx_abs((0.50f * luma[0][1]) + (-1.0f * luma[1][1]) + (0.50f * luma[2][1])) +
+                          flx_abs((0.25f * luma[0][2]) + (-0.5f * luma[1][2]) + (0.25f * luma[2][2]));
+  const bool horz_span = edge_horz >= edge_vert;
+  const int sx = horz_span ? 1 : 0, sy = horz_span ? 0 : 1;
+  {
+    const float c = luma[1][1], n = luma[0][1], w = luma[1][0], s = luma[2][1], e = luma[1][2];
+    const float lo = flx_min(c, flx_min(flx_min(n, w), flx_min(s, e))), hi = flx_max(c, flx_max(flx_max(n, w), flx_max(s, e)));
+    const float range = hi - lo;
+    if (range < flx_max(1.0f / 32.0f, hi * 1.0f / 2.0f)) { *dst = make_float4(original.x, original.y, original.z, original.w); return; }
+  }
+  int nx = -sx, ny = -sy, qx = sx, qy = sy;
+  f4 color = original;
+  float pixel_count = 1.0f;
+  bool done_n = false, done_p = false;
+  const float luma_mcn = flx_max(flx_max(flx_abs(luma[0][1] - luma[1][1]), flx_abs(luma[1][2] - luma[1][1])),
+                                 flx_max(flx_abs(luma[2][1] - luma[1][1]), flx_abs(luma[1][0] - luma[1][1])));
+  const float gradient = flx_abs(luma_mcn - luma[1][1]);
+  for (int i = 0; i < 6; i++) {
+    int x, y;
+    if (!done_n) { x = nx; y = ny; }
+    else if (!done_p) { x = qx; y = qy; }
+    else break;
+    const f4 f00 = FETCH(x - 1, y - 1), f10 = FETCH(x, y - 1), f20 = FETCH(x + 1, y - 1);
+    const f4 f01 = FETCH(x - 1, y), f11 = FETCH(x, y), f21 = FETCH(x + 1, y);
+    const f4 f02 = FETCH(x - 1, y + 1), f12 = FETCH(x, y + 1), f22 = FETCH(x + 1, y + 1);
+    f4 sum = add4(add4(add4(add4(add4(add4(add4(add4(f00, f10), f20), f01), f11), f21), f02), f12), f22);
+    const f4 blur = scale4(sum, 1.0f / 9.0f);
+    const bool done = flx_abs(fxaa_luma(blur) - luma_mcn) >= gradient;
+    const float c = fxaa_luma(f11), n = fxaa_luma(f10), w = fxaa_luma(f01), s = fxaa_luma(f12), e = fxaa_luma(f21);
+    const float luma_l = 0.25f * (((n + w) + e) + s);
+    const float range_l = flx_abs(luma_l - c);
+    const float lo = flx_min(c, flx_min(flx_min(n, w), flx_min(s, e))), hi = flx_max(c, flx_max(flx_max(n, w), flx_max(s, e)));
+    const float range = hi - lo;
+    float blend = flx_max(0.0f, (range_l / range) - 0.0f) * 1.0f;
+    blend = flx_min(7.0f / 8.0f, blend);
+    color = add4(color, mix4(f11, blur, blend));
+    pixel_count += 1.0f;
+    if (!done_n) { done_n = done; nx -= sx; ny -= sy; }
+    else { done_p = done; qx += sx; qy += sy; }
+  }
+  *dst = make_float4(color.x / pixel_count, color.y / pixel_count, color.z / pixel_count, color.w / pixel_count);
+#undef FETCH
+#undef LUMA
+}
+
+struct TaaRing { const uint32_t *p[9]; };          /* newest first; null = not rendered yet (zero texture) */
+__global__ __launch_bounds__(256) void k_taa(TaaRing r, int W, int H, float4 *__restrict__ out) {
+  int x, y;
+  if (!texel_of_thread(W, H, x, y)) return;
+  const Tex t0 = { r.p[0] };
+  f4 lo = F4(1.0f, 1.0f, 1.0f, 1.0f), hi = F4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const f4 p = fetch(t0, W, H, x + (i - 1), y + (j - 1));
+      lo = F4(flx_min(lo.x, p.x), flx_min(lo.y, p.y), flx_min(lo.z, p.z), flx_min(lo.w, p.w));
+      hi = F4(flx_max(hi.x, p.x), flx_max(hi.y, p.y), flx_max(hi.z, p.z), flx_max(hi.w, p.w));
+    }
+  f4 o = fetch(t0, W, H, x, y);
+#pragma unroll
+  for (int k = 1; k < 9; k++) {
+    const Tex tk = { r.p[k] };
+    const f4 c = fetch(tk, W, H, x, y);
+    o = add4(o, F4(flx_min(flx_max(c.x, lo.x), hi.x), flx_min(flx_max(c.y, lo.y), hi.y), flx_min(flx_max(c.z, lo.z), hi.z), flx_min(flx_max(c.w, lo.w), hi.w)));
+  }
+  out[(size_t)(H - 1 - y) * W + x] = make_float4(o.x / 9.0f, o.y / 9.0f, o.z / 9.0f, o.w / 9.0f);
+}
+
+void launch_fxaa(const uint32_t *plane, float4 *out, int W, int H, hipStream_t stream) {
+  const dim3 grid(((W + 15) >> 4) * ((H + 15) >> 4)), block(256);
+  Tex t = { plane };
+  hipLaunchKernelGGL(k_fxaa, grid, block, 0, stream, t, W, H, out);
+}
+
+void launch_taa(const uint32_t *const planes[9], float4 *out, int W, int H, hipStream_t stream) {
+  const dim3 grid(((W + 15) >> 4) * ((H + 15) >> 4)), block(256);
+  TaaRing r;
+  for (int i = 0; i < 9; i++) r.p[i] = planes[i];
+  hipLaunchKernelGGL(k_taa, grid, block, 0, stream, r, W, H, out);
+}
+
 void launch_quantize(const float4 *src, uint32_t *dst, size_t n, hipStream_t stream) {
   hipLaunchKernelGGL(k_quantize, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
 }

@@ -46,6 +46,9 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
 /* denoise chain (flx_filter.hip): 13 RGBA8 planes = the reference's RenderTexture[0..3], IpRenderTexture[0..3],
  * OriginalRenderTexture[0..1], IdRenderTexture[0..1], OriginalIdRenderTexture (pathtracerWGL2.js:224-252). */
 struct FilterPlanes { uint32_t *R[4], *Ip[4], *O[2], *Id[2], *OId; };
+/* anti-aliasing post passes over RGBA8 planes (modules/fxaa.js, modules/taa.js); taa planes newest first, null = zero texture */
+void launch_fxaa(const uint32_t *plane, float4 *out, int W, int H, hipStream_t stream);
+void launch_taa(const uint32_t *const planes[9], float4 *out, int W, int H, hipStream_t stream);
 /* float4 plane -> RGBA8 plane (a render-target store) */
 void launch_quantize(const float4 *src, uint32_t *dst, size_t n, hipStream_t stream);
 /* the chain over planes whose slot 0 (R[0], Ip[0], O[0], Id[0], OId) holds the frame */

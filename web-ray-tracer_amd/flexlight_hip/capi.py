@@ -20,7 +20,7 @@ EXPORTS = [
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
     "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
-    "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack",
+    "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset",
 ]
 
 
@@ -74,6 +74,11 @@ def _load():
         "flx_mesh_bounding": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "flx_mesh_flatten": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
         "flx_transforms_pack": (C.c_int, [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "flx_fxaa_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+        "flx_taa_device": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+        "flx_fxaa": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+        "flx_taa": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+        "flx_taa_reset": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -196,6 +201,23 @@ class Context:
     def filter_planes_device(self, params, planes_ptr, out_ptr):
         """uint32[5][height][width] render targets of the whole frame -> float4[height][width] through the denoise chain"""
         self._check(LIB.flx_filter_planes_device(self._h, C.byref(params), C.c_void_p(planes_ptr), C.c_void_p(out_ptr)), "flx_filter_planes_device")
+
+    def fxaa(self, frame):
+        """[H, W, 4] float32 frame -> the FXAA pass of the reference over it"""
+        a = np.ascontiguousarray(frame, np.float32)
+        out = np.empty_like(a)
+        self._check(LIB.flx_fxaa(self._h, a.shape[1], a.shape[0], a.ctypes.data, out.ctypes.data), "flx_fxaa")
+        return out
+
+    def taa(self, frame):
+        """the TAA pass: the context keeps the last nine frames"""
+        a = np.ascontiguousarray(frame, np.float32)
+        out = np.empty_like(a)
+        self._check(LIB.flx_taa(self._h, a.shape[1], a.shape[0], a.ctypes.data, out.ctypes.data), "flx_taa")
+        return out
+
+    def taa_reset(self):
+        self._check(LIB.flx_taa_reset(self._h), "flx_taa_reset")
 
     def set_walk_scheduler(self, scheduler, suspend_walks=0):
         """0 one walk per lane (default), 1 LDS test queues, 2 lanes + cooperative finisher; identical results"""

@@ -86,12 +86,13 @@ class PathTracerHIP {
     });
   }
 
-  frameParams () {                                        // pathtracerWGL2.js:307-347
+  frameParams (jitter) {                                  // pathtracerWGL2.js:307-347
     const w = this._canvas.width, h = this._canvas.height;
+    const cam = jitter ? Object.assign(Object.create(this.camera), { fx: this.camera.fx + jitter.x, fy: this.camera.fy + jitter.y }) : this.camera;
     const p = {
       width: w, height: h,
       camera: [this.camera.x, this.camera.y, this.camera.z],
-      viewMatrix: Array.from(sceneFile.buildViewMatrix(this.camera, w, h)),
+      viewMatrix: Array.from(sceneFile.buildViewMatrix(cam, w, h)),                 // view rotation and TAA jitter (pathtracerWGL2.js:310-318)
       samples: this.config.samplesPerRay,
       maxReflections: this.config.maxReflections,
       minImportancy: this.config.minImportancy,
@@ -107,6 +108,26 @@ class PathTracerHIP {
     return p;
   }
 
+  /* config.antialiasing (pathtracerWGL2.js:268-286): 'fxaa' | 'taa' | anything else = none.  TAA turns the camera by a sub-pixel
+   * offset every frame (taa.js:120-127); the nine offsets sum to zero and are drawn once per renderer (taa.js:130-149) from
+   * this.random, Math.random unless the application supplies its own. */
+  _antialiasing () {
+    const v = typeof this.config.antialiasing === 'string' ? this.config.antialiasing.toLowerCase() : undefined;
+    const mode = (v === 'fxaa' || v === 'taa') ? v : undefined;
+    if (mode !== this._aaMode) {
+      this._aaMode = mode;
+      this._taaNum = 0;
+      if (mode === 'taa') { this._taaVecs = taaVectors(9, this.random || Math.random); if (this._ctx) native().taaReset(this._ctx); }
+    }
+    return mode;
+  }
+
+  _jitter () {                                            // taa.js:120-127
+    this._taaNum = (this._taaNum + 1) % 9;
+    const scale = 0.3 / Math.min(this._canvas.width, this._canvas.height);
+    return { x: this._taaVecs[this._taaNum][0] * scale, y: this._taaVecs[this._taaNum][1] * scale };
+  }
+
   /* One frame, synchronously.  Returns {width, height, rows, radiance: Float32Array(rows*width*4), frameMs, traceMs, counters?}. */
   renderFrame (options) {
     const ctx = this._context();
@@ -119,10 +140,18 @@ class PathTracerHIP {
     native().uploadLights(ctx, sceneFile.buildLightArray(this.scene));
     const tr = Transform.buildWGL2Arrays();
     native().uploadTransforms(ctx, tr[0], tr[1]);
-    const p = this.frameParams();
+    const aa = this._antialiasing();
+    const jitter = aa === 'taa' ? this._jitter() : { x: 0, y: 0 };
+    const p = this.frameParams(jitter);
     const rows = native().tileRowCount(p);
-    const radiance = new Float32Array(rows * p.width * 4);
+    let radiance = new Float32Array(rows * p.width * 4);
     const info = native().render(ctx, p, radiance, !!(options && options.counters));
+    if (aa && rows === p.height) {                        // the pass reads neighbouring texels: whole frames only (pathtracerWGL2.js:552-553)
+      const out = new Float32Array(radiance.length);
+      if (aa === 'fxaa') native().fxaa(ctx, p.width, p.height, radiance, out);
+      else native().taa(ctx, p.width, p.height, radiance, out);
+      radiance = out;
+    }
     this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);     // pathtracerWGL2.js:291
     this.lastFrame = Object.assign({ width: p.width, height: p.height, rows, radiance }, info);
     return this.lastFrame;
@@ -156,4 +185,21 @@ class PathTracerHIP {
   }
 }
 
-module.exports = { PathTracerHIP };
+/* taa.js:130-149: n two-dimensional offsets that add up to zero */
+function taaVectors (n, random) {
+  const vecs = new Array(n).fill(0).map(() => new Array(2));
+  vecs[0] = [0, 1];
+  vecs[1] = [1, 0];
+  const combined = [1, 1];
+  for (let i = 2; i < n; i++) {
+    for (let j = 0; j < 2; j++) {
+      const lo = Math.max(-Math.min(i + 1, n - 1 - i), combined[j] - 1);
+      const hi = Math.min(Math.min(i + 1, n - 1 - i), combined[j] + 1);
+      vecs[i][j] = 0.5 * ((hi + lo) + (hi - lo) * Math.sign(random() - 0.5) * Math.pow(random() * 0.5, 1 / 2)) - combined[j];
+      combined[j] += vecs[i][j];
+    }
+  }
+  return vecs;
+}
+
+module.exports = { PathTracerHIP, taaVectors };

@@ -395,6 +395,34 @@ static napi_value MeshFlatten(napi_env env, napi_callback_info info) {
   return res;
 }
 
+/* fxaa / taa (handle, width, height, Float32Array in, Float32Array out); taaReset(handle) */
+static napi_value post_pass(napi_env env, napi_callback_info info, int which) {
+  napi_value argv[5];
+  if (!get_args(env, info, 5, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  uint32_t w = 0, h = 0;
+  NAPI_OK(env, napi_get_value_uint32(env, argv[1], &w));
+  NAPI_OK(env, napi_get_value_uint32(env, argv[2], &h));
+  void *in = nullptr, *out = nullptr; size_t ni = 0, no = 0;
+  if (!typed(env, argv[3], napi_float32_array, &in, &ni) || !typed(env, argv[4], napi_float32_array, &out, &no)) return nullptr;
+  if (ni < (size_t)w * h * 4 || no < (size_t)w * h * 4) { napi_throw_range_error(env, nullptr, "anti-aliasing pass: arrays smaller than width * height * 4"); return nullptr; }
+  flx_status rc = which == 0 ? flx_fxaa(ctx, w, h, static_cast<const float *>(in), static_cast<float *>(out))
+                             : flx_taa(ctx, w, h, static_cast<const float *>(in), static_cast<float *>(out));
+  if (rc != FLX_OK) return fail(env, ctx, which == 0 ? "flx_fxaa" : "flx_taa", rc);
+  return nullptr;
+}
+static napi_value Fxaa(napi_env env, napi_callback_info info) { return post_pass(env, info, 0); }
+static napi_value Taa(napi_env env, napi_callback_info info) { return post_pass(env, info, 1); }
+static napi_value TaaReset(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  flx_taa_reset(ctx);
+  return nullptr;
+}
+
 /* packTransforms(Float64Array matrices[9 T], Float64Array positions[3 T], Float32Array rotation[24 T], Float32Array shift[8 T]) */
 static napi_value PackTransforms(napi_env env, napi_callback_info info) {
   napi_value argv[4];
@@ -423,6 +451,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     { "tileRowCount", TileRowCount }, { "render", Render }, { "temporalReset", TemporalReset }, { "deviceInfo", DeviceInfo }, { "version", Version },
     { "meshImport", MeshImport }, { "meshCounts", MeshCounts }, { "meshSetTransform", MeshSetTransform }, { "meshMove", MeshMove },
     { "meshScale", MeshScale }, { "meshSetMaterial", MeshSetMaterial }, { "meshFlatten", MeshFlatten }, { "meshBounding", MeshBounding }, { "packTransforms", PackTransforms },
+    { "fxaa", Fxaa }, { "taa", Taa }, { "taaReset", TaaReset },
   };
   for (const auto &f : fns) {
     napi_value fn;
