@@ -29,6 +29,23 @@ __device__ __forceinline__ f4 fetch(Tex t, int W, int H, int x, int y_gl) {
   const uint32_t q = t.p[(size_t)(H - 1 - y_gl) * W + x];
   return F4((float)(q & 255u) / 255.0f, (float)((q >> 8) & 255u) / 255.0f, (float)((q >> 16) & 255u) / 255.0f, (float)(q >> 24) / 255.0f);
 }
+/* The texel as stored.  Two texels are equal as vec4s exactly when their bytes are (k / 255 is injective), a channel is zero
+ * exactly when its byte is, k / 255 > 0.1 (or >= 0.1) exactly when k >= 26, and int(k / 255 * 255.0) == k for every byte
+ * (build/unorm_check.c walks all 256): the filters decide on the bytes and turn into floats only what they accumulate. */
+__device__ __forceinline__ uint32_t fetchRaw(Tex t, int W, int H, int x, int y_gl) {
+  if (!t.p || x < 0 || y_gl < 0 || x >= W || y_gl >= H) return 0u;
+  return t.p[(size_t)(H - 1 - y_gl) * W + x];
+}
+/* k / 255 correctly rounded without the division: RN(k * RN(1/255)) and one residual correction (exact for all 256 bytes) */
+__device__ __forceinline__ float unorm8(uint32_t k) {
+  const float r = 1.0f / 255.0f, kf = (float)k;
+  const float q = kf * r;
+  return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, kf), r, q);
+}
+__device__ __forceinline__ f4 unpack(uint32_t q) { return F4(unorm8(q & 255u), unorm8((q >> 8) & 255u), unorm8((q >> 16) & 255u), unorm8(q >> 24)); }
+__device__ __forceinline__ bool rawEq3(uint32_t a, uint32_t b) { return ((a ^ b) & 0x00ffffffu) == 0u; }
+__device__ __forceinline__ uint32_t rawW(uint32_t q) { return q >> 24; }
+
 __device__ __forceinline__ uint32_t quant(float x) {
   if (!(x > 0.0f)) return 0u;
   if (x >= 1.0f) return 255u;
@@ -134,60 +151,57 @@ __global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex t
                                                       uint32_t *dId, int W, int H) {
   int x, y;
   if (!texel_of_thread(W, H, x, y)) return;
-  const f4 centerColor = fetch(tColor, W, H, x, y);
-  const f4 centerColorIp = fetch(tIp, W, H, x, y);
-  const f4 centerOColor = fetch(tOColor, W, H, x, y);
-  const f4 centerId = fetch(tId, W, H, x, y);
-  const int centerIdw = (int)(centerId.w * 255.0f);
+  const f4 centerColor = unpack(fetchRaw(tColor, W, H, x, y));
+  const uint32_t rCenterIp = fetchRaw(tIp, W, H, x, y), rCenterOColor = fetchRaw(tOColor, W, H, x, y);
+  const uint32_t rCenterId = fetchRaw(tId, W, H, x, y), rCenterOId = fetchRaw(tOId, W, H, x, y);
+  const int centerIdw = (int)rawW(rCenterId);               /* int(centerId.w * 255.0) */
   const int centerLightNum = centerIdw / 2;
   const int centerShadow = centerIdw % 2;
-  f4 renderId = centerId;
+  uint32_t rRenderId = rCenterId;
   f4 renderColorIp = F4(0.0f, 0.0f, 0.0f, 0.0f);
-  const f4 centerOId = fetch(tOId, W, H, x, y);
   f4 color = F4(0.0f, 0.0f, 0.0f, 0.0f);
   float count = 0.0f;
-  if (centerOId.w != 0.0f && centerColorIp.w != 0.0f) {
-    f4 ids[4], oIds[4];
-    float ipws[4];
+  if (rawW(rCenterOId) != 0u && rawW(rCenterIp) != 0u) {
+    uint32_t ids[4], oIds[4], ipws[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      ids[i] = fetch(tId, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]);
-      oIds[i] = fetch(tOId, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]);
-      ipws[i] = fetch(tIp, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]).w;
+      ids[i] = fetchRaw(tId, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]);
+      oIds[i] = fetchRaw(tOId, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]);
+      ipws[i] = rawW(fetchRaw(tIp, W, H, x + STENCIL1[i][0], y + STENCIL1[i][1]));
     }
     int vote[4] = { 0, 0, 0, 0 };
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      if (ipws[i] == 0.0f) {
+      if (ipws[i] == 0u) {
         vote[i] = 1;
-        if (eq3(ids[i], centerId) && eq4(oIds[i], centerOId)) vote[i]++;
+        if (rawEq3(ids[i], rCenterId) && oIds[i] == rCenterOId) vote[i]++;
 #pragma unroll
-        for (int j = i + 1; j < 4; j++) if (eq3(ids[i], ids[j]) && eq4(oIds[i], oIds[j])) vote[i]++;
+        for (int j = i + 1; j < 4; j++) if (rawEq3(ids[i], ids[j]) && oIds[i] == oIds[j]) vote[i]++;
       }
     }
     int maxVote = vote[0];
     int idNumber = 0;
 #pragma unroll
     for (int i = 1; i < 4; i++) if (vote[i] >= maxVote) { maxVote = vote[i]; idNumber = i; }
-    renderId = idNumber == 0 ? ids[0] : idNumber == 1 ? ids[1] : idNumber == 2 ? ids[2] : ids[3];
+    rRenderId = idNumber == 0 ? ids[0] : idNumber == 1 ? ids[1] : idNumber == 2 ? ids[2] : ids[3];
     renderColorIp.w = flx_max(1.0f - flx_sign((float)maxVote), 0.0f);
   }
-  if (centerOColor.w == 0.0f) {
+  if (rawW(rCenterOColor) == 0u) {
     color = centerColor;
     count = 1.0f;
   } else {
-    const float k = 1.0f + centerOColor.w;
+    const float k = 1.0f + unorm8(rawW(rCenterOColor));
     for (int i = 0; i < 37; i++) {
       const int cx = x + (int)(STENCIL3_37[i][0] * k * k * 3.5f);
       const int cy = y + (int)(STENCIL3_37[i][1] * k * k * 3.5f);
-      const f4 id = fetch(tId, W, H, cx, cy);
-      const f4 originalId = fetch(tOId, W, H, cx, cy);
-      const int idW = (int)(id.w * 255.0f);
+      const uint32_t id = fetchRaw(tId, W, H, cx, cy);
+      const uint32_t originalId = fetchRaw(tOId, W, H, cx, cy);
+      const int idW = (int)rawW(id);
       const int lightNum = idW / 2;
       const int shadow = idW % 2;
-      const f4 nextColor = fetch(tColor, W, H, cx, cy);
-      const f4 nextColorIp = fetch(tIp, W, H, cx, cy);
-      if (eq3(centerId, id) && eq4(centerOId, originalId) && (centerLightNum != lightNum || centerShadow == shadow)) {
+      if (rawEq3(rCenterId, id) && rCenterOId == originalId && (centerLightNum != lightNum || centerShadow == shadow)) {
+        const f4 nextColor = unpack(fetchRaw(tColor, W, H, cx, cy));
+        const f4 nextColorIp = unpack(fetchRaw(tIp, W, H, cx, cy));
         color = add4(color, add4(nextColor, scale4(nextColorIp, 256.0f)));
         count += 1.0f;
       }
@@ -199,43 +213,43 @@ __global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex t
   const size_t o = (size_t)(H - 1 - y) * W + x;
   dColor[o] = pack(F4(sg * flx_mod(cx_, 1.0f), sg * flx_mod(cy_, 1.0f), sg * flx_mod(cz_, 1.0f), sg * centerColor.w));
   dIp[o] = pack(F4(sg * (flx_floor(cx_) * INV_256), sg * (flx_floor(cy_) * INV_256), sg * (flx_floor(cz_) * INV_256), sg * renderColorIp.w));
-  if (dId) dId[o] = pack(renderId);
+  if (dId) dId[o] = rRenderId;                               /* a texel copied as it is stored */
 }
 
-/* pathtracer_second_filter.glsl:17-79 */
 __global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, uint32_t *dColor, uint32_t *dIp,
                                                        uint32_t *dOrig, int W, int H) {
   int x, y;
   if (!texel_of_thread(W, H, x, y)) return;
-  const f4 centerColor = fetch(tColor, W, H, x, y);
-  const f4 centerColorIp = fetch(tIp, W, H, x, y);
-  const f4 centerOColor = fetch(tOColor, W, H, x, y);
-  const f4 centerId = fetch(tId, W, H, x, y);
-  const f4 centerOId = fetch(tOId, W, H, x, y);
+  const f4 centerColor = unpack(fetchRaw(tColor, W, H, x, y));
+  const f4 centerColorIp = unpack(fetchRaw(tIp, W, H, x, y));
+  const f4 centerOColor = unpack(fetchRaw(tOColor, W, H, x, y));
+  const uint32_t rCenterId = fetchRaw(tId, W, H, x, y), rCenterOId = fetchRaw(tOId, W, H, x, y);
+  const uint32_t centerIpW = rawW(fetchRaw(tIp, W, H, x, y));
   f4 color = add4(centerColor, scale4(F4(centerColorIp.x, centerColorIp.y, centerColorIp.z, 0.0f), 256.0f));
   f4 oColor = centerOColor;
   float ipw = centerColorIp.w;
   float count = 1.0f, oCount = 1.0f;
-  const float scale = 1.0f + 2.0f * flx_tanh(centerOColor.w + centerOId.w * 4.0f);
+  const float scale = 1.0f + 2.0f * flx_tanh(centerOColor.w + unorm8(rawW(rCenterOId)) * 4.0f);
   for (int i = 0; i < 36; i++) {
     const int cx = x + (int)(STENCIL3_36[i][0] * scale);
     const int cy = y + (int)(STENCIL3_36[i][1] * scale);
-    const f4 id = fetch(tId, W, H, cx, cy);
-    const f4 nextOId = fetch(tOId, W, H, cx, cy);
-    const f4 nextColor = fetch(tColor, W, H, cx, cy);
-    const f4 nextColorIp = fetch(tIp, W, H, cx, cy);
-    const f4 nextOColor = fetch(tOColor, W, H, cx, cy);
-    if (eq3(centerOId, nextOId)) {
-      if (flx_min(centerOId.w, nextOId.w) > 0.1f && (eq4(id, centerId) || flx_max(nextColorIp.w, centerColorIp.w) >= 0.1f)) {
-        color = add4(color, add4(nextColor, scale4(F4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
-        count += 1.0f;
-        ipw += nextColorIp.w;
-        oColor = add4(oColor, nextOColor);
-        oCount += 1.0f;
-      } else if (eq3(id, centerId)) {
-        color = add4(color, add4(nextColor, scale4(F4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
-        count += 1.0f;
-      }
+    const uint32_t nextOId = fetchRaw(tOId, W, H, cx, cy);
+    if (!rawEq3(rCenterOId, nextOId)) continue;
+    const uint32_t id = fetchRaw(tId, W, H, cx, cy);
+    const uint32_t rNextIp = fetchRaw(tIp, W, H, cx, cy);
+    const uint32_t minOIdW = rawW(rCenterOId) < rawW(nextOId) ? rawW(rCenterOId) : rawW(nextOId);
+    const uint32_t maxIpW = rawW(rNextIp) > centerIpW ? rawW(rNextIp) : centerIpW;
+    if (minOIdW >= 26u && (id == rCenterId || maxIpW >= 26u)) {                 /* min(...) > 0.1 && (ids equal || max(...) >= 0.1) */
+      const f4 nextColor = unpack(fetchRaw(tColor, W, H, cx, cy)), nextColorIp = unpack(rNextIp), nextOColor = unpack(fetchRaw(tOColor, W, H, cx, cy));
+      color = add4(color, add4(nextColor, scale4(F4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
+      count += 1.0f;
+      ipw += nextColorIp.w;
+      oColor = add4(oColor, nextOColor);
+      oCount += 1.0f;
+    } else if (rawEq3(id, rCenterId)) {
+      const f4 nextColor = unpack(fetchRaw(tColor, W, H, cx, cy)), nextColorIp = unpack(rNextIp);
+      color = add4(color, add4(nextColor, scale4(F4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
+      count += 1.0f;
     }
   }
   const float invCount = 1.0f / count;
@@ -247,38 +261,36 @@ __global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex 
   if (dOrig) dOrig[o] = pack(F4((w * oColor.x) / oCount, (w * oColor.y) / oCount, (w * oColor.z) / oCount, (w * oColor.w) / oCount));
 }
 
-/* pathtracer_final_filter.glsl:13-71; writes the canvas colour as float4 (before its RGBA8 store) */
 __global__ __launch_bounds__(256) void k_filter_final(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, float4 *out, int W, int H, int hdr) {
   int x, y;
   if (!texel_of_thread(W, H, x, y)) return;
-  const f4 centerColor = fetch(tColor, W, H, x, y);
-  const f4 centerColorIp = fetch(tIp, W, H, x, y);
-  const f4 centerOColor = fetch(tOColor, W, H, x, y);
-  const f4 centerId = fetch(tId, W, H, x, y);
-  const f4 centerOId = fetch(tOId, W, H, x, y);
+  const uint32_t rCenterColor = fetchRaw(tColor, W, H, x, y);
+  const uint32_t centerIpW = rawW(fetchRaw(tIp, W, H, x, y));
+  const f4 centerOColor = unpack(fetchRaw(tOColor, W, H, x, y));
+  const uint32_t rCenterId = fetchRaw(tId, W, H, x, y), rCenterOId = fetchRaw(tOId, W, H, x, y);
   f4 color = F4(0.0f, 0.0f, 0.0f, 0.0f), oColor = color;
   float count = 0.0f, oCount = 0.0f;
-  const float scale = 0.7f + 2.0f * flx_tanh(centerOColor.w + centerOId.w * 4.0f);
+  const float scale = 0.7f + 2.0f * flx_tanh(centerOColor.w + unorm8(rawW(rCenterOId)) * 4.0f);
   for (int i = 0; i < 37; i++) {
     const int cx = x + (int)(STENCIL3_37[i][0] * scale);
     const int cy = y + (int)(STENCIL3_37[i][1] * scale);
-    const f4 id = fetch(tId, W, H, cx, cy);
-    const f4 nextOId = fetch(tOId, W, H, cx, cy);
-    const f4 nextColor = fetch(tColor, W, H, cx, cy);
-    const f4 nextColorIp = fetch(tIp, W, H, cx, cy);
-    const f4 nextOColor = fetch(tOColor, W, H, cx, cy);
-    const bool blurTranslucent = flx_max(nextColorIp.w, centerColorIp.w) != 0.0f && flx_min(centerOId.w, nextOId.w) > 0.0f;
-    if (blurTranslucent && eq3(centerOId, nextOId)) {
-      oColor = add4(oColor, nextOColor);
+    const uint32_t nextOId = fetchRaw(tOId, W, H, cx, cy);
+    if (!rawEq3(rCenterOId, nextOId)) continue;               /* both accumulations need the original ids to agree */
+    const uint32_t rNextIp = fetchRaw(tIp, W, H, cx, cy);
+    const uint32_t maxIpW = rawW(rNextIp) > centerIpW ? rawW(rNextIp) : centerIpW;
+    const uint32_t minOIdW = rawW(rCenterOId) < rawW(nextOId) ? rawW(rCenterOId) : rawW(nextOId);
+    const bool blurTranslucent = maxIpW != 0u && minOIdW > 0u;
+    if (blurTranslucent) {
+      oColor = add4(oColor, unpack(fetchRaw(tOColor, W, H, cx, cy)));
       oCount += 1.0f;
     }
-    if ((blurTranslucent || eq3(centerId, id)) && eq3(centerOId, nextOId)) {
-      color = add4(color, add4(nextColor, scale4(nextColorIp, 255.0f)));
+    if (blurTranslucent || rawEq3(rCenterId, fetchRaw(tId, W, H, cx, cy))) {
+      color = add4(color, add4(unpack(fetchRaw(tColor, W, H, cx, cy)), scale4(unpack(rNextIp), 255.0f)));
       count += 1.0f;
     }
   }
   float4 res = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  if (centerColor.w > 0.0f) {
+  if (rawW(rCenterColor) > 0u) {
     float f[3] = { color.x / count, color.y / count, color.z / count };
     float m[3];
     if (oCount == 0.0f) { m[0] = centerOColor.x; m[1] = centerOColor.y; m[2] = centerOColor.z; }
@@ -297,7 +309,6 @@ __global__ __launch_bounds__(256) void k_filter_final(Tex tColor, Tex tIp, Tex t
   out[(size_t)(H - 1 - y) * W + x] = res;
 }
 
-/* Replays modules/pathtracerWGL2.js:462-550 (firstPasses = secondPasses = 3).  planes: R[4], Ip[4], O[2], Id[2], OId. */
 /* ---- anti-aliasing post passes: modules/fxaa.js:7-137, modules/taa.js:11-59 — one thread per texel over the RGBA8
  * texture the renderer drew into; the float the shader outputs is kept ---- */
 __device__ __forceinline__ float fxaa_luma(f4 c) { return (c.y * (0.587f / 0.299f) + c.x) * c.w; }
