@@ -24,11 +24,6 @@ __device__ __forceinline__ f4 scale4(f4 a, float s) { return F4(a.x * s, a.y * s
 __device__ __forceinline__ bool eq3(f4 a, f4 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 __device__ __forceinline__ bool eq4(f4 a, f4 b) { return a.x == b.x && a.y == b.y && a.z == b.z && a.w == b.w; }
 
-__device__ __forceinline__ f4 fetch(Tex t, int W, int H, int x, int y_gl) {
-  if (!t.p || x < 0 || y_gl < 0 || x >= W || y_gl >= H) return F4(0.0f, 0.0f, 0.0f, 0.0f);
-  const uint32_t q = t.p[(size_t)(H - 1 - y_gl) * W + x];
-  return F4((float)(q & 255u) / 255.0f, (float)((q >> 8) & 255u) / 255.0f, (float)((q >> 16) & 255u) / 255.0f, (float)(q >> 24) / 255.0f);
-}
 /* The texel as stored.  Two texels are equal as vec4s exactly when their bytes are (k / 255 is injective), a channel is zero
  * exactly when its byte is, k / 255 > 0.1 (or >= 0.1) exactly when k >= 26, and int(k / 255 * 255.0) == k for every byte
  * (build/unorm_check.c walks all 256): the filters decide on the bytes and turn into floats only what they accumulate. */
@@ -43,6 +38,7 @@ __device__ __forceinline__ float unorm8(uint32_t k) {
   return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, kf), r, q);
 }
 __device__ __forceinline__ f4 unpack(uint32_t q) { return F4(unorm8(q & 255u), unorm8((q >> 8) & 255u), unorm8((q >> 16) & 255u), unorm8(q >> 24)); }
+__device__ __forceinline__ f4 fetch(Tex t, int W, int H, int x, int y_gl) { return unpack(fetchRaw(t, W, H, x, y_gl)); }      /* texelFetch, zero outside */
 __device__ __forceinline__ bool rawEq3(uint32_t a, uint32_t b) { return ((a ^ b) & 0x00ffffffu) == 0u; }
 __device__ __forceinline__ uint32_t rawW(uint32_t q) { return q >> 24; }
 
