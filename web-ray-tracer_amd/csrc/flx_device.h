@@ -948,12 +948,57 @@ FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, const Ray &shado
                         bool &shadowed, Hit &hit, WorkCounters &cnt) {
   WalkState w;
   walkClearResults(w);
-  if (needShadow) walkStart(w, 0, shadowRay, shadowLen); else walkStart(w, 1, nextRay, POW32);
-  if (COUNT) { if (needShadow) cnt.shadow_walks++; cnt.closest_walks++; }
-  while (w.mode != 2) {
-    if (walkStep<COUNT>(sc, w, cnt)) {
-      if (w.mode == 0) walkStart(w, 1, nextRay, POW32); else w.mode = 2;
+  if (sc.n_transforms > 1u) {
+    /* scenes with several object spaces: a ray changes space a few times per walk and the reciprocal would have to be taken
+     * again each time (three divisions) — the plain walk over the reference's array measures faster here (dragon: 26.2 vs 27.1 ms) */
+    if (needShadow) walkStart(w, 0, shadowRay, shadowLen); else walkStart(w, 1, nextRay, POW32);
+    if (COUNT) { if (needShadow) cnt.shadow_walks++; cnt.closest_walks++; }
+    while (w.mode != 2) {
+      if (walkStep<COUNT>(sc, w, cnt)) {
+        if (w.mode == 0) walkStart(w, 1, nextRay, POW32); else w.mode = 2;
+      }
     }
+    shadowed = w.shadowed;
+    hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri;
+    return;
+  }
+  /* one object space: over the threaded copy — explicit successors, stored edges, exact reciprocal box test, one test stream for
+   * both kinds of walk (moellerTrumboreAny).  Entries, order, arithmetic and visit counts are those of walkStep(). */
+  w.mode = needShadow ? 0 : 1;
+  w.src = needShadow ? shadowRay : nextRay;
+  w.minLen = needShadow ? shadowLen : POW32;
+  if (COUNT) { if (needShadow) cnt.shadow_walks++; cnt.closest_walks++; }
+  for (;;) {
+    w.tR = w.src; w.cachedTI = 0;
+    reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
+    uint32_t link = sc.walk_root;
+    while (link != WALK_END) {
+      const size_t i = (size_t)linkIndex(link) * 3u;
+      WalkEntry cur;
+      cur.e0 = sc.walk[i]; cur.e1 = sc.walk[i + 1]; cur.e2 = sc.walk[i + 2];
+      if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
+      const int meta = __float_as_int(cur.e2.z);
+      if ((meta & 3) == 0) break;                          /* terminator */
+      const int tI = (meta >> 2) << 1;
+      if (tI != w.cachedTI) {
+        const int iI = tI + 1;
+        const M3 rotationII = rotation_at(sc, iI);
+        w.cachedTI = tI;
+        w.tR.origin = mul(rotationII, w.src.origin + shift_at(sc, iI));
+        const f3 d = mul(rotationII, w.src.dir);
+        w.tR.dir = (w.mode == 0) ? normalize(d) : d;        /* fragment:261 normalises, fragment:201 does not */
+        reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
+      }
+      if ((meta & 3) == 1) {
+        walkBoxP(w, cur);
+        link = (uint32_t)w.i;
+      } else {
+        const bool ended = walkTriT(w, cur);
+        link = ended ? WALK_END : (uint32_t)w.i;
+      }
+    }
+    if (w.mode == 0) { w.mode = 1; w.src = nextRay; w.minLen = POW32; continue; }
+    break;
   }
   shadowed = w.shadowed;
   hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri;
