@@ -1013,6 +1013,20 @@ FLX_DEV void bounceFinish(PixelState &ps, PathState &p, const ShadeOut &so, bool
 }
 
 /* One full bounce iteration (fragment:476-595); false when the path ends on a miss (fragment:593). */
+/* bounce() with the surface part given: bounce 0 of a pixel's samples, which share the primary hit */
+template <bool COUNT>
+FLX_DEV bool bounceOn(const DeviceScene &sc, const DeviceFrame &fr, const SurfaceCtx &sf, PixelState &ps, PathState &p, f3 camera, float cosSampleN,
+                      int i, WorkCounters &cnt) {
+  ShadeOut so;
+  shadeSample(sc, fr, sf, ps, p, camera, cosSampleN, i, so);
+  bool shadowed;
+  walkBounce<COUNT>(sc, so.needShadow, so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
+  bounceFinish(ps, p, so, shadowed);
+  if (p.hit.triangleId == -1) return false;
+  p.lastHitPoint = p.ray.origin;
+  return true;
+}
+
 template <bool COUNT>
 FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, PathState &p, f3 camera, float cosSampleN, int i,
                     WorkCounters &cnt) {

@@ -39,12 +39,18 @@ __global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFram
     f3 dir0 = primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
     const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
     Ray pr; pr.origin = camera; pr.dir = dir0;
-    Hit hit0 = rayTracer<true>(sc, pr, viewDepthPerS, cnt.primary_visits);
+    Hit hit0 = primaryWalkT(sc, pr, viewDepthPerS, cnt.primary_visits);
     const size_t o = (size_t)k * fr.width + px;
     float4 color = make_float4(0.f, 0.f, 0.f, 0.f), colorIp = color, origColor = color, rid = color, roid = color, loc = color;
     if (hit0.triangleId != -1) {
       if (COUNT) cnt.primary_hits++;
       f3 finalColor = F3(0.0f, 0.0f, 0.0f);
+      /* every sample's first bounce lands on the primary hit: what its shading knows before it draws a random number
+       * (fetches, normals, the acos / tan of the normal deviation, material) is computed once */
+      SurfaceCtx sf0;
+      WorkCounters sfCnt = {};
+      const bool firstBounce = fr.max_reflections > 0 && length(F3(1.0f, 1.0f, 1.0f) * F3(1.0f, 1.0f, 1.0f)) >= fr.min_importancy * SQRT3;
+      if (firstBounce) shadeSurface<COUNT>(sc, fr, hit0, pr, camera, sf0, sfCnt);
       for (int s = 0; s < fr.samples; s++) {
         float cosSampleN = flx_cos((float)s);
         PathState p;
@@ -55,7 +61,12 @@ __global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFram
         p.ray.origin = camera; p.ray.dir = dir0;
         p.lastHitPoint = camera;
         p.hit = hit0;
-        for (int i = 0; i < fr.max_reflections && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3; i++) {
+        bool alive = firstBounce;
+        if (firstBounce) {
+          if (COUNT) { cnt.shades += sfCnt.shades; cnt.atlas_texels += sfCnt.atlas_texels; }      /* counted per path, as when each path shades it */
+          alive = bounceOn<COUNT>(sc, fr, sf0, ps, p, camera, cosSampleN, 0, cnt);
+        }
+        for (int i = 1; alive && i < fr.max_reflections && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3; i++) {
           if (!bounce<COUNT>(sc, fr, ps, p, camera, cosSampleN, i, cnt)) break;
         }
         finalColor = finalColor + (p.finalColor + p.importancyFactor * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]));
