@@ -169,10 +169,12 @@ flx_status flx_fxaa(flx_context *ctx, uint32_t width, uint32_t height, const flo
 flx_status flx_taa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba);
 flx_status flx_taa_reset(flx_context *ctx);
 
-/* Kernel organisation of the path-trace pass: 0 = automatic (persistent path kernel; the
- * sample-sequential per-pixel kernel when use_filter needs the cross-sample G-buffer state),
- * 1 = per-pixel kernel, 2 = persistent path kernel.  Results are identical; for A/B timing and tests. */
+/* Kernel organisation of the path-trace pass.  0 = automatic: the sample-sequential per-pixel kernel when use_filter /
+ * is_temporal need the cross-sample G-buffer state, else the persistent path kernel for scenes of up to 128 entries (in frames of at
+ * least 2^20 paths) and the wavefront pipeline for everything else; 1 = per-pixel kernel, 2 = persistent path kernel, 3 = wavefront pipeline.
+ * Results are identical; the explicit values are for A/B timing and tests.  flx_last_pipeline: what the last frame ran. */
 flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
+flx_status flx_last_pipeline(flx_context *ctx, int *pipeline);
 /* Wavefront pipeline: run the bounce loop as 1..4 independent chains of screen-tile ranges on separate HIP
  * streams (default 2), so that the tail of one chain's persistent walk kernel overlaps the other's work. */
 flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);

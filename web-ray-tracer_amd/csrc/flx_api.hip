@@ -77,6 +77,7 @@ struct flx_context {
   size_t live_capacity = 0;
   uint32_t *d_wfcounts = nullptr;                /* per chain: counts, walkQueue, stragCount, [WF_MAX_ROUNDS + 2] each */
   int pipeline = 0;                              /* 0 auto, 1 per-pixel megakernel, 2 persistent paths, 3 wavefront */
+  int last_pipeline = 0;                         /* what the last frame ran */
   int wf_groups = FLX_WF_GROUPS;                 /* wavefront pipeline: independent item groups on separate streams (tails of one overlap the other) */
   hipStream_t aux_stream[3] = { nullptr, nullptr, nullptr };
   hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
@@ -405,8 +406,12 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   /* The G-buffer accumulators of the filter path carry state from sample to sample (fragment:83-89),
    * so filter frames use the sample-sequential kernel; everything else runs the wavefront pipeline. */
   int pipeline = ctx->pipeline;
-  if (pipeline == 0) pipeline = (fr.use_filter || fr.is_temporal) ? 1 : 3;
+  /* automatic: tiny scenes (a Cornell box, the theater: a few dozen entries) spend the wavefront pipeline's time on its 128-byte
+   * path records, not on walks — the persistent path kernel, which keeps a path in registers from bounce to bounce, is faster
+   * there (tools/pipeline_crossover.py: 48 entries 1.96 vs 2.41 ms, 329 entries 4.03 vs 2.85 ms) */
+  if (pipeline == 0) pipeline = (fr.use_filter || fr.is_temporal) ? 1 : ((ctx->walk_entries <= 128u && path_item_count(fr) >= (1u << 20)) ? 2 : 3);       /* (a 256 x 256 frame does not fill the persistent grid) */
   if (pipeline == 3 && fr.max_reflections > WF_MAX_BOUNCES) pipeline = 2;
+  ctx->last_pipeline = pipeline;
   if (pipeline != 1 && (fr.use_filter || fr.is_temporal)) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the G-buffers of filter / temporal frames");
   const size_t P = (size_t)fr.rows * fr.width;
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
@@ -659,6 +664,12 @@ extern "C" flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, ui
   if (scheduler == FLX_WALK_QUEUES && suspend_walks != 0u) return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: the queue scheduler does not suspend walks");
   ctx->walk_scheduler = scheduler;
   ctx->walk_suspend = suspend_walks;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_last_pipeline(flx_context *ctx, int *pipeline) {
+  if (!ctx || !pipeline) return FLX_ERR_INVALID;
+  *pipeline = ctx->last_pipeline;
   return FLX_OK;
 }
 

@@ -18,7 +18,7 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_planes_device", "flx_filter_planes_device",
+    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset",
 ]
@@ -59,6 +59,7 @@ def _load():
         "flx_set_pipeline": (C.c_int, [vp, C.c_int]),
         "flx_get_diag": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_set_wavefront_groups": (C.c_int, [vp, C.c_int]),
+        "flx_last_pipeline": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "flx_temporal_reset": (C.c_int, [vp]),
         "flx_set_walk_scheduler": (C.c_int, [vp, C.c_int, C.c_uint32]),
         "flx_render_planes_device": (C.c_int, [vp, C.c_void_p, C.c_void_p]),
@@ -190,6 +191,11 @@ class Context:
 
     def temporal_reset(self):
         self._check(LIB.flx_temporal_reset(self._h), "flx_temporal_reset")
+
+    def last_pipeline(self):
+        v = C.c_int()
+        self._check(LIB.flx_last_pipeline(self._h, C.byref(v)), "flx_last_pipeline")
+        return v.value
 
     def set_wavefront_groups(self, groups):
         self._check(LIB.flx_set_wavefront_groups(self._h, int(groups)), "flx_set_wavefront_groups")
