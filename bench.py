@@ -235,11 +235,12 @@ def main():
         pipe = ctx.last_pipeline()
         if pipe == 1:              # per-pixel kernel: the whole trace
             kernel_name, bytes_launch = "k_trace_pixels", frame_bytes - (244 * rows_local * W if use_filter else 0)
-        elif pipe == 2 or cnt_b0 is None:       # persistent path kernel (tiny scenes): every bounce of every path, no primary walk, no output
+        elif pipe == 2:            # persistent path kernel (tiny scenes): every bounce of every path, no primary walk, no output
             kernel_name = "k_paths (persistent path kernel)"
             bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * cnt["shades"] + 4 * cnt["atlas_texels"]
         else:                      # the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
-            kernel_name, bytes_launch = "k_wf_walk_pre<false, true> (walk kernel of bounce 0)", 48 * (cnt_b0["closest_visits"] + cnt_b0["shadow_visits"])
+            b0 = cnt_b0 if cnt_b0 is not None else cnt        # a one-bounce frame: all of its walks are bounce 0's
+            kernel_name, bytes_launch = "k_wf_walk_pre<false, true> (walk kernel of bounce 0)", 48 * (b0["closest_visits"] + b0["shadow_visits"])
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         traffic = None
         try:                       # HBM bytes of that kernel from rocprofv3 PMC passes (profiles/, not measurable from inside bench.py)
