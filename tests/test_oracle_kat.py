@@ -212,3 +212,13 @@ def test_fxaa_and_taa_known_answers(oracle):
     t1 = oracle.taa([flat])
     assert np.allclose(t1[1:-1, 1:-1], q, atol=1e-6)
     assert np.allclose(t1[0, 0], q / 9, atol=1e-6)            # at the border the neighbourhood's minimum is the zero outside
+
+
+def test_unorm8_recipe_is_exact(tmp_path):
+    """the filters' division-free k / 255 and their byte comparisons (tools/unorm_check.c) hold for all 256 bytes"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "unorm_check"
+    subprocess.check_call(["gcc", "-O0", "-ffp-contract=off", "-o", str(exe), os.path.join(root, "tools", "unorm_check.c"), "-lm"])
+    out = subprocess.check_output([str(exe)]).decode()
+    assert "one Markstein step mismatches 0" in out and "!= k: 0" in out and "> 0.1f: 26" in out and out.strip().endswith(": 0")

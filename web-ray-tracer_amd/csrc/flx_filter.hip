@@ -26,7 +26,7 @@ __device__ __forceinline__ bool eq4(f4 a, f4 b) { return a.x == b.x && a.y == b.
 
 /* The texel as stored.  Two texels are equal as vec4s exactly when their bytes are (k / 255 is injective), a channel is zero
  * exactly when its byte is, k / 255 > 0.1 (or >= 0.1) exactly when k >= 26, and int(k / 255 * 255.0) == k for every byte
- * (build/unorm_check.c walks all 256): the filters decide on the bytes and turn into floats only what they accumulate. */
+ * (tools/unorm_check.c walks all 256): the filters decide on the bytes and turn into floats only what they accumulate. */
 __device__ __forceinline__ uint32_t fetchRaw(Tex t, int W, int H, int x, int y_gl) {
   if (!t.p || x < 0 || y_gl < 0 || x >= W || y_gl >= H) return 0u;
   return t.p[(size_t)(H - 1 - y_gl) * W + x];
