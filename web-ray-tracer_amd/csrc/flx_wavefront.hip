@@ -50,7 +50,7 @@ __device__ unsigned long long g_diagSlow[4];
 #define FLX_WF_LDS_TOTAL (156 * 1024)         /* LDS a walk workgroup may use (of 160 KB per CU) */
 #endif
 #ifndef FLX_WF_INNER
-#define FLX_WF_INNER 4
+#define FLX_WF_INNER 8
 #endif
 #ifndef FLX_WF_VOTE
 #define FLX_WF_VOTE 0
@@ -68,6 +68,9 @@ __device__ unsigned long long g_diagSlow[4];
 #define FLX_WF_TAIL_TRIPS 8                 /* trips of the scheduler loop between two consolidation rounds */
 #endif
 enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_ROUND = 4 };   /* LDS words of the tail consolidation */
+#ifndef FLX_WF_UNROLL
+#define FLX_WF_UNROLL 1
+#endif
 #ifndef FLX_WF_WAVES_PER_EU
 #define FLX_WF_WAVES_PER_EU 4               /* occupancy the register allocation of k_wf_walk_pre must allow */
 #endif
@@ -706,7 +709,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     }
     long long t2 = COUNT ? clock64() : 0;
     /* ---- FLX_WF_INNER entries for every walking lane ------------------------------------------------- */
-#pragma unroll 1
+#pragma unroll FLX_WF_UNROLL
     for (int it = 0; it < FLX_WF_INNER; it++) {
       if (COUNT) diagIters++;
       if (st == P_WALKING) {
