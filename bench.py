@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the rank logic)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--verify", action="store_true", help="after the run, rank 0 renders the whole frame on its own and compares the gathered frame with it (bit for bit)")
     args = ap.parse_args()
 
     import numpy as np
@@ -150,6 +151,9 @@ def main():
                 src_rank.append(r); src_row.append(k); dst_row.append(y)
         src_index = torch.tensor([r * rows_max + k for r, k in zip(src_rank, src_row)], device="cuda")
         dst_index = torch.tensor(dst_row, device="cuda")
+        # one gather instead of select + scatter: image row y comes from slot perm[y] of the gathered strips
+        perm = torch.empty(H, dtype=torch.long, device="cuda")
+        perm[dst_index] = src_index
         assert sorted(dst_row) == list(range(H))
 
     if filter_multi:
@@ -167,14 +171,14 @@ def main():
                 ctx.render_planes_device(params, planes_tight.data_ptr())
                 planes_local[:, :rows_local, :] = planes_tight
             dist.all_gather_into_tensor(planes_all.view(-1), planes_local.view(-1))
-            sel = planes_all.permute(1, 0, 2, 3).reshape(5, world * rows_max, W).index_select(1, src_index)
-            planes.index_copy_(1, dst_index, sel)
+            for k in range(5):
+                torch.index_select(planes_all[:, k].reshape(world * rows_max, W), 0, perm, out=planes[k])
             ctx.filter_planes_device(full, planes.data_ptr(), frame.data_ptr())      # every rank ends up with the frame
             return
         ctx.render_device(params, local.data_ptr())         # filter-on frames: trace + denoise chain, all on the GPU
         if multi:
             dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
-            frame.index_copy_(0, dst_index, gathered.view(world * rows_max, W, 4).index_select(0, src_index))
+            torch.index_select(gathered.view(world * rows_max, W, 4), 0, perm, out=frame)
 
     def fence():
         torch.cuda.synchronize()
@@ -224,6 +228,13 @@ def main():
     ctx.set_counters_enabled(False)
     torch.cuda.synchronize()
 
+    verified = None
+    if args.verify and multi and rank == 0:
+        torch.cuda.synchronize()                             # `frame` holds the last gathered frame of the timed loop
+        whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        ctx.render_device(full, whole.data_ptr())
+        ctx.sync()
+        verified = bool(torch.equal(whole.view(torch.int32), frame.view(torch.int32)))
     if rank == 0:
         spp, bounces = full.samples, full.max_reflections
         rays = spp * bounces * W * H
@@ -272,6 +283,8 @@ def main():
             },
             "counters": cnt,
         }
+        if verified is not None:
+            line["gathered_frame_equals_single_context_frame"] = verified
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, full)
         print(json.dumps(line), flush=True)
