@@ -8,7 +8,7 @@ from flexlight_hip.scene_io import Scene
 sc = Scene.golden("dragon")
 ctx = capi.Context(0)
 ctx.update_scene(sc)
-for (w, h, spp) in ((8, 8, 1), (64, 64, 1), (1920, 1080, 8)):
+for (w, h, spp) in ((1, 1, 1), (2, 2, 1), (8, 8, 1), (64, 64, 1), (1920, 1080, 8)):
     p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=1, use_filter=0)
     _, cnt, _ = ctx.render(p, counters=True)
     d = ctx.get_diag()

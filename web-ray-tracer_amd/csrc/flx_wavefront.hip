@@ -64,10 +64,13 @@ __device__ unsigned long long g_diagSlow[4];
 #ifndef FLX_WF_CONSOLIDATE
 #define FLX_WF_CONSOLIDATE 1                /* k_wf_walk_pre: merge the walks of thinning waves once the queue is dry */
 #endif
+#ifndef FLX_WF_SPREAD_DIV
+#define FLX_WF_SPREAD_DIV 4                 /* tail: deal the walks out evenly once they fill less than 1/DIV of the workgroup's lanes */
+#endif
 #ifndef FLX_WF_TAIL_TRIPS
 #define FLX_WF_TAIL_TRIPS 8                 /* trips of the scheduler loop between two consolidation rounds */
 #endif
-enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_ROUND = 4 };   /* LDS words of the tail consolidation */
+enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_ROUND = 4, TC_MAX = 8, TC_BUSY = 10, TC_MASK = 12 };   /* LDS words of the tail consolidation */
 #ifndef FLX_WF_UNROLL
 #define FLX_WF_UNROLL 1
 #endif
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
      * only changes lane: its state, entry order and arithmetic are untouched. */
     if (!tailMode && !(itemsLeft || chunkNext != chunkEnd)) {
       tailMode = true;
-      if (lane == 0) atomicAdd(&tailCtl[TC_TAIL], 1u);
+      if (lane == 0) { atomicAdd(&tailCtl[TC_TAIL], 1u); atomicOr(&tailCtl[TC_MASK], 1u << (threadIdx.x >> 6)); }
     }
     if (tailMode) {
       if (!tailSynced) {
@@ -492,19 +495,46 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         const uint32_t par = (tailRound++ & 1u) * 2u;
         const unsigned long long mine = __ballot(st != P_EMPTY);
         const uint32_t myCount = (uint32_t)__popcll(mine);
-        if (lane == 0) { atomicAdd(&tailCtl[TC_ROUND + par], myCount); atomicAdd(&tailCtl[TC_ROUND + par + 1u], 1u); }
+        if (lane == 0) {
+          atomicAdd(&tailCtl[TC_ROUND + par], myCount); atomicAdd(&tailCtl[TC_ROUND + par + 1u], 1u);
+          atomicMax(&tailCtl[TC_MAX + (par >> 1)], myCount); if (myCount) atomicAdd(&tailCtl[TC_BUSY + (par >> 1)], 1u);
+        }
         __syncthreads();
-        uint32_t total = 0, waves = 0;
+        uint32_t total = 0, waves = 0, most = 0, busy = 0;
         if (lane == 0) {
           total = __hip_atomic_load(&tailCtl[TC_ROUND + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           waves = __hip_atomic_load(&tailCtl[TC_ROUND + par + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          most = __hip_atomic_load(&tailCtl[TC_MAX + (par >> 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          busy = __hip_atomic_load(&tailCtl[TC_BUSY + (par >> 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           __hip_atomic_store(&tailCtl[TC_ROUND + (par ^ 2u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      /* the next round's tallies */
           __hip_atomic_store(&tailCtl[TC_ROUND + (par ^ 2u) + 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&tailCtl[TC_MAX + ((par >> 1) ^ 1u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&tailCtl[TC_BUSY + ((par >> 1) ^ 1u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         total = __builtin_amdgcn_readfirstlane(total); waves = __builtin_amdgcn_readfirstlane(waves);
+        most = __builtin_amdgcn_readfirstlane(most); busy = __builtin_amdgcn_readfirstlane(busy);
+        /* Plenty of walks: pack them 64 to a wave (fewer waves issue the same tests).  Few walks (under a quarter of the
+         * lanes): what counts is how fast each walk goes, and a lane goes 2-2.5x faster in a wave with one or two walks
+         * than in a full one whose lanes are at boxes and triangles at once (tools/diag_lone.py: 787 cycles per entry for
+         * one lane, 2 030 for 64): deal them out evenly over the waves, which all stay for that. */
+        /* dealt out = one wave per SIMD gets the walks: a SIMD issues one wave instruction per four cycles whatever the wave's
+         * lane count, so four thin waves on a SIMD each run at a quarter of the speed of one; the workgroup's waves sit
+         * on the SIMDs round robin, the lowest live wave of each residue class is that SIMD's taker */
+        const uint32_t myWave = threadIdx.x >> 6;
+        uint32_t liveMask = 0;
+        if (lane == 0) liveMask = __hip_atomic_load(&tailCtl[TC_MASK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        liveMask = __builtin_amdgcn_readfirstlane(liveMask);
+        uint32_t takers = 0, myRank = 0xffffffffu;
+        for (uint32_t c = 0; c < 4u; c++) {
+          const uint32_t cls = liveMask & (0x1111u << c);
+          if (cls) { if (((cls & (0u - cls)) >> myWave) == 1u) myRank = takers; takers++; }
+        }
+        const bool spread = total * (uint32_t)FLX_WF_SPREAD_DIV < 64u * waves && takers > 0u && total <= 64u * takers;
+        const uint32_t share = spread ? (total + takers - 1u) / takers : 64u;
+        const bool uneven = spread ? (most > share || busy > takers) : busy > (total + 63u) / 64u;
         if (total <= suspendMax) {
           suspendNow = true;                                   /* every wave of the workgroup reads the same total */
-        } else if (waves > 1u && total <= 64u * (waves - 1u)) {
+        } else if (waves > 1u && uneven) {
           /* export */
           uint32_t pos0 = 0;
           if (lane == 0 && myCount) pos0 = atomicAdd(&tailCtl[TC_POOL], myCount);
@@ -522,11 +552,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             st = P_EMPTY;
           }
           __syncthreads();
-          /* import: 64 walks per claim; waves that find the pool taken up leave through the loop's normal exit */
-          uint32_t at = 0;
-          if (lane == 0) at = atomicAdd(&tailCtl[TC_TAKE], 64u);
-          at = __builtin_amdgcn_readfirstlane(at);
-          if (at + lane < total) {
+          /* import: 64 walks per claim when packing; the SIMDs' takers a share each when dealing out */
+          uint32_t at = 0xffffffffu;
+          if (spread) { if (myRank != 0xffffffffu) at = myRank * share; }
+          else {
+            if (lane == 0) at = atomicAdd(&tailCtl[TC_TAKE], share);
+            at = __builtin_amdgcn_readfirstlane(at);
+          }
+          if (at != 0xffffffffu && lane < share && at + lane < total) {
             const float4 *r = pool + (size_t)(at + lane) * 8u;
             const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
             pathId = (uint32_t)__float_as_int(r0.x); flags = __float_as_int(r0.y); base = r0.z;
@@ -704,6 +737,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       if (COUNT) tRefill += clock64() - t1;
       if (__ballot(st == P_WALKING) == 0ull) {
         if (itemsLeft || chunkNext != chunkEnd || __ballot(st == P_SWITCH || st == P_DONE) != 0ull) continue;
+#if FLX_WF_CONSOLIDATE
+        if (tailSynced) continue;          /* walks may be dealt this way at the next round; the round that counts none ends every wave */
+#endif
         break;
       }
     }
@@ -722,7 +758,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     if (COUNT) tInner += clock64() - t2;
   }
 #if FLX_WF_CONSOLIDATE
-  if (lane == 0) { atomicSub(&tailCtl[TC_LIVE], 1u); if (tailMode) atomicSub(&tailCtl[TC_TAIL], 1u); }
+  if (lane == 0) { atomicSub(&tailCtl[TC_LIVE], 1u); if (tailMode) { atomicSub(&tailCtl[TC_TAIL], 1u); atomicAnd(&tailCtl[TC_MASK], ~(1u << (threadIdx.x >> 6))); } }
 #endif
   if (outValid) {
     for (uint32_t t = outUsed + lane; t < WF_OUT_CHUNK; t += 64u) listOut[outBase + t] = WF_INVALID;
