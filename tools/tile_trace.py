@@ -8,6 +8,9 @@ from flexlight_hip.scene_io import Scene
 sc = Scene.golden("dragon")
 ctx = capi.Context(0)
 ctx.update_scene(sc)
+if os.environ.get("FLX_SCHED"):
+    a, b = os.environ["FLX_SCHED"].split(",")
+    ctx.set_walk_scheduler(int(a), int(b))
 p = sc.frame_params(use_filter=0)
 p.tile_rows, p.tile_count, p.tile_index = 8, int(sys.argv[1]), 0
 for _ in range(4): ctx.render(p)
