@@ -245,14 +245,8 @@ FLX_DEV bool moellerTrumborePrimaryE(f3 a, f3 edge1, f3 edge2, const Ray &ray, f
 
 /* fragment:161-167 */
 FLX_DEV bool rayCuboid(float l, const Ray &ray, f3 minCorner, f3 maxCorner) {
-#ifdef FLX_EXPERIMENT_FASTDIV   /* timing experiment only: NOT the reference arithmetic */
-  f3 inv = F3(__builtin_amdgcn_rcpf(ray.dir.x), __builtin_amdgcn_rcpf(ray.dir.y), __builtin_amdgcn_rcpf(ray.dir.z));
-  f3 v0 = (minCorner - ray.origin) * inv;
-  f3 v1 = (maxCorner - ray.origin) * inv;
-#else
   f3 v0 = (minCorner - ray.origin) / ray.dir;
   f3 v1 = (maxCorner - ray.origin) / ray.dir;
-#endif
   float tmin = flx_max(flx_max(flx_min(v0.x, v1.x), flx_min(v0.y, v1.y)), flx_min(v0.z, v1.z));
   float tmax = flx_min(flx_min(flx_max(v0.x, v1.x), flx_max(v0.y, v1.y)), flx_max(v0.z, v1.z));
   return tmax >= flx_max(tmin, BIAS) && tmin < l;
@@ -724,13 +718,6 @@ FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCor
   const bool aOk = m >= 0x2b800000u - 1u;
   f3 v0, v1;
   float tmin, tmax;
-#ifdef FLX_DIAG_SLOW
-  { extern __device__ unsigned long long g_diagSlow[4];
-    const bool slow = !(w.fastDiv && aOk);
-    const unsigned long long sm = __ballot(slow);
-    if (sm && (threadIdx.x & 63u) == (unsigned)__ffsll((long long)sm) - 1u) { atomicAdd(&g_diagSlow[0], (unsigned long long)__popcll(sm)); atomicAdd(&g_diagSlow[1], 1ull); if (!w.fastDiv) atomicAdd(&g_diagSlow[2], 1ull); }
-    if ((threadIdx.x & 63u) == 0u || !(__ballot(1) & 1ull)) {} }
-#endif
   if (w.fastDiv && aOk) {
     v0 = F3(divByRecip(a0.x, d.x, y.x), divByRecip(a0.y, d.y, y.y), divByRecip(a0.z, d.z, y.z));
     v1 = F3(divByRecip(a1.x, d.x, y.x), divByRecip(a1.y, d.y, y.y), divByRecip(a1.z, d.z, y.z));

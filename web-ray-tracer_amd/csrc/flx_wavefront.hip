@@ -30,15 +30,9 @@
 
 namespace flx {
 
-#ifdef FLX_DIAG_SLOW
-__device__ unsigned long long g_diagSlow[4];
-#endif
 
 #ifndef FLX_WF_WALK_THREADS
 #define FLX_WF_WALK_THREADS 1024
-#endif
-#ifndef FLX_WF_LDS_BYTES
-#define FLX_WF_LDS_BYTES 131072              /* LDS given to the hot prefix of the threaded skip list (of 160 KB per CU) */
 #endif
 #ifndef FLX_WF_DRAWS_PER_WAVE
 #define FLX_WF_DRAWS_PER_WAVE 16
@@ -51,12 +45,6 @@ __device__ unsigned long long g_diagSlow[4];
 #endif
 #ifndef FLX_WF_INNER
 #define FLX_WF_INNER 8
-#endif
-#ifndef FLX_WF_VOTE
-#define FLX_WF_VOTE 0
-#endif
-#ifndef FLX_WALK_WAVES
-#define FLX_WALK_WAVES 1
 #endif
 #ifndef FLX_WF_ITEMS_PER_LANE
 #define FLX_WF_ITEMS_PER_LANE 4
@@ -349,25 +337,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
 #pragma unroll 1
     for (int it = 0; it < FLX_WF_INNER; it++) {
       if (COUNT) diagIters++;
-#if FLX_WF_VOTE
-      /* the wave votes and runs the entry type most lanes stand at: box and triangle tests are different
-       * code, run per lane in lock step they serialise */
-      const bool atBox = st == L_WALKING && walkIsBoxT(cur);
-      const bool atTri = st == L_WALKING && !walkIsBoxT(cur);
-      const uint32_t nBox = (uint32_t)__popcll(__ballot(atBox)), nTri = (uint32_t)__popcll(__ballot(atTri));
-      if (nBox + nTri == 0u) break;
-      bool ended = false, stepped = false;
-      if (nBox >= nTri) {
-        if (atBox) { walkBoxT(w, cur); stepped = true; }
-      } else {
-        if (atTri) { ended = walkTriT(w, cur); stepped = true; }
-      }
-      if (stepped) {
-#else
       if (st == L_WALKING) {
         bool ended = false;
         if (walkIsBoxT(cur)) walkBoxT(w, cur); else ended = walkTriT(w, cur);
-#endif
         if (!ended) ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt);
         if (ended && w.mode == 0) {                      /* shadow walk over: start the closest-hit walk at entry 0 */
           walkStartT(sc, w, 1, nextRay, POW32);
@@ -780,9 +752,6 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
                       int walk_scheduler, uint32_t suspend_max, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
-#ifdef FLX_DIAG_SLOW
-  { unsigned long long h[4]; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_diagSlow), sizeof h); fprintf(stderr, "diag slow-box: lanes %llu wave-events %llu notFast %llu\n", h[0], h[1], h[2]); }
-#endif
   const uint32_t total = wb.item_count;                 /* items of this group (all of the frame when there is one group) */
   const uint32_t maxBlocks = compute_units * 8u;
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
