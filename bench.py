@@ -74,9 +74,17 @@ def cpu_baseline(scene, params_full, seconds_budget=12.0):
     for _ in range(frames):
         flx_oracle.render(scene, p, threads=threads)
     dt = time.time() - t0
+    # one core beside it: every 16th strip of the same frame, ~1/16 of its rays, about 3 s
+    p1 = scene.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0, tile=(8, 0, 16))
+    rows1 = len(flx_oracle.tile_rows(p1))
+    t1 = time.time()
+    flx_oracle.render(scene, p1, threads=1)
+    dt1 = max(time.time() - t1, 1e-6)
     return {
         "value": frames * spp * bounces * w * h / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port",
         "sample": "same scene/spp/bounces, %dx%d frame x %d (%.1f s of CPU oracle, %d OpenMP threads, filter off)" % (w, h, frames, dt, threads),
+        "single_thread": {"value": spp * bounces * w * rows1 / dt1 / 1e6, "unit": "Mray/s", "cores": 1,
+                          "sample": "every 16th 8-row strip of that frame (%d rows, %.1f s)" % (rows1, dt1)},
     }
 
 
