@@ -46,6 +46,42 @@ def test_radiance_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounces, 
     assert (got[..., 3] == 1).sum() == want_cnt["primary_hits"]
 
 
+def test_headline_frame_at_full_size(hip, oracle, scenes):
+    """The configuration BASELINE.json's target is quoted on (configs[2]) at full size — dragon, 1920x1080, 8 samples,
+    4 bounces, filter off, the frame bench.py times —
+    against the oracle on all host cores (66 M rays: a few seconds on the GPU box), bit for bit, with the work counters;
+    then the same frame as the strips of 8 ranks (what `bench.py --gpus 8` gathers)."""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    p = sc.frame_params(use_filter=0)
+    assert (p.width, p.height, p.samples, p.max_reflections) == (1920, 1080, 8, 4)
+    got, got_cnt, _ = hip.render(p, counters=True)
+    want, want_cnt = oracle.render(sc, p, threads=0)[:2]
+    assert np.array_equal(got, want, equal_nan=True)
+    assert got_cnt == want_cnt
+    assert hip.last_pipeline() == 3
+    whole = np.full_like(got, np.nan)
+    for rank in range(8):
+        p.tile_rows, p.tile_index, p.tile_count = 8, rank, 8
+        part, _, _ = hip.render(p)
+        whole[hip.tile_rows(p)] = part
+    assert np.array_equal(whole, want, equal_nan=True)
+
+
+@pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 3840, 2160, 8, 4), ("theater", 1920, 1080, 16, 6)],
+                         ids=["dragon_4k", "theater_1080p"])
+def test_multi_gpu_configs_at_full_size(hip, oracle, scenes, name, w, h, spp, bounces):
+    """BASELINE.json configs[3] and configs[4] (the 8-GPU workloads) at full size on one GPU, bit for bit against the oracle
+    on all host cores (265 M and 199 M rays)."""
+    sc = scenes(name)
+    hip.update_scene(sc)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+    got, got_cnt, _ = hip.render(p, counters=True)
+    want, want_cnt = oracle.render(sc, p, threads=0)[:2]
+    assert np.array_equal(got, want, equal_nan=True)
+    assert got_cnt == want_cnt
+
+
 def test_tiles_reassemble_full_frame(hip, scenes):
     """Row-strip tile policy (multi-GPU split): strips dealt round-robin reproduce the whole frame."""
     sc = scenes("cornell")
@@ -161,6 +197,22 @@ def test_filter_chain_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounc
     rms, mism = assert_parity(got, want, name + " filtered")
     assert mism == 0, "%s filtered frame: %d of %d floats differ (rms %s)" % (name, mism, got.size, rms)
     assert got_cnt == want_cnt
+
+
+def test_filter_frame_at_full_size(hip, oracle, scenes):
+    """BASELINE.json configs[1] at full size: cornell_obj, 1920x1080, 4 samples, 3 bounces, filter ON — trace with G-buffers
+    and the whole denoise chain against the oracle, bit for bit, with the work counters."""
+    sc = scenes("cornell_obj")
+    hip.update_scene(sc)
+    p = sc.frame_params(use_filter=1)
+    assert (p.width, p.height, p.samples, p.max_reflections) == (1920, 1080, 4, 3)
+    got, got_cnt, got_gb = hip.render(p, gbuffers=True, counters=True)
+    want, want_cnt, want_gb = oracle.render(sc, p, gbuffers=True)
+    for key in want_gb:
+        assert np.array_equal(got_gb[key], want_gb[key], equal_nan=True), key
+    assert np.array_equal(got, want, equal_nan=True)
+    assert got_cnt == want_cnt
+    assert hip.last_pipeline() == 1
 
 
 def test_filter_refuses_tiles(hip, scenes):

@@ -11,6 +11,8 @@ ctx.update_scene(sc)
 if os.environ.get("FLX_SCHED"):                     # "scheduler,suspend_walks"
     a, b = os.environ["FLX_SCHED"].split(",")
     ctx.set_walk_scheduler(int(a), int(b))
+if os.environ.get("FLX_GROUPS"):
+    ctx.set_wavefront_groups(int(os.environ["FLX_GROUPS"]))
 if os.environ.get("FLX_PIPELINE"):
     ctx.set_pipeline(int(os.environ["FLX_PIPELINE"]))
 for n in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]:
