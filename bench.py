@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--tile-rows", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=16, help="frames per pass of the pipeline (flx_render_batch_device); 1 = frame after frame; filter frames are never batched")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the rank logic)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
@@ -105,7 +106,7 @@ def main():
 
     import numpy as np
     import torch
-    from flexlight_hip import capi
+    from flexlight_hip import capi, tiles
     from flexlight_hip.scene_io import Scene
 
     rank = int(os.environ.get("RANK", "0"))
@@ -144,25 +145,28 @@ def main():
     torch.cuda.set_stream(stream)             # no host sync between trace kernel, all-gather and reassembly
     ctx.set_stream(stream.cuda_stream)
 
+    # Frames per pass: a walk kernel lasts as long as its longest walk whatever the number of paths, so the
+    # bench renders the K frames of the timed region in batches of F (the last one may be smaller): throughput mode.
     rows_local = ctx.tile_row_count(params)
-    strips = (H + args.tile_rows - 1) // args.tile_rows if multi else 1
-    rows_max = ((strips + world - 1) // world) * args.tile_rows if multi else H
-    local = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world, rows_max, W, 4), dtype=torch.float32, device="cuda") if multi else None
-    frame = torch.empty((H, W, 4), dtype=torch.float32, device="cuda") if multi else None
+    F = 1 if use_filter else max(1, min(args.batch, capi.MAX_BATCH_FRAMES))
+    F = max(1, min(F, (1 << 28) // max(1, rows_local * W * full.samples)))      # at most 2^28 paths (34 GB of path records) per pass
+    rows_max = tiles.padded_rows(H, args.tile_rows, world) if multi else H
+    local = torch.zeros((F, rows_max, W, 4), dtype=torch.float32, device="cuda")
+    gathered = torch.empty((world, F, rows_max, W, 4), dtype=torch.float32, device="cuda") if multi else None
+    frame = torch.empty((F, H, W, 4), dtype=torch.float32, device="cuda") if multi else None      # the frames of the last batch, every rank has them
+    perms = {}
     if multi:
-        # image row of every (rank, packed row) slot, -1 for padding
-        src_rank, src_row, dst_row = [], [], []
+        rows_of = []                      # image rows of every rank's packed rows
         for r in range(world):
             pr = scene.frame_params(width=args.width, height=args.height, tile=(args.tile_rows, r, world))
-            for k, y in enumerate(capi.Context.tile_rows(pr)):
-                src_rank.append(r); src_row.append(k); dst_row.append(y)
-        src_index = torch.tensor([r * rows_max + k for r, k in zip(src_rank, src_row)], device="cuda")
-        dst_index = torch.tensor(dst_row, device="cuda")
-        # one gather instead of select + scatter: image row y comes from slot perm[y] of the gathered strips
-        perm = torch.empty(H, dtype=torch.long, device="cuda")
-        perm[dst_index] = src_index
-        assert sorted(dst_row) == list(range(H))
+            rows_of.append(list(capi.Context.tile_rows(pr)))
+
+        def perm_for(f):
+            """one gather instead of select + scatter: flexlight_hip/tiles.py gather_index, cached per batch size"""
+            if f not in perms:
+                perms[f] = torch.from_numpy(tiles.gather_index(rows_of, f, rows_max, H)).cuda()
+            return perms[f]
+        perm = perm_for(1)
 
     if filter_multi:
         planes_local = torch.zeros((5, rows_max, W), dtype=torch.int32, device="cuda")
@@ -170,6 +174,28 @@ def main():
         planes = torch.empty((5, H, W), dtype=torch.int32, device="cuda")
         if rows_local != rows_max:            # the C ABI packs [5][rows_local][W]; ranks with a strip less use a view of that shape
             planes_tight = torch.zeros((5, rows_local, W), dtype=torch.int32, device="cuda")
+
+    def render_batch(f):
+        """f frames of this rank's strips, then (N > 1) the gather: every rank ends up with the f whole frames"""
+        ctx.render_batch_device([params] * f, local.data_ptr())
+        if multi:
+            n = f * rows_max * W * 4
+            dist.all_gather_into_tensor(gathered.view(-1)[:world * n], local.view(-1)[:n])
+            torch.index_select(gathered.view(-1)[:world * n].view(world * f * rows_max, W, 4), 0, perm_for(f), out=frame.view(F * H, W, 4)[:f * H])
+
+    def batch_sizes(k):
+        """k frames in the fewest batches of at most F frames, sized evenly (20 frames, F = 8: 7 + 7 + 6)"""
+        n = (k + F - 1) // F
+        return [k // n + (1 if i < k % n else 0) for i in range(n)] if n else []
+
+    def run_frames(k):
+        """k frames, in batches of F"""
+        if F == 1:
+            for _ in range(k):
+                step()
+            return
+        for f in batch_sizes(k):
+            render_batch(f)
 
     def step():
         if filter_multi:
@@ -186,7 +212,7 @@ def main():
         ctx.render_device(params, local.data_ptr())         # filter-on frames: trace + denoise chain, all on the GPU
         if multi:
             dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
-            torch.index_select(gathered.view(world * rows_max, W, 4), 0, perm, out=frame)
+            torch.index_select(gathered.view(world * F * rows_max, W, 4), 0, perm, out=frame[0])
 
     def fence():
         torch.cuda.synchronize()
@@ -194,13 +220,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if multi and F > 1:
+        for f in set(batch_sizes(args.steps) + batch_sizes(args.warmup) + [F]):
+            perm_for(f)                  # index tables built before the timed region
+    run_frames(args.warmup)
     fence()
     kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_frames(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if multi:
@@ -213,8 +240,20 @@ def main():
     def trace_share():                   # this rank's share of the trace, without gather / chain
         if filter_multi:
             ctx.render_planes_device(params, (planes_local if rows_local == rows_max else planes_tight).data_ptr())
+        elif F > 1:
+            ctx.render_batch_device([params] * F, local.data_ptr())
         else:
             ctx.render_device(params, local.data_ptr())
+
+    # frame after frame (latency mode), for the record: the same share of the frame, one frame per pass
+    single_ms = None
+    if F > 1:
+        for it in range(3 + 10):
+            if it == 3:
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+            ctx.render_device(params, local.data_ptr())
+        torch.cuda.synchronize()
+        single_ms = (time.perf_counter() - t1) / 10 * 1e3
 
     ctx.set_wavefront_groups(1)          # one chain, so the bounce-0 walk kernel is ONE launch over the whole share of the frame
     for _ in range(min(args.steps, 10)):
@@ -224,7 +263,10 @@ def main():
     # Work counters of this rank's share of the frame (a counted launch; not timed), and of bounce 0 alone
     # (the same frame cut after one bounce: identical paths) for the dominant kernel's roofline.
     ctx.set_counters_enabled(True)
-    trace_share()
+    if filter_multi:
+        trace_share()
+    else:
+        ctx.render_device(params, local.data_ptr())      # ONE frame's share: the counters below are per frame
     ctx.sync()
     cnt = ctx.get_counters()
     cnt_b0 = None
@@ -242,7 +284,8 @@ def main():
         whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
         ctx.render_device(full, whole.data_ptr())
         ctx.sync()
-        verified = bool(torch.equal(whole.view(torch.int32), frame.view(torch.int32)))
+        last = batch_sizes(args.steps)[-1] - 1 if F > 1 else 0           # position of the last frame in the last batch
+        verified = bool(torch.equal(whole.view(torch.int32), frame[last].view(torch.int32)))
     if rank == 0:
         spp, bounces = full.samples, full.max_reflections
         rays = spp * bounces * W * H
@@ -250,7 +293,7 @@ def main():
         value = rays / (elapsed / args.steps) / 1e6
         n_lights = scene.arrays["lights"].size // 6
         k_ms = float(np.mean(kernel_ms))
-        frame_bytes = algorithmic_bytes(cnt, n_lights, rows_local * W, use_filter)
+        frame_bytes = algorithmic_bytes(cnt, n_lights, rows_local * W, use_filter)      # per frame
         pipe = ctx.last_pipeline()
         if pipe == 1:              # per-pixel kernel: the whole trace
             kernel_name, bytes_launch = "k_trace_pixels", frame_bytes - (244 * rows_local * W if use_filter else 0)
@@ -260,12 +303,13 @@ def main():
         else:                      # the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
             b0 = cnt_b0 if cnt_b0 is not None else cnt        # a one-bounce frame: all of its walks are bounce 0's
             kernel_name, bytes_launch = "k_wf_walk_pre<false, true> (walk kernel of bounce 0)", 48 * (b0["closest_visits"] + b0["shadow_visits"])
+        bytes_launch *= F              # one launch walks the F frames of a batch
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         traffic = None
         try:                       # HBM bytes of that kernel from rocprofv3 PMC passes (profiles/, not measurable from inside bench.py)
             with open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")) as fh:
                 t = json.load(fh)
-            if t["workload"] == args.workload and world == 1 and W == 1920 and H == 1080 and kernel_name == t["kernel"]:
+            if t["workload"] == args.workload and world == 1 and W == 1920 and H == 1080 and kernel_name == t["kernel"] and t.get("frames_per_launch", 1) == F:
                 traffic = t["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
@@ -276,7 +320,7 @@ def main():
             "config": {
                 "workload": config_name, "width": W, "height": H, "spp": spp, "bounces": bounces, "filter": bool(use_filter),
                 "scene_entries": int(scene.meta["textureLength"]), "parallelism": "row-strip tiles x%d, %d rows/strip, RCCL all-gather" % (world, args.tile_rows) if world > 1 else "single GPU",
-                "rays_per_frame": rays,
+                "rays_per_frame": rays, "frames_per_pass": F,
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -291,6 +335,9 @@ def main():
             },
             "counters": cnt,
         }
+        if single_ms is not None:
+            line["frame_after_frame"] = {"ms_per_frame": single_ms, "value": rays / (single_ms * 1e-3) / 1e6, "unit": "Mray/s",
+                                         "note": "same share of the frame rendered one frame per pass (flx_render_device), without the gather; `value` above renders %d frames per pass (flx_render_batch_device): every frame complete, latency %d frames" % (F, F)}
         if verified is not None:
             line["gathered_frame_equals_single_context_frame"] = verified
         if not args.no_cpu_baseline:

@@ -82,6 +82,62 @@ def test_multi_gpu_configs_at_full_size(hip, oracle, scenes, name, w, h, spp, bo
     assert got_cnt == want_cnt
 
 
+def _moved(sc, p, i):
+    """frame i of a camera move: another position, view direction, seed and ambient"""
+    from flexlight_hip.scene_io import view_matrix
+    cam = sc.meta["camera"]
+    q = type(p).from_buffer_copy(p)
+    q.camera[:] = [cam["x"] + 0.35 * i, cam["y"] + 0.1 * i, cam["z"] - 0.2 * i]
+    q.view_matrix[:] = view_matrix(cam["fx"] + 0.07 * i, cam["fy"] - 0.03 * i, cam["fov"], p.width, p.height).tolist()
+    q.random_seed = float(i % 3)
+    q.ambient[:] = [a * (1.0 + 0.25 * i) for a in sc.meta["ambient"]]
+    return q
+
+
+@pytest.mark.parametrize("pipeline", [3, 2, 1], ids=["wavefront", "persistent", "per_pixel"])
+@pytest.mark.parametrize("name,w,h,spp,bounces,tile", [("dragon", 320, 180, 2, 4, (0, 0, 0)), ("dragon", 200, 117, 2, 3, (8, 1, 3)),
+                                                       ("theater", 160, 90, 2, 4, (0, 0, 0))])
+def test_batch_of_frames_equals_the_frames(hip, scenes, name, w, h, spp, bounces, tile, pipeline):
+    """flx_render_batch: five frames of a camera move in one pass (117 rows and strips of 8: frames and tiles that do not
+    align) — every frame bit-identical to its own flx_render, the work counters the sum."""
+    sc = scenes(name)
+    hip.update_scene(sc)
+    p0 = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0, tile=tile)
+    frames = [_moved(sc, p0, i) for i in range(5)]
+    hip.set_pipeline(pipeline)
+    try:
+        singles = [hip.render(q, counters=True) for q in frames]
+        got, cnt = hip.render_batch(frames, counters=True)
+        again, _ = hip.render_batch(frames)
+    finally:
+        hip.set_pipeline(0)
+    assert got.shape == (5,) + singles[0][0].shape
+    for i, (want, _, _) in enumerate(singles):
+        assert np.array_equal(got[i], want, equal_nan=True), "frame %d" % i
+        assert np.array_equal(again[i], want, equal_nan=True), "frame %d (uncounted)" % i
+    assert not np.array_equal(got[0], got[1])
+    assert cnt == {k: sum(c[k] for _, c, _ in singles) for k in cnt}
+
+
+def test_batch_arguments(hip, scenes):
+    from flexlight_hip import capi
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=32, height=24, use_filter=0)
+    for bad in ([], [p] * 17):
+        with pytest.raises(capi.FlexLightHipError, match="1 .. 16"):
+            hip.render_batch(bad)
+    q = type(p).from_buffer_copy(p)
+    q.samples = p.samples + 1
+    with pytest.raises(capi.FlexLightHipError, match="differ in camera"):
+        hip.render_batch([p, q])
+    f = sc.frame_params(width=32, height=24, use_filter=1)
+    with pytest.raises(capi.FlexLightHipError, match="cannot be batched"):
+        hip.render_batch([f, f])
+    one, _ = hip.render_batch([p])
+    assert np.array_equal(one[0], hip.render(p)[0], equal_nan=True)
+
+
 def test_tiles_reassemble_full_frame(hip, scenes):
     """Row-strip tile policy (multi-GPU split): strips dealt round-robin reproduce the whole frame."""
     sc = scenes("cornell")

@@ -1,7 +1,7 @@
 """Multi-process shape of the multi-GPU path on CPU (gloo, world_size 2): every rank takes the
 row strips its tile policy assigns (flx_tile_row_count / flx_tile_row_at, the same C entry points
-bench.py uses), the strips are all-gathered with padding and scattered back to image rows exactly
-as bench.py does after the RCCL all-gather.  The per-rank "renderer" here is the CPU oracle (test
+bench.py uses), the strips — of one frame or of a batch of frames — are all-gathered with padding and put
+in image order with the index table bench.py uses after the RCCL all-gather (flexlight_hip/tiles.py).  The per-rank "renderer" here is the CPU oracle (test
 infrastructure), which honours the same tile policy; the point is the partition + gather + reassembly."""
 import os
 import sys
@@ -15,49 +15,61 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tile_rows, w, h, out_dir):
+def _worker(rank, world, port, tile_rows, w, h, frames, out_dir):
     sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import flx_oracle
-    from flexlight_hip import capi
+    from flexlight_hip import capi, tiles
     from flexlight_hip.scene_io import Scene
     sc = Scene.golden("cornell")
     p = sc.frame_params(width=w, height=h, samples=1, max_reflections=2, use_filter=0, tile=(tile_rows, rank, world))
     rows = capi.Context.tile_rows(p)
-    part, _, _ = flx_oracle.render(sc, p, threads=2)
-    assert part.shape[0] == len(rows)
-    strips = (h + tile_rows - 1) // tile_rows
-    rows_max = ((strips + world - 1) // world) * tile_rows
-    local = torch.zeros((rows_max, w, 4))
-    local[:len(rows)] = torch.from_numpy(part)
+    rows_max = tiles.padded_rows(h, tile_rows, world)
+    # what flx_render_batch_device leaves in this rank's buffer: the batch packed tight at the start of frames * rows_max rows
+    local = torch.zeros((frames * rows_max, w, 4))
+    for i in range(frames):
+        p.random_seed = float(i)
+        part, _, _ = flx_oracle.render(sc, p, threads=2)
+        assert part.shape[0] == len(rows)
+        local[i * len(rows):(i + 1) * len(rows)] = torch.from_numpy(part)
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
-    frame = torch.full((h, w, 4), float("nan"))
-    for r in range(world):
-        pr = sc.frame_params(width=w, height=h, tile=(tile_rows, r, world))
-        rr = capi.Context.tile_rows(pr)
-        frame[rr] = gathered[r][:len(rr)]
+    rows_of = [capi.Context.tile_rows(sc.frame_params(width=w, height=h, tile=(tile_rows, r, world))) for r in range(world)]
+    perm = torch.from_numpy(tiles.gather_index(rows_of, frames, rows_max, h))
+    out = torch.index_select(torch.cat(gathered), 0, perm).view(frames, h, w, 4)
     if rank == 0:
-        np.save(os.path.join(out_dir, "frame.npy"), frame.numpy())
+        np.save(os.path.join(out_dir, "frames.npy"), out.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tile_rows,h", [(8, 64), (8, 52), (5, 37)])
-def test_two_ranks_reassemble_the_frame(tmp_path, tile_rows, h):
+@pytest.mark.parametrize("tile_rows,h,frames", [(8, 64, 1), (8, 52, 1), (5, 37, 1), (8, 52, 3)])
+def test_two_ranks_reassemble_the_frames(tmp_path, tile_rows, h, frames):
     sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import flx_oracle
     from flexlight_hip.scene_io import Scene
     flx_oracle.build()
     w = 48
-    port = 29500 + (os.getpid() % 2000) + tile_rows
-    mp.spawn(_worker, args=(2, port, tile_rows, w, h, str(tmp_path)), nprocs=2, join=True)
-    frame = np.load(tmp_path / "frame.npy")
+    port = 29500 + (os.getpid() % 2000) + tile_rows + 16 * frames
+    mp.spawn(_worker, args=(2, port, tile_rows, w, h, frames, str(tmp_path)), nprocs=2, join=True)
+    got = np.load(tmp_path / "frames.npy")
     sc = Scene.golden("cornell")
-    full, _, _ = flx_oracle.render(sc, sc.frame_params(width=w, height=h, samples=1, max_reflections=2, use_filter=0), threads=2)
-    assert not np.isnan(frame[..., 3]).any()
-    assert np.array_equal(frame, full, equal_nan=True)
+    p = sc.frame_params(width=w, height=h, samples=1, max_reflections=2, use_filter=0)
+    for i in range(frames):
+        p.random_seed = float(i)
+        full, _, _ = flx_oracle.render(sc, p, threads=2)
+        assert np.array_equal(got[i], full, equal_nan=True)
+    if frames > 1:
+        assert not np.array_equal(got[0], got[1])
+
+
+def test_gather_index_refuses_uncovered_frames():
+    sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+    from flexlight_hip import tiles
+    assert tiles.padded_rows(1080, 8, 8) == 136
+    with pytest.raises(ValueError):
+        tiles.gather_index([[0, 1], [3]], 1, 2, 4)

@@ -363,6 +363,14 @@ extern "C" uint32_t flx_tile_row_at(const flx_frame_params *p, uint32_t k) {
   return (strip * tc + ti) * tr + (k - strip * tr);
 }
 
+static void fill_view(const flx_frame_params *p, FrameView &v) {
+  memcpy(v.camera, p->camera, sizeof v.camera);
+  flx_invert3x3(p->view_matrix, v.inv_view);
+  v.view_row2[0] = p->view_matrix[6]; v.view_row2[1] = p->view_matrix[7]; v.view_row2[2] = p->view_matrix[8];
+  memcpy(v.ambient, p->ambient, sizeof v.ambient);
+  v.random_seed = p->random_seed;
+}
+
 static flx_status make_frame(flx_context *ctx, const flx_frame_params *p, DeviceScene &sc, DeviceFrame &fr) {
   if (!p) return fail(ctx, FLX_ERR_INVALID, "frame params are NULL");
   if (!ctx->have_scene || !ctx->have_transforms) return fail(ctx, FLX_ERR_NO_SCENE, "render before flx_scene_upload / flx_transforms_upload");
@@ -378,15 +386,13 @@ static flx_status make_frame(flx_context *ctx, const flx_frame_params *p, Device
   tile_normalise(p, tr, ti, tc);
   fr.width = p->width; fr.height = p->height;
   fr.rows = flx_tile_row_count(p);
+  fr.frame_rows = fr.rows; fr.frames = 1;
   fr.tile_rows = tr; fr.tile_index = ti; fr.tile_count = tc;
-  memcpy(fr.camera, p->camera, sizeof fr.camera);
-  flx_invert3x3(p->view_matrix, fr.inv_view);
-  fr.view_row2[0] = p->view_matrix[6]; fr.view_row2[1] = p->view_matrix[7]; fr.view_row2[2] = p->view_matrix[8];
+  memset(fr.view, 0, sizeof fr.view);
+  fill_view(p, fr.view[0]);
   fr.samples = p->samples; fr.max_reflections = p->max_reflections;
   fr.min_importancy = p->min_importancy;
   fr.use_filter = p->use_filter; fr.is_temporal = p->is_temporal;
-  memcpy(fr.ambient, p->ambient, sizeof fr.ambient);
-  fr.random_seed = p->random_seed;
   fr.texture_width = (float)p->texture_width;
   /* An entry names a transform; the shader indexes the UBO unchecked, we refuse an index past the upload. */
   if (ctx->max_transform >= ctx->n_transforms) return fail(ctx, FLX_ERR_INVALID, "scene names a transform that was not uploaded");
@@ -690,6 +696,68 @@ extern "C" flx_status flx_render_device(flx_context *ctx, const flx_frame_params
   if (params->use_filter || params->is_temporal) return run_post_frame(ctx, sc, fr, params, (float4 *)d_out_rgba);
   GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   return run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
+}
+
+/* A batch of frames in ONE pass of the pipeline: the frames are stacked in the packed-row dimension, so every kernel of the
+ * pass — primary, shade, walk, resolve — runs once over n times the paths.  A walk kernel lasts as long as its longest walk
+ * (DESIGN.md §4); over a batch that tail is paid once per n frames. */
+static_assert(FLX_MAX_BATCH == FLX_MAX_BATCH_FRAMES, "flx_device.h and flexlight_hip.h disagree on the batch limit");
+static flx_status make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, DeviceScene &sc, DeviceFrame &fr) {
+  if (!params || n_frames < 1 || n_frames > FLX_MAX_BATCH) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: 1 .. 16 frames per batch");
+  flx_status s = make_frame(ctx, params, sc, fr);
+  if (s) return s;
+  if (params->use_filter || params->is_temporal)
+    return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: filter / temporal frames depend on the frame before and cannot be batched");
+  for (uint32_t i = 1; i < n_frames; i++) {
+    const flx_frame_params &a = params[0], &b = params[i];
+    if (a.width != b.width || a.height != b.height || a.samples != b.samples || a.max_reflections != b.max_reflections ||
+        a.min_importancy != b.min_importancy || a.use_filter != b.use_filter || a.is_temporal != b.is_temporal || a.hdr != b.hdr ||
+        a.texture_width != b.texture_width || a.tile_rows != b.tile_rows || a.tile_index != b.tile_index || a.tile_count != b.tile_count)
+      return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: the frames of a batch may differ in camera, view_matrix, ambient and random_seed only");
+    fill_view(&b, fr.view[i]);
+  }
+  fr.frames = n_frames;
+  fr.rows = fr.frame_rows * n_frames;
+  if ((double)fr.rows * fr.width >= 4294967296.0) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: batch too large");
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_render_batch_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, void *d_out_rgba) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch_device: output pointer is NULL");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceScene sc; DeviceFrame fr;
+  flx_status s = make_batch(ctx, params, n_frames, sc, fr);
+  if (s) return s;
+  GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  return run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
+}
+
+extern "C" flx_status flx_render_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, float *out_rgba, flx_counters *counters) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: out_rgba is NULL");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceScene sc; DeviceFrame fr;
+  flx_status s = make_batch(ctx, params, n_frames, sc, fr);
+  if (s) return s;
+  const size_t pixels = (size_t)fr.rows * fr.width;
+  if (pixels == 0) return FLX_OK;
+  if ((s = ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
+  const bool saved = ctx->counters_enabled;
+  if (counters) ctx->counters_enabled = true;
+  GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  s = run_frame(ctx, sc, fr, ctx->d_out, gb);
+  ctx->counters_enabled = saved;
+  if (s) return s;
+  FLX_HIP(ctx, hipMemcpyAsync(out_rgba, ctx->d_out, pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
+  unsigned long long host_cnt[8];
+  if (counters) FLX_HIP(ctx, hipMemcpyAsync(host_cnt, ctx->d_counters, sizeof host_cnt, hipMemcpyDeviceToHost, ctx->stream));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (counters) {
+    memcpy(counters, host_cnt, sizeof host_cnt);
+    ctx->last_counters = *counters;
+  }
+  return FLX_OK;
 }
 
 /* ---- filter frames across GPUs: the trace is per pixel and shards by row strips, the denoise chain is not ---- */

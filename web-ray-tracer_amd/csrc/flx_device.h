@@ -100,19 +100,26 @@ FLX_DEV uint32_t linkIndex(uint32_t link) { return link & LINK_INDEX; }
 FLX_DEV uint32_t linkKind(uint32_t link) { return (link >> LINK_KIND_SHIFT) & 3u; }
 
 /* Per-frame constants (flx_frame_params + what the host derives from it). */
-struct DeviceFrame {
-  uint32_t width, height;       /* full canvas */
-  uint32_t rows;                /* packed rows this context renders */
-  uint32_t tile_rows, tile_index, tile_count;
+/* What may differ between the frames of one batch (flx_render_batch_device): the camera and the per-frame uniforms. */
+struct FrameView {
   float camera[3];
   float inv_view[9];            /* row-major inverse of viewMatrix */
   float view_row2[3];
+  float ambient[3];
+  float random_seed;
+};
+#define FLX_MAX_BATCH 16
+struct DeviceFrame {
+  uint32_t width, height;       /* full canvas of ONE frame */
+  uint32_t rows;                /* packed rows this context renders: frames x frame_rows */
+  uint32_t frame_rows;          /* packed rows of one frame (this context's strips of it) */
+  uint32_t frames;              /* frames of the batch, stacked in the packed-row dimension; 1 for a single frame */
+  uint32_t tile_rows, tile_index, tile_count;
   int samples, max_reflections;
   float min_importancy;
   int use_filter, is_temporal;
-  float ambient[3];
-  float random_seed;
   float texture_width;
+  FrameView view[FLX_MAX_BATCH];
 };
 
 struct WorkCounters {           /* per-thread tallies, mirrors flx_counters */
@@ -126,8 +133,13 @@ FLX_DEV M3 rotation_at(const DeviceScene &sc, int i) {
 }
 FLX_DEV f3 shift_at(const DeviceScene &sc, int i) { float4 s = sc.shift[i]; return F3(s.x, s.y, s.z); }
 
-/* image row (0 = top) of packed row k under the tile policy */
+/* frame of the batch packed row k belongs to */
+FLX_DEV uint32_t frame_index(const DeviceFrame &fr, uint32_t k) { return fr.frames > 1u ? k / fr.frame_rows : 0u; }
+FLX_DEV f3 frame_camera(const DeviceFrame &fr, uint32_t f) { return F3(fr.view[f].camera[0], fr.view[f].camera[1], fr.view[f].camera[2]); }
+FLX_DEV f3 frame_ambient(const DeviceFrame &fr, uint32_t f) { return F3(fr.view[f].ambient[0], fr.view[f].ambient[1], fr.view[f].ambient[2]); }
+/* image row (0 = top, within its frame) of packed row k under the tile policy */
 FLX_DEV uint32_t image_row(const DeviceFrame &fr, uint32_t k) {
+  if (fr.frames > 1u) k %= fr.frame_rows;
   if (fr.tile_count <= 1u) return k;
   uint32_t strip = k / fr.tile_rows;
   return (strip * fr.tile_count + fr.tile_index) * fr.tile_rows + (k - strip * fr.tile_rows);
@@ -365,6 +377,7 @@ struct PixelState {
   f3 originalColor;
   f4 renderId, renderOriginalId;
   float ndc_x, ndc_y;
+  float seed;                   /* randomSeed of the pixel's frame */
 };
 
 /* State of one path between bounces (what lightTrace keeps in locals, fragment:464-474). */
@@ -397,7 +410,7 @@ FLX_DEV void reservoirPick(const DeviceScene &sc, const DeviceFrame &fr, PixelSt
   int reservoirNum = 0;
   float reservoirWeight = 0.0f;
   f3 reservoirLightDir = F3(0.0f, 0.0f, 0.0f);
-  f4 n0 = noise(fr.random_seed, randomVec.z, randomVec.w, BIAS);
+  f4 n0 = noise(ps.seed, randomVec.z, randomVec.w, BIAS);
   float lastRandomX = n0.x, lastRandomY = n0.y;
   const int size = (int)sc.n_lights;
   for (int j = 0; j < size; j++) {
@@ -416,7 +429,7 @@ FLX_DEV void reservoirPick(const DeviceScene &sc, const DeviceFrame &fr, PixelSt
       reservoirWeight = weight;
       reservoirLightDir = dir;
     }
-    f4 n1 = noise(fr.random_seed, lastRandomX, lastRandomY, BIAS);
+    f4 n1 = noise(ps.seed, lastRandomX, lastRandomY, BIAS);
     lastRandomX = n1.z; lastRandomY = n1.w;
   }
   f3 unitLightDir = normalize(reservoirLightDir);
@@ -500,7 +513,7 @@ FLX_DEV void shadeSample(const DeviceScene &sc, const DeviceFrame &fr, const Sur
   const f3 smoothNormal = sf.smoothNormal;
   p.ray.origin = sf.origin;
   p.ray.dir = sf.dir;
-  f4 randomVec = noise(fr.random_seed, ps.ndc_x, ps.ndc_y, fi + cosSampleN);
+  f4 randomVec = noise(ps.seed, ps.ndc_x, ps.ndc_y, fi + cosSampleN);
   f3 randomSpheareVec = normalize(smoothNormal + normalize(F3(randomVec.x, randomVec.y, randomVec.z)));
   f3 roughNormal = normalize(mix(smoothNormal, randomSpheareVec, sf.roughnessBRDF));
   f3 H = normalize(roughNormal - p.ray.dir);
@@ -1027,14 +1040,14 @@ FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps
   return true;
 }
 
-/* Primary ray of pixel (px, py_gl): unit direction, NDC, view depth per unit s. */
-FLX_DEV f3 primary_dir(const DeviceFrame &fr, uint32_t px, uint32_t py_gl, float &nx, float &ny, float &viewDepthPerS) {
+/* Primary ray of pixel (px, py_gl) of frame f of the batch: unit direction, NDC, view depth per unit s. */
+FLX_DEV f3 primary_dir(const DeviceFrame &fr, uint32_t f, uint32_t px, uint32_t py_gl, float &nx, float &ny, float &viewDepthPerS) {
   nx = ((float)px + 0.5f) / (float)fr.width * 2.0f - 1.0f;
   ny = ((float)py_gl + 0.5f) / (float)fr.height * 2.0f - 1.0f;
-  const float *iv = fr.inv_view;
+  const float *iv = fr.view[f].inv_view;
   f3 d = F3((iv[0] * nx + iv[1] * ny) + iv[2], (iv[3] * nx + iv[4] * ny) + iv[5], (iv[6] * nx + iv[7] * ny) + iv[8]);
   d = normalize(d);
-  viewDepthPerS = dot(F3(fr.view_row2[0], fr.view_row2[1], fr.view_row2[2]), d);
+  viewDepthPerS = dot(F3(fr.view[f].view_row2[0], fr.view[f].view_row2[1], fr.view[f].view_row2[2]), d);
   return d;
 }
 

@@ -36,8 +36,10 @@ __global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFram
     ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
     ps.renderOriginalId = ps.renderId;
     float viewDepthPerS;
-    f3 dir0 = primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
-    const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
+    const uint32_t frameIdx = frame_index(fr, k);
+    ps.seed = fr.view[frameIdx].random_seed;
+    f3 dir0 = primary_dir(fr, frameIdx, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+    const f3 camera = frame_camera(fr, frameIdx);
     Ray pr; pr.origin = camera; pr.dir = dir0;
     Hit hit0 = primaryWalkT(sc, pr, viewDepthPerS, cnt.primary_visits);
     const size_t o = (size_t)k * fr.width + px;
@@ -69,7 +71,7 @@ __global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFram
         for (int i = 1; alive && i < fr.max_reflections && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3; i++) {
           if (!bounce<COUNT>(sc, fr, ps, p, camera, cosSampleN, i, cnt)) break;
         }
-        finalColor = finalColor + (p.finalColor + p.importancyFactor * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]));
+        finalColor = finalColor + (p.finalColor + p.importancyFactor * frame_ambient(fr, frameIdx));
       }
       float invSamples = 1.0f / (float)fr.samples;
       finalColor = finalColor * invSamples;
@@ -139,8 +141,9 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
     const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
     float nx, ny, viewDepthPerS;
     Ray pr;
-    pr.dir = primary_dir(fr, px, py_gl, nx, ny, viewDepthPerS);
-    pr.origin = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
+    const uint32_t frameIdx = frame_index(fr, k);
+    pr.dir = primary_dir(fr, frameIdx, px, py_gl, nx, ny, viewDepthPerS);
+    pr.origin = frame_camera(fr, frameIdx);
     Hit h = primaryWalkT(sc, pr, viewDepthPerS, cnt.primary_visits);
     if (COUNT && h.triangleId != -1) cnt.primary_hits++;
     hits[(size_t)k * fr.width + px] = make_float4(h.suv.x, h.suv.y, h.suv.z, __int_as_float(h.triangleId));
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t S = (uint32_t)fr.samples;
   const size_t P = (size_t)fr.rows * fr.width;
-  const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
+  f3 camera = F3(0.0f, 0.0f, 0.0f);             /* of the frame the lane's path belongs to */
+  uint32_t frameIdx = 0;
   WorkCounters cnt = {};
   bool alive = false;
   PathState p;
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
   uint32_t chunkNext = 0, chunkEnd = 0;      /* wave-uniform */
   bool itemsLeft = true;                     /* wave-uniform */
   auto finishPath = [&]() {                  /* fragment:598 + what main() needs from the last sample */
-    const f3 r = p.finalColor + p.importancyFactor * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]);
+    const f3 r = p.finalColor + p.importancyFactor * frame_ambient(fr, frameIdx);
     sampleRadiance[slot] = make_float4(r.x, r.y, r.z, 1.0f);
     if (sampleIdx == S - 1u)
       lastOriginal[slot - (size_t)sampleIdx * P] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 1.0f);
@@ -208,7 +212,10 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
           if (tri != -1) {
             const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
             float viewDepthPerS;
-            const f3 dir0 = primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+            frameIdx = frame_index(fr, k);
+            camera = frame_camera(fr, frameIdx);
+            ps.seed = fr.view[frameIdx].random_seed;
+            const f3 dir0 = primary_dir(fr, frameIdx, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
             ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
             ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
             ps.renderOriginalId = ps.renderId;

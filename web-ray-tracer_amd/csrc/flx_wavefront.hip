@@ -81,11 +81,12 @@ __global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame f
   const uint32_t tileLocal = t >> 6;
   if (tileLocal * S * 64u >= total_items) return;
   const uint32_t tile = wb.item_base / (S * 64u) + tileLocal;
-  const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
   WorkCounters cnt = {};
   uint32_t px, k;
   tile8_pixel(fr, tile, lane, px, k);
   const bool inFrame = px < fr.width && k < fr.rows;
+  const uint32_t frameIdx = inFrame ? frame_index(fr, k) : 0u;
+  const f3 camera = frame_camera(fr, frameIdx);
   int tri = -1;
   float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
   if (inFrame) { h = wb.hits[(size_t)k * fr.width + px]; tri = __float_as_int(h.w); }
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame f
     float viewDepthPerS;
     Ray pr;
     pr.origin = camera;
-    pr.dir = primary_dir(fr, px, py_gl, ndcX, ndcY, viewDepthPerS);
+    pr.dir = primary_dir(fr, frameIdx, px, py_gl, ndcX, ndcY, viewDepthPerS);
     const WorkCounters before = cnt;
     shadeSurface<COUNT>(sc, fr, hit, pr, camera, sf, cnt);
     if (COUNT) {                                            /* the per-path kernel counts these once per path */
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame f
     ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
     ps.renderOriginalId = ps.renderId;
     ps.ndc_x = ndcX; ps.ndc_y = ndcY;
+    ps.seed = fr.view[frameIdx].random_seed;
     ps.originalColor = F3(1.0f, 1.0f, 1.0f);
     p.hit = hit;
     p.lastHitPoint = camera;
@@ -148,7 +150,6 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b) {
   const uint32_t n = wb.counts[b];
   const uint32_t *__restrict__ listIn = wb.live[b & 1];
-  const f3 camera = F3(fr.camera[0], fr.camera[1], fr.camera[2]);
   WorkCounters cnt = {};
   for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
     const uint32_t pathId = listIn[j];
@@ -156,6 +157,8 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
     float4 *rec = wb.rec + (size_t)pathId * 8;
     uint32_t px, k, s;
     item_pixel(fr, pathId, px, k, s);
+    const uint32_t frameIdx = frame_index(fr, k);
+    const f3 camera = frame_camera(fr, frameIdx);
     PathState p;
     PixelState ps;
     ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
     ps.originalColor = F3(q7.x, q7.y, q7.z);
     const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
     float viewDepthPerS;
-    (void)primary_dir(fr, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+    (void)primary_dir(fr, frameIdx, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+    ps.seed = fr.view[frameIdx].random_seed;
     const float cosSampleN = flx_cos((float)s);
     ShadeOut so;
     bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, pb, so, cnt);

@@ -25,7 +25,7 @@ __device__ __forceinline__ void finalize_path(const DeviceFrame &fr, const Wavef
   item_pixel(fr, pathId, px, k, s);
   const size_t P = (size_t)fr.rows * fr.width;
   const size_t o = (size_t)k * fr.width + px;
-  const f3 r = finalColor + importancy * F3(fr.ambient[0], fr.ambient[1], fr.ambient[2]);          /* fragment:598 */
+  const f3 r = finalColor + importancy * frame_ambient(fr, frame_index(fr, k));          /* fragment:598 */
   wb.sampleRadiance[(size_t)s * P + o] = make_float4(r.x, r.y, r.z, 1.0f);
   if (s == (uint32_t)fr.samples - 1u) wb.lastOriginal[o] = make_float4(originalColor.x, originalColor.y, originalColor.z, 1.0f);
 }

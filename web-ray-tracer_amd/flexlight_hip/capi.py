@@ -18,10 +18,13 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_planes_device", "flx_filter_planes_device",
+    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset",
 ]
+
+
+MAX_BATCH_FRAMES = 16          # FLX_MAX_BATCH_FRAMES of include/flexlight_hip.h
 
 
 class FlexLightHipError(RuntimeError):
@@ -62,6 +65,8 @@ def _load():
         "flx_last_pipeline": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "flx_temporal_reset": (C.c_int, [vp]),
         "flx_set_walk_scheduler": (C.c_int, [vp, C.c_int, C.c_uint32]),
+        "flx_render_batch": (C.c_int, [vp, C.POINTER(FrameParams), u32, fp, C.POINTER(Counters)]),
+        "flx_render_batch_device": (C.c_int, [vp, C.POINTER(FrameParams), u32, vp]),
         "flx_render_planes_device": (C.c_int, [vp, C.c_void_p, C.c_void_p]),
         "flx_filter_planes_device": (C.c_int, [vp, C.c_void_p, C.c_void_p, C.c_void_p]),
         "flx_mesh_import_obj": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(vp)]),
@@ -167,6 +172,21 @@ class Context:
         rc = LIB.flx_render(self._h, C.byref(params), _fp(out), C.byref(gb) if gb else None, C.byref(cnt) if cnt else None)
         self._check(rc, "flx_render")
         return out, (cnt.as_dict() if cnt else None), gbs
+
+    def render_batch(self, params_list, counters=False):
+        """1 .. 16 frames in one pass -> (rgba [n, rows, W, 4] float32, counters dict (summed over the batch) or None)."""
+        n = len(params_list)
+        arr = (FrameParams * n)(*params_list)
+        rows, width = (self.tile_row_count(params_list[0]), params_list[0].width) if n else (0, 0)
+        out = np.zeros((n, rows, width, 4), np.float32) if n else np.zeros(4, np.float32)      # an empty batch is the library's to refuse
+        cnt = Counters() if counters else None
+        self._check(LIB.flx_render_batch(self._h, arr, n, _fp(out), C.byref(cnt) if cnt else None), "flx_render_batch")
+        return out, (cnt.as_dict() if cnt else None)
+
+    def render_batch_device(self, params_list, device_ptr):
+        n = len(params_list)
+        arr = (FrameParams * n)(*params_list)
+        self._check(LIB.flx_render_batch_device(self._h, arr, n, C.c_void_p(device_ptr)), "flx_render_batch_device")
 
     def render_device(self, params, device_ptr):
         self._check(LIB.flx_render_device(self._h, C.byref(params), C.c_void_p(device_ptr)), "flx_render_device")
