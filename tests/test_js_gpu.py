@@ -59,3 +59,22 @@ def test_antialiasing_through_node(hip, oracle, scenes, tmp_path):
     subprocess.check_output(base + ["--out", str(out), "--aa", "taa", "--frames", "3"], timeout=300)
     taa = np.fromfile(out, np.float32).reshape(h, w, 4)
     assert np.isfinite(taa).all() and taa.max() > 0 and not np.array_equal(taa, plain)
+
+
+def test_render_batch_through_node(hip, scenes, tmp_path):
+    """renderer.renderBatch(cameras): four frames of a camera move in one pass, each equal to the renderFrame() of its camera
+    (compared inside Node, bit for bit) and — frame 0, the fixture's camera — to the ctypes binding's frame."""
+    node = shutil.which("node")
+    w, h, spp, bounces = 96, 64, 2, 3
+    out = tmp_path / "batch.f32"
+    info = json.loads(subprocess.check_output(
+        [node, os.path.join(ROOT, "tools", "render_scene.js"), "cornell", "--out", str(out), "--width", str(w), "--height", str(h), "--spp", str(spp),
+         "--bounces", str(bounces), "--filter", "0", "--assets", "/nonexistent", "--batch", "4"], timeout=300).decode().splitlines()[-1])
+    assert info["frames"] == 4 and info["batchEqualsFrames"] is True
+    got = np.fromfile(out, np.float32).reshape(4, h, w, 4)
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    first, cnt, _ = hip.render(sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0), counters=True)
+    assert np.array_equal(got[0], first, equal_nan=True)
+    assert not np.array_equal(got[0], got[1])
+    assert info["counters"]["primaryHits"] >= cnt["primary_hits"]

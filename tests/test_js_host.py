@@ -88,7 +88,7 @@ def test_napi_addon_loads_and_exports():
         pytest.skip("addon not built (run __graft_entry__.build())")
     js = "const a = require('%s'); console.log(JSON.stringify({keys: Object.keys(a), version: a.version()}));" % addon
     out = json.loads(subprocess.check_output([NODE, "-e", js]).decode())
-    for name in ("createContext", "destroyContext", "uploadScene", "uploadTransforms", "uploadLights", "uploadAtlas", "tileRowCount", "render",
+    for name in ("createContext", "destroyContext", "uploadScene", "uploadTransforms", "uploadLights", "uploadAtlas", "tileRowCount", "render", "renderBatch",
                  "meshImport", "meshCounts", "meshSetTransform", "meshMove", "meshScale", "meshSetMaterial", "meshBounding", "meshFlatten", "packTransforms", "fxaa", "taa", "taaReset"):
         assert name in out["keys"]
     assert "flexlight-hip" in out["version"]

@@ -2,7 +2,7 @@
 /*
  * Render one BASELINE scene through the whole JavaScript path — FlexLight facade, scene graph, host
  * flattening, N-API addon, libflexlight_hip.so — and write the float32 radiance to a file.
- *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --aa fxaa|taa --frames N --assets DIR]
+ *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --aa fxaa|taa --frames N --batch N --assets DIR]
  */
 const fs = require('fs');
 const os = require('os');
@@ -41,6 +41,22 @@ function loadImage (rel) {
   engine.config.antialiasing = opt('--aa', undefined);               // 'fxaa' | 'taa'
   engine.renderer = 'pathtracer';
   await engine.renderer.updateScene();
+  const batch = Number(opt('--batch', 0));                            // N frames of a camera move through renderBatch: all N are written
+  if (batch > 0) {
+    const cam = engine.camera;
+    const cameras = Array.from({ length: batch }, (_, i) => ({ x: cam.x + 0.3 * i, y: cam.y + 0.1 * i, fx: cam.fx + 0.05 * i, fy: cam.fy - 0.02 * i }));
+    const b = engine.renderer.renderBatch(cameras, { counters: true });
+    let same = true;                                                  // every frame of the batch against the renderFrame() of its camera
+    cameras.forEach((c, i) => {
+      Object.assign(cam, c);
+      const single = engine.renderer.renderFrame().radiance;
+      same = same && single.length === b.frames[i].length && single.every((v, k) => Object.is(v, b.frames[i][k]));
+    });
+    fs.writeFileSync(opt('--out', 'frame.f32'), Buffer.concat(b.frames.map(f => Buffer.from(f.buffer, f.byteOffset, f.byteLength))));
+    console.log(JSON.stringify({ width: b.width, height: b.height, rows: b.rows, frames: batch, frameMs: b.frameMs, counters: b.counters, batchEqualsFrames: same }));
+    engine.renderer.halt();
+    return;
+  }
   const frames = Number(opt('--frames', 1));                          // the last of `frames` frames is written (TAA keeps history)
   let f;
   for (let k = 0; k < frames; k++) f = engine.renderer.renderFrame({ counters: true });

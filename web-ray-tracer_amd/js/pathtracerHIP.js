@@ -157,6 +157,36 @@ class PathTracerHIP {
     return this.lastFrame;
   }
 
+  /* Several frames of a camera path in ONE pass of the GPU pipeline (flx_render_batch; not in the reference, which renders frame
+   * after frame): `cameras` is an array of up to 16 camera states { x, y, z, fx, fy } (missing fields default to this.camera's;
+   * fov comes from this.camera).  Frames without filter, temporal accumulation and anti-aliasing only — those depend on the frame
+   * before.  Returns { width, height, rows, frames: [Float32Array(rows*width*4), ...], frameMs, counters? }; every frame equals
+   * the renderFrame() of its camera. */
+  renderBatch (cameras, options) {
+    if (this.config.filter || this.config.temporal || this._antialiasing()) throw new Error('renderBatch: filter, temporal and antialiasing frames depend on the frame before');
+    const ctx = this._context();
+    if (!this._haveScene) {
+      const built = this.scene.generateArraysFromGraph();
+      native().uploadScene(ctx, built.geometryBuffer, built.sceneBuffer, built.idBuffer);
+      this._haveScene = true;
+    }
+    this._updateAtlases();
+    native().uploadLights(ctx, sceneFile.buildLightArray(this.scene));
+    const tr = Transform.buildWGL2Arrays();
+    native().uploadTransforms(ctx, tr[0], tr[1]);
+    const saved = this.camera;
+    const params = cameras.map(c => {
+      this.camera = Object.assign(Object.create(saved), c);
+      try { return this.frameParams(); } finally { this.camera = saved; }
+    });
+    const rows = native().tileRowCount(params[0]);
+    const per = rows * params[0].width * 4;
+    const all = new Float32Array(per * params.length);
+    const info = native().renderBatch(ctx, params, all, !!(options && options.counters));
+    const frames = params.map((_, i) => all.subarray(i * per, (i + 1) * per));
+    return Object.assign({ width: params[0].width, height: params[0].height, rows, frames }, info);
+  }
+
   async render () {                                       // pathtracerWGL2.js:191-831: start the frame loop
     if (!this._halt) return;                              // already running (the WebGPU renderer guards the same way)
     this._halt = false;

@@ -248,6 +248,50 @@ static napi_value Render(napi_env env, napi_callback_info info) {
   return res;
 }
 
+/* renderBatch(handle, [params, ...], out Float32Array, wantCounters) -> { frameMs, counters? }: flx_render_batch, the frames
+ * one after the other in `out` */
+static napi_value RenderBatch(napi_env env, napi_callback_info info) {
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  uint32_t count = 0;
+  bool isArray = false;
+  napi_is_array(env, argv[1], &isArray);
+  if (!isArray || napi_get_array_length(env, argv[1], &count) != napi_ok || count < 1 || count > FLX_MAX_BATCH_FRAMES) {
+    napi_throw_range_error(env, nullptr, "renderBatch: an array of 1 .. 16 frame parameter objects");
+    return nullptr;
+  }
+  flx_frame_params p[FLX_MAX_BATCH_FRAMES];
+  for (uint32_t i = 0; i < count; i++) {
+    napi_value e;
+    NAPI_OK(env, napi_get_element(env, argv[1], i, &e));
+    if (!read_params(env, e, &p[i])) return nullptr;
+  }
+  void *out; size_t n;
+  if (!typed(env, argv[2], napi_float32_array, &out, &n)) return nullptr;
+  if (!out || n != (size_t)count * flx_tile_row_count(&p[0]) * p[0].width * 4) { napi_throw_range_error(env, nullptr, "out needs frames*rows*width*4 floats"); return nullptr; }
+  bool want = false;
+  napi_get_value_bool(env, argv[3], &want);
+  flx_counters c;
+  flx_status rc = flx_render_batch(ctx, p, count, (float *)out, want ? &c : nullptr);
+  if (rc != FLX_OK) return fail(env, ctx, "flx_render_batch", rc);
+  float frame_ms = 0.f, trace_ms = 0.f;
+  flx_last_frame_ms(ctx, &frame_ms, &trace_ms);
+  napi_value res, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  napi_create_double(env, frame_ms, &v); napi_set_named_property(env, res, "frameMs", v);
+  if (want) {
+    napi_value co;
+    napi_create_object(env, &co);
+    const char *names[8] = { "primaryVisits", "closestVisits", "shadowVisits", "closestWalks", "shadowWalks", "shades", "primaryHits", "atlasTexels" };
+    const uint64_t vals[8] = { c.primary_visits, c.closest_visits, c.shadow_visits, c.closest_walks, c.shadow_walks, c.shades, c.primary_hits, c.atlas_texels };
+    for (int i = 0; i < 8; i++) { napi_create_double(env, (double)vals[i], &v); napi_set_named_property(env, co, names[i], v); }
+    napi_set_named_property(env, res, "counters", co);
+  }
+  return res;
+}
+
 /* temporalReset(handle): forget the temporal history */
 static napi_value TemporalReset(napi_env env, napi_callback_info info) {
   napi_value argv[1];
@@ -448,7 +492,7 @@ static napi_value Init(napi_env env, napi_value exports) {
   const struct { const char *name; napi_callback fn; } fns[] = {
     { "createContext", CreateContext }, { "destroyContext", DestroyContext }, { "uploadScene", UploadScene },
     { "uploadTransforms", UploadTransforms }, { "uploadLights", UploadLights }, { "uploadAtlas", UploadAtlas },
-    { "tileRowCount", TileRowCount }, { "render", Render }, { "temporalReset", TemporalReset }, { "deviceInfo", DeviceInfo }, { "version", Version },
+    { "tileRowCount", TileRowCount }, { "render", Render }, { "renderBatch", RenderBatch }, { "temporalReset", TemporalReset }, { "deviceInfo", DeviceInfo }, { "version", Version },
     { "meshImport", MeshImport }, { "meshCounts", MeshCounts }, { "meshSetTransform", MeshSetTransform }, { "meshMove", MeshMove },
     { "meshScale", MeshScale }, { "meshSetMaterial", MeshSetMaterial }, { "meshFlatten", MeshFlatten }, { "meshBounding", MeshBounding }, { "packTransforms", PackTransforms },
     { "fxaa", Fxaa }, { "taa", Taa }, { "taaReset", TaaReset },
