@@ -92,13 +92,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--tile-rows", type=int, default=8)
     ap.add_argument("--batch", type=int, default=16, help="frames per pass of the pipeline (flx_render_batch_device); 1 = frame after frame; filter frames are never batched")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame-after-frame", action="store_true", help="skip the one-frame-per-pass measurement after the timed region (profiling runs: every launch of a kernel is then a whole batch)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the rank logic)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     ap.add_argument("--verify", action="store_true", help="after the run, rank 0 renders the whole frame on its own and compares the gathered frame with it (bit for bit)")
@@ -249,7 +250,7 @@ def main():
 
     # frame after frame (latency mode), for the record: the same share of the frame, one frame per pass
     single_ms = None
-    if F > 1:
+    if F > 1 and not args.no_frame_after_frame:
         for it in range(3 + 10):
             if it == 3:
                 torch.cuda.synchronize(); t1 = time.perf_counter()

@@ -16,4 +16,5 @@ for path in sys.argv[1:]:
             continue
         print(name, "dispatches", max(len(v) for v in ctrs.values()))
         for c, v in sorted(ctrs.items()):
-            print("   %-28s %.4g" % (c, sum(v) / len(v)))
+            big = [x for x in v if x >= 0.5 * max(v)]       # bench.py launches batches of frames and single frames: the batches on their own
+            print("   %-28s %.4g   (the %d largest launches: %.4g)" % (c, sum(v) / len(v), len(big), sum(big) / len(big)))
