@@ -415,7 +415,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   /* automatic: tiny scenes (a Cornell box, the theater: a few dozen entries) spend the wavefront pipeline's time on its 128-byte
    * path records, not on walks — the persistent path kernel, which keeps a path in registers from bounce to bounce, is faster
    * there (tools/pipeline_crossover.py: 48 entries 1.96 vs 2.41 ms, 329 entries 4.03 vs 2.85 ms) */
-  if (pipeline == 0) pipeline = (fr.use_filter || fr.is_temporal) ? 1 : ((ctx->walk_entries <= 128u && path_item_count(fr) >= (1u << 20)) ? 2 : 3);       /* (a 256 x 256 frame does not fill the persistent grid) */
+  if (pipeline == 0) pipeline = (fr.use_filter || fr.is_temporal) ? 1 : ((ctx->walk_entries <= 128u && path_item_count64(fr) >= (1u << 20)) ? 2 : 3);       /* (a 256 x 256 frame does not fill the persistent grid) */
   if (pipeline == 3 && fr.max_reflections > WF_MAX_BOUNCES) pipeline = 2;
   ctx->last_pipeline = pipeline;
   if (pipeline != 1 && (fr.use_filter || fr.is_temporal)) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the G-buffers of filter / temporal frames");
@@ -423,10 +423,10 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
   if (pipeline != 1) {
     flx_status s;
+    if (path_item_count64(fr) + 1000000ull >= 4294967296ull) return fail(ctx, FLX_ERR_INVALID, "frame (or batch of frames) too large: more than 2^32 path items");
     if ((s = ensure_pixels(ctx, &ctx->d_hits, &ctx->hits_capacity, P))) return s;
     if ((s = ensure_pixels(ctx, &ctx->d_last, &ctx->last_capacity, P))) return s;
     if ((s = ensure_pixels(ctx, &ctx->d_samples, &ctx->samples_capacity, P * (size_t)fr.samples))) return s;
-    if ((double)path_item_count(fr) + 1.0e6 >= 4294967296.0) return fail(ctx, FLX_ERR_INVALID, "frame too large: more than 2^32 path items");
   }
   if (pipeline == 3) {
     flx_status s;

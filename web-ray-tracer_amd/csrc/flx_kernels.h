@@ -13,6 +13,7 @@ void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *o
                          unsigned long long *counters, hipStream_t stream);
 /* v2 pipeline: primary hits (float4 s,u,v,triangleId-as-bits per pixel) -> persistent path kernel -> resolve. */
 uint32_t path_item_count(const DeviceFrame &fr);
+uint64_t path_item_count64(const DeviceFrame &fr);
 void launch_primary(const DeviceScene &sc, const DeviceFrame &fr, float4 *hits, unsigned long long *counters, hipStream_t stream);
 void launch_paths(const DeviceScene &sc, const DeviceFrame &fr, const float4 *hits, float4 *sampleRadiance, float4 *lastOriginal,
                   uint32_t *queue, uint32_t blocks, unsigned long long *counters, hipStream_t stream);

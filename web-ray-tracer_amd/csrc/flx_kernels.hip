@@ -277,9 +277,10 @@ __global__ __launch_bounds__(256) void k_resolve(DeviceFrame fr, const float4 *_
   out[o] = color;
 }
 
-uint32_t path_item_count(const DeviceFrame &fr) {
-  return ((fr.width + 7u) >> 3) * ((fr.rows + 7u) >> 3) * (uint32_t)fr.samples * 64u;
+uint64_t path_item_count64(const DeviceFrame &fr) {
+  return (uint64_t)((fr.width + 7u) >> 3) * ((fr.rows + 7u) >> 3) * (uint64_t)fr.samples * 64u;
 }
+uint32_t path_item_count(const DeviceFrame &fr) { return (uint32_t)path_item_count64(fr); }      /* callers have checked it fits */
 
 void launch_primary(const DeviceScene &sc, const DeviceFrame &fr, float4 *hits, unsigned long long *counters, hipStream_t stream) {
   const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.rows + 7u) >> 3);
