@@ -34,6 +34,7 @@ WORKLOADS = {
     "cornell_obj": ("cornell_obj", "configs[1]: cornell.obj 1080p, 4 spp, 3 bounces, filter on"),
     "cornell": ("cornell", "configs[0]: examples/cornell.js 256x256, 1 spp, 1 bounce, filter off"),
     "theater": ("theater", "configs[4]: examples/theater.js 1080p, 16 spp, 6 bounces"),
+    "dragon_4k": ("dragon", "configs[3]: dragon.obj (dragon_lp.obj) 3840x2160, 8 spp, 4 bounces", 3840, 2160),
 }
 
 
@@ -130,7 +131,9 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    fixture, config_name = WORKLOADS[args.workload]
+    fixture, config_name = WORKLOADS[args.workload][:2]
+    if len(WORKLOADS[args.workload]) > 2 and args.width is None and args.height is None:
+        args.width, args.height = WORKLOADS[args.workload][2:]
     scene = Scene.golden(fixture)
     full = scene.frame_params(width=args.width, height=args.height)
     use_filter = int(full.use_filter)
