@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--tile-rows", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=16, help="frames per pass of the pipeline (flx_render_batch_device); 1 = frame after frame; filter frames are never batched")
+    ap.add_argument("--batch", type=int, default=32, help="most frames per pass of the pipeline (flx_render_batch_device; a pass also holds at most 2^28 paths: 16 whole 1080p frames of 8 samples); 1 = frame after frame; filter frames are never batched")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frame-after-frame", action="store_true", help="skip the one-frame-per-pass measurement after the timed region (profiling runs: every launch of a kernel is then a whole batch)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the rank logic)")

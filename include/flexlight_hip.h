@@ -135,7 +135,7 @@ flx_status flx_temporal_reset(flx_context *ctx);
  * torch tensor's data_ptr) and enqueued on the context's stream without a host sync: for the
  * multi-GPU gather over RCCL.  Call flx_sync before reading on another stream. */
 flx_status flx_render_device(flx_context *ctx, const flx_frame_params *params, void *d_out_rgba);
-/* A batch of 1 .. 16 frames in one pass of the pipeline (the reference renders frame after frame, pathtracerWGL2.js:329
+/* A batch of 1 .. 32 frames in one pass of the pipeline (the reference renders frame after frame, pathtracerWGL2.js:329
  * frameCycle; frames without filter and without temporal accumulation do not depend on each other).  The frames may differ
  * in camera, view_matrix, ambient and random_seed only; every other field must equal params[0]'s.  Output: the frames one
  * after the other, float4[n_frames][rows][width] with rows = flx_tile_row_count(params) — each frame bit-identical to its
@@ -143,7 +143,7 @@ flx_status flx_render_device(flx_context *ctx, const flx_frame_params *params, v
  * with the frame (the tail of every walk kernel, launches) are paid once per batch: throughput mode, latency n frames. */
 flx_status flx_render_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, float *out_rgba, flx_counters *counters);
 flx_status flx_render_batch_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, void *d_out_rgba);
-#define FLX_MAX_BATCH_FRAMES 16
+#define FLX_MAX_BATCH_FRAMES 32
 flx_status flx_sync(flx_context *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. NULL restores it. */
 flx_status flx_set_stream(flx_context *ctx, void *hip_stream);

@@ -124,8 +124,8 @@ def test_batch_arguments(hip, scenes):
     sc = scenes("cornell")
     hip.update_scene(sc)
     p = sc.frame_params(width=32, height=24, use_filter=0)
-    for bad in ([], [p] * 17):
-        with pytest.raises(capi.FlexLightHipError, match="1 .. 16"):
+    for bad in ([], [p] * 33):
+        with pytest.raises(capi.FlexLightHipError, match="1 .. 32"):
             hip.render_batch(bad)
     q = type(p).from_buffer_copy(p)
     q.samples = p.samples + 1

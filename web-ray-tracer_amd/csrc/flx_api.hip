@@ -703,7 +703,7 @@ extern "C" flx_status flx_render_device(flx_context *ctx, const flx_frame_params
  * (DESIGN.md §4); over a batch that tail is paid once per n frames. */
 static_assert(FLX_MAX_BATCH == FLX_MAX_BATCH_FRAMES, "flx_device.h and flexlight_hip.h disagree on the batch limit");
 static flx_status make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, DeviceScene &sc, DeviceFrame &fr) {
-  if (!params || n_frames < 1 || n_frames > FLX_MAX_BATCH) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: 1 .. 16 frames per batch");
+  if (!params || n_frames < 1 || n_frames > FLX_MAX_BATCH) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: 1 .. 32 frames per batch");
   flx_status s = make_frame(ctx, params, sc, fr);
   if (s) return s;
   if (params->use_filter || params->is_temporal)

@@ -108,7 +108,7 @@ struct FrameView {
   float ambient[3];
   float random_seed;
 };
-#define FLX_MAX_BATCH 16
+#define FLX_MAX_BATCH 32
 struct DeviceFrame {
   uint32_t width, height;       /* full canvas of ONE frame */
   uint32_t rows;                /* packed rows this context renders: frames x frame_rows */

@@ -24,7 +24,7 @@ EXPORTS = [
 ]
 
 
-MAX_BATCH_FRAMES = 16          # FLX_MAX_BATCH_FRAMES of include/flexlight_hip.h
+MAX_BATCH_FRAMES = 32          # FLX_MAX_BATCH_FRAMES of include/flexlight_hip.h
 
 
 class FlexLightHipError(RuntimeError):
@@ -174,7 +174,7 @@ class Context:
         return out, (cnt.as_dict() if cnt else None), gbs
 
     def render_batch(self, params_list, counters=False):
-        """1 .. 16 frames in one pass -> (rgba [n, rows, W, 4] float32, counters dict (summed over the batch) or None)."""
+        """1 .. 32 frames in one pass -> (rgba [n, rows, W, 4] float32, counters dict (summed over the batch) or None)."""
         n = len(params_list)
         arr = (FrameParams * n)(*params_list)
         rows, width = (self.tile_row_count(params_list[0]), params_list[0].width) if n else (0, 0)

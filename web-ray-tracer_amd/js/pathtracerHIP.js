@@ -158,7 +158,7 @@ class PathTracerHIP {
   }
 
   /* Several frames of a camera path in ONE pass of the GPU pipeline (flx_render_batch; not in the reference, which renders frame
-   * after frame): `cameras` is an array of up to 16 camera states { x, y, z, fx, fy } (missing fields default to this.camera's;
+   * after frame): `cameras` is an array of up to 32 camera states { x, y, z, fx, fy } (missing fields default to this.camera's;
    * fov comes from this.camera).  Frames without filter, temporal accumulation and anti-aliasing only — those depend on the frame
    * before.  Returns { width, height, rows, frames: [Float32Array(rows*width*4), ...], frameMs, counters? }; every frame equals
    * the renderFrame() of its camera. */

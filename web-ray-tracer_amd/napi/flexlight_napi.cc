@@ -259,7 +259,7 @@ static napi_value RenderBatch(napi_env env, napi_callback_info info) {
   bool isArray = false;
   napi_is_array(env, argv[1], &isArray);
   if (!isArray || napi_get_array_length(env, argv[1], &count) != napi_ok || count < 1 || count > FLX_MAX_BATCH_FRAMES) {
-    napi_throw_range_error(env, nullptr, "renderBatch: an array of 1 .. 16 frame parameter objects");
+    napi_throw_range_error(env, nullptr, "renderBatch: an array of 1 .. 32 frame parameter objects");
     return nullptr;
   }
   flx_frame_params p[FLX_MAX_BATCH_FRAMES];
