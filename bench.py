@@ -3,9 +3,12 @@
 
 A "step" is one frame of the workload through libflexlight_hip.so's C ABI with the scene resident in
 HBM: path-trace pass (+ denoise chain when the workload has filter on) and, for N > 1, the RCCL
-all-gather of the row-strip tiles plus the reassembly of the frame on every rank.
+all-gather of the row-strip tiles plus the reassembly of the frame on every rank.  The K frames of the
+timed region are rendered in batches of up to --batch frames per pass of the pipeline
+(flx_render_batch_device: every frame complete and bit-identical to its own render) —
+filter frames one by one — and the frame-after-frame rate is reported beside it ("frame_after_frame").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dragon|cornell_obj|cornell|theater]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch F] [--workload dragon|dragon_4k|cornell_obj|cornell|theater]
 
 N > 1 is launched by torch.distributed.run, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
 MASTER_* from the environment).  The frame is cut into strips of --tile-rows image rows dealt
