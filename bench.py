@@ -330,6 +330,7 @@ def main():
                 "workload": config_name, "width": W, "height": H, "spp": spp, "bounces": bounces, "filter": bool(use_filter),
                 "scene_entries": int(scene.meta["textureLength"]), "parallelism": "row-strip tiles x%d, %d rows/strip, RCCL all-gather" % (world, args.tile_rows) if world > 1 else "single GPU",
                 "rays_per_frame": rays, "frames_per_pass": F,
+                "frames": "the static camera of the BASELINE config for every frame, as in the reference's frame loop; every frame is traced in full, nothing is reused between frames",
             },
             "roofline": {
                 "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Frame time of the dragon frame rendered in batches of F frames (flx_render_batch_device), for a rank's share 1/N of the
-frame.  usage: batch_time.py [N ...]   (GPU box)"""
+frame.  usage: [FLX_SCENE=theater] [FLX_PIPELINE=3] [FLX_BATCHES=1,8] batch_time.py [N ...]   (GPU box)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
 import torch
 from flexlight_hip import capi
 from flexlight_hip.scene_io import Scene
-sc = Scene.golden("dragon")
+sc = Scene.golden(os.environ.get("FLX_SCENE", "dragon"))
 ctx = capi.Context(0)
 ctx.update_scene(sc)
+if os.environ.get("FLX_PIPELINE"):
+    ctx.set_pipeline(int(os.environ["FLX_PIPELINE"]))
 for n in [int(a) for a in sys.argv[1:]] or [1, 8]:
     for F in [int(x) for x in os.environ.get("FLX_BATCHES", "1,2,4,8").split(",")]:
         p = sc.frame_params(use_filter=0)
