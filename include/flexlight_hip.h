@@ -177,6 +177,11 @@ flx_status flx_taa_device(flx_context *ctx, uint32_t width, uint32_t height, con
 flx_status flx_fxaa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba);
 flx_status flx_taa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba);
 flx_status flx_taa_reset(flx_context *ctx);
+/* 8-bit present: what the RGBA8 drawing buffer of the reference's canvas holds after the last pass wrote
+ * `out_color` to it (pathtracerWGL2.js:552-553, gl.bindFramebuffer(null)): floor(clamp(x, 0, 1) * 255 + 0.5) per channel,
+ * bytes R G B A, rows top-down.  out_rgba8: width * height * 4 bytes. */
+flx_status flx_present_device(flx_context *ctx, uint32_t width, uint32_t height, const void *d_in_rgba, void *d_out_rgba8);
+flx_status flx_present(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, uint8_t *out_rgba8);
 
 /* Kernel organisation of the path-trace pass.  0 = automatic: the sample-sequential per-pixel kernel when use_filter /
  * is_temporal need the cross-sample G-buffer state, else the persistent path kernel for scenes of up to 128 entries (in frames of at
@@ -185,7 +190,7 @@ flx_status flx_taa_reset(flx_context *ctx);
 flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
 flx_status flx_last_pipeline(flx_context *ctx, int *pipeline);
 /* Wavefront pipeline: run the bounce loop as 1..4 independent chains of screen-tile ranges on separate HIP
- * streams (default 2), so that the tail of one chain's persistent walk kernel overlaps the other's work. */
+ * streams (default 1: more chains measured slower, profiles/r01_ab_stream_groups.txt), so that the tail of one chain's persistent walk kernel overlaps the other's work. */
 flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
 /* Wavefront pipeline: how the bounce walks are scheduled.  Every mode walks every ray through the same entries with the
  * same arithmetic (frames and work counters are identical); they differ in speed and exist for A/B measurements

@@ -91,3 +91,13 @@ def taa(frames_newest_first):
     if rc != 0:
         raise RuntimeError("flx_oracle_taa failed: %d" % rc)
     return out
+
+
+def present(frame):
+    """float RGBA frame [H, W, 4] -> the uint8 RGBA the canvas' drawing buffer holds"""
+    a = np.ascontiguousarray(frame, np.float32)
+    out = np.zeros(a.shape, np.uint8)
+    rc = lib().flx_oracle_present(a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0], out.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise RuntimeError("flx_oracle_present failed: %d" % rc)
+    return out

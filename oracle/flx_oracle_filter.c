@@ -523,3 +523,10 @@ int flx_oracle_taa(const float *const *frames_newest_first, int n_frames, uint32
   for (int i = 0; i < 9; i++) free(q[i]);
   return FLX_OK;
 }
+
+/* 8-bit present: the canvas' RGBA8 drawing buffer (pathtracerWGL2.js:552-553 draws the last pass into framebuffer null) */
+int flx_oracle_present(const float *in_rgba, uint32_t width, uint32_t height, uint8_t *out_rgba8) {
+  if (!in_rgba || !out_rgba8 || width == 0 || height == 0) return 1;
+  for (size_t i = 0; i < (size_t)width * height * 4; i++) out_rgba8[i] = quant(in_rgba[i]);
+  return 0;
+}

@@ -78,3 +78,15 @@ def test_render_batch_through_node(hip, scenes, tmp_path):
     assert np.array_equal(got[0], first, equal_nan=True)
     assert not np.array_equal(got[0], got[1])
     assert info["counters"]["primaryHits"] >= cnt["primary_hits"]
+
+
+def test_present_through_node(oracle, tmp_path):
+    """renderer.presentFrame(): the RGBA8 of the canvas for the frame renderFrame() returned"""
+    node = shutil.which("node")
+    out, pix = tmp_path / "frame.f32", tmp_path / "frame.u8"
+    subprocess.check_output([node, os.path.join(ROOT, "tools", "render_scene.js"), "cornell", "--out", str(out), "--present", str(pix), "--width", "96",
+                             "--height", "64", "--spp", "2", "--bounces", "3", "--filter", "1", "--assets", "/nonexistent"], timeout=300)
+    frame = np.fromfile(out, np.float32).reshape(64, 96, 4)
+    got = np.fromfile(pix, np.uint8).reshape(64, 96, 4)
+    assert np.array_equal(got, oracle.present(frame))
+    assert got[..., :3].max() > 0

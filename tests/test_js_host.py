@@ -89,7 +89,7 @@ def test_napi_addon_loads_and_exports():
     js = "const a = require('%s'); console.log(JSON.stringify({keys: Object.keys(a), version: a.version()}));" % addon
     out = json.loads(subprocess.check_output([NODE, "-e", js]).decode())
     for name in ("createContext", "destroyContext", "uploadScene", "uploadTransforms", "uploadLights", "uploadAtlas", "tileRowCount", "render", "renderBatch",
-                 "meshImport", "meshCounts", "meshSetTransform", "meshMove", "meshScale", "meshSetMaterial", "meshBounding", "meshFlatten", "packTransforms", "fxaa", "taa", "taaReset"):
+                 "meshImport", "meshCounts", "meshSetTransform", "meshMove", "meshScale", "meshSetMaterial", "meshBounding", "meshFlatten", "packTransforms", "fxaa", "taa", "taaReset", "present"):
         assert name in out["keys"]
     assert "flexlight-hip" in out["version"]
 

@@ -222,3 +222,12 @@ def test_unorm8_recipe_is_exact(tmp_path):
     subprocess.check_call(["gcc", "-O0", "-ffp-contract=off", "-o", str(exe), os.path.join(root, "tools", "unorm_check.c"), "-lm"])
     out = subprocess.check_output([str(exe)]).decode()
     assert "one Markstein step mismatches 0" in out and "!= k: 0" in out and "> 0.1f: 26" in out and out.strip().endswith(": 0")
+
+
+def test_present_kat():
+    """floor(clamp(x) * 255 + 0.5): known answers"""
+    import flx_oracle
+    f = np.zeros((1, 8, 4), np.float32)
+    f[0, :, 0] = [0.0, 1.0, 0.5, -3.0, 7.0, np.nan, 1.0 / 255.0, 0.999]
+    got = flx_oracle.present(f)[0, :, 0].tolist()
+    assert got[:5] == [0, 255, 128, 0, 255] and got[6] == 1 and got[7] == 255

@@ -47,3 +47,23 @@ def test_taa_sequence_matches_oracle(hip, oracle, scenes):
     assert np.array_equal(hip.taa(small[1]).view(np.uint32), oracle.taa(small[1::-1]).view(np.uint32))
     hip.taa_reset()
     assert np.array_equal(hip.taa(small[1]).view(np.uint32), oracle.taa(small[1:2]).view(np.uint32))
+
+
+def test_present_matches_oracle(hip, oracle, scenes):
+    """8-bit present: the RGBA8 of the canvas for a rendered frame and for a synthetic one with NaN, infinities, negative and
+    > 1 values and the rounding midpoints k / 255 +- half a step."""
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    frame, _, _ = hip.render(sc.frame_params(width=96, height=64, samples=2, max_reflections=3, use_filter=0))
+    rng = np.random.default_rng(7)
+    synth = rng.uniform(-0.25, 1.25, (33, 47, 4)).astype(np.float32)
+    synth[0, :8, 0] = [np.nan, np.inf, -np.inf, 0.0, -0.0, 1.0, 0.5, 2.0]
+    k = np.arange(33 * 47, dtype=np.float32) % 256
+    synth[..., 3] = ((k + 0.5) / 255.0).reshape(33, 47)
+    synth[..., 2] = np.nextafter(synth[..., 3], np.float32(0))
+    for f in (frame, synth):
+        got = hip.present(f)
+        want = oracle.present(f)
+        assert got.dtype == np.uint8 and got.shape == f.shape
+        assert np.array_equal(got, want)
+    assert hip.present(frame)[..., 3].max() == 255

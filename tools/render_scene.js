@@ -2,7 +2,7 @@
 /*
  * Render one BASELINE scene through the whole JavaScript path — FlexLight facade, scene graph, host
  * flattening, N-API addon, libflexlight_hip.so — and write the float32 radiance to a file.
- *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --aa fxaa|taa --frames N --batch N --assets DIR]
+ *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --aa fxaa|taa --frames N --batch N --present FILE --assets DIR]
  */
 const fs = require('fs');
 const os = require('os');
@@ -61,6 +61,7 @@ function loadImage (rel) {
   let f;
   for (let k = 0; k < frames; k++) f = engine.renderer.renderFrame({ counters: true });
   fs.writeFileSync(opt('--out', 'frame.f32'), Buffer.from(f.radiance.buffer));
+  if (opt('--present', null)) fs.writeFileSync(opt('--present', null), Buffer.from(engine.renderer.presentFrame(f).data.buffer));      // the canvas' RGBA8
   console.log(JSON.stringify({ width: f.width, height: f.height, rows: f.rows, frameMs: f.frameMs, counters: f.counters }));
   engine.renderer.halt();
 })().catch(e => { console.error(e); process.exit(1); });

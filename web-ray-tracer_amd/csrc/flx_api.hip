@@ -663,6 +663,33 @@ static flx_status aa_host(flx_context *ctx, int which, uint32_t width, uint32_t 
 extern "C" flx_status flx_fxaa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba) { return aa_host(ctx, 0, width, height, in_rgba, out_rgba); }
 extern "C" flx_status flx_taa(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, float *out_rgba) { return aa_host(ctx, 1, width, height, in_rgba, out_rgba); }
 
+extern "C" flx_status flx_present_device(flx_context *ctx, uint32_t width, uint32_t height, const void *d_in_rgba, void *d_out_rgba8) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!d_in_rgba || !d_out_rgba8) return fail(ctx, FLX_ERR_INVALID, "flx_present_device: NULL pointer");
+  if (width == 0 || height == 0) return fail(ctx, FLX_ERR_INVALID, "flx_present_device: empty frame");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  launch_quantize((const float4 *)d_in_rgba, (uint32_t *)d_out_rgba8, (size_t)width * height, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  return FLX_OK;
+}
+extern "C" flx_status flx_present(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, uint8_t *out_rgba8) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!in_rgba || !out_rgba8) return fail(ctx, FLX_ERR_INVALID, "flx_present: NULL pointer");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t pixels = (size_t)width * height;
+  if (pixels == 0) return fail(ctx, FLX_ERR_INVALID, "flx_present: empty frame");
+  if (ctx->aa_io_capacity < pixels) {
+    for (auto &b : ctx->d_aa_io) { if (b) { FLX_HIP(ctx, hipFree(b)); b = nullptr; } FLX_HIP(ctx, hipMalloc(&b, pixels * sizeof(float4))); }
+    ctx->aa_io_capacity = pixels;
+  }
+  FLX_HIP(ctx, hipMemcpyAsync(ctx->d_aa_io[0], in_rgba, pixels * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  flx_status s = flx_present_device(ctx, width, height, ctx->d_aa_io[0], ctx->d_aa_io[1]);
+  if (s) return s;
+  FLX_HIP(ctx, hipMemcpyAsync(out_rgba8, ctx->d_aa_io[1], pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, uint32_t suspend_walks) {
   if (!ctx) return FLX_ERR_INVALID;
   if (scheduler < FLX_WALK_LANES || scheduler > FLX_WALK_LANES_FINISHER) return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: scheduler 0 lanes, 1 queues, 2 lanes + finisher");

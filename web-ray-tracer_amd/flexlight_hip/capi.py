@@ -20,7 +20,7 @@ EXPORTS = [
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
     "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
-    "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset",
+    "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
 ]
 
 
@@ -85,6 +85,8 @@ def _load():
         "flx_fxaa": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
         "flx_taa": (C.c_int, [vp, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
         "flx_taa_reset": (C.c_int, [vp]),
+        "flx_present": (C.c_int, [vp, u32, u32, vp, vp]),
+        "flx_present_device": (C.c_int, [vp, u32, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -233,6 +235,13 @@ class Context:
         a = np.ascontiguousarray(frame, np.float32)
         out = np.empty_like(a)
         self._check(LIB.flx_fxaa(self._h, a.shape[1], a.shape[0], a.ctypes.data, out.ctypes.data), "flx_fxaa")
+        return out
+
+    def present(self, frame):
+        """[H, W, 4] float32 frame -> the uint8 RGBA of the canvas' drawing buffer"""
+        a = np.ascontiguousarray(frame, np.float32)
+        out = np.empty(a.shape, np.uint8)
+        self._check(LIB.flx_present(self._h, a.shape[1], a.shape[0], a.ctypes.data, out.ctypes.data), "flx_present")
         return out
 
     def taa(self, frame):

@@ -157,6 +157,16 @@ class PathTracerHIP {
     return this.lastFrame;
   }
 
+  /* The RGBA8 the reference's canvas would hold for a frame of renderFrame() (whole frames): { width, height, data: Uint8ClampedArray },
+   * the shape of an ImageData. */
+  presentFrame (frame) {
+    const f = frame || this.lastFrame;
+    if (!f || f.rows !== f.height) throw new Error('presentFrame: a whole frame of renderFrame() is needed');
+    const data = new Uint8ClampedArray(f.width * f.height * 4);
+    native().present(this._context(), f.width, f.height, f.radiance, data);
+    return { width: f.width, height: f.height, data };
+  }
+
   /* Several frames of a camera path in ONE pass of the GPU pipeline (flx_render_batch; not in the reference, which renders frame
    * after frame): `cameras` is an array of up to 32 camera states { x, y, z, fx, fy } (missing fields default to this.camera's;
    * fov comes from this.camera).  Frames without filter, temporal accumulation and anti-aliasing only — those depend on the frame

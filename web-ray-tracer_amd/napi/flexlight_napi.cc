@@ -456,6 +456,26 @@ static napi_value post_pass(napi_env env, napi_callback_info info, int which) {
   if (rc != FLX_OK) return fail(env, ctx, which == 0 ? "flx_fxaa" : "flx_taa", rc);
   return nullptr;
 }
+/* present(handle, width, height, in Float32Array, out Uint8Array | Uint8ClampedArray): the canvas' RGBA8 drawing buffer */
+static napi_value Present(napi_env env, napi_callback_info info) {
+  napi_value argv[5];
+  if (!get_args(env, info, 5, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  uint32_t w = 0, h = 0;
+  napi_get_value_uint32(env, argv[1], &w); napi_get_value_uint32(env, argv[2], &h);
+  void *in; size_t n_in;
+  if (!typed(env, argv[3], napi_float32_array, &in, &n_in)) return nullptr;
+  napi_typedarray_type type; size_t n_out; void *out; napi_value buf; size_t off;
+  if (napi_get_typedarray_info(env, argv[4], &type, &n_out, &out, &buf, &off) != napi_ok || (type != napi_uint8_array && type != napi_uint8_clamped_array)) {
+    napi_throw_type_error(env, nullptr, "present: out must be a Uint8Array or Uint8ClampedArray");
+    return nullptr;
+  }
+  if (!in || !out || n_in != (size_t)w * h * 4 || n_out != n_in) { napi_throw_range_error(env, nullptr, "present: in and out need width*height*4 elements"); return nullptr; }
+  flx_status rc = flx_present(ctx, w, h, (const float *)in, (uint8_t *)out);
+  if (rc != FLX_OK) return fail(env, ctx, "flx_present", rc);
+  return nullptr;
+}
 static napi_value Fxaa(napi_env env, napi_callback_info info) { return post_pass(env, info, 0); }
 static napi_value Taa(napi_env env, napi_callback_info info) { return post_pass(env, info, 1); }
 static napi_value TaaReset(napi_env env, napi_callback_info info) {
@@ -495,7 +515,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     { "tileRowCount", TileRowCount }, { "render", Render }, { "renderBatch", RenderBatch }, { "temporalReset", TemporalReset }, { "deviceInfo", DeviceInfo }, { "version", Version },
     { "meshImport", MeshImport }, { "meshCounts", MeshCounts }, { "meshSetTransform", MeshSetTransform }, { "meshMove", MeshMove },
     { "meshScale", MeshScale }, { "meshSetMaterial", MeshSetMaterial }, { "meshFlatten", MeshFlatten }, { "meshBounding", MeshBounding }, { "packTransforms", PackTransforms },
-    { "fxaa", Fxaa }, { "taa", Taa }, { "taaReset", TaaReset },
+    { "present", Present }, { "fxaa", Fxaa }, { "taa", Taa }, { "taaReset", TaaReset },
   };
   for (const auto &f : fns) {
     napi_value fn;
