@@ -217,11 +217,11 @@ static int rayCuboid(float l, Ray ray, v3 minCorner, v3 maxCorner) {
 
 static const Hit NO_HIT = { { 0.0f, 0.0f, 0.0f }, 0, -1 };     /* fragment:81 */
 
-/* analysis hook (tools/visit_histogram.py): when set, every entry fetch is tallied per entry index */
+/* analysis hook (tests/analysis/visit_histogram.py): when set, every entry fetch is tallied per entry index */
 static uint64_t *g_visit_hist = NULL;
 /* analysis hook: g_walk_hist[k] counts walks with 2^k <= visits < 2^(k+1) (k < 31), [31] = longest walk */
 static uint64_t *g_walk_hist = NULL;
-/* analysis hook (tools/walk_sim.py, single-threaded runs only): byte trace of every bounce walk — an 8-byte header
+/* analysis hook (tests/analysis/walk_sim.py, single-threaded runs only): byte trace of every bounce walk — an 8-byte header
  * {0xF0 | kind (0 shadow, 1 closest), bounce, sample, 0, px lo, px hi, py lo, py hi}, one byte per entry visited
  * (its type: 0 terminator, 1 box, 2 triangle; | 0x10 when the entry's transform differs from the cached one), then 0xFF */
 static uint8_t *g_trace = NULL;

@@ -3,7 +3,7 @@
 restatement itself.  Re-generate only when the oracle's definition changes on purpose."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
 import flx_oracle
 from flexlight_hip.scene_io import Scene

@@ -4,7 +4,7 @@ Prints the share of all entry fetches covered by the N shallowest entries (depth
 i.e. what an LDS-resident top of the tree would absorb."""
 import ctypes as C, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
 import flx_oracle
 from flexlight_hip.scene_io import Scene

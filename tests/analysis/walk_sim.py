@@ -6,10 +6,10 @@ them through models of one wave (64 lanes) under different stepping policies and
 entry visited.  Costs are VALU issue slots of the current kernel's blocks (build/asm): box test, triangle test, entry
 fetch, per-trip scheduler overhead, batch (fold + refill + setup).
 
-  python tools/walk_sim.py [scene] [strips]"""
+  python tests/analysis/walk_sim.py [scene] [strips]"""
 import ctypes as C, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
 import flx_oracle
 from flexlight_hip.scene_io import Scene

@@ -4,7 +4,7 @@
  * A skip-list walk alternates between two very different tests: ray/box (fragment:161-167) on ~75 % of the entries it
  * visits and ray/triangle (fragment:123-158) on the rest.  With one walk per lane (k_wf_walk_pre) nearly every trip
  * of a wave has lanes at both kinds of entry, so the wave runs BOTH tests on every trip with part of its lanes masked
- * (~45 % SIMD efficiency; tools/walk_sim.py models 3.3-3.9 issue slots per entry against 1.8 with perfect grouping).
+ * (~45 % SIMD efficiency; tests/analysis/walk_sim.py models 3.3-3.9 issue slots per entry against 1.8 with perfect grouping).
  *
  * Here a walk is not tied to a lane.  The state of the walks in flight lives in LDS (96 bytes per walk: next link,
  * minLen, closest hit so far, the ray in world space and in the current object space with 1/dir), and every walk

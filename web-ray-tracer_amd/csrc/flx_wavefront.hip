@@ -200,7 +200,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b, uint32_t total_items,
                                                                  uint32_t ldsCount) {
   /* The shallow levels of the tree — the front of the threaded array — are crossed by every ray
-   * (2 730 entries take 73 % of all entry fetches of the dragon frame, tools/visit_histogram.py), so
+   * (2 730 entries take 73 % of all entry fetches of the dragon frame, tests/analysis/visit_histogram.py), so
    * each workgroup keeps them in LDS: ds_read_b128 instead of three divergent 16-byte global loads. */
   extern __shared__ float4 ldsEntries[];
   for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
