@@ -61,3 +61,24 @@ def test_synthetic_scene_filter_and_temporal(hip, oracle, case):
         frame, _, _ = hip.render(p)
         _, mism = assert_parity(frame, seq[f], "%s temporal %d" % (case, f))
         assert mism == 0
+
+
+@pytest.mark.parametrize("case", ["many_transforms", "no_lights", "no_terminator"])
+def test_synthetic_scene_in_batches(hip, case):
+    """flx_render_batch over the walk kernel's on-the-fly variant (nine transforms), a scene without lights and one without
+    terminator: three frames with different seeds and ambients, each equal to its own render."""
+    sc = synth_scene.make(**CASES[case])
+    hip.update_scene(sc)
+    p0 = sc.frame_params(use_filter=0)
+    frames = []
+    for i in range(3):
+        q = type(p0).from_buffer_copy(p0)
+        q.random_seed = float(i)
+        q.ambient[:] = [0.05 * (i + 1)] * 3
+        q.camera[0] = p0.camera[0] + 0.2 * i
+        frames.append(q)
+    singles = [hip.render(q, counters=True) for q in frames]
+    got, cnt = hip.render_batch(frames, counters=True)
+    for i, (want, _, _) in enumerate(singles):
+        assert np.array_equal(got[i], want, equal_nan=True), "frame %d" % i
+    assert cnt == {k: sum(c[k] for _, c, _ in singles) for k in cnt}
