@@ -182,13 +182,32 @@ def main():
         if rows_local != rows_max:            # the C ABI packs [5][rows_local][W]; ranks with a strip less use a view of that shape
             planes_tight = torch.zeros((5, rows_local, W), dtype=torch.int32, device="cuda")
 
+    # N > 1, batches: the gather of a batch (all-gather + reassembly, on their own stream) runs while the next batch is traced;
+    # two sets of buffers, events in both directions (a slot's strips are not overwritten before their gather has read them)
+    comm_stream = torch.cuda.Stream() if multi else None
+    if multi and F > 1:
+        slots = [(local, gathered, frame), (torch.zeros_like(local), torch.empty_like(gathered), torch.empty_like(frame))]
+        traced = [torch.cuda.Event(), torch.cuda.Event()]
+        gathered_done = [torch.cuda.Event(), torch.cuda.Event()]
+    state = {"slot": 0, "last": 0}
+
     def render_batch(f):
         """f frames of this rank's strips, then (N > 1) the gather: every rank ends up with the f whole frames"""
-        ctx.render_batch_device([params] * f, local.data_ptr())
-        if multi:
-            n = f * rows_max * W * 4
-            dist.all_gather_into_tensor(gathered.view(-1)[:world * n], local.view(-1)[:n])
-            torch.index_select(gathered.view(-1)[:world * n].view(world * f * rows_max, W, 4), 0, perm_for(f), out=frame.view(F * H, W, 4)[:f * H])
+        if not multi:
+            ctx.render_batch_device([params] * f, local.data_ptr())
+            return
+        k = state["slot"]
+        state["slot"], state["last"] = k ^ 1, k
+        loc, gat, frm = slots[k]
+        stream.wait_event(gathered_done[k])                  # (a no-op the first time round)
+        ctx.render_batch_device([params] * f, loc.data_ptr())
+        traced[k].record(stream)
+        n = f * rows_max * W * 4
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(traced[k])
+            dist.all_gather_into_tensor(gat.view(-1)[:world * n], loc.view(-1)[:n])
+            torch.index_select(gat.view(-1)[:world * n].view(world * f * rows_max, W, 4), 0, perm_for(f), out=frm.view(F * H, W, 4)[:f * H])
+            gathered_done[k].record(comm_stream)
 
     def batch_sizes(k):
         """k frames in the fewest batches of at most F frames, sized evenly (20 frames, F = 8: 7 + 7 + 6)"""
@@ -294,7 +313,8 @@ def main():
         ctx.render_device(full, whole.data_ptr())
         ctx.sync()
         last = batch_sizes(args.steps)[-1] - 1 if F > 1 else 0           # position of the last frame in the last batch
-        verified = bool(torch.equal(whole.view(torch.int32), frame[last].view(torch.int32)))
+        last_frames = slots[state["last"]][2] if F > 1 else frame
+        verified = bool(torch.equal(whole.view(torch.int32), last_frames[last].view(torch.int32)))
     if rank == 0:
         spp, bounces = full.samples, full.max_reflections
         rays = spp * bounces * W * H
@@ -328,7 +348,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": config_name, "width": W, "height": H, "spp": spp, "bounces": bounces, "filter": bool(use_filter),
-                "scene_entries": int(scene.meta["textureLength"]), "parallelism": "row-strip tiles x%d, %d rows/strip, RCCL all-gather" % (world, args.tile_rows) if world > 1 else "single GPU",
+                "scene_entries": int(scene.meta["textureLength"]), "parallelism": "row-strip tiles x%d, %d rows/strip, RCCL all-gather%s" % (world, args.tile_rows, " of a batch overlapped with the trace of the next" if F > 1 else "") if world > 1 else "single GPU",
                 "rays_per_frame": rays, "frames_per_pass": F,
                 "frames": "the static camera of the BASELINE config for every frame, as in the reference's frame loop; every frame is traced in full, nothing is reused between frames",
             },
