@@ -155,9 +155,9 @@ def main():
     # Frames per pass: a walk kernel lasts as long as its longest walk whatever the number of paths, so the
     # bench renders the K frames of the timed region in batches of F (the last one may be smaller): throughput mode.
     rows_local = ctx.tile_row_count(params)
-    F = 1 if use_filter else max(1, min(args.batch, capi.MAX_BATCH_FRAMES))
-    F = max(1, min(F, (1 << 28) // max(1, rows_local * W * full.samples)))      # at most 2^28 paths (34 GB of path records) per pass
     rows_max = tiles.padded_rows(H, args.tile_rows, world) if multi else H
+    F = 1 if use_filter else max(1, min(args.batch, capi.MAX_BATCH_FRAMES))
+    F = max(1, min(F, (1 << 28) // max(1, rows_max * W * full.samples)))        # at most 2^28 paths (34 GB of path records) per pass; the same F on every rank
     local = torch.zeros((F, rows_max, W, 4), dtype=torch.float32, device="cuda")
     gathered = torch.empty((world, F, rows_max, W, 4), dtype=torch.float32, device="cuda") if multi else None
     frame = torch.empty((F, H, W, 4), dtype=torch.float32, device="cuda") if multi else None      # the frames of the last batch, every rank has them
