@@ -74,3 +74,11 @@ int main(void) {
     assert sizes == [C.sizeof(FrameParams), C.sizeof(Counters), C.sizeof(GBuffers), C.sizeof(SceneView)]
     assert offs == [FrameParams.view_matrix.offset, FrameParams.ambient.offset, FrameParams.tile_rows.offset,
                     SceneView.atlas.offset, SceneView.atlas_h.offset]
+
+
+def test_batch_limit_matches_the_header():
+    from flexlight_hip import capi
+    text = open(os.path.join(ROOT, "include", "flexlight_hip.h")).read()
+    assert int(re.search(r"#define FLX_MAX_BATCH_FRAMES (\d+)", text).group(1)) == capi.MAX_BATCH_FRAMES
+    dev = open(os.path.join(ROOT, "web-ray-tracer_amd", "csrc", "flx_device.h")).read()
+    assert int(re.search(r"#define FLX_MAX_BATCH (\d+)", dev).group(1)) == capi.MAX_BATCH_FRAMES
