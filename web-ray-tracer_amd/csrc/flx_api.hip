@@ -433,6 +433,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     if ((s = ensure_pixels(ctx, &ctx->d_rec, &ctx->rec_capacity, (size_t)path_item_count(fr) * 8))) return s;
     const size_t need = wavefront_live_capacity(fr, cus) * WF_MAX_GROUPS;      /* every group gets a slice that could hold the whole frame */
     if (ctx->live_capacity < need) {
+      ctx->live_capacity = 0;               /* a failed allocation below must not leave the old size standing over freed lists */
       for (int i = 0; i < 2; i++) {
         if (ctx->d_live[i]) { FLX_HIP(ctx, hipFree(ctx->d_live[i])); ctx->d_live[i] = nullptr; }
         FLX_HIP(ctx, hipMalloc(&ctx->d_live[i], need * sizeof(uint32_t)));
@@ -460,10 +461,9 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     FLX_HIP(ctx, hipGetLastError());
   } else {
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t), ctx->stream));
-    if (!ctx->d_tail_pool) {     /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
-      FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
-      FLX_HIP(ctx, hipMalloc(&ctx->d_strag, (size_t)WF_MAX_GROUPS * 2 * cus * 8u * WF_STRAG_MAX * WF_STRAG_F4 * sizeof(float4)));
-    }
+    /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
+    if (!ctx->d_tail_pool) FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
+    if (!ctx->d_strag) FLX_HIP(ctx, hipMalloc(&ctx->d_strag, (size_t)WF_MAX_GROUPS * 2 * cus * 8u * WF_STRAG_MAX * WF_STRAG_F4 * sizeof(float4)));
     launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     /* The bounce loop runs as `groups` independent chains (contiguous ranges of screen tiles), group 0 on the
@@ -516,6 +516,7 @@ static flx_status run_post_frame(flx_context *ctx, const DeviceScene &sc, const 
   const bool temporal = fr.is_temporal == 1, filter = fr.use_filter == 1;
   flx_status s;
   if (ctx->gb_capacity < pixels) {
+    ctx->gb_capacity = 0;                 /* a failed allocation below must not leave the old size standing */
     for (int i = 0; i < 6; i++) {
       size_t cap = 0;
       if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
@@ -524,6 +525,7 @@ static flx_status run_post_frame(flx_context *ctx, const DeviceScene &sc, const 
     ctx->gb_capacity = pixels;
   }
   if (ctx->planes_capacity < pixels) {
+    ctx->planes_capacity = 0;                 /* a failed allocation below must not leave the old size standing */
     for (int i = 0; i < 13; i++) {
       if (ctx->d_planes[i]) { FLX_HIP(ctx, hipFree(ctx->d_planes[i])); ctx->d_planes[i] = nullptr; }
       FLX_HIP(ctx, hipMalloc(&ctx->d_planes[i], pixels * sizeof(uint32_t)));
@@ -537,6 +539,7 @@ static flx_status run_post_frame(flx_context *ctx, const DeviceScene &sc, const 
   if (temporal) {
     N = p->temporal_samples <= 0 ? 4 : (p->temporal_samples > 16 ? 16 : p->temporal_samples);
     if (ctx->ring_n != N || ctx->ring_w != fr.width || ctx->ring_h != fr.height) {      /* new size: fresh (zero) history, like a resize */
+      ctx->ring_n = 0;                     /* (re)allocation in progress: a failure below leaves no size to match */
       for (auto &ring : ctx->d_ring) for (uint32_t *&plane : ring) if (plane) { FLX_HIP(ctx, hipFree(plane)); plane = nullptr; }
       for (int r = 0; r < 4; r++) for (int i = 0; i < N; i++) {
         FLX_HIP(ctx, hipMalloc(&ctx->d_ring[r][i], pixels * sizeof(uint32_t)));
@@ -597,6 +600,7 @@ static flx_status aa_prepare(flx_context *ctx, uint32_t w, uint32_t h) {
   if (w == 0 || h == 0) return fail(ctx, FLX_ERR_INVALID, "anti-aliasing pass: empty frame");
   const size_t pixels = (size_t)w * h;
   if (ctx->aa_capacity < pixels) {
+    ctx->aa_capacity = 0;
     for (auto &pl : ctx->d_aa) { if (pl) { FLX_HIP(ctx, hipFree(pl)); pl = nullptr; } FLX_HIP(ctx, hipMalloc(&pl, pixels * sizeof(uint32_t))); }
     ctx->aa_capacity = pixels;
     ctx->aa_w = 0;
@@ -650,6 +654,7 @@ static flx_status aa_host(flx_context *ctx, int which, uint32_t width, uint32_t 
   const size_t pixels = (size_t)width * height;
   if (pixels == 0) return fail(ctx, FLX_ERR_INVALID, "anti-aliasing pass: empty frame");
   if (ctx->aa_io_capacity < pixels) {
+    ctx->aa_io_capacity = 0;
     for (auto &b : ctx->d_aa_io) { if (b) { FLX_HIP(ctx, hipFree(b)); b = nullptr; } FLX_HIP(ctx, hipMalloc(&b, pixels * sizeof(float4))); }
     ctx->aa_io_capacity = pixels;
   }
@@ -679,6 +684,7 @@ extern "C" flx_status flx_present(flx_context *ctx, uint32_t width, uint32_t hei
   const size_t pixels = (size_t)width * height;
   if (pixels == 0) return fail(ctx, FLX_ERR_INVALID, "flx_present: empty frame");
   if (ctx->aa_io_capacity < pixels) {
+    ctx->aa_io_capacity = 0;
     for (auto &b : ctx->d_aa_io) { if (b) { FLX_HIP(ctx, hipFree(b)); b = nullptr; } FLX_HIP(ctx, hipMalloc(&b, pixels * sizeof(float4))); }
     ctx->aa_io_capacity = pixels;
   }
@@ -791,6 +797,7 @@ extern "C" flx_status flx_render_batch(flx_context *ctx, const flx_frame_params 
 static flx_status ensure_post_buffers(flx_context *ctx, size_t pixels, bool gbuffers, bool planes) {
   flx_status s;
   if (gbuffers && ctx->gb_capacity < pixels) {
+    ctx->gb_capacity = 0;                 /* a failed allocation below must not leave the old size standing */
     for (int i = 0; i < 6; i++) {
       size_t cap = 0;
       if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
@@ -799,6 +806,7 @@ static flx_status ensure_post_buffers(flx_context *ctx, size_t pixels, bool gbuf
     ctx->gb_capacity = pixels;
   }
   if (planes && ctx->planes_capacity < pixels) {
+    ctx->planes_capacity = 0;                 /* a failed allocation below must not leave the old size standing */
     for (int i = 0; i < 13; i++) {
       if (ctx->d_planes[i]) { FLX_HIP(ctx, hipFree(ctx->d_planes[i])); ctx->d_planes[i] = nullptr; }
       FLX_HIP(ctx, hipMalloc(&ctx->d_planes[i], pixels * sizeof(uint32_t)));
