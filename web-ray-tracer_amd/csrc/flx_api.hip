@@ -70,6 +70,8 @@ struct flx_context {
   int taa_head = 0, taa_filled = 0;
   float4 *d_aa_io[2] = {};                       /* staging for the host-pointer variants */
   size_t aa_io_capacity = 0;
+  float4 *d_rec0 = nullptr, *d_pix0 = nullptr;   /* compact bounce-0 records: 3 float4 per path, 3 float4 per pixel */
+  size_t rec0_capacity = 0, pix0_capacity = 0;
   float4 *d_strag = nullptr;                     /* per chain 2 x (walk workgroups x WF_STRAG_MAX) suspended walks */
   uint32_t walk_suspend = 0;                     /* walks a walk workgroup may leave to the next round (0 = off) */
   size_t rec_capacity = 0;                       /* float4 units */
@@ -150,7 +152,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_rec, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
+                   ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -431,6 +433,8 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   if (pipeline == 3) {
     flx_status s;
     if ((s = ensure_pixels(ctx, &ctx->d_rec, &ctx->rec_capacity, (size_t)path_item_count(fr) * 8))) return s;
+    if ((s = ensure_pixels(ctx, &ctx->d_rec0, &ctx->rec0_capacity, (size_t)path_item_count(fr) * 3))) return s;
+    if ((s = ensure_pixels(ctx, &ctx->d_pix0, &ctx->pix0_capacity, P * 3))) return s;
     const size_t need = wavefront_live_capacity(fr, cus) * WF_MAX_GROUPS;      /* every group gets a slice that could hold the whole frame */
     if (ctx->live_capacity < need) {
       ctx->live_capacity = 0;               /* a failed allocation below must not leave the old size standing over freed lists */
@@ -483,7 +487,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     for (int g = 0; g < groups; g++) {
       const uint32_t t0 = (uint32_t)((uint64_t)tiles * g / groups), t1 = (uint32_t)((uint64_t)tiles * (g + 1) / groups);
       WavefrontBuffers wb;
-      wb.rec = ctx->d_rec;
+      wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);

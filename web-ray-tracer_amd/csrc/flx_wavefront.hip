@@ -109,12 +109,14 @@ __global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame f
       cnt.atlas_texels = before.atlas_texels + (cnt.atlas_texels - before.atlas_texels) * S;
     }
   }
+  const bool compact = wb.rec0 != nullptr;
   for (uint32_t s = 0; s < S; s++) {
     const uint32_t pathId = ((tile * S + s) << 6) | lane;
     float4 *rec = wb.rec + (size_t)pathId * 8;
     if (!alive) {
       if (tri != -1) finalize_path(fr, wb, pathId, F3(0.0f, 0.0f, 0.0f), F3(1.0f, 1.0f, 1.0f), F3(1.0f, 1.0f, 1.0f));
-      rec[0] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD));
+      if (compact) wb.rec0[(size_t)pathId * 3] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD));
+      else rec[0] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD));
       continue;
     }
     PathState p;
@@ -133,6 +135,21 @@ __global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame f
     ShadeOut so;
     shadeSample(sc, fr, sf, ps, p, camera, cosSampleN, 0, so);
     const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0);
+    if (compact) {
+      /* the per-pixel part is the same for every sample (sf is; importancy stays (1,1,1) while dontFilter holds, as it does
+       * on entry to bounce 0): written once */
+      if (s == 0u) {
+        float4 *pp = wb.pix0 + ((size_t)k * fr.width + px) * 3;
+        pp[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, 0.0f);
+        pp[1] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, 0.0f);
+        pp[2] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, so.baseLuminance.x);
+      }
+      float4 *r0 = wb.rec0 + (size_t)pathId * 3;
+      r0[0] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, __int_as_float(flags));
+      r0[1] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, so.shadowLen);
+      r0[2] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
+      continue;
+    }
     rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
     rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
     rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
@@ -382,6 +399,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
    * finisher (flx_walkcoop.hip, resumePrev == 0), are completed right after this kernel, a wave per walk. */
   const uint32_t nStrag = (resumePrev && b > 0) ? wb.stragCount[b - 1] : 0u;     /* with the cooperative finisher nothing is carried over */
   const uint32_t nList = FIRST ? total_items : wb.counts[b];
+  const bool compact0 = FIRST && wb.rec0 != nullptr;         /* bounce 0 reads the compact records (flx_kernels.h) */
   const uint32_t n = nStrag + nList;                       /* queue positions: stragglers first, then the live list */
   if (n == 0u) return;
   /* LDS: [tree top: ldsCount entries x 48 B][nTransforms x (inverse rotation columns, inverse shift) float4 quadruples]
@@ -571,7 +589,17 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         bool append = false;
         if (st == P_DONE) {
           float4 *rec = wb.rec + (size_t)pathId * 8;
-          const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+          float4 q4, q5, q6, q7;
+          const float4 *pp = nullptr;
+          if (compact0) {                                     /* bounce 0, compact records: lit colour per sample, albedo per pixel */
+            uint32_t px, k, s;
+            item_pixel(fr, pathId, px, k, s);
+            pp = wb.pix0 + ((size_t)k * fr.width + px) * 3;
+            q4 = wb.rec0[(size_t)pathId * 3 + 2]; q7 = pp[2];
+            q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+          } else {
+            q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
+          }
           const bool shadowed = (flags & RF_SHADOWED_NO_WALK) || ((flags & RF_NEED_SHADOW) && w.shadowed);
           const f3 localColor = shadowed ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
           const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
@@ -579,6 +607,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           bool cont = w.tri != -1;
           if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
           if (cont) {
+            if (compact0) {                                   /* the path goes on: now it gets its full record (what shade0 would have written) */
+              const float4 a = wb.rec0[(size_t)pathId * 3], bq = wb.rec0[(size_t)pathId * 3 + 1], p0 = pp[0];
+              rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
+              rec[1] = make_float4(a.x, a.y, a.z, bq.w);
+              rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+              rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+              rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
+            }
             rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
             rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
             append = true;
@@ -661,7 +697,24 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           const uint32_t id = resume ? (uint32_t)__float_as_int(s0.x) : (FIRST ? wb.item_base + (j - nStrag) : listIn[j - nStrag]);
           if (id != WF_INVALID) {
             const float4 *rec = wb.rec + (size_t)id * 8;
-            const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];     /* one cache line, four loads in flight */
+            float4 q0, q1, q2, q3;
+            if (compact0) {                                   /* bounce 0, compact records: the record shade0 would have written, reassembled */
+              const float4 a = wb.rec0[(size_t)id * 3];
+              q0 = make_float4(0.f, 0.f, 0.f, a.w); q1 = q0; q2 = q0; q3 = q0;
+              if (!(__float_as_int(a.w) & RF_DEAD)) {
+                const float4 bq = wb.rec0[(size_t)id * 3 + 1];
+                uint32_t px, k, s;
+                item_pixel(fr, id, px, k, s);
+                const float4 *pp = wb.pix0 + ((size_t)k * fr.width + px) * 3;
+                const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+                q0 = make_float4(p0.x, p0.y, p0.z, a.w);
+                q1 = make_float4(a.x, a.y, a.z, bq.w);
+                q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
+                q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+              }
+            } else {
+              q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];     /* one cache line, four loads in flight */
+            }
             const int fl = __float_as_int(q0.w);
             if (!(fl & RF_DEAD)) {
               pathId = id; flags = fl; base = q2.w; pathBounce = __float_as_int(q3.w);
@@ -754,8 +807,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   }
 }
 
-void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
+void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wbIn, uint32_t compute_units, bool count,
                       int walk_scheduler, uint32_t suspend_max, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
+  WavefrontBuffers wb = wbIn;
   const uint32_t total = wb.item_count;                 /* items of this group (all of the frame when there is one group) */
   const uint32_t maxBlocks = compute_units * 8u;
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
@@ -788,6 +842,8 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   const bool lanes = (walk_scheduler & 1) == 0;             /* one walk per lane (not the queue scheduler) */
   const bool suspend = suspend_max > 0u && pre && lanes && (bounces >= 2 || finisher) && FLX_WF_CONSOLIDATE;
   const int rounds = (suspend && !finisher) ? 2 * bounces : bounces;
+  /* compact bounce-0 records: only the default walk kernel reads them (and a suspended walk re-reads its full record) */
+  if (!(pre && lanes && !suspend)) { wb.rec0 = nullptr; wb.pix0 = nullptr; }
   for (int r = 0; r < rounds; r++) {
     if (r == 0) {
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);        /* 64 per screen tile */
