@@ -393,6 +393,8 @@ static flx_status make_frame(flx_context *ctx, const flx_frame_params *p, Device
   memset(fr.view, 0, sizeof fr.view);
   fill_view(p, fr.view[0]);
   fr.samples = p->samples; fr.max_reflections = p->max_reflections;
+  fr.samples_shift = -1;
+  if ((p->samples & (p->samples - 1)) == 0) { fr.samples_shift = 0; while ((1 << fr.samples_shift) < p->samples) fr.samples_shift++; }
   fr.min_importancy = p->min_importancy;
   fr.use_filter = p->use_filter; fr.is_temporal = p->is_temporal;
   fr.texture_width = (float)p->texture_width;
@@ -434,7 +436,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     flx_status s;
     if ((s = ensure_pixels(ctx, &ctx->d_rec, &ctx->rec_capacity, (size_t)path_item_count(fr) * 8))) return s;
     if ((s = ensure_pixels(ctx, &ctx->d_rec0, &ctx->rec0_capacity, (size_t)path_item_count(fr) * 3))) return s;
-    if ((s = ensure_pixels(ctx, &ctx->d_pix0, &ctx->pix0_capacity, P * 3))) return s;
+    if ((s = ensure_pixels(ctx, &ctx->d_pix0, &ctx->pix0_capacity, (size_t)path_item_count(fr) / (size_t)fr.samples * 3))) return s;      /* 64 per screen tile */
     const size_t need = wavefront_live_capacity(fr, cus) * WF_MAX_GROUPS;      /* every group gets a slice that could hold the whole frame */
     if (ctx->live_capacity < need) {
       ctx->live_capacity = 0;               /* a failed allocation below must not leave the old size standing over freed lists */

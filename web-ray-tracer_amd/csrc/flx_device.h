@@ -116,6 +116,7 @@ struct DeviceFrame {
   uint32_t frames;              /* frames of the batch, stacked in the packed-row dimension; 1 for a single frame */
   uint32_t tile_rows, tile_index, tile_count;
   int samples, max_reflections;
+  int samples_shift;            /* log2(samples) when samples is a power of two, else -1 (item -> tile without a division) */
   float min_importancy;
   int use_filter, is_temporal;
   float texture_width;

@@ -14,13 +14,20 @@ __device__ __forceinline__ void tile8_pixel(const DeviceFrame &fr, uint32_t tile
   k = (ty << 3) + (lane >> 3);
 }
 
+/* Path item -> (screen tile, sample); the lane is item & 63. */
+__device__ __forceinline__ void item_tile(const DeviceFrame &fr, uint32_t item, uint32_t &tile, uint32_t &s) {
+  const uint32_t ts = item >> 6;
+  if (fr.samples_shift >= 0) { tile = ts >> fr.samples_shift; s = ts & ((1u << fr.samples_shift) - 1u); }
+  else { const uint32_t S = (uint32_t)fr.samples; tile = ts / S; s = ts - tile * S; }
+}
+
 /* Path item -> (pixel, sample).  Items are numbered [8x8 tile][sample][lane]: the 64 items a wave draws
  * together are one sample of one screen tile. Returns false for lanes outside the frame. */
 __device__ __forceinline__ bool item_pixel(const DeviceFrame &fr, uint32_t item, uint32_t &px, uint32_t &k, uint32_t &s) {
-  const uint32_t S = (uint32_t)fr.samples;
-  const uint32_t l = item & 63u, ts = item >> 6;
-  s = ts % S;
-  tile8_pixel(fr, ts / S, l, px, k);
+  const uint32_t l = item & 63u;
+  uint32_t tile;
+  item_tile(fr, item, tile, s);
+  tile8_pixel(fr, tile, l, px, k);
   return px < fr.width && k < fr.rows;
 }
 

@@ -35,7 +35,8 @@ struct WavefrontBuffers {
   uint32_t *stragCount;         /* [WF_MAX_ROUNDS + 2] walks suspended in round r */
   uint32_t *coopQueue;          /* [WF_MAX_ROUNDS + 2] cursor of the cooperative finisher over round r's suspended walks */
   /* Compact records of bounce 0 (or nullptr: full records).  The samples of a pixel share the primary hit, so what their
-   * first shading yields splits into a part per pixel — next origin, shadow origin, albedo, base luminance: pix0, 3 float4 —
+   * first shading yields splits into a part per pixel — next origin, shadow origin, albedo, base luminance: pix0, 3 float4,
+   * indexed [screen tile][lane] —
    * and a part per sample — next direction + flags, shadow direction + length, lit colour: rec0, 3 float4; importancy is
    * (1,1,1) and the running colour 0 there.  48 B per path instead of a 128-byte line: shade0 writes, and the bounce-0 walk
    * kernel reads, 0.9 GB per 1080p x 8 frame instead of 2.1; the walk kernel's fold writes a full record for the paths

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame f
       /* the per-pixel part is the same for every sample (sf is; importancy stays (1,1,1) while dontFilter holds, as it does
        * on entry to bounce 0): written once */
       if (s == 0u) {
-        float4 *pp = wb.pix0 + ((size_t)k * fr.width + px) * 3;
+        float4 *pp = wb.pix0 + (((size_t)tile << 6) | lane) * 3;      /* [screen tile][lane]: what a path id gives without a division */
         pp[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, 0.0f);
         pp[1] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, 0.0f);
         pp[2] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, so.baseLuminance.x);
@@ -592,9 +592,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           float4 q4, q5, q6, q7;
           const float4 *pp = nullptr;
           if (compact0) {                                     /* bounce 0, compact records: lit colour per sample, albedo per pixel */
-            uint32_t px, k, s;
-            item_pixel(fr, pathId, px, k, s);
-            pp = wb.pix0 + ((size_t)k * fr.width + px) * 3;
+            uint32_t tile0, s0;
+            item_tile(fr, pathId, tile0, s0);
+            pp = wb.pix0 + (((size_t)tile0 << 6) | (pathId & 63u)) * 3;
             q4 = wb.rec0[(size_t)pathId * 3 + 2]; q7 = pp[2];
             q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
           } else {
@@ -699,19 +699,16 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             const float4 *rec = wb.rec + (size_t)id * 8;
             float4 q0, q1, q2, q3;
             if (compact0) {                                   /* bounce 0, compact records: the record shade0 would have written, reassembled */
-              const float4 a = wb.rec0[(size_t)id * 3];
-              q0 = make_float4(0.f, 0.f, 0.f, a.w); q1 = q0; q2 = q0; q3 = q0;
-              if (!(__float_as_int(a.w) & RF_DEAD)) {
-                const float4 bq = wb.rec0[(size_t)id * 3 + 1];
-                uint32_t px, k, s;
-                item_pixel(fr, id, px, k, s);
-                const float4 *pp = wb.pix0 + ((size_t)k * fr.width + px) * 3;
-                const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
-                q0 = make_float4(p0.x, p0.y, p0.z, a.w);
-                q1 = make_float4(a.x, a.y, a.z, bq.w);
-                q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
-                q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
-              }
+              /* five loads in flight (a dead path's pixel part was never written: whatever is there is not used) */
+              uint32_t tile0, s0;
+              item_tile(fr, id, tile0, s0);
+              const float4 *pp = wb.pix0 + (((size_t)tile0 << 6) | (id & 63u)) * 3;
+              const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
+              const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+              q0 = make_float4(p0.x, p0.y, p0.z, a.w);
+              q1 = make_float4(a.x, a.y, a.z, bq.w);
+              q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
+              q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
             } else {
               q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];     /* one cache line, four loads in flight */
             }
