@@ -430,8 +430,10 @@ FLX_DEV void reservoirPick(const DeviceScene &sc, const DeviceFrame &fr, PixelSt
       reservoirWeight = weight;
       reservoirLightDir = dir;
     }
-    f4 n1 = noise(ps.seed, lastRandomX, lastRandomY, BIAS);
-    lastRandomX = n1.z; lastRandomY = n1.w;
+    if (j + 1 < size) {                /* the draw feeds the next light's test (fragment:433): after the last light nobody reads it */
+      f4 n1 = noise(ps.seed, lastRandomX, lastRandomY, BIAS);
+      lastRandomX = n1.z; lastRandomY = n1.w;
+    }
   }
   f3 unitLightDir = normalize(reservoirLightDir);
   bool showColor = reservoirLength == 0.0f || reservoirWeight == 0.0f;
