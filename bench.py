@@ -297,12 +297,8 @@ def main():
         ctx.render_device(params, local.data_ptr())      # ONE frame's share: the counters below are per frame
     ctx.sync()
     cnt = ctx.get_counters()
-    cnt_b0 = None
-    if not use_filter and params.max_reflections > 1:
-        p1 = scene.frame_params(width=args.width, height=args.height, tile=tile, max_reflections=1)
-        ctx.render_device(p1, local.data_ptr())
-        ctx.sync()
-        cnt_b0 = ctx.get_counters()
+    # entries the round-0 walk kernel visited in that frame (its own tally, diag slot 15; 0 when another kernel walked)
+    b0_visits = ctx.get_diag()[15] if not use_filter else 0
     ctx.set_counters_enabled(False)
     torch.cuda.synchronize()
 
@@ -330,8 +326,8 @@ def main():
             kernel_name = "k_paths (persistent path kernel)"
             bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * cnt["shades"] + 4 * cnt["atlas_texels"]
         else:                      # the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
-            b0 = cnt_b0 if cnt_b0 is not None else cnt        # a one-bounce frame: all of its walks are bounce 0's
-            kernel_name, bytes_launch = "k_wf_walk_pre<false, true> (walk kernel of bounce 0)", 48 * (b0["closest_visits"] + b0["shadow_visits"])
+            visits = b0_visits if b0_visits else cnt["closest_visits"] + cnt["shadow_visits"]      # (a one-bounce frame, or another walk kernel: all of them)
+            kernel_name, bytes_launch = "k_wf_walk_pre<false, true> (walk kernel of bounce 0)", 48 * visits
         bytes_launch *= F              # one launch walks the F frames of a batch
         achieved = bytes_launch / (k_ms * 1e-3) / 1e9
         traffic = None

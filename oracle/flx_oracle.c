@@ -511,6 +511,10 @@ static v3 lightTrace(Frag *f, Hit hit, v3 dir0, v3 camera, float cosSampleN, int
       float eta = flx_mix(1.0f / material.tpo.z, material.tpo.z, flx_max(signDir, 0.0f));
       ray.unitDirection = normalize3(mix3(refract3(ray.unitDirection, smoothNormal, eta), randomSpheareVec, roughnessBRDF));
     }
+    /* fragment:591 traces the next ray even when the loop guard (:475) is about to end the loop — in the last iteration,
+     * or once the path's importancy has dropped below the threshold: a hit nobody shades ("incl. the useless
+     * last one").  Its result reaches no output, so it is not walked, here and in the kernels alike. */
+    if (!(i + 1 < bounces && length3(mul3(importancyFactor, f->originalColor)) >= fp->min_importancy * SQRT3)) break;
     f->cnt.closest_walks++;
     hit = rayTracerImpl(sc, ray, 0, 0.0f, &f->cnt.closest_visits);
     if (hit.triangleId == -1) break;

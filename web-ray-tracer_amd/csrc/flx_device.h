@@ -946,19 +946,30 @@ FLX_DEV void walkBoxP(WalkState &w, const WalkEntry &cur) {
  * starts its closest-hit walk the moment its own shadow walk ends instead of waiting for the
  * slowest shadow ray of the wave.  Per ray the entries visited, their order and every arithmetic
  * operation are unchanged. */
+/* fragment:591 traces the next ray even when the loop guard (:475) is about to end the loop — in the last iteration, or once the
+ * path's importancy has dropped below the threshold: a hit nobody shades ("incl. the useless last one").  Its
+ * result reaches no output, so such a walk is not made (needClosest = false; the bounce then ends like a miss).  The guard: */
+FLX_DEV bool nextBounceRuns(const DeviceFrame &fr, int i, f3 importancyFactor, f3 originalColor) {
+  return (i + 1) < fr.max_reflections && length(importancyFactor * originalColor) >= fr.min_importancy * SQRT3;
+}
 template <bool COUNT>
-FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, const Ray &shadowRay, float shadowLen, const Ray &nextRay,
+FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, bool needClosest, const Ray &shadowRay, float shadowLen, const Ray &nextRay,
                         bool &shadowed, Hit &hit, WorkCounters &cnt) {
   WalkState w;
   walkClearResults(w);
+  if (!needShadow && !needClosest) {
+    shadowed = false;
+    hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri;
+    return;
+  }
   if (sc.n_transforms > 1u) {
     /* scenes with several object spaces: a ray changes space a few times per walk and the reciprocal would have to be taken
      * again each time (three divisions) — the plain walk over the reference's array measures faster here (dragon: 26.2 vs 27.1 ms) */
     if (needShadow) walkStart(w, 0, shadowRay, shadowLen); else walkStart(w, 1, nextRay, POW32);
-    if (COUNT) { if (needShadow) cnt.shadow_walks++; cnt.closest_walks++; }
+    if (COUNT) { if (needShadow) cnt.shadow_walks++; if (needClosest) cnt.closest_walks++; }
     while (w.mode != 2) {
       if (walkStep<COUNT>(sc, w, cnt)) {
-        if (w.mode == 0) walkStart(w, 1, nextRay, POW32); else w.mode = 2;
+        if (w.mode == 0 && needClosest) walkStart(w, 1, nextRay, POW32); else w.mode = 2;
       }
     }
     shadowed = w.shadowed;
@@ -970,7 +981,7 @@ FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, const Ray &shado
   w.mode = needShadow ? 0 : 1;
   w.src = needShadow ? shadowRay : nextRay;
   w.minLen = needShadow ? shadowLen : POW32;
-  if (COUNT) { if (needShadow) cnt.shadow_walks++; cnt.closest_walks++; }
+  if (COUNT) { if (needShadow) cnt.shadow_walks++; if (needClosest) cnt.closest_walks++; }
   for (;;) {
     w.tR = w.src; w.cachedTI = 0;
     reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
@@ -1000,7 +1011,7 @@ FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, const Ray &shado
         link = ended ? WALK_END : (uint32_t)w.i;
       }
     }
-    if (w.mode == 0) { w.mode = 1; w.src = nextRay; w.minLen = POW32; continue; }
+    if (w.mode == 0 && needClosest) { w.mode = 1; w.src = nextRay; w.minLen = POW32; continue; }
     break;
   }
   shadowed = w.shadowed;
@@ -1023,7 +1034,7 @@ FLX_DEV bool bounceOn(const DeviceScene &sc, const DeviceFrame &fr, const Surfac
   ShadeOut so;
   shadeSample(sc, fr, sf, ps, p, camera, cosSampleN, i, so);
   bool shadowed;
-  walkBounce<COUNT>(sc, so.needShadow, so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
+  walkBounce<COUNT>(sc, so.needShadow, nextBounceRuns(fr, i, p.importancyFactor, ps.originalColor), so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
   bounceFinish(ps, p, so, shadowed);
   if (p.hit.triangleId == -1) return false;
   p.lastHitPoint = p.ray.origin;
@@ -1036,7 +1047,7 @@ FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps
   ShadeOut so;
   bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, i, so, cnt);
   bool shadowed;
-  walkBounce<COUNT>(sc, so.needShadow, so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
+  walkBounce<COUNT>(sc, so.needShadow, nextBounceRuns(fr, i, p.importancyFactor, ps.originalColor), so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
   bounceFinish(ps, p, so, shadowed);
   if (p.hit.triangleId == -1) return false;
   p.lastHitPoint = p.ray.origin;

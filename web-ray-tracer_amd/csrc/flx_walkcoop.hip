@@ -83,6 +83,7 @@ __global__ __launch_bounds__(FLX_COOP_THREADS) void k_wf_walk_coop(DeviceScene s
     }
 
     for (;;) {                                              /* shadow walk, then closest-hit walk */
+      if (startClosest && (flags & RF_NO_CLOSEST)) break;   /* the path ends after this bounce: no closest-hit walk (nextBounceRuns) */
       if (startClosest) {
         mode = 1; cur = nextRay; cachedTI = 0; minLen = POW32; i = 0; firstCounted = false;
         reciprocalOfDir(sc, cur.dir, cur.origin, curInv, curFast);

@@ -298,6 +298,8 @@ __global__ __launch_bounds__(FLX_WQ_THREADS) void k_wf_walk_queue(DeviceScene sc
       uint32_t pathId = 0, flags = act ? 0u : 0u;
       float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f);
       if (act) { r0 = slot[0]; pathId = fbits(r0.z); flags = fbits(r0.w); }
+      /* shadow walk over and the path ends after this bounce: no closest-hit walk (nextBounceRuns), fold it now with "no hit" */
+      if (act && (flags & SF_ENDED) && !(flags & SF_CLOSEST) && ((int)(flags >> SF_RF_SHIFT) & RF_NO_CLOSEST)) flags |= SF_CLOSEST;
       /* closest-hit walk over: fragment:445-460, 580, 593-598 and the guard of :475 */
       const bool foldMe = act && (flags & SF_ENDED) && (flags & SF_CLOSEST);
       if (__ballot(foldMe) != 0ull) {
@@ -372,13 +374,20 @@ __global__ __launch_bounds__(FLX_WQ_THREADS) void k_wf_walk_queue(DeviceScene sc
             const float4 *rec = wb.rec + (size_t)id * 8;
             const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];     /* one cache line */
             const int fl = __float_as_int(q0.w);
-            if (!(fl & RF_DEAD)) {
+            if (!(fl & RF_DEAD) && !(fl & RF_NEED_SHADOW) && (fl & RF_NO_CLOSEST)) {
+              /* nothing to walk (no shadow ray, and the path ends after this bounce): folded here, the slot stays free */
+              const float4 q4 = rec[4], q5 = rec[5], q6 = rec[6], q7 = rec[7];
+              const float base = q2.w;
+              const f3 localColor = (fl & RF_SHADOWED_NO_WALK) ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
+              const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
+              finalize_path(fr, wb, id, F3(q5.x, q5.y, q5.z) + localColor * importancy, importancy, originalColor);
+            } else if (!(fl & RF_DEAD)) {
               pathId = id;
               const bool needShadow = (fl & RF_NEED_SHADOW) != 0;
               if (needShadow) { wo = F3(q2.x, q2.y, q2.z); wd = F3(q3.x, q3.y, q3.z); minLen = q1.w; }
               else { wo = F3(q0.x, q0.y, q0.z); wd = F3(q1.x, q1.y, q1.z); minLen = POW32; }
               flags = SF_START | (needShadow ? 0u : SF_CLOSEST) | ((uint32_t)fl << SF_RF_SHIFT);
-              if (COUNT) { if (needShadow) cnt.shadow_walks++; cnt.closest_walks++; }
+              if (COUNT) { if (needShadow) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
               start = true; fresh = true;
             }
           }

@@ -134,7 +134,8 @@ __global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame f
     const float cosSampleN = flx_cos((float)s);
     ShadeOut so;
     shadeSample(sc, fr, sf, ps, p, camera, cosSampleN, 0, so);
-    const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0);
+    const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0) |
+                      (nextBounceRuns(fr, 0, p.importancyFactor, ps.originalColor) ? 0 : RF_NO_CLOSEST);
     if (compact) {
       /* the per-pixel part is the same for every sample (sf is; importancy stays (1,1,1) while dontFilter holds, as it does
        * on entry to bounce 0): written once */
@@ -199,7 +200,8 @@ __global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr
     const float cosSampleN = flx_cos((float)s);
     ShadeOut so;
     bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, pb, so, cnt);
-    const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0);
+    const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0) |
+                      (nextBounceRuns(fr, pb, p.importancyFactor, ps.originalColor) ? 0 : RF_NO_CLOSEST);
     rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
     rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
     rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
@@ -329,18 +331,23 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
               nextRay.origin = F3(q0.x, q0.y, q0.z);
               nextRay.dir = F3(q1.x, q1.y, q1.z);
               walkClearResults(w);
-              if (fl & RF_NEED_SHADOW) {
-                Ray sr; sr.origin = F3(q2.x, q2.y, q2.z); sr.dir = F3(q3.x, q3.y, q3.z);
-                walkStartT(sc, w, 0, sr, q1.w);
-                if (COUNT) cnt.shadow_walks++;
+              const bool noClosest = (fl & RF_NO_CLOSEST) != 0;
+              if (COUNT && !noClosest) cnt.closest_walks++;
+              if (!(fl & RF_NEED_SHADOW) && noClosest) {
+                w.mode = 2; st = L_DONE;                       /* nothing to walk: the fold finalises the path */
               } else {
-                walkStartT(sc, w, 1, nextRay, POW32);
+                if (fl & RF_NEED_SHADOW) {
+                  Ray sr; sr.origin = F3(q2.x, q2.y, q2.z); sr.dir = F3(q3.x, q3.y, q3.z);
+                  walkStartT(sc, w, 0, sr, q1.w);
+                  if (COUNT) cnt.shadow_walks++;
+                } else {
+                  walkStartT(sc, w, 1, nextRay, POW32);
+                }
+                st = L_WALKING;
+                bool ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt);
+                if (ended && w.mode == 0 && !noClosest) { walkStartT(sc, w, 1, nextRay, POW32); ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt); }
+                if (ended) { w.mode = 2; st = L_DONE; }
               }
-              if (COUNT) cnt.closest_walks++;
-              st = L_WALKING;
-              bool ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt);
-              if (ended && w.mode == 0) { walkStartT(sc, w, 1, nextRay, POW32); ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt); }
-              if (ended) { w.mode = 2; st = L_DONE; }
             }
           }
         }
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
       }
       if (COUNT) tRefill += clock64() - t1;
       if (__ballot(st == L_WALKING) == 0ull) {
-        if (itemsLeft || chunkNext != chunkEnd) continue;
+        if (itemsLeft || chunkNext != chunkEnd || __ballot(st == L_DONE) != 0ull) continue;      /* (lanes that had nothing to walk wait for the fold) */
         break;
       }
     }
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
         bool ended = false;
         if (walkIsBoxT(cur)) walkBoxT(w, cur); else ended = walkTriT(w, cur);
         if (!ended) ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt);
-        if (ended && w.mode == 0) {                      /* shadow walk over: start the closest-hit walk at entry 0 */
+        if (ended && w.mode == 0 && !(flags & RF_NO_CLOSEST)) {      /* shadow walk over: start the closest-hit walk at entry 0 */
           walkStartT(sc, w, 1, nextRay, POW32);
           ended = walkFetchT<COUNT>(sc, ldsEntries, ldsCount, w, cur, cnt);
         }
@@ -731,8 +738,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
               } else {
                 walkClearResults(w);
                 w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
-                if (COUNT) { if (w.mode == 0) cnt.shadow_walks++; cnt.closest_walks++; }
-                st = P_SETUP;
+                if (COUNT) { if (w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
+                st = (w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;      /* nothing to walk: straight to the fold */
               }
             }
           }
@@ -741,7 +748,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       }
       /* ---- set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended -------- */
       if (COUNT) { const long long tl = clock64(); tLoad += tl - t1; }
-      if (st == P_SWITCH) { w.mode = 1; st = P_SETUP; }
+      if (st == P_SWITCH) {
+        if (flags & RF_NO_CLOSEST) st = P_DONE;              /* the path ends after this bounce: no closest-hit walk (nextBounceRuns) */
+        else { w.mode = 1; st = P_SETUP; }
+      }
       if (__ballot(st == P_SETUP || st == P_RESUME) != 0ull) {
         if (st == P_SETUP || st == P_RESUME) {
           const bool shadowMode = w.mode == 0;
@@ -789,6 +799,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   if (outValid) {
     for (uint32_t t = outUsed + lane; t < WF_OUT_CHUNK; t += 64u) listOut[outBase + t] = WF_INVALID;
   }
+  /* counted frames: the entries this kernel's walks visited in round 0 (bench.py: algorithmic bytes of the bounce-0 launch) */
+  if (COUNT && b == 0 && (cnt.closest_visits | cnt.shadow_visits) != 0u) atomicAdd(wb.counters + 23, (unsigned long long)cnt.closest_visits + cnt.shadow_visits);
   flush_counters<COUNT>(cnt, wb.counters);
   if (COUNT && lane == 0) {
     atomicAdd(wb.counters + 8 + 2 * (b < 4 ? b : 3), (unsigned long long)diagIters); atomicAdd(wb.counters + 9 + 2 * (b < 4 ? b : 3), (unsigned long long)diagBatches);

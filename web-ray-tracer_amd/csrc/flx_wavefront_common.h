@@ -15,6 +15,7 @@ enum { P_EMPTY = 0, P_WALKING = 1, P_DONE = 2, P_SWITCH = 3, P_SETUP = 4, P_RESU
 
 /* record flags (q0.w as int bits) */
 constexpr int RF_DEAD = 1, RF_DONT_FILTER = 2, RF_NEED_SHADOW = 4, RF_SHADOWED_NO_WALK = 8;
+constexpr int RF_NO_CLOSEST = 16;      /* the loop guard ends the path after this bounce: its closest-hit walk would reach no output (nextBounceRuns) */
 
 /* q0 origin.xyz flags | q1 nextDir.xyz shadowLen | q2 shadowOrigin.xyz baseLuminance  (after the walk: hit s,u,v,tri)
  * q3 shadowDir.xyz bounce | q4 litColor.xyz - | q5 finalColor.xyz - | q6 importancyFactor.xyz - | q7 originalColor.xyz - */
