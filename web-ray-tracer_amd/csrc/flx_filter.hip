@@ -42,6 +42,30 @@ __device__ __forceinline__ f4 fetch(Tex t, int W, int H, int x, int y_gl) { retu
 __device__ __forceinline__ bool rawEq3(uint32_t a, uint32_t b) { return ((a ^ b) & 0x00ffffffu) == 0u; }
 __device__ __forceinline__ uint32_t rawW(uint32_t q) { return q >> 24; }
 
+/* The second and the final filter reach at most 9 texels from the centre (stencil radius 3 x a scale of at most 3, SURVEY §8a
+ * F2 / F3): a workgroup's 16 x 16 texels and their halo of the five planes are staged in LDS once (34 x 34 x 5 words = 23 KB)
+ * and the ~37 x 5 data-dependent taps of every texel read from there.  Outside the image, and for a plane that is not bound,
+ * the tile holds the 0 texelFetch yields there (fetchRaw). */
+constexpr int FILTER_HALO = 9;
+constexpr int FILTER_TW = 16 + 2 * FILTER_HALO;
+struct TileOrigin { int x0, row0; };      /* image coordinates (x, row from the top) of the tile's first texel */
+__device__ __forceinline__ TileOrigin tile_origin(int W) {
+  const int tiles_x = (W + 15) >> 4;
+  TileOrigin o; o.x0 = (int)(blockIdx.x % tiles_x) << 4; o.row0 = (int)(blockIdx.x / tiles_x) << 4;
+  return o;
+}
+__device__ __forceinline__ void stage_tile(uint32_t *lds, Tex t, int W, int H, TileOrigin o) {
+  for (int idx = threadIdx.x; idx < FILTER_TW * FILTER_TW; idx += 256) {
+    const int lr = idx / FILTER_TW, lc = idx - lr * FILTER_TW;
+    const int gx = o.x0 - FILTER_HALO + lc, grow = o.row0 - FILTER_HALO + lr;
+    lds[idx] = (t.p && gx >= 0 && grow >= 0 && gx < W && grow < H) ? t.p[(size_t)grow * W + gx] : 0u;
+  }
+}
+/* fetchRaw(t, W, H, x, y_gl) from the staged tile; (x, y_gl) within FILTER_HALO of the workgroup's texels */
+__device__ __forceinline__ uint32_t fetchTile(const uint32_t *lds, int H, TileOrigin o, int x, int y_gl) {
+  return lds[((H - 1 - y_gl) - o.row0 + FILTER_HALO) * FILTER_TW + (x - o.x0 + FILTER_HALO)];
+}
+
 __device__ __forceinline__ uint32_t quant(float x) {
   if (!(x > 0.0f)) return 0u;
   if (x >= 1.0f) return 255u;
@@ -214,13 +238,18 @@ __global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex t
 
 __global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, uint32_t *dColor, uint32_t *dIp,
                                                        uint32_t *dOrig, int W, int H) {
+  __shared__ uint32_t tile[5][FILTER_TW * FILTER_TW];
+  const TileOrigin org = tile_origin(W);
+  stage_tile(tile[0], tColor, W, H, org); stage_tile(tile[1], tIp, W, H, org); stage_tile(tile[2], tOColor, W, H, org);
+  stage_tile(tile[3], tId, W, H, org); stage_tile(tile[4], tOId, W, H, org);
+  __syncthreads();
   int x, y;
   if (!texel_of_thread(W, H, x, y)) return;
-  const f4 centerColor = unpack(fetchRaw(tColor, W, H, x, y));
-  const f4 centerColorIp = unpack(fetchRaw(tIp, W, H, x, y));
-  const f4 centerOColor = unpack(fetchRaw(tOColor, W, H, x, y));
-  const uint32_t rCenterId = fetchRaw(tId, W, H, x, y), rCenterOId = fetchRaw(tOId, W, H, x, y);
-  const uint32_t centerIpW = rawW(fetchRaw(tIp, W, H, x, y));
+  const f4 centerColor = unpack(fetchTile(tile[0], H, org, x, y));
+  const f4 centerColorIp = unpack(fetchTile(tile[1], H, org, x, y));
+  const f4 centerOColor = unpack(fetchTile(tile[2], H, org, x, y));
+  const uint32_t rCenterId = fetchTile(tile[3], H, org, x, y), rCenterOId = fetchTile(tile[4], H, org, x, y);
+  const uint32_t centerIpW = rawW(fetchTile(tile[1], H, org, x, y));
   f4 color = add4(centerColor, scale4(F4(centerColorIp.x, centerColorIp.y, centerColorIp.z, 0.0f), 256.0f));
   f4 oColor = centerOColor;
   float ipw = centerColorIp.w;
@@ -229,21 +258,21 @@ __global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex 
   for (int i = 0; i < 36; i++) {
     const int cx = x + (int)(STENCIL3_36[i][0] * scale);
     const int cy = y + (int)(STENCIL3_36[i][1] * scale);
-    const uint32_t nextOId = fetchRaw(tOId, W, H, cx, cy);
+    const uint32_t nextOId = fetchTile(tile[4], H, org, cx, cy);
     if (!rawEq3(rCenterOId, nextOId)) continue;
-    const uint32_t id = fetchRaw(tId, W, H, cx, cy);
-    const uint32_t rNextIp = fetchRaw(tIp, W, H, cx, cy);
+    const uint32_t id = fetchTile(tile[3], H, org, cx, cy);
+    const uint32_t rNextIp = fetchTile(tile[1], H, org, cx, cy);
     const uint32_t minOIdW = rawW(rCenterOId) < rawW(nextOId) ? rawW(rCenterOId) : rawW(nextOId);
     const uint32_t maxIpW = rawW(rNextIp) > centerIpW ? rawW(rNextIp) : centerIpW;
     if (minOIdW >= 26u && (id == rCenterId || maxIpW >= 26u)) {                 /* min(...) > 0.1 && (ids equal || max(...) >= 0.1) */
-      const f4 nextColor = unpack(fetchRaw(tColor, W, H, cx, cy)), nextColorIp = unpack(rNextIp), nextOColor = unpack(fetchRaw(tOColor, W, H, cx, cy));
+      const f4 nextColor = unpack(fetchTile(tile[0], H, org, cx, cy)), nextColorIp = unpack(rNextIp), nextOColor = unpack(fetchTile(tile[2], H, org, cx, cy));
       color = add4(color, add4(nextColor, scale4(F4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
       count += 1.0f;
       ipw += nextColorIp.w;
       oColor = add4(oColor, nextOColor);
       oCount += 1.0f;
     } else if (rawEq3(id, rCenterId)) {
-      const f4 nextColor = unpack(fetchRaw(tColor, W, H, cx, cy)), nextColorIp = unpack(rNextIp);
+      const f4 nextColor = unpack(fetchTile(tile[0], H, org, cx, cy)), nextColorIp = unpack(rNextIp);
       color = add4(color, add4(nextColor, scale4(F4(nextColorIp.x, nextColorIp.y, nextColorIp.z, 0.0f), 256.0f)));
       count += 1.0f;
     }
@@ -258,30 +287,35 @@ __global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex 
 }
 
 __global__ __launch_bounds__(256) void k_filter_final(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, float4 *out, int W, int H, int hdr) {
+  __shared__ uint32_t tile[5][FILTER_TW * FILTER_TW];
+  const TileOrigin org = tile_origin(W);
+  stage_tile(tile[0], tColor, W, H, org); stage_tile(tile[1], tIp, W, H, org); stage_tile(tile[2], tOColor, W, H, org);
+  stage_tile(tile[3], tId, W, H, org); stage_tile(tile[4], tOId, W, H, org);
+  __syncthreads();
   int x, y;
   if (!texel_of_thread(W, H, x, y)) return;
-  const uint32_t rCenterColor = fetchRaw(tColor, W, H, x, y);
-  const uint32_t centerIpW = rawW(fetchRaw(tIp, W, H, x, y));
-  const f4 centerOColor = unpack(fetchRaw(tOColor, W, H, x, y));
-  const uint32_t rCenterId = fetchRaw(tId, W, H, x, y), rCenterOId = fetchRaw(tOId, W, H, x, y);
+  const uint32_t rCenterColor = fetchTile(tile[0], H, org, x, y);
+  const uint32_t centerIpW = rawW(fetchTile(tile[1], H, org, x, y));
+  const f4 centerOColor = unpack(fetchTile(tile[2], H, org, x, y));
+  const uint32_t rCenterId = fetchTile(tile[3], H, org, x, y), rCenterOId = fetchTile(tile[4], H, org, x, y);
   f4 color = F4(0.0f, 0.0f, 0.0f, 0.0f), oColor = color;
   float count = 0.0f, oCount = 0.0f;
   const float scale = 0.7f + 2.0f * flx_tanh(centerOColor.w + unorm8(rawW(rCenterOId)) * 4.0f);
   for (int i = 0; i < 37; i++) {
     const int cx = x + (int)(STENCIL3_37[i][0] * scale);
     const int cy = y + (int)(STENCIL3_37[i][1] * scale);
-    const uint32_t nextOId = fetchRaw(tOId, W, H, cx, cy);
+    const uint32_t nextOId = fetchTile(tile[4], H, org, cx, cy);
     if (!rawEq3(rCenterOId, nextOId)) continue;               /* both accumulations need the original ids to agree */
-    const uint32_t rNextIp = fetchRaw(tIp, W, H, cx, cy);
+    const uint32_t rNextIp = fetchTile(tile[1], H, org, cx, cy);
     const uint32_t maxIpW = rawW(rNextIp) > centerIpW ? rawW(rNextIp) : centerIpW;
     const uint32_t minOIdW = rawW(rCenterOId) < rawW(nextOId) ? rawW(rCenterOId) : rawW(nextOId);
     const bool blurTranslucent = maxIpW != 0u && minOIdW > 0u;
     if (blurTranslucent) {
-      oColor = add4(oColor, unpack(fetchRaw(tOColor, W, H, cx, cy)));
+      oColor = add4(oColor, unpack(fetchTile(tile[2], H, org, cx, cy)));
       oCount += 1.0f;
     }
-    if (blurTranslucent || rawEq3(rCenterId, fetchRaw(tId, W, H, cx, cy))) {
-      color = add4(color, add4(unpack(fetchRaw(tColor, W, H, cx, cy)), scale4(unpack(rNextIp), 255.0f)));
+    if (blurTranslucent || rawEq3(rCenterId, fetchTile(tile[3], H, org, cx, cy))) {
+      color = add4(color, add4(unpack(fetchTile(tile[0], H, org, cx, cy)), scale4(unpack(rNextIp), 255.0f)));
       count += 1.0f;
     }
   }
