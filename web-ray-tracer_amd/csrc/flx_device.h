@@ -194,6 +194,21 @@ FLX_DEV f4 noise(float random_seed, float nx, float ny, float seed) {
   return r;
 }
 
+/* RN(1 / d) without the division: v_rcp_f32 and ONE FMA correction give exactly the bits of 1.0f / d for every float with
+ * 2^-60 <= |d| <= 2^60 (tools/micro/rcp_exact.hip walks all 2^32 bit patterns on the MI355X: 0 differences in that range; the
+ * division is ~12 dependent instructions).  recipOf() takes that path when every lane of the wave that needs the value is
+ * inside the range and divides otherwise; lanes that do not need it may get anything. */
+FLX_DEV float recipFast(float d) {
+  const float y = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
+}
+FLX_DEV float recipOf(float d, bool needed) {
+  const float a = flx_abs(d);
+  const bool ok = !needed || (a >= 8.673617379884035e-19f && a <= 1.152921504606847e18f);      /* 2^-60, 2^60; NaN is not ok */
+  if (__ballot(!ok) == 0ull) return recipFast(d);
+  return 1.0f / d;
+}
+
 /* fragment:123-140; returns false on miss, else suv */
 FLX_DEV bool moellerTrumbore(f3 a, f3 b, f3 c, const Ray &ray, float l, f3 &suv) {
   f3 edge1 = b - a;
@@ -201,7 +216,7 @@ FLX_DEV bool moellerTrumbore(f3 a, f3 b, f3 c, const Ray &ray, float l, f3 &suv)
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
   if (flx_abs(det) < BIAS) return false;
-  float inv_det = 1.0f / det;
+  float inv_det = recipOf(det, true);
   f3 tvec = ray.origin - a;
   float u = dot(tvec, pvec) * inv_det;
   if (u < BIAS || u > 1.0f) return false;
@@ -221,7 +236,7 @@ FLX_DEV bool moellerTrumboreCull(f3 a, f3 b, f3 c, const Ray &ray, float l) {
   f3 edge2 = c - a;
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
-  float invDet = 1.0f / det;
+  float invDet = recipOf(det, !(det < BIAS));        /* (the shader divides before the test; a rejected lane never uses the value) */
   if (det < BIAS) return false;
   f3 tvec = ray.origin - a;
   float u = dot(tvec, pvec) * invDet;
@@ -243,7 +258,7 @@ FLX_DEV bool moellerTrumborePrimaryE(f3 a, f3 edge1, f3 edge2, const Ray &ray, f
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
   if (!(det < 0.0f)) return false;
-  float inv_det = 1.0f / det;
+  float inv_det = recipOf(det, true);
   f3 tvec = ray.origin - a;
   float u = dot(tvec, pvec) * inv_det;
   if (!(u >= 0.0f && u <= 1.0f)) return false;
@@ -691,7 +706,7 @@ FLX_DEV float divByRecip(float a, float d, float y) {
 /* tR changed: refresh the reciprocal and decide whether the fast box test may be used for this ray. */
 /* RN(1/d) per component and whether (d, o) are in the range where divByRecip() is proven exact. */
 FLX_DEV void reciprocalOfDir(const DeviceScene &sc, f3 d, f3 o, f3 &inv, bool &fast) {
-  inv = F3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  inv = F3(recipFast(d.x), recipFast(d.y), recipFast(d.z));      /* read only when `fast` holds, i.e. inside recipFast's proven range */
   const float LO = 8.673617379884035e-19f, HI = 1.152921504606847e18f, OHI = 5.764607523034235e17f;   /* 2^-60, 2^60, 2^59 */
   const float ax = flx_abs(d.x), ay = flx_abs(d.y), az = flx_abs(d.z);
   fast = sc.walk_fast_boxes != 0u && ax >= LO && ax <= HI && ay >= LO && ay <= HI && az >= LO && az <= HI &&
@@ -825,14 +840,14 @@ FLX_DEV void walkBoxT(WalkState &w, const WalkEntry &cur) {
 FLX_DEV bool moellerTrumboreAny(f3 a, f3 edge1, f3 edge2, const Ray &ray, float l, bool cull, f3 &suv) {
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
-  float inv_det = 1.0f / det;
+  bool detBad = cull ? (det < BIAS) : (flx_abs(det) < BIAS);
+  float inv_det = recipOf(det, !detBad);                 /* a rejected lane's u, v, s are never read */
   f3 tvec = ray.origin - a;
   float u = dot(tvec, pvec) * inv_det;
   f3 qvec = cross(tvec, edge1);
   float v = dot(ray.dir, qvec) * inv_det;
   float uvSum = u + v;
   float s = dot(edge2, qvec) * inv_det;
-  bool detBad = cull ? (det < BIAS) : (flx_abs(det) < BIAS);
   bool uBad = (u < BIAS) || (u > 1.0f);
   bool vBad = (v < BIAS) || (uvSum > 1.0f);
   bool sOk = cull ? ((s <= l) && (s > BIAS)) : (!(s > l) && !(s <= BIAS));
