@@ -166,6 +166,50 @@ flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_ker
 flx_status flx_render_planes_device(flx_context *ctx, const flx_frame_params *params, void *d_planes);
 flx_status flx_filter_planes_device(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba);
 
+/* ---- several GPUs -----------------------------------------------------------------------
+ * The path shards by pixels: the frame is cut into strips of tile_rows image rows, strip s belongs to rank s % n, the scene is
+ * replicated on every GPU, and ONE exchange step per frame (or batch of frames) brings the strips together: ncclAllGather
+ * (RCCL over xGMI) of the packed strips on the contexts' streams, then a kernel of the library puts the gathered rows in
+ * image order.  With use_filter the five RGBA8 render targets are gathered instead (5 x 8.3 MB at 1080p) and the denoise
+ * chain, which reads up to ~194 rows around a pixel, runs on the whole frame.  Temporal frames keep their history in one
+ * context and are not sharded.  The reference has one WebGL2 context per renderer (pathtracerWGL2.js:60-68); this is what
+ * `new FlexLight(canvas, { devices: N })` of the JavaScript host layer sits on. */
+
+/* One process per GPU (bench.py under torch.distributed.run).  Rank 0 makes an id (ncclGetUniqueId) and hands it to the other
+ * ranks by any means; every rank then joins its context to the communicator (ncclCommInitRank; collective: all ranks call). */
+#define FLX_COMM_ID_BYTES 128
+flx_status flx_comm_unique_id(uint8_t *id /* FLX_COMM_ID_BYTES */);
+flx_status flx_comm_init_rank(flx_context *ctx, const uint8_t *id, int n_ranks, int rank);
+flx_status flx_comm_destroy(flx_context *ctx);          /* also done by flx_context_destroy */
+/* This rank's strips of n_frames frames (1 .. 32; params[i].tile_rows > 0, tile_index = the rank, tile_count = n_ranks; a
+ * filter frame alone): traced, all-gathered, reassembled — d_frames = float4[n_frames][height][width] in device memory, the
+ * same on every rank and bit-identical to the frames one context renders.  Everything is enqueued on the context's stream
+ * without a host synchronisation; flx_last_frame_ms then spans first kernel .. last byte of the gathered frame. */
+flx_status flx_render_gathered_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, void *d_frames);
+
+/* One process, n GPUs (the JavaScript host: Node is one process): n contexts, one RCCL communicator each (ncclCommInitAll).
+ * `devices` may name one GPU more than once — a rehearsal on a one-GPU box, where RCCL refuses two ranks on a device: the
+ * strips are then exchanged with device-to-device copies, everything else is unchanged (flx_group_uses_rccl says which). */
+typedef struct flx_group flx_group;
+flx_status flx_group_create(int n, const int *devices, flx_group **out);
+void flx_group_destroy(flx_group *group);
+const char *flx_group_last_error(const flx_group *group);   /* group may be NULL: last creation error */
+int flx_group_size(const flx_group *group);
+int flx_group_uses_rccl(const flx_group *group);
+flx_context *flx_group_context(flx_group *group, int rank);          /* owned by the group; for per-context settings and timings */
+/* the uploads of a context, applied to every context of the group (the scene is replicated) */
+flx_status flx_group_scene_upload(flx_group *group, const float *geometry, const float *attributes, uint32_t n_entries_padded,
+                                  const int32_t *ids, uint32_t n_ids);
+flx_status flx_group_transforms_upload(flx_group *group, const float *rotation, const float *shift, uint32_t n_transforms);
+flx_status flx_group_lights_upload(flx_group *group, const float *lights, uint32_t n_lights);
+flx_status flx_group_atlas_upload(flx_group *group, int which, const uint8_t *rgba, uint32_t width, uint32_t height);
+flx_status flx_group_scene_upload_view(flx_group *group, const flx_scene_view *scene);
+/* n_frames frames (1 = one frame; a batch like flx_render_batch; a filter frame alone) rendered by all contexts of the group:
+ * params[i].tile_* are ignored, strips of tile_rows rows.  out_rgba = float4[n_frames][height][width] on the host, equal to
+ * flx_render / flx_render_batch of one context bit for bit.  counters (may be NULL): summed over the contexts. */
+flx_status flx_group_render(flx_group *group, const flx_frame_params *params, uint32_t n_frames, uint32_t tile_rows, float *out_rgba,
+                            flx_counters *counters);
+
 /* Anti-aliasing post passes: config.antialiasing = 'fxaa' | 'taa' of the reference (modules/fxaa.js:7-137,
  * modules/taa.js:11-59).  Both read the RGBA8 texture the renderer drew into — the frame is stored as the reference stores it,
  * floor(clamp(x) * 255 + 0.5) — and return the float the shader writes to the canvas, rows top-down like every frame here.

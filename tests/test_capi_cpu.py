@@ -50,6 +50,10 @@ def test_tile_policy_helpers():
         assert rows == [y for y in range(37) if (y // 8) % 3 == idx]
         seen += rows
     assert sorted(seen) == list(range(37))
+    # more ranks than strips (37 rows in strips of 8 = 5 strips, 8 ranks): the ranks past the last strip own nothing
+    for idx in range(8):
+        p.tile_rows, p.tile_index, p.tile_count = 8, idx, 8
+        assert capi.Context.tile_row_count(p) == (8 if idx < 4 else (5 if idx == 4 else 0))
 
 
 def test_struct_layouts_match_the_c_compiler(tmp_path):

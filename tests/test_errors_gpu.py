@@ -1,0 +1,107 @@
+"""Error paths and corner cases of the C ABI on the GPU: everything is reported through the status code + flx_last_error,
+nothing throws or aborts, and the context stays usable afterwards."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_tile_share_through_the_device_entry_points(hip, scenes):
+    """tile_count greater than the number of strips: a rank without a strip renders nothing — FLX_OK from the *_device entry
+    points too (bench.py calls only those), and the frame events are recorded"""
+    import torch
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    out = torch.zeros((64, 4), dtype=torch.float32, device="cuda")
+    p = sc.frame_params(width=64, height=16, samples=1, max_reflections=1, use_filter=0, tile=(8, 5, 8))
+    assert hip.tile_row_count(p) == 0
+    hip.render_device(p, out.data_ptr())
+    hip.render_batch_device([p, p], out.data_ptr())
+    assert hip.last_frame_ms()[0] >= 0
+    f = sc.frame_params(width=64, height=16, samples=1, max_reflections=1, use_filter=1, tile=(8, 5, 8))
+    hip.render_planes_device(f, out.data_ptr())
+    hip.sync()
+    assert float(out.abs().sum()) == 0.0
+    got, _, _ = hip.render(p)
+    assert got.shape == (0, 64, 4)
+
+
+def test_two_contexts_on_one_device_render_concurrently(hip, scenes):
+    """a second context on the same GPU while the first has frames in flight: separate streams and workspaces"""
+    import torch
+    from flexlight_hip import capi
+    sc, sc2 = scenes("dragon"), scenes("cornell")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=480, height=270, samples=4, max_reflections=4, use_filter=0)
+    p2 = sc2.frame_params(width=128, height=96, samples=2, max_reflections=3, use_filter=0)
+    want = hip.render(p)[0]
+    other = capi.Context(0)
+    try:
+        other.update_scene(sc2)
+        want2 = other.render(p2)[0]
+        a = torch.zeros((3, 270, 480, 4), dtype=torch.float32, device="cuda")
+        for i in range(3):
+            hip.render_device(p, a[i].data_ptr())          # enqueued, not waited for
+        got2 = other.render(p2)[0]                         # the other context renders meanwhile
+        hip.sync()
+        assert np.array_equal(got2, want2, equal_nan=True)
+        for i in range(3):
+            assert np.array_equal(a[i].cpu().numpy(), want, equal_nan=True)
+    finally:
+        other.close()
+
+
+def test_a_batch_whose_records_do_not_fit_is_refused_with_advice(hip, scenes):
+    """32 frames of 8192 x 4320 x 8 samples = 9e9 paths do not even index; 32 x 4K x 8 samples need ~400 GB of path records:
+    refused before anything is allocated, the message says what to do, and the context renders on"""
+    from flexlight_hip import capi
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    small = sc.frame_params(width=160, height=90, samples=2, max_reflections=3, use_filter=0)
+    want = hip.render(small)[0]
+    huge = sc.frame_params(width=8192, height=4320, samples=8, max_reflections=4, use_filter=0)
+    with pytest.raises(capi.FlexLightHipError, match="too large"):
+        hip.render_batch_device([huge] * 32, 0x1000)
+    big = sc.frame_params(width=3840, height=2160, samples=8, max_reflections=4, use_filter=0)
+    with pytest.raises(capi.FlexLightHipError, match="fewer frames per batch"):
+        hip.render_batch_device([big] * 32, 0x1000)          # (refused before the output pointer is touched)
+    assert np.array_equal(hip.render(small)[0], want, equal_nan=True)
+
+
+def test_set_stream_of_another_device_is_refused(hip):
+    import torch
+    from flexlight_hip import capi
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: a stream of another device cannot be made on this box")
+    with torch.cuda.device(1):
+        s = torch.cuda.Stream()
+    with pytest.raises(capi.FlexLightHipError, match="belongs to device"):
+        hip.set_stream(s.cuda_stream)
+
+
+def test_dynamic_uploads_reuse_their_buffers(hip, oracle, scenes):
+    """transforms and lights re-uploaded every frame (pathtracerWGL2.js:258-262, 361-365) go to persistent device buffers in
+    stream order: three frames in flight with three different light arrays each keep their own lights"""
+    import torch
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=96, height=64, samples=2, max_reflections=2, use_filter=0)
+    lights = [sc.arrays["lights"].copy() for _ in range(3)]
+    for i, l in enumerate(lights):
+        l.reshape(-1, 6)[:, 0] += 1.5 * i
+        l.reshape(-1, 6)[:, 3] *= (1.0 + 0.5 * i)
+    out = torch.zeros((3, 64, 96, 4), dtype=torch.float32, device="cuda")
+    for i in range(3):
+        hip.update_primary_light_sources(lights[i])
+        hip.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+        hip.render_device(p, out[i].data_ptr())              # no wait between the frames
+    hip.sync()
+    got = out.cpu().numpy()
+    import copy
+    for i in range(3):
+        sci = copy.copy(sc)
+        sci.arrays = dict(sc.arrays, lights=lights[i])
+        want, _, _ = oracle.render(sci, p)
+        assert np.array_equal(got[i], want, equal_nan=True), "frame %d" % i
+    assert not np.array_equal(got[0], got[2])
+    hip.update_scene(sc)

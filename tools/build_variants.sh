@@ -7,7 +7,8 @@ mkdir -p ../../build/variants
 while [ $# -gt 1 ]; do
   name=$1; flags=$2; shift 2
   /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -Wno-unused-function \
-    -I../../include -I. $flags -shared -o ../../build/variants/lib_$name.so flx_api.hip flx_kernels.hip flx_wavefront.hip flx_walkq.hip flx_walkcoop.hip flx_filter.hip flx_mesh.hip &
+    -I../../include -I. -I/opt/rocm/include $flags -shared -o ../../build/variants/lib_$name.so flx_api.hip flx_group.hip flx_kernels.hip flx_wavefront.hip flx_walkq.hip flx_walkcoop.hip flx_filter.hip flx_mesh.hip \
+    -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib &
 done
 wait
 ls -la ../../build/variants/

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""One workload of bench.py, a few frames, one frame per launch, through libflexlight_hip.so — and nothing else: the program
+bench.py (and profiles/README.md's commands) put under `rocprofv3 --pmc ... --` to read hardware counters of the frame's
+kernels.  No torch (its import is most of a short run's time), host output through flx_render.
+
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d out -- python3 tools/pmc_pass.py --workload dragon --frames 3
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+
+
+def main():
+    from bench import WORKLOADS
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="dragon", choices=sorted(WORKLOADS))
+    ap.add_argument("--frames", type=int, default=3)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--batch", type=int, default=1, help="frames per launch (flx_render_batch) instead of one")
+    args = ap.parse_args()
+    from flexlight_hip import capi
+    from flexlight_hip.scene_io import Scene
+    w = WORKLOADS[args.workload]
+    if len(w) > 2 and args.width is None and args.height is None:
+        args.width, args.height = w[2:]
+    scene = Scene.golden(w[0])
+    p = scene.frame_params(width=args.width, height=args.height)
+    with capi.Context(0) as ctx:
+        ctx.update_scene(scene)
+        for _ in range(args.frames):
+            if args.batch > 1:
+                ctx.render_batch([p] * args.batch)
+            else:
+                ctx.render(p)
+        print("pmc_pass: %s %dx%d, %d launches of %d frame(s), pipeline %d" % (args.workload, p.width, p.height, args.frames, args.batch, ctx.last_pipeline()))
+
+
+if __name__ == "__main__":
+    main()

@@ -13,96 +13,21 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
-#include "flexlight_hip.h"
-#include "flx_kernels.h"
+#include "flx_context.h"
 
 using namespace flx;
 
-#ifndef FLX_WF_GROUPS
-#define FLX_WF_GROUPS 1      /* measured on MI355X: 2-4 concurrent chains are slower than one (profiles/r01_ab_stream_groups.txt) */
-#endif
-constexpr int WF_MAX_GROUPS = 4;
-constexpr uint32_t WF_STRAG_MAX = 512;         /* most walks a walk workgroup can suspend */
+thread_local std::string g_create_error;
 
-static thread_local std::string g_create_error;
-
-struct flx_context {
-  int device = 0;
-  hipStream_t own_stream = nullptr, stream = nullptr;
-  std::string err;
-  hipDeviceProp_t prop;
-  /* resident scene */
-  float4 *d_geometry = nullptr, *d_attributes = nullptr, *d_rotation = nullptr, *d_shift = nullptr;
-  float4 *d_walk = nullptr;                      /* threaded hot-first copy of the skip list */
-  uint32_t walk_entries = 0, walk_hot = 0, walk_root = 0, walk_fast_boxes = 0;
-  int walk_scheduler = 0;
-  int32_t *d_ids = nullptr;
-  float *d_lights = nullptr;
-  uchar4 *d_atlas[3] = { nullptr, nullptr, nullptr };
-  uint32_t atlas_w[3] = { 0, 0, 0 }, atlas_h[3] = { 0, 0, 0 };
-  uint32_t n_entries = 0, n_ids = 0, n_transforms = 0, n_lights = 0;
-  uint32_t max_transform = 0;                   /* largest transform number an entry names */
-  bool have_scene = false, have_transforms = false;
-  /* frame workspace */
-  float4 *d_out = nullptr;
-  size_t out_capacity = 0;                       /* pixels */
-  float4 *d_gb[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  size_t gb_capacity = 0;
-  uint32_t *d_planes[13] = {};                   /* the filter chain's RGBA8 render targets */
-  size_t planes_capacity = 0;
-  /* temporal history: rings of RGBA8 planes (colour, colour ip, location id, original id), newest at ring_head */
-  uint32_t *d_ring[4][16] = {};
-  int ring_n = 0, ring_head = 0;
-  uint32_t ring_w = 0, ring_h = 0;
-  /* v2 pipeline workspace: primary hits, per-(sample,pixel) radiance, last sample's originalColor, item queue */
-  float4 *d_hits = nullptr, *d_samples = nullptr, *d_last = nullptr;
-  size_t hits_capacity = 0, samples_capacity = 0, last_capacity = 0;
-  uint32_t *d_queue = nullptr;
-  /* pipeline 3 (wavefront) workspace */
-  float4 *d_rec = nullptr;
-  float4 *d_tail_pool = nullptr;                 /* per walk workgroup: WF_TAIL_POOL_F4 float4 */
-  uint32_t *d_aa[10] = {};                       /* RGBA8 planes of the anti-aliasing passes: [0..8] the TAA ring, [9] FXAA's input */
-  size_t aa_capacity = 0;
-  uint32_t aa_w = 0, aa_h = 0;
-  int taa_head = 0, taa_filled = 0;
-  float4 *d_aa_io[2] = {};                       /* staging for the host-pointer variants */
-  size_t aa_io_capacity = 0;
-  float4 *d_rec0 = nullptr, *d_pix0 = nullptr;   /* compact bounce-0 records: 3 float4 per path, 3 float4 per pixel */
-  size_t rec0_capacity = 0, pix0_capacity = 0;
-  float4 *d_strag = nullptr;                     /* per chain 2 x (walk workgroups x WF_STRAG_MAX) suspended walks */
-  uint32_t walk_suspend = 0;                     /* walks a walk workgroup may leave to the next round (0 = off) */
-  size_t rec_capacity = 0;                       /* float4 units */
-  uint32_t *d_live[2] = { nullptr, nullptr };
-  size_t live_capacity = 0;
-  uint32_t *d_wfcounts = nullptr;                /* per chain: counts, walkQueue, stragCount, [WF_MAX_ROUNDS + 2] each */
-  int pipeline = 0;                              /* 0 auto, 1 per-pixel megakernel, 2 persistent paths, 3 wavefront */
-  int last_pipeline = 0;                         /* what the last frame ran */
-  int wf_groups = FLX_WF_GROUPS;                 /* wavefront pipeline: independent item groups on separate streams (tails of one overlap the other) */
-  hipStream_t aux_stream[3] = { nullptr, nullptr, nullptr };
-  hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
-  unsigned long long *d_counters = nullptr;
-  bool counters_enabled = false;
-  flx_counters last_counters = {};
-  hipEvent_t ev_frame0 = nullptr, ev_frame1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
-  bool timed = false;
-};
-
-#define FLX_HIP(ctx, expr)                                                                    \
-  do {                                                                                        \
-    hipError_t e_ = (expr);                                                                   \
-    if (e_ != hipSuccess) {                                                                   \
-      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
-      return FLX_ERR_DEVICE;                                                                  \
-    }                                                                                         \
-  } while (0)
-
-static flx_status fail(flx_context *ctx, flx_status code, const char *msg) {
+flx_status flx_fail(flx_context *ctx, flx_status code, const char *msg) {
   if (ctx) ctx->err = msg;
   return code;
 }
+static flx_status fail(flx_context *ctx, flx_status code, const char *msg) { return flx_fail(ctx, code, msg); }
 
 extern "C" const char *flx_version(void) { return "flexlight-hip 0.1 (gfx950)"; }
 
@@ -149,10 +74,11 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)flx_comm_destroy(ctx);
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
+                   ctx->d_send, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -162,15 +88,49 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < 3; i++) { if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  for (hipEvent_t ev : ctx->stage_done) if (ev) (void)hipEventDestroy(ev);
+  if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
 
+/* Scene arrays live in device buffers that persist across uploads: an upload of the same or a smaller size reuses the
+ * buffer (the reference refills its transform UBO and light texture every frame, pathtracerWGL2.js:258-262, 361-365 — a
+ * per-frame hipFree + hipMalloc would put two device synchronisations into every frame).  Small arrays (transforms, lights:
+ * a few hundred bytes per frame) go through a ring of pinned staging slots and are copied in stream order, without waiting
+ * for the frames already enqueued; large ones are copied from the caller's memory and waited for.  Either way the caller's
+ * buffer is not retained. */
+constexpr size_t STAGE_SLOT_BYTES = 64 * 1024;
+constexpr int STAGE_SLOTS = 8;
+
 template <typename T>
 static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t bytes) {
-  if (*dst) { FLX_HIP(ctx, hipFree(*dst)); *dst = nullptr; }
-  if (bytes == 0) return FLX_OK;
-  FLX_HIP(ctx, hipMalloc(dst, bytes));
+  size_t &cap = ctx->upload_capacity[(void **)dst];
+  if (bytes == 0) {                      /* "none": the kernels test the pointer */
+    if (*dst) { FLX_HIP(ctx, hipFree(*dst)); *dst = nullptr; }
+    cap = 0;
+    return FLX_OK;
+  }
+  if (bytes > cap || !*dst) {
+    if (*dst) { FLX_HIP(ctx, hipStreamSynchronize(ctx->stream)); FLX_HIP(ctx, hipFree(*dst)); *dst = nullptr; }
+    cap = 0;
+    FLX_HIP(ctx, hipMalloc(dst, bytes));
+    cap = bytes;
+  }
+  if (bytes <= STAGE_SLOT_BYTES) {
+    if (!ctx->stage) {
+      FLX_HIP(ctx, hipHostMalloc((void **)&ctx->stage, STAGE_SLOT_BYTES * STAGE_SLOTS, hipHostMallocDefault));
+      for (auto &ev : ctx->stage_done) FLX_HIP(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    const int k = ctx->stage_next;
+    ctx->stage_next = (k + 1) % STAGE_SLOTS;
+    if (ctx->stage_used[k]) FLX_HIP(ctx, hipEventSynchronize(ctx->stage_done[k]));      /* the copy that last read this slot (eight uploads ago) */
+    memcpy(ctx->stage + (size_t)k * STAGE_SLOT_BYTES, src, bytes);
+    FLX_HIP(ctx, hipMemcpyAsync(*dst, ctx->stage + (size_t)k * STAGE_SLOT_BYTES, bytes, hipMemcpyHostToDevice, ctx->stream));
+    FLX_HIP(ctx, hipEventRecord(ctx->stage_done[k], ctx->stream));
+    ctx->stage_used[k] = true;
+    return FLX_OK;
+  }
   FLX_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));          /* the caller's buffer is not retained */
   return FLX_OK;
@@ -373,7 +333,7 @@ static void fill_view(const flx_frame_params *p, FrameView &v) {
   v.random_seed = p->random_seed;
 }
 
-static flx_status make_frame(flx_context *ctx, const flx_frame_params *p, DeviceScene &sc, DeviceFrame &fr) {
+flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, DeviceScene &sc, DeviceFrame &fr) {
   if (!p) return fail(ctx, FLX_ERR_INVALID, "frame params are NULL");
   if (!ctx->have_scene || !ctx->have_transforms) return fail(ctx, FLX_ERR_NO_SCENE, "render before flx_scene_upload / flx_transforms_upload");
   if (p->width == 0 || p->height == 0 || p->samples < 1 || p->max_reflections < 0 || p->texture_width < 1)
@@ -403,7 +363,7 @@ static flx_status make_frame(flx_context *ctx, const flx_frame_params *p, Device
   return FLX_OK;
 }
 
-static flx_status ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels) {
+flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels) {
   if (*cap >= pixels && *buf) return FLX_OK;
   if (*buf) { FLX_HIP(ctx, hipFree(*buf)); *buf = nullptr; *cap = 0; }
   FLX_HIP(ctx, hipMalloc(buf, pixels * sizeof(float4)));
@@ -411,7 +371,7 @@ static flx_status ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, siz
   return FLX_OK;
 }
 
-static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
+flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
   unsigned long long *cnt = ctx->counters_enabled ? ctx->d_counters : nullptr;
   /* The G-buffer accumulators of the filter path carry state from sample to sample (fragment:83-89),
    * so filter frames use the sample-sequential kernel; everything else runs the wavefront pipeline. */
@@ -425,19 +385,49 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
   if (pipeline != 1 && (fr.use_filter || fr.is_temporal)) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the G-buffers of filter / temporal frames");
   const size_t P = (size_t)fr.rows * fr.width;
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+  int wf_chains = 1;
   if (pipeline != 1) {
     flx_status s;
     if (path_item_count64(fr) + 1000000ull >= 4294967296ull) return fail(ctx, FLX_ERR_INVALID, "frame (or batch of frames) too large: more than 2^32 path items");
-    if ((s = ensure_pixels(ctx, &ctx->d_hits, &ctx->hits_capacity, P))) return s;
-    if ((s = ensure_pixels(ctx, &ctx->d_last, &ctx->last_capacity, P))) return s;
-    if ((s = ensure_pixels(ctx, &ctx->d_samples, &ctx->samples_capacity, P * (size_t)fr.samples))) return s;
+    /* Does the workspace fit?  Asked before anything is freed or allocated, so that a batch that is too large is refused with
+     * a message that says what to do, and the context keeps the buffers it has. */
+    {
+      const size_t items = (size_t)path_item_count64(fr);
+      struct { size_t need, have; } w[] = {
+        { P, ctx->hits_capacity }, { P, ctx->last_capacity }, { P * (size_t)fr.samples, ctx->samples_capacity },
+        { pipeline == 3 ? items * 8 : 0, ctx->rec_capacity }, { pipeline == 3 ? items * 3 : 0, ctx->rec0_capacity },
+        { pipeline == 3 ? items / (size_t)fr.samples * 3 : 0, ctx->pix0_capacity } };
+      size_t grow = 0, freed = 0;
+      for (auto &b : w) if (b.need > b.have) { grow += b.need * sizeof(float4); freed += b.have * sizeof(float4); }
+      if (pipeline == 3) {
+        const size_t live = wavefront_live_capacity(fr, cus) * (size_t)WF_MAX_GROUPS;
+        if (live > ctx->live_capacity) { grow += 2 * live * sizeof(uint32_t); freed += 2 * ctx->live_capacity * sizeof(uint32_t); }
+      }
+      size_t memFree = 0, memTotal = 0;
+      if (grow && hipMemGetInfo(&memFree, &memTotal) == hipSuccess && grow > memFree + freed) {
+        char msg[256];
+        snprintf(msg, sizeof msg, "the path records of this frame / batch need %.1f GB of device memory, %.1f GB are free (of %.1f GB): render fewer frames per batch or a smaller frame",
+                 grow / 1e9, (memFree + freed) / 1e9, memTotal / 1e9);
+        return fail(ctx, FLX_ERR_DEVICE, msg);
+      }
+    }
+    if ((s = flx_ensure_pixels(ctx, &ctx->d_hits, &ctx->hits_capacity, P))) return s;
+    if ((s = flx_ensure_pixels(ctx, &ctx->d_last, &ctx->last_capacity, P))) return s;
+    if ((s = flx_ensure_pixels(ctx, &ctx->d_samples, &ctx->samples_capacity, P * (size_t)fr.samples))) return s;
   }
   if (pipeline == 3) {
     flx_status s;
-    if ((s = ensure_pixels(ctx, &ctx->d_rec, &ctx->rec_capacity, (size_t)path_item_count(fr) * 8))) return s;
-    if ((s = ensure_pixels(ctx, &ctx->d_rec0, &ctx->rec0_capacity, (size_t)path_item_count(fr) * 3))) return s;
-    if ((s = ensure_pixels(ctx, &ctx->d_pix0, &ctx->pix0_capacity, (size_t)path_item_count(fr) / (size_t)fr.samples * 3))) return s;      /* 64 per screen tile */
-    const size_t need = wavefront_live_capacity(fr, cus) * WF_MAX_GROUPS;      /* every group gets a slice that could hold the whole frame */
+    if ((s = flx_ensure_pixels(ctx, &ctx->d_rec, &ctx->rec_capacity, (size_t)path_item_count(fr) * 8))) return s;
+    if ((s = flx_ensure_pixels(ctx, &ctx->d_rec0, &ctx->rec0_capacity, (size_t)path_item_count(fr) * 3))) return s;
+    if ((s = flx_ensure_pixels(ctx, &ctx->d_pix0, &ctx->pix0_capacity, (size_t)path_item_count(fr) / (size_t)fr.samples * 3))) return s;      /* 64 per screen tile */
+    /* the live lists are cut into one slice per chain of the bounce loop (flx_set_wavefront_groups; counted frames run one
+     * chain), each able to hold the whole frame */
+    wf_chains = ctx->wf_groups < 1 ? 1 : (ctx->wf_groups > WF_MAX_GROUPS ? WF_MAX_GROUPS : ctx->wf_groups);
+    {
+      const uint32_t tiles = path_item_count(fr) / ((uint32_t)fr.samples * 64u);
+      if ((uint32_t)wf_chains > tiles || cnt) wf_chains = 1;
+    }
+    const size_t need = wavefront_live_capacity(fr, cus) * (size_t)wf_chains;
     if (ctx->live_capacity < need) {
       ctx->live_capacity = 0;               /* a failed allocation below must not leave the old size standing over freed lists */
       for (int i = 0; i < 2; i++) {
@@ -445,6 +435,14 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
         FLX_HIP(ctx, hipMalloc(&ctx->d_live[i], need * sizeof(uint32_t)));
       }
       ctx->live_capacity = need;
+    }
+    /* suspended walks (flx_set_walk_scheduler): room for every possible walk workgroup of every chain, only while suspension is on */
+    const size_t needStrag = ctx->walk_suspend ? (size_t)wf_chains * 2 * cus * 8u * ctx->walk_suspend * WF_STRAG_F4 : 0;
+    if (ctx->strag_capacity < needStrag) {
+      ctx->strag_capacity = 0;
+      if (ctx->d_strag) { FLX_HIP(ctx, hipFree(ctx->d_strag)); ctx->d_strag = nullptr; }
+      FLX_HIP(ctx, hipMalloc(&ctx->d_strag, needStrag * sizeof(float4)));
+      ctx->strag_capacity = needStrag;
     }
   }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
@@ -469,7 +467,6 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t), ctx->stream));
     /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
     if (!ctx->d_tail_pool) FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
-    if (!ctx->d_strag) FLX_HIP(ctx, hipMalloc(&ctx->d_strag, (size_t)WF_MAX_GROUPS * 2 * cus * 8u * WF_STRAG_MAX * WF_STRAG_F4 * sizeof(float4)));
     launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     /* The bounce loop runs as `groups` independent chains (contiguous ranges of screen tiles), group 0 on the
@@ -478,10 +475,8 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
     const uint32_t total = path_item_count(fr);
     const uint32_t perTile = (uint32_t)fr.samples * 64u;
     const uint32_t tiles = total / perTile;
-    int groups = ctx->wf_groups < 1 ? 1 : (ctx->wf_groups > WF_MAX_GROUPS ? WF_MAX_GROUPS : ctx->wf_groups);
-    if ((uint32_t)groups > tiles) groups = 1;
-    if (cnt) groups = 1;                               /* counted frames: one chain, so the scheduler statistics describe whole kernels */
-    const size_t listSlice = ctx->live_capacity / WF_MAX_GROUPS;
+    const int groups = wf_chains;                      /* (counted frames: one chain, so the scheduler statistics describe whole kernels) */
+    const size_t listSlice = ctx->live_capacity / (size_t)groups;
     if (groups > 1) {
       FLX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
       for (int g = 1; g < groups; g++) FLX_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream[g - 1], ctx->ev_fork, 0));
@@ -494,7 +489,7 @@ static flx_status run_frame(flx_context *ctx, const DeviceScene &sc, const Devic
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
       wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
-      for (int k = 0; k < 2; k++) wb.strag[k] = ctx->d_strag + ((size_t)g * 2 + k) * cus * 8u * WF_STRAG_MAX * WF_STRAG_F4;
+      for (int k = 0; k < 2; k++) wb.strag[k] = ctx->d_strag ? ctx->d_strag + ((size_t)g * 2 + k) * cus * 8u * ctx->walk_suspend * WF_STRAG_F4 : nullptr;
       wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;
       wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
       hipStream_t st = g == 0 ? ctx->stream : ctx->aux_stream[g - 1];
@@ -526,7 +521,7 @@ static flx_status run_post_frame(flx_context *ctx, const DeviceScene &sc, const 
     for (int i = 0; i < 6; i++) {
       size_t cap = 0;
       if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
-      if ((s = ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
+      if ((s = flx_ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
     }
     ctx->gb_capacity = pixels;
   }
@@ -555,7 +550,7 @@ static flx_status run_post_frame(flx_context *ctx, const DeviceScene &sc, const 
     }
   }
   GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5] };
-  if ((s = run_frame(ctx, sc, fr, nullptr, gb))) return s;
+  if ((s = flx_run_frame(ctx, sc, fr, nullptr, gb))) return s;
   launch_quantize(gb.color, pl.R[0], pixels, ctx->stream);
   launch_quantize(gb.color_ip, pl.Ip[0], pixels, ctx->stream);
   if (temporal) {
@@ -725,25 +720,37 @@ extern "C" flx_status flx_set_pipeline(flx_context *ctx, int pipeline) {
   return FLX_OK;
 }
 
+/* A context whose tile policy gives it no strip (tile_count greater than the number of strips) has nothing to render: the
+ * device entry points return FLX_OK like flx_render does, with the frame events recorded so that flx_last_frame_ms works. */
+static flx_status empty_share(flx_context *ctx) {
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  ctx->timed = true;
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_render_device(flx_context *ctx, const flx_frame_params *params, void *d_out_rgba) {
   if (!ctx) return FLX_ERR_INVALID;
   if (!d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render_device: output pointer is NULL");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
-  flx_status s = make_frame(ctx, params, sc, fr);
+  flx_status s = flx_make_frame(ctx, params, sc, fr);
   if (s) return s;
+  if ((size_t)fr.rows * fr.width == 0) return empty_share(ctx);
   if (params->use_filter || params->is_temporal) return run_post_frame(ctx, sc, fr, params, (float4 *)d_out_rgba);
   GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  return run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
+  return flx_run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
 }
 
 /* A batch of frames in ONE pass of the pipeline: the frames are stacked in the packed-row dimension, so every kernel of the
  * pass — primary, shade, walk, resolve — runs once over n times the paths.  A walk kernel lasts as long as its longest walk
  * (DESIGN.md §4); over a batch that tail is paid once per n frames. */
 static_assert(FLX_MAX_BATCH == FLX_MAX_BATCH_FRAMES, "flx_device.h and flexlight_hip.h disagree on the batch limit");
-static flx_status make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, DeviceScene &sc, DeviceFrame &fr) {
+flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, DeviceScene &sc, DeviceFrame &fr) {
   if (!params || n_frames < 1 || n_frames > FLX_MAX_BATCH) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: 1 .. 32 frames per batch");
-  flx_status s = make_frame(ctx, params, sc, fr);
+  flx_status s = flx_make_frame(ctx, params, sc, fr);
   if (s) return s;
   if (params->use_filter || params->is_temporal)
     return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: filter / temporal frames depend on the frame before and cannot be batched");
@@ -766,10 +773,11 @@ extern "C" flx_status flx_render_batch_device(flx_context *ctx, const flx_frame_
   if (!d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch_device: output pointer is NULL");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
-  flx_status s = make_batch(ctx, params, n_frames, sc, fr);
+  flx_status s = flx_make_batch(ctx, params, n_frames, sc, fr);
   if (s) return s;
+  if ((size_t)fr.rows * fr.width == 0) return empty_share(ctx);
   GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  return run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
+  return flx_run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
 }
 
 extern "C" flx_status flx_render_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, float *out_rgba, flx_counters *counters) {
@@ -777,15 +785,15 @@ extern "C" flx_status flx_render_batch(flx_context *ctx, const flx_frame_params 
   if (!out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: out_rgba is NULL");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
-  flx_status s = make_batch(ctx, params, n_frames, sc, fr);
+  flx_status s = flx_make_batch(ctx, params, n_frames, sc, fr);
   if (s) return s;
   const size_t pixels = (size_t)fr.rows * fr.width;
   if (pixels == 0) return FLX_OK;
-  if ((s = ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
+  if ((s = flx_ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
   const bool saved = ctx->counters_enabled;
   if (counters) ctx->counters_enabled = true;
   GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  s = run_frame(ctx, sc, fr, ctx->d_out, gb);
+  s = flx_run_frame(ctx, sc, fr, ctx->d_out, gb);
   ctx->counters_enabled = saved;
   if (s) return s;
   FLX_HIP(ctx, hipMemcpyAsync(out_rgba, ctx->d_out, pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));
@@ -807,7 +815,7 @@ static flx_status ensure_post_buffers(flx_context *ctx, size_t pixels, bool gbuf
     for (int i = 0; i < 6; i++) {
       size_t cap = 0;
       if (ctx->d_gb[i]) { FLX_HIP(ctx, hipFree(ctx->d_gb[i])); ctx->d_gb[i] = nullptr; }
-      if ((s = ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
+      if ((s = flx_ensure_pixels(ctx, &ctx->d_gb[i], &cap, pixels))) return s;
     }
     ctx->gb_capacity = pixels;
   }
@@ -829,13 +837,13 @@ extern "C" flx_status flx_render_planes_device(flx_context *ctx, const flx_frame
     return fail(ctx, FLX_ERR_INVALID, "flx_render_planes_device: needs use_filter = 1 and is_temporal = 0 (history is per context)");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
-  flx_status s = make_frame(ctx, params, sc, fr);
+  flx_status s = flx_make_frame(ctx, params, sc, fr);
   if (s) return s;
   const size_t pixels = (size_t)fr.rows * fr.width;
-  if (pixels == 0) return FLX_OK;
+  if (pixels == 0) return empty_share(ctx);
   if ((s = ensure_post_buffers(ctx, pixels, true, false))) return s;
   GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5] };
-  if ((s = run_frame(ctx, sc, fr, nullptr, gb))) return s;
+  if ((s = flx_run_frame(ctx, sc, fr, nullptr, gb))) return s;
   /* the reference's five render targets, stored as it stores them (RGBA8), strips packed like the radiance of a tiled frame */
   uint32_t *out = (uint32_t *)d_planes;
   const float4 *src[5] = { gb.color, gb.color_ip, gb.original_color, gb.id, gb.original_id };
@@ -846,6 +854,10 @@ extern "C" flx_status flx_render_planes_device(flx_context *ctx, const flx_frame
 }
 
 extern "C" flx_status flx_filter_planes_device(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba) {
+  return flx_filter_planes_enqueue(ctx, params, d_planes, d_out_rgba, true);
+}
+
+flx_status flx_filter_planes_enqueue(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba, bool stamp_start) {
   if (!ctx) return FLX_ERR_INVALID;
   if (!d_planes || !d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_filter_planes_device: NULL pointer");
   if (!params || params->width == 0 || params->height == 0) return fail(ctx, FLX_ERR_INVALID, "flx_filter_planes_device: empty frame");
@@ -858,7 +870,7 @@ extern "C" flx_status flx_filter_planes_device(flx_context *ctx, const flx_frame
   pl.O[0] = ctx->d_planes[8]; pl.O[1] = ctx->d_planes[9]; pl.Id[0] = ctx->d_planes[10]; pl.Id[1] = ctx->d_planes[11]; pl.OId = ctx->d_planes[12];
   const uint32_t *in = (const uint32_t *)d_planes;
   uint32_t *dst[5] = { pl.R[0], pl.Ip[0], pl.O[0], pl.Id[0], pl.OId };
-  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
+  if (stamp_start) FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
   for (int k = 0; k < 5; k++) FLX_HIP(ctx, hipMemcpyAsync(dst[k], in + (size_t)k * pixels, pixels * 4, hipMemcpyDeviceToDevice, ctx->stream));
   launch_filter_chain(pl, (float4 *)d_out_rgba, (int)params->width, (int)params->height, params->hdr, ctx->stream);
   FLX_HIP(ctx, hipGetLastError());
@@ -873,19 +885,19 @@ extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *param
   if (!out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render: out_rgba is NULL");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
-  flx_status s = make_frame(ctx, params, sc, fr);
+  flx_status s = flx_make_frame(ctx, params, sc, fr);
   if (s) return s;
   if (gbuffers && !params->use_filter && !params->is_temporal) return fail(ctx, FLX_ERR_INVALID, "flx_render: G-buffers are only produced with use_filter = 1 or is_temporal = 1");
   const size_t pixels = (size_t)fr.rows * fr.width;
   if (pixels == 0) return FLX_OK;
-  if ((s = ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
+  if ((s = flx_ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
   const bool saved = ctx->counters_enabled;
   if (counters) ctx->counters_enabled = true;
   if (params->use_filter || params->is_temporal) {
     s = run_post_frame(ctx, sc, fr, params, ctx->d_out);
   } else {
     GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-    s = run_frame(ctx, sc, fr, ctx->d_out, gb);
+    s = flx_run_frame(ctx, sc, fr, ctx->d_out, gb);
   }
   ctx->counters_enabled = saved;
   if (s) return s;
@@ -916,6 +928,14 @@ extern "C" flx_status flx_sync(flx_context *ctx) {
 extern "C" flx_status flx_set_stream(flx_context *ctx, void *hip_stream) {
   if (!ctx) return FLX_ERR_INVALID;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
+  if (hip_stream) {                      /* kernels of this context launched on another GPU's stream would fail one by one, later and less clearly */
+    hipDevice_t dev = 0;
+    if (hipStreamGetDevice((hipStream_t)hip_stream, &dev) == hipSuccess && (int)dev != ctx->device) {
+      char msg[160];
+      snprintf(msg, sizeof msg, "flx_set_stream: the stream belongs to device %d, the context to device %d", (int)dev, ctx->device);
+      return fail(ctx, FLX_ERR_INVALID, msg);
+    }
+  }
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   ctx->timed = false;

@@ -1,0 +1,123 @@
+/* flx_context.h — the context behind the C ABI and the internal helpers flx_api.hip shares with flx_group.hip (the RCCL
+ * gather across contexts).  Private to the library. */
+#ifndef FLX_CONTEXT_H
+#define FLX_CONTEXT_H
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <string>
+
+#include "flexlight_hip.h"
+#include "flx_kernels.h"
+
+typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept out of this header */
+
+#ifndef FLX_WF_GROUPS
+#define FLX_WF_GROUPS 1      /* measured on MI355X: 2-4 concurrent chains are slower than one (profiles/r01_ab_stream_groups.txt) */
+#endif
+constexpr int WF_MAX_GROUPS = 4;
+constexpr uint32_t WF_STRAG_MAX = 512;         /* most walks a walk workgroup can suspend */
+
+extern thread_local std::string g_create_error;
+
+struct flx_context {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+  /* resident scene */
+  float4 *d_geometry = nullptr, *d_attributes = nullptr, *d_rotation = nullptr, *d_shift = nullptr;
+  float4 *d_walk = nullptr;                      /* threaded hot-first copy of the skip list */
+  uint32_t walk_entries = 0, walk_hot = 0, walk_root = 0, walk_fast_boxes = 0;
+  int walk_scheduler = 0;
+  int32_t *d_ids = nullptr;
+  float *d_lights = nullptr;
+  uchar4 *d_atlas[3] = { nullptr, nullptr, nullptr };
+  uint32_t atlas_w[3] = { 0, 0, 0 }, atlas_h[3] = { 0, 0, 0 };
+  uint32_t n_entries = 0, n_ids = 0, n_transforms = 0, n_lights = 0;
+  uint32_t max_transform = 0;                   /* largest transform number an entry names */
+  bool have_scene = false, have_transforms = false;
+  /* frame workspace */
+  float4 *d_out = nullptr;
+  size_t out_capacity = 0;                       /* pixels */
+  float4 *d_gb[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  size_t gb_capacity = 0;
+  uint32_t *d_planes[13] = {};                   /* the filter chain's RGBA8 render targets */
+  size_t planes_capacity = 0;
+  /* temporal history: rings of RGBA8 planes (colour, colour ip, location id, original id), newest at ring_head */
+  uint32_t *d_ring[4][16] = {};
+  int ring_n = 0, ring_head = 0;
+  uint32_t ring_w = 0, ring_h = 0;
+  /* v2 pipeline workspace: primary hits, per-(sample,pixel) radiance, last sample's originalColor, item queue */
+  float4 *d_hits = nullptr, *d_samples = nullptr, *d_last = nullptr;
+  size_t hits_capacity = 0, samples_capacity = 0, last_capacity = 0;
+  uint32_t *d_queue = nullptr;
+  /* pipeline 3 (wavefront) workspace */
+  float4 *d_rec = nullptr;
+  float4 *d_tail_pool = nullptr;                 /* per walk workgroup: WF_TAIL_POOL_F4 float4 */
+  uint32_t *d_aa[10] = {};                       /* RGBA8 planes of the anti-aliasing passes: [0..8] the TAA ring, [9] FXAA's input */
+  size_t aa_capacity = 0;
+  uint32_t aa_w = 0, aa_h = 0;
+  int taa_head = 0, taa_filled = 0;
+  float4 *d_aa_io[2] = {};                       /* staging for the host-pointer variants */
+  size_t aa_io_capacity = 0;
+  float4 *d_rec0 = nullptr, *d_pix0 = nullptr;   /* compact bounce-0 records: 3 float4 per path, 3 float4 per pixel */
+  size_t rec0_capacity = 0, pix0_capacity = 0;
+  float4 *d_strag = nullptr;                     /* per chain 2 x (walk workgroups x strag_walks) suspended walks; allocated only while suspension is on */
+  size_t strag_capacity = 0;                     /* float4 units */
+  uint32_t walk_suspend = 0;                     /* walks a walk workgroup may leave to the next round (0 = off) */
+  size_t rec_capacity = 0;                       /* float4 units */
+  uint32_t *d_live[2] = { nullptr, nullptr };
+  size_t live_capacity = 0;
+  uint32_t *d_wfcounts = nullptr;                /* per chain: counts, walkQueue, stragCount, [WF_MAX_ROUNDS + 2] each */
+  int pipeline = 0;                              /* 0 auto, 1 per-pixel megakernel, 2 persistent paths, 3 wavefront */
+  int last_pipeline = 0;                         /* what the last frame ran */
+  int wf_groups = FLX_WF_GROUPS;                 /* wavefront pipeline: independent item groups on separate streams (tails of one overlap the other) */
+  hipStream_t aux_stream[3] = { nullptr, nullptr, nullptr };
+  hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
+  unsigned long long *d_counters = nullptr;
+  bool counters_enabled = false;
+  flx_counters last_counters = {};
+  hipEvent_t ev_frame0 = nullptr, ev_frame1 = nullptr, ev_k0 = nullptr, ev_k1 = nullptr;
+  bool timed = false;
+  /* several GPUs (flx_group.hip): this context's RCCL communicator and the buffers of the gather */
+  flx_nccl_comm comm = nullptr;
+  int comm_rank = 0, comm_size = 1;
+  bool comm_owned = false;                       /* made by flx_comm_init_rank (else by a group's ncclCommInitAll) */
+  float4 *d_send = nullptr, *d_recv = nullptr;   /* this rank's packed strips; every rank's */
+  size_t send_capacity = 0, recv_capacity = 0;   /* float4 units */
+  float4 *d_frames = nullptr;                    /* group mode: the gathered frames in image order */
+  size_t frames_capacity = 0;
+  float4 *d_gplanes = nullptr;                   /* filter frames: the five gathered render targets in image order */
+  size_t gplanes_capacity = 0;
+  /* uploads: capacity of every persistent scene buffer (keyed by the address of its pointer), pinned staging ring */
+  std::map<void **, size_t> upload_capacity;
+  uint8_t *stage = nullptr;
+  hipEvent_t stage_done[8] = {};
+  bool stage_used[8] = {};
+  int stage_next = 0;
+};
+
+#define FLX_HIP(ctx, expr)                                                                    \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                          \
+      return FLX_ERR_DEVICE;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+flx_status flx_fail(flx_context *ctx, flx_status code, const char *msg);
+
+
+/* flx_api.hip */
+flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, flx::DeviceScene &sc, flx::DeviceFrame &fr);
+flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, flx::DeviceScene &sc, flx::DeviceFrame &fr);
+flx_status flx_run_frame(flx_context *ctx, const flx::DeviceScene &sc, const flx::DeviceFrame &fr, float4 *d_out, const flx::GBufferPtrs &gb);
+flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels);
+/* flx_filter_planes_device; stamp_start = false leaves the frame's start event alone (the trace of the same frame recorded it) */
+flx_status flx_filter_planes_enqueue(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba, bool stamp_start);
+
+#endif

@@ -194,6 +194,10 @@ FLX_DEV f4 noise(float random_seed, float nx, float ny, float seed) {
   return r;
 }
 
+/* vote of the wave: the builtin takes the condition as it is (HIP's flx_ballot(int) first materialises it as 0 / 1 and compares
+ * again: two VALU instructions per vote, and the walk kernel votes several times per entry) */
+FLX_DEV unsigned long long flx_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 /* RN(1 / d) without the division: v_rcp_f32 and ONE FMA correction give exactly the bits of 1.0f / d for every float with
  * 2^-60 <= |d| <= 2^60 (tools/micro/rcp_exact.hip walks all 2^32 bit patterns on the MI355X: 0 differences in that range; the
  * division is ~12 dependent instructions).  recipOf() takes that path when every lane of the wave that needs the value is
@@ -205,7 +209,7 @@ FLX_DEV float recipFast(float d) {
 FLX_DEV float recipOf(float d, bool needed) {
   const float a = flx_abs(d);
   const bool ok = !needed || (a >= 8.673617379884035e-19f && a <= 1.152921504606847e18f);      /* 2^-60, 2^60; NaN is not ok */
-  if (__ballot(!ok) == 0ull) return recipFast(d);
+  if (flx_ballot(!ok) == 0ull) return recipFast(d);
   return 1.0f / d;
 }
 
@@ -892,7 +896,7 @@ FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, const fl
     M3 rotationII; rotationII.c0 = F3(c0.x, c0.y, c0.z); rotationII.c1 = F3(c1.x, c1.y, c1.z); rotationII.c2 = F3(c2.x, c2.y, c2.z);
     f3 o = mul(rotationII, src.origin + F3(sh.x, sh.y, sh.z));
     f3 d = mul(rotationII, src.dir);
-    if (__ballot(shadowMode) != 0ull) {                   /* skip the normalize when no lane of the wave sets up a shadow walk */
+    if (flx_ballot(shadowMode) != 0ull) {                   /* skip the normalize when no lane of the wave sets up a shadow walk */
       f3 dn = normalize(d);
       if (shadowMode) d = dn;                             /* fragment:261 normalises, fragment:201 does not */
     }
@@ -906,9 +910,18 @@ FLX_DEV void walkSetupRays(const DeviceScene &sc, uint32_t nTransforms, const fl
     rays[5 * t + 4] = make_float2(inv.z, fast ? 1.0f : 0.0f);
   }
 }
+/* The tree top and the pre-transformed rays live in LDS; the walk kernel hands them around as plain pointers, and indexing
+ * those costs 64-bit address arithmetic per fetch (v_mad_u64_u32: a quarter-rate instruction).  Saying that they are LDS
+ * pointers makes it one 32-bit multiply-add. */
+typedef float flx_v4f __attribute__((ext_vector_type(4)));
+typedef float flx_v2f __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) const flx_v4f lds_cf4;
+typedef __attribute__((address_space(3))) const flx_v2f lds_cf2;
+FLX_DEV float4 ldsLoad4(const lds_cf4 *p) { const flx_v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 /* the walk's ray in the object space of transform t, from the lane's pre-transformed set */
-FLX_DEV void walkLoadRay(const float2 *rays, int t, WalkState &w) {
-  const float2 a = rays[5 * t], b = rays[5 * t + 1], c = rays[5 * t + 2], d = rays[5 * t + 3], e = rays[5 * t + 4];
+FLX_DEV void walkLoadRay(const float2 *raysGeneric, int t, WalkState &w) {
+  const lds_cf2 *rays = (const lds_cf2 *)raysGeneric + __umul24((unsigned)t, 5u);      /* (a transform number: 24 bits are plenty) */
+  const flx_v2f a = rays[0], b = rays[1], c = rays[2], d = rays[3], e = rays[4];
   w.tR.origin = F3(a.x, a.y, b.x);
   w.tR.dir = F3(b.y, c.x, c.y);
   w.inv = F3(d.x, d.y, e.x);
@@ -919,7 +932,7 @@ FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
                         WorkCounters &cnt) {
   if ((uint32_t)w.i == WALK_END) return true;
   const uint32_t i = linkIndex((uint32_t)w.i);
-  if (i < ldsCount) { cur.e0 = lds[3 * i]; cur.e1 = lds[3 * i + 1]; cur.e2 = lds[3 * i + 2]; }
+  if (i < ldsCount) { const lds_cf4 *L = (const lds_cf4 *)lds + __umul24(i, 3u); cur.e0 = ldsLoad4(L); cur.e1 = ldsLoad4(L + 1); cur.e2 = ldsLoad4(L + 2); }      /* (i < ldsCount <= 3 328) */
   else { cur.e0 = sc.walk[3 * (size_t)i]; cur.e1 = sc.walk[3 * (size_t)i + 1]; cur.e2 = sc.walk[3 * (size_t)i + 2]; }
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
   const int meta = __float_as_int(cur.e2.z);
@@ -935,7 +948,7 @@ FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
 FLX_DEV void walkLoadEntry(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, uint32_t i, WalkEntry &e) {
   if (i == WALK_END) { e.e0 = e.e1 = e.e2 = make_float4(0.f, 0.f, 0.f, 0.f); return; }
   i = linkIndex(i);
-  if (i < ldsCount) { e.e0 = lds[3 * i]; e.e1 = lds[3 * i + 1]; e.e2 = lds[3 * i + 2]; }
+  if (i < ldsCount) { const lds_cf4 *L = (const lds_cf4 *)lds + __umul24(i, 3u); e.e0 = ldsLoad4(L); e.e1 = ldsLoad4(L + 1); e.e2 = ldsLoad4(L + 2); }
   else { e.e0 = sc.walk[3 * (size_t)i]; e.e1 = sc.walk[3 * (size_t)i + 1]; e.e2 = sc.walk[3 * (size_t)i + 2]; }
 }
 /* The rest of walkFetchP once `cur` holds entry w.i: visit count, transform change, terminator test. */
@@ -951,8 +964,60 @@ FLX_DEV bool walkArriveP(const float2 *rays, WalkState &w, const WalkEntry &cur,
   }
   return (meta & 3) == 0;
 }
+/* rayCuboid (fragment:161-167) decided from ONE multiplication per quotient where that is provably enough.
+ *
+ * What the shader computes: the six quotients R = RN(a / d) (a = corner - origin), per axis near_k = min, far_k = max of its
+ * two, tmin = max_k near_k, tmax = min_k far_k, and the boolean  tmax >= max(tmin, BIAS) && tmin < l.  Only the boolean
+ * leaves the function.  With y = RN(1 / d) (w.inv; exact bits of 1.0f / d inside w.fastDiv's range, tools/micro/rcp_exact.hip)
+ * the product q = RN(a * y) is within 3 ulp-halves of the quotient: q = (a/d)(1 + e1)(1 + e2), R = (a/d)(1 + e3), |e| <= 2^-24,
+ * hence |q - R| < 2^-22 |q| while both are normal (|a| <= 2^60 and 2^-60 <= |d| <= 2^60 under w.fastDiv: no overflow; results
+ * below 2^-126 are off by at most 2^-149 in absolute terms and far below BIAS = 2^-16 and below every l this function accepts).
+ * lo(x) = x - 2^-21 |x| and hi(x) = x + 2^-21 |x| (one FMA each; its own rounding, 2^-24 |x|, fits in the slack between 2^-22 and
+ * 2^-21) therefore bracket R, and being monotone they commute with min / max: lo(far_k') <= far_k, near_k <= hi(near_k'),
+ * lo(min_k far') <= tmax <= hi(min_k far'), and the same for tmin.
+ *   sure TRUE   every cross pair has room, lo(far_i') >= hi(max(near_j', near_k')) for the three i (the pairs of ONE axis hold by
+ *               monotonicity of x -> RN(x / d): near_i <= far_i always — this is what keeps a flat box, whose two planes on an
+ *               axis coincide, decidable), and lo(tmax') >= BIAS, and hi(tmin') < l;
+ *   sure FALSE  hi(tmax') < max(lo(tmin'), BIAS), or lo(tmin') >= l.
+ * Anything else — a ray grazing an edge within 2^-21, a direction outside the range, l below 2^-60 — is `unsure` and the caller
+ * takes the exact quotients (rayCuboidRecip).  Same boolean as the shader in every case; ~40 instead of ~61 VALU instructions
+ * per box test and a dependent chain of 7 instead of 10 (profiles/r02_ab_box_interval.txt). */
+#ifndef FLX_WF_BOX_INTERVAL
+#define FLX_WF_BOX_INTERVAL 1
+#endif
+FLX_DEV bool rayCuboidInterval(float l, const WalkState &w, f3 minCorner, f3 maxCorner, bool &sure) {
+  const f3 o = w.tR.origin, y = w.inv;
+  const float qx0 = (minCorner.x - o.x) * y.x, qx1 = (maxCorner.x - o.x) * y.x;
+  const float qy0 = (minCorner.y - o.y) * y.y, qy1 = (maxCorner.y - o.y) * y.y;
+  const float qz0 = (minCorner.z - o.z) * y.z, qz1 = (maxCorner.z - o.z) * y.z;
+  const float nx = __builtin_fminf(qx0, qx1), fx = __builtin_fmaxf(qx0, qx1);
+  const float ny = __builtin_fminf(qy0, qy1), fy = __builtin_fmaxf(qy0, qy1);
+  const float nz = __builtin_fminf(qz0, qz1), fz = __builtin_fmaxf(qz0, qz1);
+  constexpr float D = 4.76837158203125e-07f;           /* 2^-21 */
+  const float nyz = __builtin_fmaxf(ny, nz), nxz = __builtin_fmaxf(nx, nz), nxy = __builtin_fmaxf(nx, ny);
+  const float tmin = __builtin_fmaxf(nxy, nz), tmax = __builtin_fminf(__builtin_fminf(fx, fy), fz);
+  /* (bitwise & and |, not && and ||: straight-line code, the wave would execute both sides of a branch anyway) */
+  const bool cx = __builtin_fmaf(-flx_abs(fx), D, fx) >= __builtin_fmaf(flx_abs(nyz), D, nyz);
+  const bool cy = __builtin_fmaf(-flx_abs(fy), D, fy) >= __builtin_fmaf(flx_abs(nxz), D, nxz);
+  const bool cz = __builtin_fmaf(-flx_abs(fz), D, fz) >= __builtin_fmaf(flx_abs(nxy), D, nxy);
+  const float tminHi = __builtin_fmaf(flx_abs(tmin), D, tmin), tminLo = __builtin_fmaf(-flx_abs(tmin), D, tmin);
+  const float tmaxHi = __builtin_fmaf(flx_abs(tmax), D, tmax), tmaxLo = __builtin_fmaf(-flx_abs(tmax), D, tmax);
+  const bool sureTrue = cx & cy & cz & (tmaxLo >= BIAS) & (tminHi < l);
+  const bool sureFalse = (tmaxHi < __builtin_fmaxf(tminLo, BIAS)) | (tminLo >= l);
+  sure = w.fastDiv & (l >= 8.673617379884035e-19f) & (sureTrue | sureFalse);      /* (NaN anywhere: every comparison false, unsure) */
+  return sureTrue;
+}
 FLX_DEV void walkBoxP(WalkState &w, const WalkEntry &cur) {
-  const bool hit = rayCuboidRecip(w.minLen, w, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y));
+  const f3 lo = F3(cur.e0.x, cur.e0.y, cur.e0.z), hi = F3(cur.e0.w, cur.e1.x, cur.e1.y);
+#if FLX_WF_BOX_INTERVAL
+  bool sure;
+  bool hit = rayCuboidInterval(w.minLen, w, lo, hi, sure);
+  if (flx_ballot(!sure) != 0ull) {                       /* rare: some lane of the wave needs the exact quotients */
+    if (!sure) hit = rayCuboidRecip(w.minLen, w, lo, hi);
+  }
+#else
+  const bool hit = rayCuboidRecip(w.minLen, w, lo, hi);
+#endif
   w.i = hit ? __float_as_int(cur.e2.x) : __float_as_int(cur.e2.y);
 }
 

@@ -1,0 +1,334 @@
+/*
+ * flx_group.hip — one frame on several GPUs: row strips dealt round robin to the contexts, scene replicated,
+ * ONE exchange step per frame or batch of frames — ncclAllGather (RCCL, over xGMI) of the packed strips on the contexts'
+ * streams — and a kernel that puts the gathered rows in image order.  The reference has nothing like it (one WebGL2 context,
+ * modules/pathtracerWGL2.js:60-68); the boundary it sits behind is still the renderer object of flexlight.js:106-129.
+ *
+ * Two ways to hold the communicator, the same gather code behind both:
+ *   flx_comm_init_rank   one process per GPU (bench.py under torch.distributed.run): ncclCommInitRank from an id rank 0 made
+ *   flx_group_create     one process, N contexts (the JavaScript host — Node is one process): ncclCommInitAll
+ * A group whose device list names one GPU more than once (the rehearsal on a one-GPU box: RCCL refuses two ranks on a device)
+ * exchanges the strips with device-to-device copies instead; everything else — tile policy, packing, reassembly — is the same.
+ */
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "flx_context.h"
+
+using namespace flx;
+
+#define FLX_NCCL(ctx, expr)                                                                   \
+  do {                                                                                        \
+    ncclResult_t r_ = (expr);                                                                 \
+    if (r_ != ncclSuccess) {                                                                  \
+      (ctx)->err = std::string(#expr) + ": " + ncclGetErrorString(r_);                         \
+      return FLX_ERR_DEVICE;                                                                  \
+    }                                                                                         \
+  } while (0)
+
+namespace {
+
+/* rows of the frame the tile policy gives rank r of n */
+__host__ __device__ inline uint32_t rows_of_rank(uint32_t height, uint32_t tile_rows, uint32_t n, uint32_t r) {
+  const uint32_t strips = (height + tile_rows - 1u) / tile_rows;
+  if (r >= strips) return 0u;
+  const uint32_t mine = (strips - r + n - 1u) / n;               /* strips s = r, r + n, ... below `strips` */
+  uint32_t rows = mine * tile_rows;
+  if ((strips - 1u) % n == r) rows -= strips * tile_rows - height;      /* the last strip may be cut by the frame's edge */
+  return rows;
+}
+inline uint32_t rows_padded(uint32_t height, uint32_t tile_rows, uint32_t n) {
+  const uint32_t strips = (height + tile_rows - 1u) / tile_rows;
+  return ((strips + n - 1u) / n) * tile_rows;
+}
+
+/* gathered = [rank][slot words]; rank r's slot starts with its strips packed tight: float4[frames][rows_r][width].
+ * out = float4[frames][height][width].  One thread per float4. */
+__global__ __launch_bounds__(256) void k_reassemble(const float4 *__restrict__ gathered, float4 *__restrict__ out, uint32_t width, uint32_t height,
+                                                    uint32_t frames, uint32_t tile_rows, uint32_t n, size_t slot) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  const size_t total = (size_t)frames * height * width;
+  if (i >= total) return;
+  const uint32_t x = (uint32_t)(i % width);
+  const size_t row = i / width;
+  const uint32_t y = (uint32_t)(row % height), f = (uint32_t)(row / height);
+  const uint32_t strip = y / tile_rows, r = strip % n;
+  const uint32_t k = (strip / n) * tile_rows + (y - strip * tile_rows);
+  const uint32_t rows_r = rows_of_rank(height, tile_rows, n, r);
+  out[i] = gathered[(size_t)r * slot + ((size_t)f * rows_r + k) * width + x];
+}
+
+/* the same for the five RGBA8 render targets of a filter frame: rank r's slot = uint32[5][rows_r][width] */
+__global__ __launch_bounds__(256) void k_reassemble_planes(const uint32_t *__restrict__ gathered, uint32_t *__restrict__ out, uint32_t width, uint32_t height,
+                                                           uint32_t tile_rows, uint32_t n, size_t slot) {
+  const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+  const size_t plane = (size_t)height * width;
+  if (i >= 5u * plane) return;
+  const uint32_t x = (uint32_t)(i % width);
+  const size_t row = i / width;
+  const uint32_t y = (uint32_t)(row % height), p = (uint32_t)(row / height);
+  const uint32_t strip = y / tile_rows, r = strip % n;
+  const uint32_t k = (strip / n) * tile_rows + (y - strip * tile_rows);
+  const uint32_t rows_r = rows_of_rank(height, tile_rows, n, r);
+  out[i] = gathered[(size_t)r * slot + ((size_t)p * rows_r + k) * width + x];
+}
+
+struct Share {                   /* what one context contributes to a gathered frame / batch */
+  uint32_t width, height, tile_rows, n, frames;
+  size_t slot;                   /* float4 (radiance) or uint32 x 4 (planes, counted in float4 units too) per rank in the exchange */
+  bool planes;
+};
+
+flx_status check_params(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int rank, int size, Share &sh) {
+  if (!params || n_frames < 1u || n_frames > FLX_MAX_BATCH_FRAMES) return flx_fail(ctx, FLX_ERR_INVALID, "gathered render: 1 .. 32 frames");
+  if (params->is_temporal) return flx_fail(ctx, FLX_ERR_INVALID, "gathered render: temporal frames keep their history in one context and are not sharded");
+  if (params->use_filter && n_frames != 1u) return flx_fail(ctx, FLX_ERR_INVALID, "gathered render: filter frames are rendered one by one");
+  if (params->tile_rows == 0u) return flx_fail(ctx, FLX_ERR_INVALID, "gathered render: tile_rows must be positive");
+  for (uint32_t i = 0; i < n_frames; i++)
+    if (params[i].tile_index != (uint32_t)rank || params[i].tile_count != (uint32_t)size)
+      return flx_fail(ctx, FLX_ERR_INVALID, "gathered render: tile_index / tile_count must be this context's rank / the communicator's size");
+  sh.width = params->width; sh.height = params->height; sh.tile_rows = params->tile_rows; sh.n = (uint32_t)size; sh.frames = n_frames;
+  sh.planes = params->use_filter != 0;
+  const size_t rmax = rows_padded(sh.height, sh.tile_rows, sh.n);
+  sh.slot = sh.planes ? (5u * rmax * sh.width + 3u) / 4u : (size_t)n_frames * rmax * sh.width;
+  return FLX_OK;
+}
+
+flx_status ensure_f4(flx_context *ctx, float4 **buf, size_t *cap, size_t n) { return flx_ensure_pixels(ctx, buf, cap, n ? n : 1); }
+
+/* step 1: this context's strips -> ctx->d_send (enqueued, no host sync) */
+flx_status trace_share(flx_context *ctx, const flx_frame_params *params, const Share &sh) {
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  flx_status s;
+  if ((s = ensure_f4(ctx, &ctx->d_send, &ctx->send_capacity, sh.slot))) return s;
+  if ((s = ensure_f4(ctx, &ctx->d_recv, &ctx->recv_capacity, sh.slot * sh.n))) return s;
+  if (sh.planes) return flx_render_planes_device(ctx, params, ctx->d_send);
+  return flx_render_batch_device(ctx, params, sh.frames, ctx->d_send);
+}
+
+/* step 3: gathered strips -> frames in image order (+ the denoise chain for filter frames), on the context's stream */
+flx_status finish_share(flx_context *ctx, const flx_frame_params *params, const Share &sh, void *d_frames) {
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  if (sh.planes) {
+    flx_status s;
+    const size_t words = 5u * (size_t)sh.height * sh.width;
+    if ((s = ensure_f4(ctx, &ctx->d_gplanes, &ctx->gplanes_capacity, (words + 3u) / 4u))) return s;
+    hipLaunchKernelGGL(k_reassemble_planes, dim3((uint32_t)((words + 255u) / 256u)), dim3(256), 0, ctx->stream, (const uint32_t *)ctx->d_recv,
+                       (uint32_t *)ctx->d_gplanes, sh.width, sh.height, sh.tile_rows, sh.n, sh.slot * 4u);
+    FLX_HIP(ctx, hipGetLastError());
+    flx_frame_params whole = *params;
+    whole.tile_rows = whole.tile_index = whole.tile_count = 0;
+    return flx_filter_planes_enqueue(ctx, &whole, ctx->d_gplanes, d_frames, false);      /* the frame began with the trace: that stamp stays */
+  }
+  const size_t total = (size_t)sh.frames * sh.height * sh.width;
+  hipLaunchKernelGGL(k_reassemble, dim3((uint32_t)((total + 255u) / 256u)), dim3(256), 0, ctx->stream, ctx->d_recv, (float4 *)d_frames, sh.width, sh.height,
+                     sh.frames, sh.tile_rows, sh.n, sh.slot);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));         /* frame time = first kernel .. last byte of the gathered frame */
+  return FLX_OK;
+}
+
+}  // namespace
+
+/* ---- one process per GPU ------------------------------------------------------------------------------------------------ */
+static_assert(FLX_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "flexlight_hip.h and rccl.h disagree on the size of a communicator id");
+
+extern "C" flx_status flx_comm_unique_id(uint8_t *id) {
+  if (!id) return FLX_ERR_INVALID;
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) { g_create_error = "ncclGetUniqueId failed"; return FLX_ERR_DEVICE; }
+  memcpy(id, u.internal, NCCL_UNIQUE_ID_BYTES);
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_comm_init_rank(flx_context *ctx, const uint8_t *id, int n_ranks, int rank) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return flx_fail(ctx, FLX_ERR_INVALID, "flx_comm_init_rank: need an id and 0 <= rank < n_ranks");
+  if (ctx->comm) return flx_fail(ctx, FLX_ERR_INVALID, "flx_comm_init_rank: the context already belongs to a communicator");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  ncclUniqueId u;
+  memcpy(u.internal, id, NCCL_UNIQUE_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  FLX_NCCL(ctx, ncclCommInitRank(&comm, n_ranks, u, rank));
+  ctx->comm = (flx_nccl_comm)comm; ctx->comm_rank = rank; ctx->comm_size = n_ranks; ctx->comm_owned = true;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_comm_destroy(flx_context *ctx) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->comm && ctx->comm_owned) {
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FLX_NCCL(ctx, ncclCommDestroy((ncclComm_t)ctx->comm));
+  }
+  ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_size = 1; ctx->comm_owned = false;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_render_gathered_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, void *d_frames) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (!d_frames) return flx_fail(ctx, FLX_ERR_INVALID, "flx_render_gathered_device: output pointer is NULL");
+  if (!ctx->comm) return flx_fail(ctx, FLX_ERR_INVALID, "flx_render_gathered_device: the context belongs to no communicator (flx_comm_init_rank)");
+  Share sh;
+  flx_status s = check_params(ctx, params, n_frames, ctx->comm_rank, ctx->comm_size, sh);
+  if (s) return s;
+  if ((s = trace_share(ctx, params, sh))) return s;
+  FLX_NCCL(ctx, ncclAllGather(ctx->d_send, ctx->d_recv, sh.slot * 4u, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
+  return finish_share(ctx, params, sh, d_frames);
+}
+
+/* ---- one process, several GPUs ------------------------------------------------------------------------------------------- */
+struct flx_group {
+  std::vector<flx_context *> ctx;
+  std::vector<ncclComm_t> comms;        /* empty: the contexts share a device, strips are exchanged by copies */
+  std::vector<hipEvent_t> traced;       /* per context: its strips are in d_send */
+  std::vector<hipEvent_t> gathered;     /* per context: every copy INTO its d_recv has been enqueued and this marks their end */
+  std::string err;
+};
+
+static thread_local std::string g_group_error;
+
+extern "C" const char *flx_group_last_error(const flx_group *g) { return g ? g->err.c_str() : g_group_error.c_str(); }
+
+extern "C" void flx_group_destroy(flx_group *g) {
+  if (!g) return;
+  for (size_t r = 0; r < g->ctx.size(); r++) {
+    if (!g->ctx[r]) continue;
+    (void)hipSetDevice(g->ctx[r]->device);
+    (void)hipStreamSynchronize(g->ctx[r]->stream);
+    if (r < g->comms.size() && g->comms[r]) (void)ncclCommDestroy(g->comms[r]);
+    g->ctx[r]->comm = nullptr;
+    if (r < g->traced.size() && g->traced[r]) (void)hipEventDestroy(g->traced[r]);
+    if (r < g->gathered.size() && g->gathered[r]) (void)hipEventDestroy(g->gathered[r]);
+    flx_context_destroy(g->ctx[r]);
+  }
+  delete g;
+}
+
+extern "C" flx_status flx_group_create(int n, const int *devices, flx_group **out) {
+  if (!out) { g_group_error = "flx_group_create: out is NULL"; return FLX_ERR_INVALID; }
+  *out = nullptr;
+  if (n < 1 || n > 64 || !devices) { g_group_error = "flx_group_create: 1 .. 64 devices"; return FLX_ERR_INVALID; }
+  flx_group *g = new flx_group();
+  bool distinct = true;
+  for (int i = 0; i < n; i++) for (int j = 0; j < i; j++) if (devices[i] == devices[j]) distinct = false;
+  for (int r = 0; r < n; r++) {
+    flx_context *c = nullptr;
+    flx_status s = flx_context_create(devices[r], &c);
+    if (s) { g_group_error = std::string("flx_group_create: ") + flx_last_error(nullptr); flx_group_destroy(g); return s; }
+    c->comm_rank = r; c->comm_size = n;
+    g->ctx.push_back(c);
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+      g_group_error = "flx_group_create: hipEventCreate failed"; flx_group_destroy(g); return FLX_ERR_DEVICE;
+    }
+    g->traced.push_back(a); g->gathered.push_back(b);
+  }
+  if (distinct && n > 1) {
+    g->comms.assign((size_t)n, nullptr);
+    ncclResult_t rc = ncclCommInitAll(g->comms.data(), n, devices);
+    if (rc != ncclSuccess) {
+      g_group_error = std::string("flx_group_create: ncclCommInitAll: ") + ncclGetErrorString(rc);
+      g->comms.clear(); flx_group_destroy(g); return FLX_ERR_DEVICE;
+    }
+    for (int r = 0; r < n; r++) g->ctx[r]->comm = (flx_nccl_comm)g->comms[r];
+  }
+  *out = g;
+  return FLX_OK;
+}
+
+extern "C" int flx_group_size(const flx_group *g) { return g ? (int)g->ctx.size() : 0; }
+extern "C" flx_context *flx_group_context(flx_group *g, int rank) { return (g && rank >= 0 && rank < (int)g->ctx.size()) ? g->ctx[rank] : nullptr; }
+extern "C" int flx_group_uses_rccl(const flx_group *g) { return g && !g->comms.empty(); }
+
+#define FLX_GROUP_EACH(g, call)                                                           \
+  do {                                                                                    \
+    if (!(g)) return FLX_ERR_INVALID;                                                     \
+    for (flx_context *c : (g)->ctx) {                                                     \
+      flx_status s_ = (call);                                                             \
+      if (s_) { (g)->err = flx_last_error(c); return s_; }                                \
+    }                                                                                     \
+    return FLX_OK;                                                                        \
+  } while (0)
+
+extern "C" flx_status flx_group_scene_upload(flx_group *g, const float *geometry, const float *attributes, uint32_t n_entries_padded, const int32_t *ids, uint32_t n_ids) {
+  FLX_GROUP_EACH(g, flx_scene_upload(c, geometry, attributes, n_entries_padded, ids, n_ids));
+}
+extern "C" flx_status flx_group_transforms_upload(flx_group *g, const float *rotation, const float *shift, uint32_t n_transforms) {
+  FLX_GROUP_EACH(g, flx_transforms_upload(c, rotation, shift, n_transforms));
+}
+extern "C" flx_status flx_group_lights_upload(flx_group *g, const float *lights, uint32_t n_lights) { FLX_GROUP_EACH(g, flx_lights_upload(c, lights, n_lights)); }
+extern "C" flx_status flx_group_atlas_upload(flx_group *g, int which, const uint8_t *rgba, uint32_t width, uint32_t height) {
+  FLX_GROUP_EACH(g, flx_atlas_upload(c, which, rgba, width, height));
+}
+extern "C" flx_status flx_group_scene_upload_view(flx_group *g, const flx_scene_view *scene) { FLX_GROUP_EACH(g, flx_scene_upload_view(c, scene)); }
+
+/* n_frames frames (a batch; 1 = one frame) of a camera path on all contexts of the group; the frames arrive on the host. */
+extern "C" flx_status flx_group_render(flx_group *g, const flx_frame_params *params, uint32_t n_frames, uint32_t tile_rows, float *out_rgba, flx_counters *counters) {
+  if (!g) return FLX_ERR_INVALID;
+  auto gfail = [&](flx_context *c, flx_status s) { g->err = c ? flx_last_error(c) : "flx_group_render: bad arguments"; return s; };
+  if (!params || !out_rgba || n_frames < 1u || n_frames > FLX_MAX_BATCH_FRAMES || tile_rows == 0u) return gfail(nullptr, FLX_ERR_INVALID);
+  const int n = (int)g->ctx.size();
+  std::vector<std::vector<flx_frame_params>> p((size_t)n, std::vector<flx_frame_params>(params, params + n_frames));
+  std::vector<Share> sh((size_t)n);
+  flx_status s;
+  for (int r = 0; r < n; r++) {
+    for (auto &q : p[r]) { q.tile_rows = tile_rows; q.tile_index = (uint32_t)r; q.tile_count = (uint32_t)n; }
+    if ((s = check_params(g->ctx[r], p[r].data(), n_frames, r, n, sh[r]))) return gfail(g->ctx[r], s);
+  }
+  /* 1. every context traces its strips (enqueued on its own stream; the GPUs run concurrently) */
+  for (int r = 0; r < n; r++) {
+    flx_context *c = g->ctx[r];
+    if (counters) (void)flx_set_counters_enabled(c, 1);
+    s = trace_share(c, p[r].data(), sh[r]);
+    if (counters) (void)flx_set_counters_enabled(c, 0);
+    if (s) return gfail(c, s);
+    if (hipEventRecord(g->traced[r], c->stream) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
+  }
+  /* 2. the exchange: one all-gather over RCCL, or (contexts on one device) plain copies ordered by events */
+  if (!g->comms.empty()) {
+    ncclResult_t rc = ncclGroupStart();
+    for (int r = 0; r < n && rc == ncclSuccess; r++) {
+      flx_context *c = g->ctx[r];
+      (void)hipSetDevice(c->device);
+      rc = ncclAllGather(c->d_send, c->d_recv, sh[r].slot * 4u, ncclFloat, g->comms[r], c->stream);
+    }
+    ncclResult_t rc2 = ncclGroupEnd();
+    if (rc != ncclSuccess || rc2 != ncclSuccess) { g->err = std::string("ncclAllGather: ") + ncclGetErrorString(rc != ncclSuccess ? rc : rc2); return FLX_ERR_DEVICE; }
+  } else {
+    for (int r = 0; r < n; r++) {
+      flx_context *c = g->ctx[r];
+      (void)hipSetDevice(c->device);
+      for (int q = 0; q < n; q++) {
+        if (hipStreamWaitEvent(c->stream, g->traced[q], 0) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
+        if (hipMemcpyAsync(c->d_recv + (size_t)q * sh[r].slot, g->ctx[q]->d_send, sh[r].slot * sizeof(float4), hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+          return gfail(nullptr, FLX_ERR_DEVICE);
+      }
+      if (hipEventRecord(g->gathered[r], c->stream) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
+    }
+    /* a context's d_send may be overwritten by its next frame only after every peer has copied it */
+    for (int r = 0; r < n; r++) for (int q = 0; q < n; q++) if (q != r && hipStreamWaitEvent(g->ctx[r]->stream, g->gathered[q], 0) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
+  }
+  /* 3. context 0 puts the rows in image order (and runs the denoise chain of a filter frame); the frames go to the host */
+  flx_context *c0 = g->ctx[0];
+  const size_t pixels = (size_t)n_frames * params->height * params->width;
+  if ((s = ensure_f4(c0, &c0->d_frames, &c0->frames_capacity, pixels))) return gfail(c0, s);
+  if ((s = finish_share(c0, p[0].data(), sh[0], c0->d_frames))) return gfail(c0, s);
+  (void)hipSetDevice(c0->device);
+  if (hipMemcpyAsync(out_rgba, c0->d_frames, pixels * sizeof(float4), hipMemcpyDeviceToHost, c0->stream) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
+  for (int r = 0; r < n; r++) if ((s = flx_sync(g->ctx[r]))) return gfail(g->ctx[r], s);
+  if (counters) {
+    memset(counters, 0, sizeof *counters);
+    uint64_t *acc = (uint64_t *)counters;
+    for (int r = 0; r < n; r++) {
+      flx_counters one;
+      if ((s = flx_get_counters(g->ctx[r], &one))) return gfail(g->ctx[r], s);
+      const uint64_t *v = (const uint64_t *)&one;
+      for (size_t k = 0; k < sizeof one / sizeof(uint64_t); k++) acc[k] += v[k];
+    }
+  }
+  return FLX_OK;
+}

@@ -58,7 +58,12 @@ namespace flx {
 #ifndef FLX_WF_TAIL_TRIPS
 #define FLX_WF_TAIL_TRIPS 8                 /* trips of the scheduler loop between two consolidation rounds */
 #endif
-enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_ROUND = 4, TC_MAX = 8, TC_BUSY = 10, TC_MASK = 12 };   /* LDS words of the tail consolidation */
+/* LDS words of the tail consolidation.  The per-round tallies rotate over THREE slots (TC_SLOT + 4 x (round % 3): walks, waves,
+ * most walks in a wave, waves with walks): round r adds to slot r % 3 before its barrier and reads it after; after that barrier
+ * every wave clears slot (r + 2) % 3 — the one round r - 1 used, which every wave has finished reading before it arrived at
+ * round r's barrier, and which nobody adds to before round r + 1's barrier.  (With two slots a fast wave could add to the
+ * next round's words before a slow wave had cleared them.) */
+enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT = 8, TC_WORDS = 32 };
 #ifndef FLX_WF_UNROLL
 #define FLX_WF_UNROLL 1
 #endif
@@ -253,8 +258,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
   bool outValid = false;
 
   for (;;) {
-    const unsigned long long walking = __ballot(st == L_WALKING);
-    const unsigned long long doneMask = __ballot(st == L_DONE);
+    const unsigned long long walking = flx_ballot(st == L_WALKING);
+    const unsigned long long doneMask = flx_ballot(st == L_DONE);
     const bool canRefill = itemsLeft || chunkNext != chunkEnd;
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (doneMask != 0ull || canRefill))) {
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
           }
           st = L_EMPTY;
         }
-        const unsigned long long am = __ballot(append);
+        const unsigned long long am = flx_ballot(append);
         if (am != 0ull) {
           const uint32_t cntA = (uint32_t)__popcll(am);
           const uint32_t r = lane_rank(am);
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
       if (COUNT) tFold += t1 - t0;
       /* ---- refill the free lanes from the walk queue ------------------------------------------------ */
       for (;;) {
-        const unsigned long long idle = __ballot(st == L_EMPTY);
+        const unsigned long long idle = flx_ballot(st == L_EMPTY);
         if (idle == 0ull) break;
         if (chunkNext == chunkEnd) {
           if (!itemsLeft) break;
@@ -354,8 +359,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS) void k_wf_walk(DeviceScene sc,
         chunkNext += take;
       }
       if (COUNT) tRefill += clock64() - t1;
-      if (__ballot(st == L_WALKING) == 0ull) {
-        if (itemsLeft || chunkNext != chunkEnd || __ballot(st == L_DONE) != 0ull) continue;      /* (lanes that had nothing to walk wait for the fold) */
+      if (flx_ballot(st == L_WALKING) == 0ull) {
+        if (itemsLeft || chunkNext != chunkEnd || flx_ballot(st == L_DONE) != 0ull) continue;      /* (lanes that had nothing to walk wait for the fold) */
         break;
       }
     }
@@ -414,8 +419,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   extern __shared__ float4 ldsAll[];
   float4 *ldsEntries = ldsAll;
   float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u;
-  uint32_t *tailCtl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);       /* 16 words, see TC_* */
-  float2 *raysBase = (float2 *)(tailCtl + 16);
+  uint32_t *tailCtl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);       /* TC_WORDS words, see TC_* */
+  float2 *raysBase = (float2 *)(tailCtl + TC_WORDS);
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;      /* follows a walk when it moves to another lane (tail consolidation) */
   for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
   for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   }
   const uint32_t waveId = blockIdx.x * (FLX_WF_WALK_THREADS / 64u) + (threadIdx.x >> 6);
   const bool surplus = waveId * (64u * FLX_WF_ITEMS_PER_LANE) >= n && waveId != 0u;       /* more waves than work */
-  if (threadIdx.x < 16u) tailCtl[threadIdx.x] = 0u;
+  if (threadIdx.x < (uint32_t)TC_WORDS) tailCtl[threadIdx.x] = 0u;
   __syncthreads();
   if (!surplus && (threadIdx.x & 63u) == 0u) atomicAdd(&tailCtl[TC_LIVE], 1u);
   __syncthreads();
@@ -493,24 +498,22 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       }
       if (tailSynced && ++tailTrips >= (uint32_t)FLX_WF_TAIL_TRIPS) {
         tailTrips = 0;
-        const uint32_t par = (tailRound++ & 1u) * 2u;
-        const unsigned long long mine = __ballot(st != P_EMPTY);
+        const uint32_t slot = TC_SLOT + 4u * (tailRound % 3u), clr = TC_SLOT + 4u * ((tailRound + 2u) % 3u);
+        tailRound++;
+        const unsigned long long mine = flx_ballot(st != P_EMPTY);
         const uint32_t myCount = (uint32_t)__popcll(mine);
         if (lane == 0) {
-          atomicAdd(&tailCtl[TC_ROUND + par], myCount); atomicAdd(&tailCtl[TC_ROUND + par + 1u], 1u);
-          atomicMax(&tailCtl[TC_MAX + (par >> 1)], myCount); if (myCount) atomicAdd(&tailCtl[TC_BUSY + (par >> 1)], 1u);
+          atomicAdd(&tailCtl[slot], myCount); atomicAdd(&tailCtl[slot + 1u], 1u);
+          atomicMax(&tailCtl[slot + 2u], myCount); if (myCount) atomicAdd(&tailCtl[slot + 3u], 1u);
         }
         __syncthreads();
         uint32_t total = 0, waves = 0, most = 0, busy = 0;
         if (lane == 0) {
-          total = __hip_atomic_load(&tailCtl[TC_ROUND + par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          waves = __hip_atomic_load(&tailCtl[TC_ROUND + par + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          most = __hip_atomic_load(&tailCtl[TC_MAX + (par >> 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          busy = __hip_atomic_load(&tailCtl[TC_BUSY + (par >> 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(&tailCtl[TC_ROUND + (par ^ 2u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      /* the next round's tallies */
-          __hip_atomic_store(&tailCtl[TC_ROUND + (par ^ 2u) + 1u], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(&tailCtl[TC_MAX + ((par >> 1) ^ 1u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_store(&tailCtl[TC_BUSY + ((par >> 1) ^ 1u)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          total = __hip_atomic_load(&tailCtl[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          waves = __hip_atomic_load(&tailCtl[slot + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          most = __hip_atomic_load(&tailCtl[slot + 2u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          busy = __hip_atomic_load(&tailCtl[slot + 3u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          for (uint32_t k = 0; k < 4u; k++) __hip_atomic_store(&tailCtl[clr + k], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      /* the tallies of round + 2 */
         }
         total = __builtin_amdgcn_readfirstlane(total); waves = __builtin_amdgcn_readfirstlane(waves);
         most = __builtin_amdgcn_readfirstlane(most); busy = __builtin_amdgcn_readfirstlane(busy);
@@ -584,15 +587,15 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     }
     if (COUNT) tTail += clock64() - tTail0;
 #endif
-    const unsigned long long walking = __ballot(st == P_WALKING);
-    const unsigned long long workMask = __ballot(st == P_DONE || st == P_SWITCH);
+    const unsigned long long walking = flx_ballot(st == P_WALKING);
+    const unsigned long long workMask = flx_ballot(st == P_DONE || st == P_SWITCH);
     const bool canRefill = itemsLeft || chunkNext != chunkEnd;
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
     if (suspendNow || walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || canRefill))) {
       if (COUNT) diagBatches++;
       long long t0 = COUNT ? clock64() : 0;
       /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475 ------------ */
-      if (__ballot(st == P_DONE) != 0ull) {
+      if (flx_ballot(st == P_DONE) != 0ull) {
         bool append = false;
         if (st == P_DONE) {
           float4 *rec = wb.rec + (size_t)pathId * 8;
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           }
           st = P_EMPTY;
         }
-        const unsigned long long am = __ballot(append);
+        const unsigned long long am = flx_ballot(append);
         if (am != 0ull) {
           const uint32_t cntA = (uint32_t)__popcll(am);
           const uint32_t r = lane_rank(am);
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         /* ---- suspend: the walks still in flight go to the straggler list (the lane's registers; rays and flags are
          * re-read from the path record when the walk is taken up again) --------------------------------------- */
         const bool keep = st == P_WALKING || st == P_SWITCH;
-        const unsigned long long km = __ballot(keep);
+        const unsigned long long km = flx_ballot(keep);
         if (COUNT && lane == 0) {
           atomicAdd(wb.counters + 37, 1ull); atomicAdd(wb.counters + 38, (unsigned long long)__popcll(km));
           atomicMax(wb.counters + 39, (unsigned long long)(clock64() - tStart)); atomicAdd(wb.counters + 36, (unsigned long long)(clock64() - tStart));
@@ -677,7 +680,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       }
       /* ---- refill the free lanes from the walk queue ------------------------------------------------ */
       for (;;) {
-        const unsigned long long idle = __ballot(st == P_EMPTY);
+        const unsigned long long idle = flx_ballot(st == P_EMPTY);
         if (idle == 0ull) break;
         if (chunkNext == chunkEnd) {
           if (!itemsLeft) break;
@@ -752,7 +755,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         if (flags & RF_NO_CLOSEST) st = P_DONE;              /* the path ends after this bounce: no closest-hit walk (nextBounceRuns) */
         else { w.mode = 1; st = P_SETUP; }
       }
-      if (__ballot(st == P_SETUP || st == P_RESUME) != 0ull) {
+      if (flx_ballot(st == P_SETUP || st == P_RESUME) != 0ull) {
         if (st == P_SETUP || st == P_RESUME) {
           const bool shadowMode = w.mode == 0;
           const Ray src = shadowMode ? shadowRay : nextRay;
@@ -771,8 +774,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         }
       }
       if (COUNT) tRefill += clock64() - t1;
-      if (__ballot(st == P_WALKING) == 0ull) {
-        if (itemsLeft || chunkNext != chunkEnd || __ballot(st == P_SWITCH || st == P_DONE) != 0ull) continue;
+      if (flx_ballot(st == P_WALKING) == 0ull) {
+        if (itemsLeft || chunkNext != chunkEnd || flx_ballot(st == P_SWITCH || st == P_DONE) != 0ull) continue;
 #if FLX_WF_CONSOLIDATE
         if (tailSynced) continue;          /* walks may be dealt this way at the next round; the round that counts none ends every wave */
 #endif
@@ -824,7 +827,7 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
    * (n_transforms x 48 B each) when they fit, the rest goes to the tree top. */
   const uint32_t T = sc.n_transforms;
-  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 40u + T * 64u + 64u;      /* per-thread rays + the staged inverse transforms + tailCtl */
+  const uint32_t rayBytes = FLX_WF_WALK_THREADS * T * 40u + T * 64u + 128u;      /* per-thread rays + the staged inverse transforms + tailCtl */
   const bool pre = FLX_WF_PRETRANSFORM && rayBytes <= 148u * 1024u && rayBytes <= (uint32_t)FLX_WF_LDS_TOTAL;
   const uint32_t ldsBudget = (uint32_t)FLX_WF_LDS_TOTAL - (pre ? rayBytes : 0u);
   uint32_t ldsCount = ldsBudget / 48u;

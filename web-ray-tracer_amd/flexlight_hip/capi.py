@@ -21,6 +21,9 @@ EXPORTS = [
     "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
+    "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
+    "flx_group_create", "flx_group_destroy", "flx_group_last_error", "flx_group_size", "flx_group_uses_rccl", "flx_group_context",
+    "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
 ]
 
 
@@ -87,6 +90,22 @@ def _load():
         "flx_taa_reset": (C.c_int, [vp]),
         "flx_present": (C.c_int, [vp, u32, u32, vp, vp]),
         "flx_present_device": (C.c_int, [vp, u32, u32, vp, vp]),
+        "flx_comm_unique_id": (C.c_int, [C.c_char_p]),
+        "flx_comm_init_rank": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
+        "flx_comm_destroy": (C.c_int, [vp]),
+        "flx_render_gathered_device": (C.c_int, [vp, C.POINTER(FrameParams), u32, vp]),
+        "flx_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
+        "flx_group_destroy": (None, [vp]),
+        "flx_group_last_error": (C.c_char_p, [vp]),
+        "flx_group_size": (C.c_int, [vp]),
+        "flx_group_uses_rccl": (C.c_int, [vp]),
+        "flx_group_context": (vp, [vp, C.c_int]),
+        "flx_group_scene_upload": (C.c_int, [vp, fp, fp, u32, C.POINTER(C.c_int32), u32]),
+        "flx_group_transforms_upload": (C.c_int, [vp, fp, fp, u32]),
+        "flx_group_lights_upload": (C.c_int, [vp, fp, u32]),
+        "flx_group_atlas_upload": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint8), u32, u32]),
+        "flx_group_scene_upload_view": (C.c_int, [vp, C.POINTER(SceneView)]),
+        "flx_group_render": (C.c_int, [vp, C.POINTER(FrameParams), u32, u32, fp, C.POINTER(Counters)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -190,6 +209,20 @@ class Context:
         arr = (FrameParams * n)(*params_list)
         self._check(LIB.flx_render_batch_device(self._h, arr, n, C.c_void_p(device_ptr)), "flx_render_batch_device")
 
+    # -- several GPUs, one process per GPU (include/flexlight_hip.h: flx_comm_*) ------------------------
+    def comm_init_rank(self, comm_id, n_ranks, rank):
+        """join this context to the RCCL communicator of `comm_id` (bytes from comm_unique_id() of rank 0); collective"""
+        self._check(LIB.flx_comm_init_rank(self._h, bytes(comm_id), int(n_ranks), int(rank)), "flx_comm_init_rank")
+
+    def comm_destroy(self):
+        self._check(LIB.flx_comm_destroy(self._h), "flx_comm_destroy")
+
+    def render_gathered_device(self, params_list, device_ptr):
+        """this rank's strips of the frames, all-gathered over RCCL and put in image order: float4[n][H][W] at device_ptr"""
+        n = len(params_list)
+        arr = (FrameParams * n)(*params_list)
+        self._check(LIB.flx_render_gathered_device(self._h, arr, n, C.c_void_p(device_ptr)), "flx_render_gathered_device")
+
     def render_device(self, params, device_ptr):
         self._check(LIB.flx_render_device(self._h, C.byref(params), C.c_void_p(device_ptr)), "flx_render_device")
 
@@ -284,6 +317,99 @@ class Context:
 
 def version():
     return LIB.flx_version().decode()
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library: FLX_COMM_ID_BYTES bytes rank 0 hands to the other ranks"""
+    buf = C.create_string_buffer(128)
+    rc = LIB.flx_comm_unique_id(buf)
+    if rc != 0:
+        raise FlexLightHipError("flx_comm_unique_id failed (%d): %s" % (rc, LIB.flx_last_error(None).decode()))
+    return buf.raw
+
+
+class _Borrowed(Context):
+    """a context owned by a Group"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def close(self):
+        self._h = None
+
+
+class Group:
+    """n contexts in one process, one frame split over them in row strips (flx_group_*): what
+    `new FlexLight(canvas, {devices: n})` of the JavaScript host sits on."""
+
+    def __init__(self, devices):
+        devices = list(devices)
+        arr = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = LIB.flx_group_create(len(devices), arr, C.byref(h))
+        if rc != 0:
+            raise FlexLightHipError("flx_group_create(%s) failed (%d): %s" % (devices, rc, LIB.flx_group_last_error(None).decode()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            LIB.flx_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise FlexLightHipError("%s failed (%d): %s" % (what, rc, LIB.flx_group_last_error(self._h).decode()))
+
+    @property
+    def size(self):
+        return int(LIB.flx_group_size(self._h))
+
+    @property
+    def uses_rccl(self):
+        return bool(LIB.flx_group_uses_rccl(self._h))
+
+    def context(self, rank):
+        h = LIB.flx_group_context(self._h, rank)
+        if not h:
+            raise FlexLightHipError("flx_group_context: no rank %d" % rank)
+        return _Borrowed(C.c_void_p(h))
+
+    def update_scene(self, scene):
+        view = scene.view()
+        self._check(LIB.flx_group_scene_upload_view(self._h, C.byref(view)), "flx_group_scene_upload_view")
+
+    def update_primary_light_sources(self, lights):
+        lights = np.ascontiguousarray(lights, np.float32).reshape(-1)
+        self._check(LIB.flx_group_lights_upload(self._h, _fp(lights), lights.size // 6), "flx_group_lights_upload")
+
+    def update_transforms(self, rotation, shift):
+        rotation = np.ascontiguousarray(rotation, np.float32).reshape(-1)
+        shift = np.ascontiguousarray(shift, np.float32).reshape(-1)
+        self._check(LIB.flx_group_transforms_upload(self._h, _fp(rotation), _fp(shift), shift.size // 8), "flx_group_transforms_upload")
+
+    def render(self, params_list, tile_rows=8, counters=False):
+        """frames (a list of FrameParams, or one) -> (rgba [n, H, W, 4] float32, counters summed over the contexts or None)"""
+        if isinstance(params_list, FrameParams):
+            params_list = [params_list]
+        n = len(params_list)
+        arr = (FrameParams * n)(*params_list)
+        h, w = (params_list[0].height, params_list[0].width) if n else (0, 0)
+        out = np.zeros((n, h, w, 4), np.float32) if n else np.zeros(4, np.float32)
+        cnt = Counters() if counters else None
+        self._check(LIB.flx_group_render(self._h, arr, n, tile_rows, _fp(out), C.byref(cnt) if cnt else None), "flx_group_render")
+        return out, (cnt.as_dict() if cnt else None)
 
 
 class Mesh:
