@@ -4,7 +4,7 @@
 # produced no bench line says why.
 for so in build/variants/lib_*.so; do
   name=$(basename $so .so)
-  FLX_LIB=$PWD/$so timeout -k 10 300 python bench.py --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline "$@" > build/variants/$name.out 2> build/variants/$name.err
+  FLX_LIB=$PWD/$so timeout -k 10 ${TMO:-120} python bench.py --steps ${STEPS:-20} --warmup 3 --no-cpu-baseline --no-pmc "$@" > build/variants/$name.out 2> build/variants/$name.err
   rc=$?
   python - "$name" "$rc" build/variants/$name.out <<'PY'
 import json, sys

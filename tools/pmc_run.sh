@@ -1,0 +1,13 @@
+#!/bin/bash
+# Hardware counters of one workload's kernels, several rocprofv3 --pmc passes (one counter set per pass; --pmc alone, no tracing):
+#   tools/pmc_run.sh <out dir under gpurun_out/> "<pmc_pass.py args>" "SET1 counters..." "SET2 counters..." ...
+# Prints, per pass, the mean of every counter per kernel (tools/pmc_summary.py).  Run on the GPU box.
+out=$1; args=$2; shift 2
+mkdir -p "$out"
+export TMPDIR=/tmp
+i=0
+for set in "$@"; do
+  i=$((i + 1))
+  rocprofv3 --pmc $set --output-format csv -d "$out/p$i" -- python3 tools/pmc_pass.py $args > "$out/p$i.log" 2>&1 || echo "pass $i failed, see $out/p$i.log"
+  for f in $(find "$out/p$i" -name "*counter_collection.csv"); do python3 tools/pmc_summary.py "$f"; done
+done

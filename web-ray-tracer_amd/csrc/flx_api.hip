@@ -59,6 +59,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_k0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&ctx->d_counters, 40 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(ctx->d_counters, 0, 40 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_wfcounts, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   for (int i = 0; i < 3; i++) {
@@ -724,6 +725,7 @@ extern "C" flx_status flx_set_pipeline(flx_context *ctx, int pipeline) {
  * device entry points return FLX_OK like flx_render does, with the frame events recorded so that flx_last_frame_ms works. */
 static flx_status empty_share(flx_context *ctx) {
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
+  if (ctx->counters_enabled) FLX_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 40 * sizeof(unsigned long long), ctx->stream));      /* no work: every counter 0 */
   FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));

@@ -859,6 +859,10 @@ FLX_DEV bool moellerTrumboreAny(f3 a, f3 edge1, f3 edge2, const Ray &ray, float 
   suv = F3(s, u, v);
   return !detBad && !uBad && !vBad && sOk;
 }
+#ifndef FLX_WF_FLAT_FETCH
+#define FLX_WF_FLAT_FETCH 1      /* entry fetch through one generic pointer (flat_load) instead of an LDS branch and a global branch: nine
+                                  * instructions fewer per trip, +0.3 % frame after frame, +0.6 % in batches (profiles/r02_ab_walk_kernel.txt) */
+#endif
 FLX_DEV bool walkTriT(WalkState &w, const WalkEntry &cur) {
   /* the threaded copy stores a triangle as (a, b - a, c - a) */
   f3 a = F3(cur.e0.x, cur.e0.y, cur.e0.z), edge1 = F3(cur.e0.w, cur.e1.x, cur.e1.y), edge2 = F3(cur.e1.z, cur.e1.w, cur.e2.x);
@@ -932,8 +936,15 @@ FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
                         WorkCounters &cnt) {
   if ((uint32_t)w.i == WALK_END) return true;
   const uint32_t i = linkIndex((uint32_t)w.i);
+#if FLX_WF_FLAT_FETCH
+  {   /* one instruction stream for both homes of an entry: a generic pointer into LDS or into the global copy (flat_load) */
+    const float4 *src = (i < ldsCount) ? lds + 3u * i : sc.walk + 3 * (size_t)i;
+    cur.e0 = src[0]; cur.e1 = src[1]; cur.e2 = src[2];
+  }
+#else
   if (i < ldsCount) { const lds_cf4 *L = (const lds_cf4 *)lds + __umul24(i, 3u); cur.e0 = ldsLoad4(L); cur.e1 = ldsLoad4(L + 1); cur.e2 = ldsLoad4(L + 2); }      /* (i < ldsCount <= 3 328) */
   else { cur.e0 = sc.walk[3 * (size_t)i]; cur.e1 = sc.walk[3 * (size_t)i + 1]; cur.e2 = sc.walk[3 * (size_t)i + 2]; }
+#endif
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
   const int meta = __float_as_int(cur.e2.z);
   const int tI = (meta >> 2) << 1;

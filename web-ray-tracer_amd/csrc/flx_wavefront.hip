@@ -70,6 +70,12 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
 #ifndef FLX_WF_WAVES_PER_EU
 #define FLX_WF_WAVES_PER_EU 4               /* occupancy the register allocation of k_wf_walk_pre must allow */
 #endif
+#ifndef FLX_DIAG_PAD_SALU
+#define FLX_DIAG_PAD_SALU 0
+#endif
+#ifndef FLX_DIAG_PAD_VALU
+#define FLX_DIAG_PAD_VALU 0
+#endif
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
 #endif
@@ -793,6 +799,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
         if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
       }
+#if FLX_DIAG_PAD_SALU        /* diagnostic builds: what do N more scalar / vector instructions per trip cost? (profiles/r02_issue_sensitivity.txt) */
+      { uint32_t a = 1, b = 2, c = 3, d = 4;
+        for (int k = 0; k < FLX_DIAG_PAD_SALU / 4; k++) asm volatile("s_mov_b32 %0, %1\n s_mov_b32 %1, %2\n s_mov_b32 %2, %3\n s_mov_b32 %3, %0" : "+s"(a), "+s"(b), "+s"(c), "+s"(d) : : "scc"); }      /* (s_mov leaves SCC alone; an s_add here without the clobber corrupts the loop's compare and the kernel never ends) */
+#endif
+#if FLX_DIAG_PAD_VALU
+      { uint32_t a = lane, b = lane, c = lane, d = lane;
+        for (int k = 0; k < FLX_DIAG_PAD_VALU / 4; k++) asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+#endif
     }
     if (COUNT) tInner += clock64() - t2;
   }
