@@ -112,13 +112,36 @@ def collect_pmc(args):
     return acc
 
 
+def usable_cores():
+    """(cores this process can really run on, its cgroup CPU quota or None): the affinity mask (= nproc) capped by the cgroup's
+    quota — a GPU box hands a one-GPU job 16 of the host's 256 cores that way, and 256 OpenMP threads on a 16-core quota are
+    slower than 16 (28.8 against 46 Mray/s on the dragon frame)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, quota
+
+
 def cpu_baseline(scene, params_full, seconds_budget=12.0):
     """CPU oracle (kind 'port': this repo's C restatement of the reference GLSL — the reference has no CPU path) on a bounded
     sample of the same workload, on ALL host cores of this box: the same scene / spp / bounces, the full frame when one frame
     fits the budget (repeated until ~seconds_budget of CPU work), otherwise a centred sub-resolution frame sized from a probe."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import flx_oracle
-    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)      # the cores this process may use = nproc
+    threads, quota = usable_cores()
     spp, bounces = params_full.samples, params_full.max_reflections
     W, H = params_full.width, params_full.height
     probe = scene.frame_params(width=240, height=135, samples=spp, max_reflections=bounces, use_filter=0)
@@ -145,8 +168,8 @@ def cpu_baseline(scene, params_full, seconds_budget=12.0):
     flx_oracle.render(scene, p1, threads=1)
     dt1 = max(time.time() - t1, 1e-6)
     return {
-        "value": frames * spp * bounces * w * h / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(),
-        "sample": "same scene/spp/bounces, %dx%d frame x %d (%.1f s of CPU oracle, %d OpenMP threads = every core this process may use, filter off)" % (w, h, frames, dt, threads),
+        "value": frames * spp * bounces * w * h / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(), "cpu_quota": quota,
+        "sample": "same scene/spp/bounces, %dx%d frame x %d (%.1f s of CPU oracle, %d OpenMP threads = every core this process can run on: nproc %d, cgroup quota %s; filter off)" % (w, h, frames, dt, threads, os.cpu_count() or 0, ("%.1f cores" % quota) if quota else "none"),
         "single_thread": {"value": spp * bounces * w * rows1 / dt1 / 1e6, "unit": "Mray/s", "cores": 1,
                           "sample": "every 16th 8-row strip of that frame (%d rows, %.1f s)" % (rows1, dt1)},
     }
@@ -384,7 +407,7 @@ def main():
                                 "note": "SURVEY.md 8d: 48 B x entries visited (+ 160 B x shades + 24 B x lights x shades + 4 B x texels + 16 B x pixels for the frame), from this frame's work counters; the <= 12 MB scene is LDS / L2 resident, so this is NOT a fraction of HBM bandwidth — the kernel is bound by VALU issue, not by memory"},
                 "secondary": {"bound": "valu_fp32", "achieved": 30.0 * bytes_launch / 48.0 / (k_ms * 1e-3) / 1e12, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": 30.0 * bytes_launch / 48.0 / (k_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, "note": "~30 flop per entry visited (SURVEY.md 8d)"},
-                "pmc": pmc.get("_meta", {"error": "not collected (--no-pmc or N > 1)"}),
+                "pmc": dict(pmc.get("_meta", {"error": "not collected (--no-pmc or N > 1)"}), counters_per_launch=k),
             },
             "counters": cnt,
         }

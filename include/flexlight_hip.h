@@ -154,6 +154,21 @@ flx_status flx_get_counters(flx_context *ctx, flx_counters *out);
  * (trace) kernel alone; milliseconds. */
 flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_kernel_ms);
 
+/* ---- the frame loop ------------------------------------------------------------------------------------
+ * The reference's renderFrame() (pathtracerWGL2.js:375-554) ends with draw calls the browser presents on its own; the
+ * JavaScript thread never waits for the GPU.  flx_frame_begin is that half: it enqueues one frame — trace, temporal pass,
+ * denoise chain as flx_render would run them, then optionally the 8-bit store of the canvas (flx_present) — and the copy of
+ * the result into a pinned host buffer the context owns (on a copy stream: the next frame's kernels start meanwhile), and
+ * returns.  flx_frame_end waits for the OLDEST frame begun and hands out its pixels and its GPU time.  At most two frames are
+ * in flight (two sets of buffers): the host prepares and begins frame N + 1 while frame N is traced and copied.  The pixels
+ * stay valid until the second flx_frame_begin after the one that made them (or the context's end); rows as flx_render. */
+#define FLX_FRAME_FLOAT 0      /* float32 RGBA, what flx_render returns */
+#define FLX_FRAME_RGBA8 1      /* bytes R G B A as the canvas' drawing buffer holds them (flx_present): a quarter of the bytes over PCIe */
+flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *params, int format);
+flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_t *bytes, float *gpu_ms);
+/* frames begun and not yet ended (0 .. 2) */
+int flx_frames_in_flight(const flx_context *ctx);
+
 /* Filter frames on several GPUs.  The path-trace pass is per pixel and shards by row strips like a frame
  * without filter; the denoise chain reads up to ~194 rows around a pixel and runs on the whole frame.  So every rank
  *   1. flx_render_planes_device: traces its strips (params->tile_*, use_filter = 1, is_temporal = 0) and stores the

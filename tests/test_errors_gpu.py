@@ -105,3 +105,31 @@ def test_dynamic_uploads_reuse_their_buffers(hip, oracle, scenes):
         assert np.array_equal(got[i], want, equal_nan=True), "frame %d" % i
     assert not np.array_equal(got[0], got[2])
     hip.update_scene(sc)
+
+
+def test_frame_loop_two_frames_in_flight(hip, oracle, scenes):
+    """flx_frame_begin / flx_frame_end: frames enqueued ahead of the host, taken in order out of pinned memory — float radiance and
+    the canvas' RGBA8 —, a third begin refused while two are in flight"""
+    from flexlight_hip import capi
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=160, height=96, samples=2, max_reflections=3, use_filter=0)
+    q = type(p).from_buffer_copy(p)
+    q.camera[0] += 1.5
+    f = sc.frame_params(width=160, height=96, samples=2, max_reflections=3, use_filter=1)
+    want_p, want_q, want_f = hip.render(p)[0], hip.render(q)[0], hip.render(f)[0]
+    with pytest.raises(capi.FlexLightHipError, match="no frame in flight"):
+        hip.frame_end()
+    hip.frame_begin(p)
+    hip.frame_begin(q, rgba8=True)
+    assert hip.frames_in_flight() == 2
+    with pytest.raises(capi.FlexLightHipError, match="two frames are in flight"):
+        hip.frame_begin(p)
+    a, ms = hip.frame_end()
+    assert np.array_equal(a, want_p, equal_nan=True) and ms > 0
+    hip.frame_begin(f)                                     # the slot of the frame just taken
+    b, _ = hip.frame_end()
+    assert b.dtype == np.uint8 and np.array_equal(b, oracle.present(want_q))
+    c, _ = hip.frame_end()
+    assert np.array_equal(c, want_f, equal_nan=True)
+    assert hip.frames_in_flight() == 0

@@ -90,3 +90,61 @@ def test_present_through_node(oracle, tmp_path):
     got = np.fromfile(pix, np.uint8).reshape(64, 96, 4)
     assert np.array_equal(got, oracle.present(frame))
     assert got[..., :3].max() > 0
+
+
+def test_frame_loop_with_a_moving_scene_through_node(hip, oracle, scenes, tmp_path):
+    """SURVEY 8f N3 / examples/dragon.js:97-110: the application moves the camera every tick and the monkey turns to face it
+    (Transform.rotateSpherical), so the transform arrays change every frame.  Three consecutive frames of the renderer's own
+    frame loop — engine.renderer.render(): two frames in flight, lights and transforms re-uploaded per frame in stream order,
+    pixels handed out of pinned memory — each equal to the oracle's frame for the camera and transforms of that tick; and the
+    transform arrays the JavaScript host derives equal the native flx_transforms_pack of the same matrices."""
+    import copy
+    from flexlight_hip import capi
+    node = shutil.which("node")
+    w, h, spp, bounces = 320, 180, 2, 3
+    prefix = str(tmp_path / "loop")
+    info = json.loads(subprocess.check_output(
+        [node, os.path.join(ROOT, "tools", "js_loop.js"), os.path.join(ROOT, "tests", "golden", "ref_dragon.flxs.gz"), "--frames", "4", "--move", "1",
+         "--width", str(w), "--height", str(h), "--spp", str(spp), "--bounces", str(bounces), "--dump", prefix, "--dump-frames", "3"], timeout=300).decode().splitlines()[-1])
+    assert info["frames"] == 4 and info["moving"] is True and info["gpuMsMedian"] > 0
+    log = json.load(open(prefix + "log.json"))
+    assert len(log) == 3
+    sc = scenes("dragon")
+    frames = []
+    for k, tick in enumerate(log):
+        rot, shift = np.asarray(tick["rotation"], np.float32), np.asarray(tick["shift"], np.float32)
+        # the same arrays from the native packer: identity, the dragon's 0.5 x identity at (15, 0, 15), the monkey's 2 x R at (5, 1, 12)
+        cam = np.asarray(tick["camera"], np.float64)
+        d = cam - np.array([5.0, 1.0, 12.0])
+        theta = np.sign(d[2]) * np.arccos(d[0] / np.sqrt(d[0] * d[0] + d[2] * d[2])) - np.pi * 0.5
+        psi = np.arccos(d[1] / np.sqrt((d * d).sum())) - np.pi * 0.5
+        sT, cT, sP, cP = np.sin(theta), np.cos(theta), np.sin(psi), np.cos(psi)
+        R = np.array([[cT, 0, sT], [-sT * sP, cP, cT * sP], [-sT * cP, -sP, cT * cP]])
+        nrot, nshift = capi.transforms_pack([np.eye(3), 0.5 * np.eye(3), 2.0 * R], [[0, 0, 0], [15, 0, 15], [5, 1, 12]])
+        assert np.abs(nrot.reshape(-1) - rot).max() <= 1e-6 and np.array_equal(nshift.reshape(-1), shift)      # (Math.sin vs libm may differ in the last place)
+        sck = copy.copy(sc)
+        sck.arrays = dict(sc.arrays, rotation=rot, shift=shift)
+        p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+        p.camera[:] = tick["camera"]
+        p.view_matrix[:] = tick["viewMatrix"]
+        want, _, _ = oracle.render(sck, p)
+        got = np.fromfile(prefix + "%d.f32" % k, np.float32).reshape(h, w, 4)
+        _, mism = assert_parity(got, want, "loop frame %d" % k)
+        assert mism == 0, "frame %d" % k
+        frames.append(got)
+    assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[1], frames[2])
+
+
+def test_group_of_two_contexts_through_node(hip, scenes, tmp_path):
+    """new FlexLight(canvas, { devices: [0, 0] }): the frame split over two contexts and gathered inside the library equals the
+    frame of one context, through the whole JavaScript path"""
+    node = shutil.which("node")
+    w, h, spp, bounces = 96, 64, 2, 3
+    base = [node, os.path.join(ROOT, "tools", "render_scene.js"), "cornell", "--width", str(w), "--height", str(h), "--spp", str(spp),
+            "--bounces", str(bounces), "--assets", "/nonexistent"]
+    for filt in ("0", "1"):
+        one, two = tmp_path / ("one%s.f32" % filt), tmp_path / ("two%s.f32" % filt)
+        subprocess.check_output(base + ["--out", str(one), "--filter", filt], timeout=300)
+        info = json.loads(subprocess.check_output(base + ["--out", str(two), "--filter", filt, "--devices", "0,0"], timeout=300).decode().splitlines()[-1])
+        assert info["gpus"] == {"size": 2, "rccl": False}
+        assert np.array_equal(np.fromfile(one, np.uint32), np.fromfile(two, np.uint32))

@@ -2,7 +2,8 @@
 /*
  * Render one BASELINE scene through the whole JavaScript path — FlexLight facade, scene graph, host
  * flattening, N-API addon, libflexlight_hip.so — and write the float32 radiance to a file.
- *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --aa fxaa|taa --frames N --batch N --present FILE --assets DIR]
+ *   node tools/render_scene.js <scene> --out frame.f32 [--width W --height H --spp S --bounces B --filter 0|1 --aa fxaa|taa --frames N --batch N --present FILE --assets DIR --devices N | a,b,...]
+ *   --devices: the frame split over several GPUs in this process (flx_group_*): N = GPUs 0 .. N - 1, or a list (a number may repeat)
  */
 const fs = require('fs');
 const os = require('os');
@@ -31,7 +32,9 @@ function loadImage (rel) {
   const canvas = { width: Number(opt('--width', frame.width)), height: Number(opt('--height', frame.height)) };
   Transform.reset();
   const log = console.log; console.log = () => {};
-  const engine = new FlexLight(canvas, { assetRoot: assets });
+  const dv = opt('--devices', null);
+  const devices = dv === null ? undefined : (dv.includes(',') ? dv.split(',').map(Number) : Number(dv));
+  const engine = new FlexLight(canvas, { assetRoot: assets, devices });
   engine.loadImage = async rel => loadImage(rel);
   await scenes[name](engine);
   console.log = log;
@@ -62,6 +65,6 @@ function loadImage (rel) {
   for (let k = 0; k < frames; k++) f = engine.renderer.renderFrame({ counters: true });
   fs.writeFileSync(opt('--out', 'frame.f32'), Buffer.from(f.radiance.buffer));
   if (opt('--present', null)) fs.writeFileSync(opt('--present', null), Buffer.from(engine.renderer.presentFrame(f).data.buffer));      // the canvas' RGBA8
-  console.log(JSON.stringify({ width: f.width, height: f.height, rows: f.rows, frameMs: f.frameMs, counters: f.counters }));
+  console.log(JSON.stringify({ width: f.width, height: f.height, rows: f.rows, frameMs: f.frameMs, counters: f.counters, gpus: engine.renderer.gpuInfo }));
   engine.renderer.halt();
 })().catch(e => { console.error(e); process.exit(1); });

@@ -89,6 +89,14 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   for (hipEvent_t ev : { ctx->ev_frame0, ctx->ev_frame1, ctx->ev_k0, ctx->ev_k1 }) if (ev) (void)hipEventDestroy(ev);
   for (int i = 0; i < 3; i++) { if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  for (int i = 0; i < 2; i++) {
+    if (ctx->d_slot[i]) (void)hipFree(ctx->d_slot[i]);
+    if (ctx->d_slot8[i]) (void)hipFree(ctx->d_slot8[i]);
+    if (ctx->h_slot[i]) (void)hipHostFree(ctx->h_slot[i]);
+    for (hipEvent_t ev : { ctx->ev_slot_start[i], ctx->ev_slot_traced[i], ctx->ev_slot_done[i] }) if (ev) (void)hipEventDestroy(ev);
+  }
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   for (hipEvent_t ev : ctx->stage_done) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -917,6 +925,75 @@ extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *param
     memcpy(counters, host_cnt, sizeof host_cnt);
     ctx->last_counters = *counters;
   }
+  return FLX_OK;
+}
+
+/* ---- the frame loop: begin / end with two frames in flight (include/flexlight_hip.h) ------------------------------------- */
+extern "C" int flx_frames_in_flight(const flx_context *ctx) { return ctx ? (int)(ctx->frames_begun - ctx->frames_ended) : 0; }
+
+extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *params, int format) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_RGBA8) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: format is FLX_FRAME_FLOAT or FLX_FRAME_RGBA8");
+  if (ctx->frames_begun - ctx->frames_ended >= 2) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: two frames are in flight already, take one with flx_frame_end first");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceScene sc; DeviceFrame fr;
+  flx_status s = flx_make_frame(ctx, params, sc, fr);
+  if (s) return s;
+  const int k = (int)(ctx->frames_begun & 1u);
+  if (!ctx->copy_stream) {
+    FLX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      FLX_HIP(ctx, hipEventCreate(&ctx->ev_slot_start[i]));
+      FLX_HIP(ctx, hipEventCreate(&ctx->ev_slot_traced[i]));
+      FLX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slot_done[i], hipEventDisableTiming));
+    }
+  }
+  const size_t pixels = (size_t)fr.rows * fr.width;
+  const size_t bytes = pixels * (format == FLX_FRAME_RGBA8 ? sizeof(uint32_t) : sizeof(float4));
+  if ((s = flx_ensure_pixels(ctx, &ctx->d_slot[k], &ctx->slot_capacity[k], pixels ? pixels : 1))) return s;
+  if (format == FLX_FRAME_RGBA8 && ctx->slot8_capacity[k] < pixels) {
+    ctx->slot8_capacity[k] = 0;
+    if (ctx->d_slot8[k]) { FLX_HIP(ctx, hipFree(ctx->d_slot8[k])); ctx->d_slot8[k] = nullptr; }
+    FLX_HIP(ctx, hipMalloc(&ctx->d_slot8[k], (pixels ? pixels : 1) * sizeof(uint32_t)));
+    ctx->slot8_capacity[k] = pixels;
+  }
+  if (ctx->h_slot_capacity[k] < bytes || !ctx->h_slot[k]) {
+    ctx->h_slot_capacity[k] = 0;
+    if (ctx->h_slot[k]) { FLX_HIP(ctx, hipHostFree(ctx->h_slot[k])); ctx->h_slot[k] = nullptr; }
+    FLX_HIP(ctx, hipHostMalloc(&ctx->h_slot[k], bytes ? bytes : 16, hipHostMallocDefault));
+    ctx->h_slot_capacity[k] = bytes;
+  }
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_start[k], ctx->stream));
+  if (pixels) {
+    if (params->use_filter || params->is_temporal) {
+      s = run_post_frame(ctx, sc, fr, params, ctx->d_slot[k]);
+    } else {
+      GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+      s = flx_run_frame(ctx, sc, fr, ctx->d_slot[k], gb);
+    }
+    if (s) return s;
+    if (format == FLX_FRAME_RGBA8) { launch_quantize(ctx->d_slot[k], ctx->d_slot8[k], pixels, ctx->stream); FLX_HIP(ctx, hipGetLastError()); }
+  }
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_traced[k], ctx->stream));
+  /* the copy to the host runs beside the next frame's kernels */
+  FLX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_slot_traced[k], 0));
+  if (bytes) FLX_HIP(ctx, hipMemcpyAsync(ctx->h_slot[k], format == FLX_FRAME_RGBA8 ? (const void *)ctx->d_slot8[k] : (const void *)ctx->d_slot[k], bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_done[k], ctx->copy_stream));
+  ctx->slot_bytes[k] = bytes;
+  ctx->frames_begun++;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_t *bytes, float *gpu_ms) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->frames_begun == ctx->frames_ended) return fail(ctx, FLX_ERR_INVALID, "flx_frame_end: no frame in flight");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  const int k = (int)(ctx->frames_ended & 1u);
+  FLX_HIP(ctx, hipEventSynchronize(ctx->ev_slot_done[k]));
+  ctx->frames_ended++;
+  if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_slot_start[k], ctx->ev_slot_traced[k])); *gpu_ms = ms; }
+  if (pixels) *pixels = ctx->h_slot[k];
+  if (bytes) *bytes = ctx->slot_bytes[k];
   return FLX_OK;
 }
 

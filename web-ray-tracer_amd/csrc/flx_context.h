@@ -92,6 +92,17 @@ struct flx_context {
   size_t frames_capacity = 0;
   float4 *d_gplanes = nullptr;                   /* filter frames: the five gathered render targets in image order */
   size_t gplanes_capacity = 0;
+  /* the frame loop (flx_frame_begin / flx_frame_end): two slots of device output + pinned host memory, a copy stream */
+  float4 *d_slot[2] = { nullptr, nullptr };
+  size_t slot_capacity[2] = { 0, 0 };            /* pixels */
+  uint32_t *d_slot8[2] = { nullptr, nullptr };
+  size_t slot8_capacity[2] = { 0, 0 };
+  void *h_slot[2] = { nullptr, nullptr };
+  size_t h_slot_capacity[2] = { 0, 0 };          /* bytes */
+  size_t slot_bytes[2] = { 0, 0 };
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_slot_start[2] = {}, ev_slot_traced[2] = {}, ev_slot_done[2] = {};
+  uint64_t frames_begun = 0, frames_ended = 0;
   /* uploads: capacity of every persistent scene buffer (keyed by the address of its pointer), pinned staging ring */
   std::map<void **, size_t> upload_capacity;
   uint8_t *stage = nullptr;

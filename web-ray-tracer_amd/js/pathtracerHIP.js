@@ -39,6 +39,14 @@ class PathTracerHIP {
     this._canvas = canvas;
     this._device = (options && options.device) || 0;
     this._tile = (options && options.tile) || null;      // {rows, index, count}: this context's strips of the frame
+    /* several GPUs in this process (SURVEY.md 8e; not in the reference, which has one WebGL2 context): devices: N = GPUs 0 .. N - 1,
+     * or a list of device numbers (a number may repeat: a rehearsal on a one-GPU box).  The frame is cut into strips of tileRows
+     * rows dealt round robin to the GPUs and gathered inside the library (flx_group_render: RCCL all-gather + reassembly). */
+    const dv = options && options.devices;
+    this._devices = Array.isArray(dv) ? dv.slice() : (dv > 1 ? Array.from({ length: dv }, (_, i) => i) : null);
+    this._tileRows = (options && options.tileRows) || 8;
+    this.present8 = !!(options && options.present8);     // the frame loop hands out the canvas' RGBA8 instead of float radiance
+    this._group = null;
     this._ctx = null;
     this._halt = true;
     this._atlasLists = [null, null, null];
@@ -50,8 +58,36 @@ class PathTracerHIP {
   get canvas () { return this._canvas; }
 
   _context () {
+    if (this._devices) throw new Error('this renderer drives a group of GPUs: per-context calls are not available');
     if (!this._ctx) this._ctx = native().createContext(this._device);
     return this._ctx;
+  }
+
+  /* the GPU(s) behind the renderer: one context or a group of them, the same four uploads and one render call */
+  _gpu () {
+    const n = native();
+    if (this._devices) {
+      if (!this._group) this._group = n.createGroup(this._devices);
+      const g = this._group;
+      return {
+        uploadScene: (a, b, c) => n.groupUploadScene(g, a, b, c), uploadTransforms: (a, b) => n.groupUploadTransforms(g, a, b),
+        uploadLights: a => n.groupUploadLights(g, a), uploadAtlas: (w, px, x, y) => n.groupUploadAtlas(g, w, px, x, y),
+        render: (p, out, counters) => n.groupRender(g, [p], this._tileRows, out, counters),
+        renderBatch: (ps, out, counters) => n.groupRender(g, ps, this._tileRows, out, counters),
+        rows: p => p.height
+      };
+    }
+    const c = this._context();
+    return {
+      uploadScene: (a, b, d) => n.uploadScene(c, a, b, d), uploadTransforms: (a, b) => n.uploadTransforms(c, a, b),
+      uploadLights: a => n.uploadLights(c, a), uploadAtlas: (w, px, x, y) => n.uploadAtlas(c, w, px, x, y),
+      render: (p, out, counters) => n.render(c, p, out, counters), renderBatch: (ps, out, counters) => n.renderBatch(c, ps, out, counters),
+      rows: p => n.tileRowCount(p)
+    };
+  }
+
+  get gpuInfo () {                                         // { size, rccl } of a group, { size: 1 } otherwise
+    return this._devices ? native().groupInfo((this._gpu(), this._group)) : { size: 1, rccl: false };
   }
 
   halt () {                                               // pathtracerWGL2.js:70-77
@@ -59,35 +95,50 @@ class PathTracerHIP {
     if (this._ctx) {
       try { native().destroyContext(this._ctx); } catch (e) { console.warn('Unable to release the GPU context', e.message); }
       this._ctx = null;
-      this._haveScene = false;
-      this._atlasLists = [null, null, null];
     }
+    if (this._group) {
+      try { native().destroyGroup(this._group); } catch (e) { console.warn('Unable to release the GPU group', e.message); }
+      this._group = null;
+    }
+    this._haveScene = false;
+    this._atlasLists = [null, null, null];
+    this._inFlight = 0;
   }
 
   async updateScene () {                                  // pathtracerWGL2.js:167-189
     const built = await this.scene.generateArraysFromGraph();
-    native().uploadScene(this._context(), built.geometryBuffer, built.sceneBuffer, built.idBuffer);
+    this._gpu().uploadScene(built.geometryBuffer, built.sceneBuffer, built.idBuffer);
     this._haveScene = true;
   }
 
   async updatePrimaryLightSources () {                    // pathtracerWGL2.js:143-165
-    native().uploadLights(this._context(), sceneFile.buildLightArray(this.scene));
+    this._gpu().uploadLights(sceneFile.buildLightArray(this.scene));
   }
 
   _updateAtlases () {                                     // pathtracerWGL2.js:106-140: rebuild only when the list object or its members changed
+    if (this.scene.prebuiltAtlases) {                    // a replayed scene (sceneFile.sceneFromFlxs): the atlases as they were built
+      if (this._atlasLists[0] !== this.scene.prebuiltAtlases) {
+        this.scene.prebuiltAtlases.forEach((a, which) => this._gpu().uploadAtlas(which, a.data, a.width, a.height));
+        this._atlasLists = [this.scene.prebuiltAtlases, null, null];
+      }
+      return;
+    }
     const lists = [this.scene.textures, this.scene.pbrTextures, this.scene.translucencyTextures];
     lists.forEach((list, which) => {
       const old = this._atlasLists[which];
       if (old && old.length === list.length && list.every((e, i) => e === old[i])) return;
       this._atlasLists[which] = list.slice();
-      if (list.length === 0) { native().uploadAtlas(this._context(), which, null, 0, 0); return; }
+      if (list.length === 0) { this._gpu().uploadAtlas(which, null, 0, 0); return; }
       const atlas = sceneFile.buildAtlas(list, this.scene.standardTextureSizes);
-      native().uploadAtlas(this._context(), which, atlas.data, atlas.width, atlas.height);
+      this._gpu().uploadAtlas(which, atlas.data, atlas.width, atlas.height);
     });
   }
 
   frameParams (jitter) {                                  // pathtracerWGL2.js:307-347
-    const w = this._canvas.width, h = this._canvas.height;
+    /* config.renderQuality scales the resolution the frame is traced at (pathtracerWGL2.js:264-267, 810-811: the canvas'
+     * drawing buffer is clientWidth x renderQuality); the frame handed back has that size */
+    const q = this.config.renderQuality > 0 ? this.config.renderQuality : 1;
+    const w = Math.max(1, Math.round(this._canvas.width * q)), h = Math.max(1, Math.round(this._canvas.height * q));
     const cam = jitter ? Object.assign(Object.create(this.camera), { fx: this.camera.fx + jitter.x, fy: this.camera.fy + jitter.y }) : this.camera;
     const p = {
       width: w, height: h,
@@ -129,27 +180,38 @@ class PathTracerHIP {
   }
 
   /* One frame, synchronously.  Returns {width, height, rows, radiance: Float32Array(rows*width*4), frameMs, traceMs, counters?}. */
-  renderFrame (options) {
-    const ctx = this._context();
+  /* scene arrays of this frame: scene once, then what the reference re-derives every frame (pathtracerWGL2.js:258-262, 361-365) */
+  _uploadFrameState () {
+    const gpu = this._gpu();
     if (!this._haveScene) {
       const built = this.scene.generateArraysFromGraph();
-      native().uploadScene(ctx, built.geometryBuffer, built.sceneBuffer, built.idBuffer);
+      gpu.uploadScene(built.geometryBuffer, built.sceneBuffer, built.idBuffer);
       this._haveScene = true;
     }
     this._updateAtlases();
-    native().uploadLights(ctx, sceneFile.buildLightArray(this.scene));
+    gpu.uploadLights(sceneFile.buildLightArray(this.scene));
     const tr = Transform.buildWGL2Arrays();
-    native().uploadTransforms(ctx, tr[0], tr[1]);
+    gpu.uploadTransforms(tr[0], tr[1]);
+    return gpu;
+  }
+
+  renderFrame (options) {
+    const gpu = this._uploadFrameState();
     const aa = this._antialiasing();
     const jitter = aa === 'taa' ? this._jitter() : { x: 0, y: 0 };
     const p = this.frameParams(jitter);
-    const rows = native().tileRowCount(p);
-    let radiance = new Float32Array(rows * p.width * 4);
-    const info = native().render(ctx, p, radiance, !!(options && options.counters));
+    const rows = gpu.rows(p);
+    /* options.reuse: write into the array of the frame before (a frame loop that consumes each frame before asking for the
+     * next saves a 33 MB allocation per 1080p frame); by default every frame gets its own */
+    const n = rows * p.width * 4;
+    let radiance = (options && options.reuse && this._out && this._out.length === n) ? this._out : new Float32Array(n);
+    this._out = radiance;
+    const info = gpu.render(p, radiance, !!(options && options.counters));
     if (aa && rows === p.height) {                        // the pass reads neighbouring texels: whole frames only (pathtracerWGL2.js:552-553)
+      if (this._devices) throw new Error('antialiasing passes run on one context: use a single device');
       const out = new Float32Array(radiance.length);
-      if (aa === 'fxaa') native().fxaa(ctx, p.width, p.height, radiance, out);
-      else native().taa(ctx, p.width, p.height, radiance, out);
+      if (aa === 'fxaa') native().fxaa(this._context(), p.width, p.height, radiance, out);
+      else native().taa(this._context(), p.width, p.height, radiance, out);
       radiance = out;
     }
     this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);     // pathtracerWGL2.js:291
@@ -174,49 +236,70 @@ class PathTracerHIP {
    * the renderFrame() of its camera. */
   renderBatch (cameras, options) {
     if (this.config.filter || this.config.temporal || this._antialiasing()) throw new Error('renderBatch: filter, temporal and antialiasing frames depend on the frame before');
-    const ctx = this._context();
-    if (!this._haveScene) {
-      const built = this.scene.generateArraysFromGraph();
-      native().uploadScene(ctx, built.geometryBuffer, built.sceneBuffer, built.idBuffer);
-      this._haveScene = true;
-    }
-    this._updateAtlases();
-    native().uploadLights(ctx, sceneFile.buildLightArray(this.scene));
-    const tr = Transform.buildWGL2Arrays();
-    native().uploadTransforms(ctx, tr[0], tr[1]);
+    const gpu = this._uploadFrameState();
     const saved = this.camera;
     const params = cameras.map(c => {
       this.camera = Object.assign(Object.create(saved), c);
       try { return this.frameParams(); } finally { this.camera = saved; }
     });
-    const rows = native().tileRowCount(params[0]);
+    const rows = gpu.rows(params[0]);
     const per = rows * params[0].width * 4;
     const all = new Float32Array(per * params.length);
-    const info = native().renderBatch(ctx, params, all, !!(options && options.counters));
+    const info = gpu.renderBatch(params, all, !!(options && options.counters));
     const frames = params.map((_, i) => all.subarray(i * per, (i + 1) * per));
     return Object.assign({ width: params[0].width, height: params[0].height, rows, frames }, info);
   }
 
-  async render () {                                       // pathtracerWGL2.js:191-831: start the frame loop
+  /* The frame loop (pathtracerWGL2.js:191-831).  Like the reference's, it does not wait for the GPU inside a frame: frame
+   * k + 1 is prepared and enqueued (flx_frame_begin) while frame k is traced and copied to pinned host memory, then frame k is
+   * taken (flx_frame_end) and handed to canvas.onFrame — `pixels` is a view of that pinned memory (Float32Array, or the canvas'
+   * RGBA8 as a Uint8ClampedArray with this.present8), valid until the frame after the next is begun.  Anti-aliasing passes,
+   * tiles and GPU groups take the synchronous renderFrame() per cycle instead.  `fps` as in pathtracerWGL2.js:293-298;
+   * `gpuMs` = GPU time of the last frame taken. */
+  async render () {
     if (!this._halt) return;                              // already running (the WebGPU renderer guards the same way)
     this._halt = false;
     await this.updateScene();
     let frames = 0, windowStart = Date.now();
-    const cycle = () => {
-      if (this._halt) return;
-      try {
-        const frame = this.renderFrame();
-        if (typeof this._canvas.onFrame === 'function') this._canvas.onFrame(frame);
-      } catch (e) {
-        console.error(e);
-        this._halt = true;
-        return;
-      }
+    this._inFlight = 0;
+    const pending = [];                                    // sizes of the frames begun and not yet taken
+    const deliver = frame => {
+      this.lastFrame = frame;
+      if (typeof this._canvas.onFrame === 'function') this._canvas.onFrame(frame);
       frames++;
       const now = Date.now();
       if (now - windowStart >= 500) {                     // pathtracerWGL2.js:293-298
         this.fps = (1000 * frames / (now - windowStart)).toFixed(0);
         frames = 0; windowStart = now;
+      }
+    };
+    const take = () => {
+      const q = pending.shift();
+      const r = native().frameEnd(this._ctx, q.rgba8);
+      this._inFlight--;
+      this.gpuMs = r.gpuMs;
+      deliver({ width: q.width, height: q.height, rows: q.rows, radiance: q.rgba8 ? undefined : r.pixels, rgba8: q.rgba8 ? r.pixels : undefined, pixels: r.pixels, frameMs: r.gpuMs });
+    };
+    const cycle = () => {
+      if (this._halt) return;
+      try {
+        const pipelined = !this._devices && !this._tile && !this._antialiasing();
+        if (pipelined) {
+          this._uploadFrameState();
+          const p = this.frameParams();
+          native().frameBegin(this._context(), p, this.present8);
+          this._inFlight++;
+          pending.push({ width: p.width, height: p.height, rows: p.height, rgba8: this.present8 });
+          this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);
+          if (this._inFlight === 2) take();
+        } else {
+          while (this._inFlight > 0) take();
+          deliver(this.renderFrame({ reuse: true }));
+        }
+      } catch (e) {
+        console.error(e);
+        this._halt = true;
+        return;
       }
       if (this.fpsLimit === Infinity) setImmediate(cycle);
       else setTimeout(cycle, 1000 / this.fpsLimit);

@@ -98,4 +98,29 @@ function save (file, name, engine, built, transformArrays, frame, extraMeta) {
   return s;
 }
 
-module.exports = { buildLightArray, buildAtlas, buildViewMatrix, assemble, save };
+/* A scene that replays a .flxs file: what the renderer asks of a Scene (generateArraysFromGraph, light list, ambient light, texture
+ * lists, standardTextureSizes) answered from the stored arrays — for boxes without the OBJ / JPEG assets (the GPU box).  The
+ * atlases come prebuilt (`prebuiltAtlases`); transforms are NOT replayed: the caller re-creates its Transform objects, so that
+ * an animation can move them (tools/js_loop.js). */
+function sceneFromFlxs (file) {
+  const { meta, arrays } = flxs.read(file);
+  const lights = [];
+  for (let i = 0; i < arrays.lights.length; i += 6) {
+    const l = [arrays.lights[i], arrays.lights[i + 1], arrays.lights[i + 2]];
+    l.intensity = arrays.lights[i + 3]; l.variation = arrays.lights[i + 4];
+    lights.push(l);
+  }
+  const atlas = k => ({ width: meta.atlas[k][0], height: meta.atlas[k][1], data: arrays['atlas' + k[0].toUpperCase() + k.slice(1)] });
+  return {
+    meta,
+    primaryLightSources: lights, defaultLightIntensity: 200, defaultLightVariation: 0.4,
+    ambientLight: meta.ambient.slice(),
+    textures: [], pbrTextures: [], translucencyTextures: [],
+    standardTextureSizes: [Math.floor(2048 / meta.textureWidth), Math.floor(2048 / meta.textureWidth)],
+    prebuiltAtlases: [atlas('albedo'), atlas('pbr'), atlas('tpo')],
+    queue: [],
+    generateArraysFromGraph: () => ({ textureLength: meta.textureLength, bufferLength: meta.bufferLength, geometryBuffer: arrays.geometry, sceneBuffer: arrays.attributes, idBuffer: arrays.ids })
+  };
+}
+
+module.exports = { buildLightArray, buildAtlas, buildViewMatrix, assemble, save, sceneFromFlxs };

@@ -502,6 +502,208 @@ static napi_value PackTransforms(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 
+
+/* ---- the frame loop: frameBegin(handle, params, rgba8) / frameEnd(handle) -> { pixels, gpuMs } ---------------------------
+ * `pixels` is a typed array over the context's pinned host buffer (no copy): valid until the second frameBegin after the one
+ * that made it, or halt(). */
+static napi_value FrameBegin(napi_env env, napi_callback_info info) {
+  napi_value argv[3];
+  if (!get_args(env, info, 3, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  flx_frame_params p;
+  if (!read_params(env, argv[1], &p)) return nullptr;
+  bool rgba8 = false;
+  napi_get_value_bool(env, argv[2], &rgba8);
+  flx_status rc = flx_frame_begin(ctx, &p, rgba8 ? FLX_FRAME_RGBA8 : FLX_FRAME_FLOAT);
+  if (rc != FLX_OK) return fail(env, ctx, "flx_frame_begin", rc);
+  return nullptr;
+}
+static void no_free(napi_env, void *, void *) {}
+static napi_value FrameEnd(napi_env env, napi_callback_info info) {
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  bool rgba8 = false;
+  napi_get_value_bool(env, argv[1], &rgba8);
+  const void *pixels = nullptr; size_t bytes = 0; float ms = 0.f;
+  flx_status rc = flx_frame_end(ctx, &pixels, &bytes, &ms);
+  if (rc != FLX_OK) return fail(env, ctx, "flx_frame_end", rc);
+  napi_value res, buf, arr, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  NAPI_OK(env, napi_create_external_arraybuffer(env, const_cast<void *>(pixels), bytes, no_free, nullptr, &buf));
+  if (rgba8) NAPI_OK(env, napi_create_typedarray(env, napi_uint8_clamped_array, bytes, buf, 0, &arr));
+  else NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, bytes / 4, buf, 0, &arr));
+  napi_set_named_property(env, res, "pixels", arr);
+  napi_create_double(env, ms, &v); napi_set_named_property(env, res, "gpuMs", v);
+  return res;
+}
+static napi_value FramesInFlight(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_context *ctx = get_ctx(env, argv[0]);
+  if (!ctx) return nullptr;
+  napi_value v;
+  napi_create_int32(env, flx_frames_in_flight(ctx), &v);
+  return v;
+}
+
+/* ---- several GPUs in this process (flx_group_*): the same calls with a group handle -------------------------------------- */
+static void finalize_group(napi_env, void *data, void *) {
+  flx_group **slot = static_cast<flx_group **>(data);
+  if (*slot) flx_group_destroy(*slot);
+  delete slot;
+}
+static flx_group *get_group(napi_env env, napi_value v) {
+  void *p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a group handle"); return nullptr; }
+  flx_group *g = *static_cast<flx_group **>(p);
+  if (!g) napi_throw_error(env, nullptr, "group was halted");
+  return g;
+}
+static napi_value gfail(napi_env env, flx_group *g, const char *what, flx_status rc) {
+  std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + flx_group_last_error(g);
+  napi_throw_error(env, nullptr, msg.c_str());
+  return nullptr;
+}
+/* createGroup([device, ...]) -> handle */
+static napi_value CreateGroup(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  uint32_t n = 0;
+  bool isArray = false;
+  napi_is_array(env, argv[0], &isArray);
+  if (!isArray || napi_get_array_length(env, argv[0], &n) != napi_ok || n < 1 || n > 64) { napi_throw_range_error(env, nullptr, "createGroup: an array of 1 .. 64 device numbers"); return nullptr; }
+  int devices[64];
+  for (uint32_t i = 0; i < n; i++) { napi_value e; int32_t d = 0; napi_get_element(env, argv[0], i, &e); NAPI_OK(env, napi_get_value_int32(env, e, &d)); devices[i] = d; }
+  flx_group *g = nullptr;
+  flx_status rc = flx_group_create((int)n, devices, &g);
+  if (rc != FLX_OK) return gfail(env, nullptr, "flx_group_create", rc);
+  napi_value ext;
+  NAPI_OK(env, napi_create_external(env, new flx_group *(g), finalize_group, nullptr, &ext));
+  return ext;
+}
+static napi_value DestroyGroup(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  void *p = nullptr;
+  if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+    flx_group **slot = static_cast<flx_group **>(p);
+    if (*slot) { flx_group_destroy(*slot); *slot = nullptr; }
+  }
+  return nullptr;
+}
+static napi_value GroupInfo(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_group *g = get_group(env, argv[0]);
+  if (!g) return nullptr;
+  napi_value res, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  napi_create_int32(env, flx_group_size(g), &v); napi_set_named_property(env, res, "size", v);
+  napi_get_boolean(env, flx_group_uses_rccl(g) != 0, &v); napi_set_named_property(env, res, "rccl", v);
+  return res;
+}
+static napi_value GroupUploadScene(napi_env env, napi_callback_info info) {
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  flx_group *grp = get_group(env, argv[0]);
+  if (!grp) return nullptr;
+  void *g, *a, *ids; size_t ng, na, nids;
+  if (!typed(env, argv[1], napi_float32_array, &g, &ng) || !typed(env, argv[2], napi_float32_array, &a, &na) ||
+      !typed(env, argv[3], napi_int32_array, &ids, &nids)) return nullptr;
+  if (ng % 12 != 0 || na / 28 != ng / 12 || na % 28 != 0) { napi_throw_range_error(env, nullptr, "geometry needs 12 and attributes 28 floats per entry"); return nullptr; }
+  flx_status rc = flx_group_scene_upload(grp, (const float *)g, (const float *)a, (uint32_t)(ng / 12), (const int32_t *)ids, (uint32_t)nids);
+  if (rc != FLX_OK) return gfail(env, grp, "flx_group_scene_upload", rc);
+  return nullptr;
+}
+static napi_value GroupUploadTransforms(napi_env env, napi_callback_info info) {
+  napi_value argv[3];
+  if (!get_args(env, info, 3, argv)) return nullptr;
+  flx_group *grp = get_group(env, argv[0]);
+  if (!grp) return nullptr;
+  void *r, *s; size_t nr, ns;
+  if (!typed(env, argv[1], napi_float32_array, &r, &nr) || !typed(env, argv[2], napi_float32_array, &s, &ns)) return nullptr;
+  if (ns % 8 != 0 || nr != ns * 3) { napi_throw_range_error(env, nullptr, "rotation needs 24 and shift 8 floats per transform"); return nullptr; }
+  flx_status rc = flx_group_transforms_upload(grp, (const float *)r, (const float *)s, (uint32_t)(ns / 8));
+  if (rc != FLX_OK) return gfail(env, grp, "flx_group_transforms_upload", rc);
+  return nullptr;
+}
+static napi_value GroupUploadLights(napi_env env, napi_callback_info info) {
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
+  flx_group *grp = get_group(env, argv[0]);
+  if (!grp) return nullptr;
+  void *l; size_t nl;
+  if (!typed(env, argv[1], napi_float32_array, &l, &nl)) return nullptr;
+  if (nl % 6 != 0) { napi_throw_range_error(env, nullptr, "lights needs 6 floats per light"); return nullptr; }
+  flx_status rc = flx_group_lights_upload(grp, (const float *)l, (uint32_t)(nl / 6));
+  if (rc != FLX_OK) return gfail(env, grp, "flx_group_lights_upload", rc);
+  return nullptr;
+}
+static napi_value GroupUploadAtlas(napi_env env, napi_callback_info info) {
+  napi_value argv[5];
+  if (!get_args(env, info, 5, argv)) return nullptr;
+  flx_group *grp = get_group(env, argv[0]);
+  if (!grp) return nullptr;
+  int32_t which; uint32_t w, h;
+  NAPI_OK(env, napi_get_value_int32(env, argv[1], &which));
+  void *px; size_t n;
+  if (!typed(env, argv[2], napi_uint8_array, &px, &n)) return nullptr;
+  NAPI_OK(env, napi_get_value_uint32(env, argv[3], &w));
+  NAPI_OK(env, napi_get_value_uint32(env, argv[4], &h));
+  if (px && n != (size_t)w * h * 4) { napi_throw_range_error(env, nullptr, "atlas needs width*height*4 bytes"); return nullptr; }
+  flx_status rc = flx_group_atlas_upload(grp, which, (const uint8_t *)px, w, h);
+  if (rc != FLX_OK) return gfail(env, grp, "flx_group_atlas_upload", rc);
+  return nullptr;
+}
+/* groupRender(handle, [params, ...], tileRows, out Float32Array(frames*height*width*4), wantCounters) -> { frameMs, counters? } */
+static napi_value GroupRender(napi_env env, napi_callback_info info) {
+  napi_value argv[5];
+  if (!get_args(env, info, 5, argv)) return nullptr;
+  flx_group *grp = get_group(env, argv[0]);
+  if (!grp) return nullptr;
+  uint32_t count = 0;
+  bool isArray = false;
+  napi_is_array(env, argv[1], &isArray);
+  if (!isArray || napi_get_array_length(env, argv[1], &count) != napi_ok || count < 1 || count > FLX_MAX_BATCH_FRAMES) {
+    napi_throw_range_error(env, nullptr, "groupRender: an array of 1 .. 32 frame parameter objects");
+    return nullptr;
+  }
+  flx_frame_params p[FLX_MAX_BATCH_FRAMES];
+  for (uint32_t i = 0; i < count; i++) {
+    napi_value e;
+    NAPI_OK(env, napi_get_element(env, argv[1], i, &e));
+    if (!read_params(env, e, &p[i])) return nullptr;
+  }
+  uint32_t tileRows = 8;
+  NAPI_OK(env, napi_get_value_uint32(env, argv[2], &tileRows));
+  void *out; size_t n;
+  if (!typed(env, argv[3], napi_float32_array, &out, &n)) return nullptr;
+  if (!out || n != (size_t)count * p[0].height * p[0].width * 4) { napi_throw_range_error(env, nullptr, "out needs frames*height*width*4 floats"); return nullptr; }
+  bool want = false;
+  napi_get_value_bool(env, argv[4], &want);
+  flx_counters c;
+  flx_status rc = flx_group_render(grp, p, count, tileRows, (float *)out, want ? &c : nullptr);
+  if (rc != FLX_OK) return gfail(env, grp, "flx_group_render", rc);
+  float frame_ms = 0.f, trace_ms = 0.f;
+  flx_last_frame_ms(flx_group_context(grp, 0), &frame_ms, &trace_ms);
+  napi_value res, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  napi_create_double(env, frame_ms, &v); napi_set_named_property(env, res, "frameMs", v);
+  napi_create_double(env, trace_ms, &v); napi_set_named_property(env, res, "traceMs", v);
+  if (want) {
+    napi_value co;
+    napi_create_object(env, &co);
+    const char *names[8] = { "primaryVisits", "closestVisits", "shadowVisits", "closestWalks", "shadowWalks", "shades", "primaryHits", "atlasTexels" };
+    const uint64_t vals[8] = { c.primary_visits, c.closest_visits, c.shadow_visits, c.closest_walks, c.shadow_walks, c.shades, c.primary_hits, c.atlas_texels };
+    for (int i = 0; i < 8; i++) { napi_create_double(env, (double)vals[i], &v); napi_set_named_property(env, co, names[i], v); }
+    napi_set_named_property(env, res, "counters", co);
+  }
+  return res;
+}
+
 static napi_value Version(napi_env env, napi_callback_info) {
   napi_value v;
   napi_create_string_utf8(env, flx_version(), NAPI_AUTO_LENGTH, &v);
@@ -516,6 +718,10 @@ static napi_value Init(napi_env env, napi_value exports) {
     { "meshImport", MeshImport }, { "meshCounts", MeshCounts }, { "meshSetTransform", MeshSetTransform }, { "meshMove", MeshMove },
     { "meshScale", MeshScale }, { "meshSetMaterial", MeshSetMaterial }, { "meshFlatten", MeshFlatten }, { "meshBounding", MeshBounding }, { "packTransforms", PackTransforms },
     { "present", Present }, { "fxaa", Fxaa }, { "taa", Taa }, { "taaReset", TaaReset },
+    { "frameBegin", FrameBegin }, { "frameEnd", FrameEnd }, { "framesInFlight", FramesInFlight },
+    { "createGroup", CreateGroup }, { "destroyGroup", DestroyGroup }, { "groupInfo", GroupInfo }, { "groupUploadScene", GroupUploadScene },
+    { "groupUploadTransforms", GroupUploadTransforms }, { "groupUploadLights", GroupUploadLights }, { "groupUploadAtlas", GroupUploadAtlas },
+    { "groupRender", GroupRender },
   };
   for (const auto &f : fns) {
     napi_value fn;
