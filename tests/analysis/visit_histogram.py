@@ -30,7 +30,7 @@ total = hist.sum()
 order = np.lexsort((np.arange(n), depth))
 cum = np.cumsum(hist[order]) / total
 print("entries", int((g[:, 10] != 0).sum()), "total fetches", int(total), "max depth", int(depth[g[:, 10] != 0].max()))
-for N in (64, 256, 512, 1024, 1365, 2048, 2730, 3400, 8192, 16384):
+for N in (64, 256, 512, 761, 1024, 1365, 2048, 2730, 3400, 8192, 16384):
     if N <= n: print("top %5d entries by depth: %.3f of fetches (depth <= %d)" % (N, cum[N - 1], depth[order[N - 1]]))
 best = np.sort(hist)[::-1].cumsum() / total
-for N in (1024, 2730): print("best possible %d entries: %.3f" % (N, best[N - 1]))
+for N in (761, 1024, 2730): print("best possible %d entries: %.3f" % (N, best[N - 1]))

@@ -68,6 +68,23 @@ def test_headline_frame_at_full_size(hip, oracle, scenes):
     assert np.array_equal(whole, want, equal_nan=True)
 
 
+def test_synthetic_100k_dragon_at_full_size(hip, oracle, scenes):
+    """configs[2] as BASELINE.json words it — "dragon.obj (~100k tris)" — with the deterministic stand-in for the absent
+    objects/dragon.obj: dragon_lp.obj split 1 -> 4 (tools/make_dragon_100k.py; 175 598 triangles, 289 189 entries in the scene, a
+    13.9 MB threaded tree that no longer fits one XCD's 4 MB L2), arrays emitted by the reference's scene.js
+    (tests/golden/ref_dragon_100k.*).  1920x1080, 8 samples, 4 bounces, bit for bit against the oracle with the work counters."""
+    sc = scenes("dragon_100k")
+    assert sc.meta["textureLength"] == 289189
+    hip.update_scene(sc)
+    p = sc.frame_params(use_filter=0)
+    assert (p.width, p.height, p.samples, p.max_reflections) == (1920, 1080, 8, 4)
+    got, got_cnt, _ = hip.render(p, counters=True)
+    want, want_cnt = oracle.render(sc, p, threads=0)[:2]
+    assert np.array_equal(got, want, equal_nan=True)
+    assert got_cnt == want_cnt
+    assert hip.last_pipeline() == 3
+
+
 @pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 3840, 2160, 8, 4), ("theater", 1920, 1080, 16, 6)],
                          ids=["dragon_4k", "theater_1080p"])
 def test_multi_gpu_configs_at_full_size(hip, oracle, scenes, name, w, h, spp, bounces):

@@ -44,7 +44,8 @@ function stageReferenceModules () {
 
 function installShims () {
   global.window = { Math };
-  global.fetch = async p => ({ text: async () => fs.readFileSync(path.join(REF, p), 'utf8') });
+  const EXTRA = process.env.FLX_EXTRA_ASSETS || path.join(ROOT, 'build', 'assets');      // generated assets (the synthetic 100k dragon) first
+  global.fetch = async p => ({ text: async () => fs.readFileSync(fs.existsSync(path.join(EXTRA, p)) ? path.join(EXTRA, p) : path.join(REF, p), 'utf8') });
   // Just enough canvas/Image for Scene.textureFromRGB (scene.js:22-39): the "image" keeps the RGBA bytes.
   global.document = {
     createElement: () => {
@@ -93,7 +94,8 @@ async function runScene (name) {
     console.log = log;
     const frame = scenes[name].frame;
     const file = path.join(OUT, 'ref_' + name + '.flxs.gz');
-    const s = sceneFile.save(file, name, engine, built, transforms, frame, { producer: 'reference modules/scene.js via tools/ref_goldens.js' });
+    const extra = scenes[name].extraAssets ? { synthetic: 'objects/dragon_100k.obj is generated (tools/make_dragon_100k.py: dragon_lp.obj, every triangle split 1 -> 4); the arrays are what the reference\'s scene.js emits for it' } : {};
+    const s = sceneFile.save(file, name, engine, built, transforms, frame, Object.assign({ producer: 'reference modules/scene.js via tools/ref_goldens.js' }, extra));
     const summary = {
       name,
       textureLength: built.textureLength,

@@ -317,7 +317,12 @@ class Scene {
     this.queue = [];
     const opts = options || {};
     this.assetRoot = opts.assetRoot || process.cwd();
-    this.readText = opts.readText || (p => fs.readFileSync(path.resolve(this.assetRoot, p), 'utf8'));
+    /* generated assets (build/assets: the synthetic 100k dragon) are looked up before the asset root */
+    this.extraAssetRoot = opts.extraAssetRoot || process.env.FLX_EXTRA_ASSETS || path.resolve(__dirname, '..', '..', 'build', 'assets');
+    this.readText = opts.readText || (p => {
+      const extra = path.resolve(this.extraAssetRoot, p);
+      return fs.readFileSync(fs.existsSync(extra) ? extra : path.resolve(this.assetRoot, p), 'utf8');
+    });
     // constructors as the API exposes them (scene.js:319-327)
     this.Transform = () => new Transform();
     this.Cuboid = (x, x2, y, y2, z, z2) => new Cuboid(x, x2, y, y2, z, z2);
