@@ -244,6 +244,11 @@ static void tally_walk(uint64_t v) {
   _Pragma("omp critical") { if (v > g_walk_hist[31]) g_walk_hist[31] = v; }
 }
 
+/* 1: walk the ray of fragment:591 in every bounce iteration, as the shader is written (see lightTrace below); 0 (default):
+ * skip the walks whose result the loop guard discards.  Same frames, different closest_* counters. */
+static int g_as_written = 0;
+void flx_oracle_set_as_written(int on) { g_as_written = on != 0; }
+
 /* fragment:172-227.  mode 0 = rayTracer as written; mode 1 = primary visibility (same walk, the
  * primary triangle rule, strict "<" so the first of equal-depth triangles is kept). */
 static Hit rayTracerImpl(const flx_scene_view *sc, Ray ray, int mode, float viewDepthPerS, uint64_t *visits) {
@@ -513,8 +518,11 @@ static v3 lightTrace(Frag *f, Hit hit, v3 dir0, v3 camera, float cosSampleN, int
     }
     /* fragment:591 traces the next ray even when the loop guard (:475) is about to end the loop — in the last iteration,
      * or once the path's importancy has dropped below the threshold: a hit nobody shades ("incl. the useless
-     * last one").  Its result reaches no output, so it is not walked, here and in the kernels alike. */
-    if (!(i + 1 < bounces && length3(mul3(importancyFactor, f->originalColor)) >= fp->min_importancy * SQRT3)) break;
+     * last one").  Its result reaches no output, so it is not walked, here and in the kernels alike — unless
+     * flx_oracle_set_as_written(1) asks for the shader's statement order as it stands: then every iteration ends with that
+     * walk (the counters are the shader's own work) and the loop guard at the top ends the loop; tests/test_oracle_kat.py
+     * holds the two modes' frames against each other bit for bit. */
+    if (!g_as_written && !(i + 1 < bounces && length3(mul3(importancyFactor, f->originalColor)) >= fp->min_importancy * SQRT3)) break;
     f->cnt.closest_walks++;
     hit = rayTracerImpl(sc, ray, 0, 0.0f, &f->cnt.closest_visits);
     if (hit.triangleId == -1) break;

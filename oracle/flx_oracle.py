@@ -35,6 +35,11 @@ def lib():
     return _LIB
 
 
+def set_as_written(on):
+    """walk fragment:591's ray in every bounce iteration, as the shader is written (same frames, more closest-hit walks)"""
+    lib().flx_oracle_set_as_written(1 if on else 0)
+
+
 def _fp(a):
     return a.ctypes.data_as(C.POINTER(C.c_float))
 

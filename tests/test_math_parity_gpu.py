@@ -52,3 +52,17 @@ def test_bit_equal(hip, oracle, fn):
     bad = np.flatnonzero(~same)
     assert bad.size == 0, "%s: %d mismatches, first a=%r b=%r gpu=%r cpu=%r" % (
         FNS[fn], bad.size, a[bad[0]], None if b is None else b[bad[0]], got[bad[0]], want[bad[0]])
+
+
+def test_gpu_math_against_the_literal_table(hip):
+    """the same literal answers (tests/golden/math_kat.json, computed in 60-digit decimal arithmetic) on the GPU"""
+    import json
+    import os
+    table = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "math_kat.json")))
+    for name, sel in (("sin", 0), ("cos", 1), ("tan", 2), ("acos", 3), ("exp", 5), ("tanh", 7)):
+        rows = np.array(table[name], np.uint32)
+        got = hip.debug_math(sel, rows[:, 0].copy().view(np.float32))
+        assert np.array_equal(got.view(np.uint32), rows[:, 1]), name
+    rows = np.array(table["atan2"], np.uint32)
+    got = hip.debug_math(4, rows[:, 0].copy().view(np.float32), rows[:, 1].copy().view(np.float32))
+    assert np.array_equal(got.view(np.uint32), rows[:, 2])

@@ -112,6 +112,36 @@ def test_noise_is_the_pinned_formula(lib):
     assert tuple(a) == tuple(b)
 
 
+def test_math_literal_known_answers(lib):
+    """the pinned sin / cos / tan / acos / atan / exp / tanh and the shader's noise() against a committed
+    table of LITERAL answers (tests/golden/math_kat.json: bit patterns computed by tests/analysis/make_math_kat.py in 60-digit
+    decimal arithmetic and rounded once — not by the oracle, not through include/flx_math.h).  A change to flx_math.h has to
+    keep every one of them."""
+    import json
+    table = json.load(open(os.path.join(ROOT, "tests", "golden", "math_kat.json")))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    for name, sel in (("sin", 0), ("cos", 1), ("tan", 2), ("acos", 3), ("exp", 5), ("tanh", 7)):
+        rows = np.array(table[name], np.uint32)
+        assert rows.shape[0] >= 100
+        x = rows[:, 0].copy().view(np.float32)
+        got = np.empty_like(x)
+        lib.flx_oracle_math(sel, fp(x), None, fp(got), x.size)
+        bad = np.nonzero(got.view(np.uint32) != rows[:, 1])[0]
+        assert bad.size == 0, "%s(%r) = %r, literal answer %r" % (name, x[bad[0]], got[bad[0]], rows[bad[0], 1:2].copy().view(np.float32)[0])
+    rows = np.array(table["atan2"], np.uint32)
+    y, x = rows[:, 0].copy().view(np.float32), rows[:, 1].copy().view(np.float32)
+    got = np.empty_like(x)
+    lib.flx_oracle_math(4, fp(y), fp(x), fp(got), x.size)
+    assert np.array_equal(got.view(np.uint32), rows[:, 2])
+    rows = np.array(table["noise"], np.uint32)
+    assert rows.shape == (64, 8)
+    out = (C.c_float * 4)()
+    for r in rows:
+        nx, ny, seed, rs = [float(v) for v in r[:4].copy().view(np.float32)]
+        lib.flx_oracle_noise(nx, ny, seed, rs, out)
+        assert np.array_equal(np.array(list(out), np.float32).view(np.uint32), r[4:]), (nx, ny, seed, rs)
+
+
 def test_forward_trace_lambert_limit(lib):
     """Fully rough dielectric lit head-on: Cook-Torrance by hand (fragment:304-334)."""
     mat = F9(0.8, 0.6, 0.4, 1.0, 0.0, 0.0, 0.0, 0.0, 1.0)
@@ -167,6 +197,36 @@ def test_oracle_reproduces_committed_frames(oracle, scenes, path):
     assert [cnt[k] for k in sorted(cnt)] == list(fix["counters"])
     single, cnt1, _ = oracle.render(sc, p, threads=1)           # OpenMP row split must not matter
     assert np.array_equal(single, img, equal_nan=True) and cnt1 == cnt
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "tests", "golden", "oracle_*.npz"))))
+def test_as_written_bounce_loop_gives_the_same_frames(oracle, scenes, path):
+    """The oracle (and the kernels) skip the rayTracer call of fragment:591 when the loop guard of :475 is about to discard
+    its hit.  That this changes no output is held here as a test, not as an argument: with the bounce loop as the shader is
+    written — every iteration ends with that walk — the five committed frames come out bit for bit the same, G-buffers
+    included; only the closest-hit work grows, to one walk per bounce iteration."""
+    name, size, s, b, f = os.path.basename(path)[len("oracle_"):-len(".npz")].rsplit("_", 4)
+    w, h = map(int, size.split("x"))
+    fix = np.load(path)
+    sc = scenes(name)
+    p = sc.frame_params(width=w, height=h, samples=int(s[1:]), max_reflections=int(b[1:]), use_filter=int(f[1:]))
+    pruned, cnt, gb = oracle.render(sc, p, gbuffers=bool(p.use_filter))
+    oracle.set_as_written(True)
+    try:
+        full, cnt_full, gb_full = oracle.render(sc, p, gbuffers=bool(p.use_filter))
+    finally:
+        oracle.set_as_written(False)
+    assert np.array_equal(full, fix["frame"], equal_nan=True) and np.array_equal(full, pruned, equal_nan=True)
+    if gb:
+        for key in gb:
+            assert np.array_equal(gb[key], gb_full[key], equal_nan=True), key
+    assert cnt_full["closest_walks"] == cnt_full["shades"]            # the shader traces once per bounce iteration
+    assert cnt_full["closest_walks"] >= cnt["closest_walks"] and cnt_full["closest_visits"] >= cnt["closest_visits"]
+    for key in cnt:
+        if not key.startswith("closest_"):
+            assert cnt_full[key] == cnt[key], key
+    if int(b[1:]) > 0 and name != "cornell_obj":
+        assert cnt_full["closest_walks"] > cnt["closest_walks"]
 
 
 def test_oracle_primary_ray_geometry(oracle, scenes):

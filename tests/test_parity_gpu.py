@@ -68,6 +68,27 @@ def test_headline_frame_at_full_size(hip, oracle, scenes):
     assert np.array_equal(whole, want, equal_nan=True)
 
 
+def test_headline_frame_against_the_bounce_loop_as_written(hip, oracle, scenes):
+    """The kernels (and the oracle by default) skip the rayTracer call of fragment:591 whose hit the loop guard discards.  The GPU
+    frame of configs[2] at full size equals the oracle's frame with the bounce loop AS THE SHADER IS WRITTEN — every iteration
+    ends with that walk — bit for bit; what differs is only the closest-hit work, which the as-written loop does once per bounce
+    iteration."""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    p = sc.frame_params(use_filter=0)
+    got, got_cnt, _ = hip.render(p, counters=True)
+    oracle.set_as_written(True)
+    try:
+        want, want_cnt = oracle.render(sc, p, threads=0)[:2]
+    finally:
+        oracle.set_as_written(False)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert want_cnt["closest_walks"] == want_cnt["shades"] > got_cnt["closest_walks"]
+    for key in got_cnt:
+        if not key.startswith("closest_"):
+            assert got_cnt[key] == want_cnt[key], key
+
+
 def test_synthetic_100k_dragon_at_full_size(hip, oracle, scenes):
     """configs[2] as BASELINE.json words it — "dragon.obj (~100k tris)" — with the deterministic stand-in for the absent
     objects/dragon.obj: dragon_lp.obj split 1 -> 4 (tools/make_dragon_100k.py; 175 598 triangles, 289 189 entries in the scene, a
