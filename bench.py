@@ -327,6 +327,25 @@ def main():
         a, b = ctx.last_frame_ms()
         gpu_ms.append(a)
         kernel_ms.append(b)
+    # two frames in flight (flx_frame_begin / flx_frame_end with two lanes: what the JavaScript frame loop runs): still one frame per
+    # pass and frames complete in order, but frame k + 1's kernels fill the CUs the tails of frame k's kernels leave idle
+    pipelined = None
+    if not multi:
+        lat = []
+        for phase in range(2):               # 0 = warm-up (the second lane sizes its workspace), 1 = timed
+            n = 6 if phase == 0 else max(args.steps, 20)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(n):
+                ctx.frame_begin(params, device=True)
+                if ctx.frames_in_flight() == 2:
+                    lat.append(ctx.frame_end()[1])
+            while ctx.frames_in_flight():
+                lat.append(ctx.frame_end()[1])
+            fence()
+            dtp = time.perf_counter() - t1
+        pipelined = {"frames_in_flight": 2, "ms_per_frame": dtp / n * 1e3, "frames": n, "frame_gpu_ms_median": float(np.median(lat[-n:])),
+                     "note": "flx_frame_begin / flx_frame_end, pixels left in device memory: one frame per pass, frames complete in order; a frame completes every ms_per_frame, its own GPU time (first kernel .. last, overlapped with its neighbours) is frame_gpu_ms_median"}
     batched = None
     if F > 1:
         passes = max(2, (args.steps + F - 1) // F)
@@ -411,6 +430,10 @@ def main():
             },
             "counters": cnt,
         }
+        if pipelined:
+            pipelined["value"] = rays / (pipelined["ms_per_frame"] * 1e-3) / 1e6
+            pipelined["unit"] = "Mray/s"
+            line["pipelined"] = pipelined
         if batched:
             batched["value"] = rays / (batched["ms_per_frame"] * 1e-3) / 1e6
             batched["unit"] = "Mray/s"

@@ -164,10 +164,16 @@ flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_ker
  * stay valid until the second flx_frame_begin after the one that made them (or the context's end); rows as flx_render. */
 #define FLX_FRAME_FLOAT 0      /* float32 RGBA, what flx_render returns */
 #define FLX_FRAME_RGBA8 1      /* bytes R G B A as the canvas' drawing buffer holds them (flx_present): a quarter of the bytes over PCIe */
+#define FLX_FRAME_DEVICE 2     /* float32 RGBA left in device memory: flx_frame_end hands out a device pointer (no copy to the host) */
 flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *params, int format);
 flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_t *bytes, float *gpu_ms);
 /* frames begun and not yet ended (0 .. 2) */
 int flx_frames_in_flight(const flx_context *ctx);
+/* 2 (default): the two frames in flight run on two lanes — two streams with a workspace each (+2 GB at 1080p x 8 spp), the static
+ * scene arrays shared — so that frame k + 1's kernels fill the CUs the tails of frame k's kernels leave idle: a frame completes
+ * every 7.3 ms instead of every 8.1 ms on the dragon workload, each frame's own time (gpu_ms) a little longer.  1: one lane, frames
+ * one after the other on the context's stream.  Temporal frames always use the first lane (their history lives there). */
+flx_status flx_set_frame_lanes(flx_context *ctx, int lanes);
 
 /* Filter frames on several GPUs.  The path-trace pass is per pixel and shards by row strips like a frame
  * without filter; the denoise chain reads up to ~194 rows around a pixel and runs on the whole frame.  So every rank
@@ -304,6 +310,10 @@ flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, const float 
 /* Scheduler statistics of the last counted frame (wavefront pipeline): for bounce b = 0..3 (3 = all
  * later ones) out[2b] = wave-iterations of the walk kernel, out[2b+1] = fold/refill batches. */
 flx_status flx_get_diag(flx_context *ctx, uint64_t out[32]);   /* out[8..12]: bounce-0 walk kernel stamps: fold, refill, step cycles, wave lifetime, waves; out[16+3b..]: per bounce sum / count / max of wave lifetimes */
+/* Tail profile of the last counted frame (wavefront pipeline, walk kernel of the round given to the build by FLX_TAIL_DIAG_ROUND, default 0):
+ * for k = 0 .. 11 out[3k], out[3k+1], out[3k+2] = sum / count / max over the walk workgroups of the shader cycles since the workgroup's start
+ * at which its walks in flight first numbered <= 2^k; out[36..38] the same for the moment the workgroup found the walk queue dry. */
+flx_status flx_get_tail_diag(flx_context *ctx, uint64_t out[40]);
 /* Device name / CU count of the context's GPU. */
 flx_status flx_device_info(flx_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units);
 const char *flx_version(void);

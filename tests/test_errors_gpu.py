@@ -133,3 +133,55 @@ def test_frame_loop_two_frames_in_flight(hip, oracle, scenes):
     c, _ = hip.frame_end()
     assert np.array_equal(c, want_f, equal_nan=True)
     assert hip.frames_in_flight() == 0
+    # one lane instead of two: the same frames
+    hip.set_frame_lanes(1)
+    try:
+        hip.frame_begin(p)
+        hip.frame_begin(q)
+        assert np.array_equal(hip.frame_end()[0], want_p, equal_nan=True) and np.array_equal(hip.frame_end()[0], want_q, equal_nan=True)
+    finally:
+        hip.set_frame_lanes(2)
+
+
+def test_frame_loop_lanes_keep_their_own_lights(hip, oracle, scenes):
+    """two frames in flight on two lanes (streams + workspaces): lights and transforms uploaded between the begins belong to the
+    frame begun after them — each of six frames with a different light array equals the oracle's, whichever lane rendered it —
+    and a frame left in device memory (FLX_FRAME_DEVICE) is the same frame"""
+    import copy
+    import torch
+    sc = scenes("cornell")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=128, height=80, samples=2, max_reflections=3, use_filter=0)
+    got, lights = [], []
+    for i in range(6):
+        l = sc.arrays["lights"].copy()
+        l.reshape(-1, 6)[:, 0] += 0.8 * i
+        l.reshape(-1, 6)[:, 3] *= (1.0 + 0.3 * i)
+        lights.append(l)
+        hip.update_primary_light_sources(l)
+        hip.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+        hip.frame_begin(p, device=(i == 5))
+        if hip.frames_in_flight() == 2:
+            got.append(hip.frame_end()[0])
+    while hip.frames_in_flight():
+        got.append(hip.frame_end()[0])
+    assert len(got) == 6 and isinstance(got[5], int)
+    dev = torch.zeros((80, 128, 4), dtype=torch.float32, device="cuda")
+    import ctypes
+    ctypes.memmove  # (no host copy of a device pointer: read it through torch)
+    hip.sync()
+    last = torch.empty_like(dev)
+    torch.cuda.synchronize()
+    # the device pointer stays valid until the second begin after its frame: copy it out with a device-to-device copy
+    from flexlight_hip import capi
+    import ctypes as C
+    hipMemcpy = C.CDLL("libamdhip64.so").hipMemcpy
+    hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    assert hipMemcpy(C.c_void_p(last.data_ptr()), C.c_void_p(got[5]), last.numel() * 4, 3) == 0      # hipMemcpyDeviceToDevice
+    got[5] = last.cpu().numpy()
+    for i in range(6):
+        sci = copy.copy(sc)
+        sci.arrays = dict(sc.arrays, lights=lights[i])
+        want, _, _ = oracle.render(sci, p)
+        assert np.array_equal(got[i], want, equal_nan=True), "frame %d" % i
+    hip.update_scene(sc)

@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--batch", type=int, default=1, help="frames per launch (flx_render_batch) instead of one")
+    ap.add_argument("--scheduler", type=int, default=0, help="flx_set_walk_scheduler: 0 lanes, 1 queues, 2 lanes + cooperative finisher")
+    ap.add_argument("--suspend", type=int, default=0, help="walks a walk workgroup may hand over (flx_set_walk_scheduler)")
     args = ap.parse_args()
     from flexlight_hip import capi
     from flexlight_hip.scene_io import Scene
@@ -32,6 +34,7 @@ def main():
     p = scene.frame_params(width=args.width, height=args.height)
     with capi.Context(0) as ctx:
         ctx.update_scene(scene)
+        ctx.set_walk_scheduler(args.scheduler, args.suspend)
         for _ in range(args.frames):
             if args.batch > 1:
                 ctx.render_batch([p] * args.batch)

@@ -58,8 +58,8 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_frame1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&ctx->d_counters, 40 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMemset(ctx->d_counters, 0, 40 * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipMalloc(&ctx->d_counters, FLX_COUNTER_SLOTS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(ctx->d_counters, 0, FLX_COUNTER_SLOTS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&ctx->d_wfcounts, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   for (int i = 0; i < 3; i++) {
@@ -75,6 +75,11 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->twin) { flx_context_destroy(ctx->twin); ctx->twin = nullptr; }
+  if (ctx->is_twin) {                      /* the static scene arrays belong to the primary context */
+    ctx->d_geometry = ctx->d_attributes = nullptr; ctx->d_ids = nullptr; ctx->d_walk = nullptr;
+    ctx->d_atlas[0] = ctx->d_atlas[1] = ctx->d_atlas[2] = nullptr;
+  }
   (void)flx_comm_destroy(ctx);
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
@@ -116,12 +121,17 @@ template <typename T>
 static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t bytes) {
   size_t &cap = ctx->upload_capacity[(void **)dst];
   if (bytes == 0) {                      /* "none": the kernels test the pointer */
+    if (*dst && ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
     if (*dst) { FLX_HIP(ctx, hipFree(*dst)); *dst = nullptr; }
     cap = 0;
     return FLX_OK;
   }
   if (bytes > cap || !*dst) {
-    if (*dst) { FLX_HIP(ctx, hipStreamSynchronize(ctx->stream)); FLX_HIP(ctx, hipFree(*dst)); *dst = nullptr; }
+    if (*dst) {
+      FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));      /* (the frame loop's second lane may be reading a shared array) */
+      FLX_HIP(ctx, hipFree(*dst)); *dst = nullptr;
+    }
     cap = 0;
     FLX_HIP(ctx, hipMalloc(dst, bytes));
     cap = bytes;
@@ -140,6 +150,7 @@ static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t byte
     ctx->stage_used[k] = true;
     return FLX_OK;
   }
+  if (ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));      /* a scene array the second lane may still be reading */
   FLX_HIP(ctx, hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));          /* the caller's buffer is not retained */
   return FLX_OK;
@@ -273,6 +284,11 @@ extern "C" flx_status flx_transforms_upload(flx_context *ctx, const float *rotat
   if ((s = upload(ctx, &ctx->d_shift, shift, (size_t)n_transforms * 32))) return s;
   ctx->n_transforms = n_transforms;
   ctx->have_transforms = true;
+  if (!ctx->is_twin) {                      /* kept for the frame loop's second lane (flx_frame_begin) */
+    ctx->h_rotation.assign(rotation, rotation + (size_t)n_transforms * 24);
+    ctx->h_shift.assign(shift, shift + (size_t)n_transforms * 8);
+    ctx->dyn_version++;
+  }
   return FLX_OK;
 }
 
@@ -283,6 +299,7 @@ extern "C" flx_status flx_lights_upload(flx_context *ctx, const float *lights, u
   flx_status s;
   if ((s = upload(ctx, &ctx->d_lights, lights, (size_t)n_lights * 24))) return s;
   ctx->n_lights = n_lights;
+  if (!ctx->is_twin) { ctx->h_lights.assign(lights, lights + (size_t)n_lights * 6); ctx->dyn_version++; }
   return FLX_OK;
 }
 
@@ -455,7 +472,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     }
   }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
-  if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, 40 * sizeof(unsigned long long), ctx->stream));
+  if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, FLX_COUNTER_SLOTS * sizeof(unsigned long long), ctx->stream));
   if (pipeline == 1) {
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     launch_trace_pixels(sc, fr, d_out, gb, cnt, ctx->stream);
@@ -733,7 +750,7 @@ extern "C" flx_status flx_set_pipeline(flx_context *ctx, int pipeline) {
  * device entry points return FLX_OK like flx_render does, with the frame events recorded so that flx_last_frame_ms works. */
 static flx_status empty_share(flx_context *ctx) {
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
-  if (ctx->counters_enabled) FLX_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, 40 * sizeof(unsigned long long), ctx->stream));      /* no work: every counter 0 */
+  if (ctx->counters_enabled) FLX_HIP(ctx, hipMemsetAsync(ctx->d_counters, 0, FLX_COUNTER_SLOTS * sizeof(unsigned long long), ctx->stream));      /* no work: every counter 0 */
   FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
@@ -928,13 +945,23 @@ extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *param
   return FLX_OK;
 }
 
-/* ---- the frame loop: begin / end with two frames in flight (include/flexlight_hip.h) ------------------------------------- */
-extern "C" int flx_frames_in_flight(const flx_context *ctx) { return ctx ? (int)(ctx->frames_begun - ctx->frames_ended) : 0; }
+/* ---- the frame loop: begin / end with two frames in flight (include/flexlight_hip.h) -------------------------------------
+ * Two frames in flight overlap on the GPU when they run on two streams with a workspace each: the kernels of a frame are a
+ * dependent chain and every one of them ends in a tail that leaves most CUs idle; frame k + 1's kernels fill those
+ * CUs.  So the context keeps a TWIN — a second context on the same device with its own stream and workspace that shares the
+ * static scene arrays — and frames alternate between the two lanes.  What changes per frame (lights, transforms) is kept as a
+ * host copy and re-sent to the twin's own small buffers on its stream, so neither lane ever overwrites what the other is
+ * reading.  Temporal frames keep their history in one context and stay on the primary lane. */
+static void mirror_scene(flx_context *ctx) {
+  flx_context *t = ctx->twin;
+  if (!t) return;
+  t->d_geometry = ctx->d_geometry; t->d_attributes = ctx->d_attributes; t->d_ids = ctx->d_ids; t->d_walk = ctx->d_walk;
+  t->walk_entries = ctx->walk_entries; t->walk_hot = ctx->walk_hot; t->walk_root = ctx->walk_root; t->walk_fast_boxes = ctx->walk_fast_boxes;
+  for (int i = 0; i < 3; i++) { t->d_atlas[i] = ctx->d_atlas[i]; t->atlas_w[i] = ctx->atlas_w[i]; t->atlas_h[i] = ctx->atlas_h[i]; }
+  t->n_entries = ctx->n_entries; t->n_ids = ctx->n_ids; t->max_transform = ctx->max_transform; t->have_scene = ctx->have_scene;
+}
 
-extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *params, int format) {
-  if (!ctx) return FLX_ERR_INVALID;
-  if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_RGBA8) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: format is FLX_FRAME_FLOAT or FLX_FRAME_RGBA8");
-  if (ctx->frames_begun - ctx->frames_ended >= 2) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: two frames are in flight already, take one with flx_frame_end first");
+static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *params, int format, int *slot) {
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
   flx_status s = flx_make_frame(ctx, params, sc, fr);
@@ -957,7 +984,7 @@ extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *
     FLX_HIP(ctx, hipMalloc(&ctx->d_slot8[k], (pixels ? pixels : 1) * sizeof(uint32_t)));
     ctx->slot8_capacity[k] = pixels;
   }
-  if (ctx->h_slot_capacity[k] < bytes || !ctx->h_slot[k]) {
+  if (format != FLX_FRAME_DEVICE && (ctx->h_slot_capacity[k] < bytes || !ctx->h_slot[k])) {
     ctx->h_slot_capacity[k] = 0;
     if (ctx->h_slot[k]) { FLX_HIP(ctx, hipHostFree(ctx->h_slot[k])); ctx->h_slot[k] = nullptr; }
     FLX_HIP(ctx, hipHostMalloc(&ctx->h_slot[k], bytes ? bytes : 16, hipHostMallocDefault));
@@ -975,25 +1002,76 @@ extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *
     if (format == FLX_FRAME_RGBA8) { launch_quantize(ctx->d_slot[k], ctx->d_slot8[k], pixels, ctx->stream); FLX_HIP(ctx, hipGetLastError()); }
   }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_traced[k], ctx->stream));
-  /* the copy to the host runs beside the next frame's kernels */
-  FLX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_slot_traced[k], 0));
-  if (bytes) FLX_HIP(ctx, hipMemcpyAsync(ctx->h_slot[k], format == FLX_FRAME_RGBA8 ? (const void *)ctx->d_slot8[k] : (const void *)ctx->d_slot[k], bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
-  FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_done[k], ctx->copy_stream));
+  if (format == FLX_FRAME_DEVICE) {
+    ctx->slot_host[k] = false;                   /* the pixels stay in device memory: nothing to copy, the frame is done when it is traced */
+  } else {
+    /* the copy to the host runs beside the next frame's kernels */
+    FLX_HIP(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_slot_traced[k], 0));
+    if (bytes) FLX_HIP(ctx, hipMemcpyAsync(ctx->h_slot[k], format == FLX_FRAME_RGBA8 ? (const void *)ctx->d_slot8[k] : (const void *)ctx->d_slot[k], bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_done[k], ctx->copy_stream));
+    ctx->slot_host[k] = true;
+  }
   ctx->slot_bytes[k] = bytes;
   ctx->frames_begun++;
+  *slot = k;
+  return FLX_OK;
+}
+
+extern "C" int flx_frames_in_flight(const flx_context *ctx) { return ctx ? ctx->fifo_n : 0; }
+
+extern "C" flx_status flx_set_frame_lanes(flx_context *ctx, int lanes) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (lanes != 1 && lanes != 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_lanes: 1 (frames one after the other) or 2 (two frames overlap on the GPU)");
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_lanes: frames are in flight");
+  ctx->frame_lanes = lanes;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *params, int format) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_RGBA8 && format != FLX_FRAME_DEVICE) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: format is FLX_FRAME_FLOAT, FLX_FRAME_RGBA8 or FLX_FRAME_DEVICE");
+  if (ctx->fifo_n >= 2) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: two frames are in flight already, take one with flx_frame_end first");
+  if (!params) return fail(ctx, FLX_ERR_INVALID, "frame params are NULL");
+  flx_context *lane = ctx;
+  if (ctx->frame_lanes == 2 && !params->is_temporal && (ctx->lane_next & 1u)) {
+    FLX_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->twin) {
+      flx_status s = flx_context_create(ctx->device, &ctx->twin);
+      if (s) return fail(ctx, s, flx_last_error(nullptr));
+      ctx->twin->is_twin = true;
+      ctx->twin_dyn_version = 0;
+    }
+    flx_context *t = ctx->twin;
+    mirror_scene(ctx);
+    t->pipeline = ctx->pipeline; t->wf_groups = ctx->wf_groups; t->walk_scheduler = ctx->walk_scheduler; t->walk_suspend = ctx->walk_suspend;
+    if (ctx->twin_dyn_version != ctx->dyn_version) {          /* lights / transforms changed since the twin's last frame: its own copies, on its stream */
+      flx_status s;
+      if (ctx->have_transforms && (s = flx_transforms_upload(t, ctx->h_rotation.data(), ctx->h_shift.data(), ctx->n_transforms))) return fail(ctx, s, flx_last_error(t));
+      if ((s = flx_lights_upload(t, ctx->h_lights.data(), ctx->n_lights))) return fail(ctx, s, flx_last_error(t));
+      ctx->twin_dyn_version = ctx->dyn_version;
+    }
+    lane = t;
+  }
+  int slot = 0;
+  flx_status s = frame_begin_on(lane, params, format, &slot);
+  if (s) { if (lane != ctx) ctx->err = lane->err; return s; }
+  ctx->fifo[ctx->fifo_n].lane = lane; ctx->fifo[ctx->fifo_n].slot = slot; ctx->fifo_n++;
+  if (!params->is_temporal) ctx->lane_next++;
   return FLX_OK;
 }
 
 extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_t *bytes, float *gpu_ms) {
   if (!ctx) return FLX_ERR_INVALID;
-  if (ctx->frames_begun == ctx->frames_ended) return fail(ctx, FLX_ERR_INVALID, "flx_frame_end: no frame in flight");
+  if (ctx->fifo_n == 0) return fail(ctx, FLX_ERR_INVALID, "flx_frame_end: no frame in flight");
+  flx_context *lane = ctx->fifo[0].lane;
+  const int k = ctx->fifo[0].slot;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
-  const int k = (int)(ctx->frames_ended & 1u);
-  FLX_HIP(ctx, hipEventSynchronize(ctx->ev_slot_done[k]));
-  ctx->frames_ended++;
-  if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_slot_start[k], ctx->ev_slot_traced[k])); *gpu_ms = ms; }
-  if (pixels) *pixels = ctx->h_slot[k];
-  if (bytes) *bytes = ctx->slot_bytes[k];
+  FLX_HIP(ctx, hipEventSynchronize(lane->slot_host[k] ? lane->ev_slot_done[k] : lane->ev_slot_traced[k]));
+  ctx->fifo[0] = ctx->fifo[1]; ctx->fifo_n--;
+  lane->frames_ended++;
+  if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, lane->ev_slot_start[k], lane->ev_slot_traced[k])); *gpu_ms = ms; }
+  if (pixels) *pixels = lane->slot_host[k] ? lane->h_slot[k] : (const void *)lane->d_slot[k];
+  if (bytes) *bytes = lane->slot_bytes[k];
   return FLX_OK;
 }
 
@@ -1001,6 +1079,7 @@ extern "C" flx_status flx_sync(flx_context *ctx) {
   if (!ctx) return FLX_ERR_INVALID;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
   return FLX_OK;
 }
 
@@ -1034,6 +1113,17 @@ extern "C" flx_status flx_get_counters(flx_context *ctx, flx_counters *out) {
   unsigned long long host_cnt[8];
   FLX_HIP(ctx, hipMemcpy(host_cnt, ctx->d_counters, sizeof host_cnt, hipMemcpyDeviceToHost));
   memcpy(out, host_cnt, sizeof host_cnt);
+  return FLX_OK;
+}
+
+/* tail profile of the last counted frame's bounce-0 walk kernel (diagnostics): for k = 0 .. 11, out[3k .. 3k+2] = sum / count / max over
+ * the walk workgroups of the cycles (since the workgroup's start) at which its walks in flight first numbered <= 2^k; out[36..38] the
+ * same for the moment the workgroup found the queue dry; out[39] = the longest workgroup lifetime */
+extern "C" flx_status flx_get_tail_diag(flx_context *ctx, uint64_t out[40]) {
+  if (!ctx || !out) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FLX_HIP(ctx, hipMemcpy(out, ctx->d_counters + 40, 40 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return FLX_OK;
 }
 

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <map>
 #include <string>
+#include <vector>
 
 #include "flexlight_hip.h"
 #include "flx_kernels.h"
@@ -18,6 +19,7 @@ typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept 
 #define FLX_WF_GROUPS 1      /* measured on MI355X: 2-4 concurrent chains are slower than one (profiles/r01_ab_stream_groups.txt) */
 #endif
 constexpr int WF_MAX_GROUPS = 4;
+constexpr int FLX_COUNTER_SLOTS = 80;          /* 8 work counters + 32 scheduler diagnostics (flx_get_diag) + 40 tail profile (flx_get_tail_diag) */
 constexpr uint32_t WF_STRAG_MAX = 512;         /* most walks a walk workgroup can suspend */
 
 extern thread_local std::string g_create_error;
@@ -103,6 +105,16 @@ struct flx_context {
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_slot_start[2] = {}, ev_slot_traced[2] = {}, ev_slot_done[2] = {};
   uint64_t frames_begun = 0, frames_ended = 0;
+  bool slot_host[2] = { true, true };            /* the slot's frame is copied to pinned host memory (else it stays in d_slot) */
+  /* two lanes: a twin context (own stream + workspace, shared static scene arrays) takes every other frame of the loop */
+  flx_context *twin = nullptr;
+  bool is_twin = false;
+  int frame_lanes = 2;
+  uint64_t lane_next = 0;
+  struct { flx_context *lane; int slot; } fifo[2] = {};
+  int fifo_n = 0;
+  std::vector<float> h_lights, h_rotation, h_shift;      /* host copies of what changes per frame, for the twin's own buffers */
+  uint64_t dyn_version = 0, twin_dyn_version = 0;
   /* uploads: capacity of every persistent scene buffer (keyed by the address of its pointer), pinned staging ring */
   std::map<void **, size_t> upload_capacity;
   uint8_t *stage = nullptr;

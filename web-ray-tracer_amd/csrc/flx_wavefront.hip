@@ -70,6 +70,9 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
 #ifndef FLX_WF_WAVES_PER_EU
 #define FLX_WF_WAVES_PER_EU 4               /* occupancy the register allocation of k_wf_walk_pre must allow */
 #endif
+#ifndef FLX_TAIL_DIAG_ROUND
+#define FLX_TAIL_DIAG_ROUND 0
+#endif
 #ifndef FLX_DIAG_PAD_SALU
 #define FLX_DIAG_PAD_SALU 0
 #endif
@@ -476,6 +479,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   uint32_t outBase = 0, outUsed = WF_OUT_CHUNK;
   bool outValid = false;
   bool tailMode = false, tailSynced = false, suspendNow = false;
+  uint32_t tailSeen = 13u;                 /* COUNT builds: the tail profile's next threshold (2^(tailSeen - 1)); 13 = queue-dry not yet reported */
   uint32_t tailTrips = 0, tailRound = 0;
   int resumeSt = P_EMPTY;
   float4 *pool = wb.tailPool + (size_t)blockIdx.x * FLX_WF_WALK_THREADS * 8u;
@@ -523,6 +527,19 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         }
         total = __builtin_amdgcn_readfirstlane(total); waves = __builtin_amdgcn_readfirstlane(waves);
         most = __builtin_amdgcn_readfirstlane(most); busy = __builtin_amdgcn_readfirstlane(busy);
+        if (COUNT && b == FLX_TAIL_DIAG_ROUND) {            /* tail profile (flx_get_tail_diag): when did this workgroup's walks in flight first number <= 2^k? */
+          uint32_t lm = 0;
+          if (lane == 0) lm = __hip_atomic_load(&tailCtl[TC_MASK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          lm = __builtin_amdgcn_readfirstlane(lm);
+          if (lane == 0 && lm != 0u && (lm & (0u - lm)) == (1u << (threadIdx.x >> 6))) {       /* the lowest live wave reports for the workgroup */
+            const unsigned long long now = (unsigned long long)(clock64() - tStart);
+            if (tailSeen == 13u) { atomicAdd(wb.counters + 40 + 36, now); atomicAdd(wb.counters + 40 + 37, 1ull); atomicMax(wb.counters + 40 + 38, now); tailSeen = 12u; }
+            while (tailSeen > 0u && total <= (1u << (tailSeen - 1u))) {
+              tailSeen--;
+              atomicAdd(wb.counters + 40 + 3 * tailSeen, now); atomicAdd(wb.counters + 40 + 3 * tailSeen + 1, 1ull); atomicMax(wb.counters + 40 + 3 * tailSeen + 2, now);
+            }
+          }
+        }
         /* Plenty of walks: pack them 64 to a wave (fewer waves issue the same tests).  Few walks (under a quarter of the
          * lanes): what counts is how fast each walk goes, and a lane goes 2-2.5x faster in a wave with one or two walks
          * than in a full one whose lanes are at boxes and triangles at once (tools/diag_lone.py: 787 cycles per entry for

@@ -23,7 +23,7 @@ EXPORTS = [
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
     "flx_group_create", "flx_group_destroy", "flx_group_last_error", "flx_group_size", "flx_group_uses_rccl", "flx_group_context",
-    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight",
+    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag",
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
 ]
 
@@ -91,9 +91,11 @@ def _load():
         "flx_taa_reset": (C.c_int, [vp]),
         "flx_present": (C.c_int, [vp, u32, u32, vp, vp]),
         "flx_present_device": (C.c_int, [vp, u32, u32, vp, vp]),
+        "flx_get_tail_diag": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_frame_begin": (C.c_int, [vp, C.POINTER(FrameParams), C.c_int]),
         "flx_frame_end": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), fp]),
         "flx_frames_in_flight": (C.c_int, [vp]),
+        "flx_set_frame_lanes": (C.c_int, [vp, C.c_int]),
         "flx_comm_unique_id": (C.c_int, [C.c_char_p]),
         "flx_comm_init_rank": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
         "flx_comm_destroy": (C.c_int, [vp]),
@@ -228,16 +230,23 @@ class Context:
         self._check(LIB.flx_render_gathered_device(self._h, arr, n, C.c_void_p(device_ptr)), "flx_render_gathered_device")
 
     # -- the frame loop: two frames in flight, pixels out of pinned host memory (flx_frame_begin / flx_frame_end) --------
-    def frame_begin(self, params, rgba8=False):
+    def set_frame_lanes(self, lanes):
+        """2 (default): the frames in flight overlap on the GPU (two streams, two workspaces); 1: one after the other"""
+        self._check(LIB.flx_set_frame_lanes(self._h, int(lanes)), "flx_set_frame_lanes")
+
+    def frame_begin(self, params, rgba8=False, device=False):
         self._pending = getattr(self, "_pending", [])
-        self._check(LIB.flx_frame_begin(self._h, C.byref(params), 1 if rgba8 else 0), "flx_frame_begin")
-        self._pending.append((self.tile_row_count(params), params.width, rgba8))
+        self._check(LIB.flx_frame_begin(self._h, C.byref(params), 2 if device else (1 if rgba8 else 0)), "flx_frame_begin")
+        self._pending.append((self.tile_row_count(params), params.width, rgba8, device))
 
     def frame_end(self):
-        """-> (pixels [rows, W, 4] float32 or uint8: a COPY of the pinned buffer, GPU ms of the frame)"""
+        """-> (pixels [rows, W, 4] float32 or uint8: a COPY of the pinned buffer — or, for a frame begun with device=True, the
+        device pointer of float4[rows][W] —, GPU ms of the frame)"""
         ptr, n, ms = C.c_void_p(), C.c_size_t(), C.c_float()
         self._check(LIB.flx_frame_end(self._h, C.byref(ptr), C.byref(n), C.byref(ms)), "flx_frame_end")
-        rows, width, rgba8 = self._pending.pop(0)
+        rows, width, rgba8, device = self._pending.pop(0)
+        if device:
+            return ptr.value, ms.value
         dt = np.uint8 if rgba8 else np.float32
         count = n.value // np.dtype(dt).itemsize
         a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8 if rgba8 else C.c_float)), shape=(count,)).copy() if count else np.zeros(0, dt)
@@ -317,6 +326,11 @@ class Context:
     def get_diag(self):
         out = (C.c_uint64 * 32)()
         self._check(LIB.flx_get_diag(self._h, out), "flx_get_diag")
+        return [int(x) for x in out]
+
+    def get_tail_diag(self):
+        out = (C.c_uint64 * 40)()
+        self._check(LIB.flx_get_tail_diag(self._h, out), "flx_get_tail_diag")
         return [int(x) for x in out]
 
     def last_frame_ms(self):
