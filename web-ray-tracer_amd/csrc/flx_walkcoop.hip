@@ -27,10 +27,6 @@ namespace flx {
 #define FLX_COOP_THREADS 256
 #endif
 
-/* value of `v` in lane `p` (p uniform) */
-FLX_DEV float laneF(float v, uint32_t p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)p)); }
-FLX_DEV int laneI(int v, uint32_t p) { return __builtin_amdgcn_readlane(v, (int)p); }
-
 template <bool COUNT>
 __global__ __launch_bounds__(FLX_COOP_THREADS) void k_wf_walk_coop(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b) {
   const uint32_t nStrag = wb.stragCount[b];

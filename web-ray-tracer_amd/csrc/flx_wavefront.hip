@@ -484,6 +484,67 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   int resumeSt = P_EMPTY;
   float4 *pool = wb.tailPool + (size_t)blockIdx.x * FLX_WF_WALK_THREADS * 8u;
 
+  /* ---- fold the finished lanes (st == P_DONE): fragment:445-460, 580, 593-598 and the guard of :475; survivors go to the next
+   * round's live list ---------------------------------------------------------------------------------------------- */
+  auto foldDone = [&]() {
+      if (flx_ballot(st == P_DONE) != 0ull) {
+        bool append = false;
+        if (st == P_DONE) {
+          float4 *rec = wb.rec + (size_t)pathId * 8;
+          float4 q4, q5, q6, q7;
+          const float4 *pp = nullptr;
+          if (compact0) {                                     /* bounce 0, compact records: lit colour per sample, albedo per pixel */
+            uint32_t tile0, s0;
+            item_tile(fr, pathId, tile0, s0);
+            pp = wb.pix0 + (((size_t)tile0 << 6) | (pathId & 63u)) * 3;
+            q4 = wb.rec0[(size_t)pathId * 3 + 2]; q7 = pp[2];
+            q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+          } else {
+            q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
+          }
+          const bool shadowed = (flags & RF_SHADOWED_NO_WALK) || ((flags & RF_NEED_SHADOW) && w.shadowed);
+          const f3 localColor = shadowed ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
+          const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
+          const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
+          bool cont = w.tri != -1;
+          if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+          if (cont) {
+            if (compact0) {                                   /* the path goes on: now it gets its full record (what shade0 would have written) */
+              const float4 a = wb.rec0[(size_t)pathId * 3], bq = wb.rec0[(size_t)pathId * 3 + 1], p0 = pp[0];
+              rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
+              rec[1] = make_float4(a.x, a.y, a.z, bq.w);
+              rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+              rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+              rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
+            }
+            rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
+            rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
+            append = true;
+          } else {
+            finalize_path(fr, wb, pathId, finalColor, importancy, originalColor);
+          }
+          st = P_EMPTY;
+        }
+        const unsigned long long am = flx_ballot(append);
+        if (am != 0ull) {
+          const uint32_t cntA = (uint32_t)__popcll(am);
+          const uint32_t r = lane_rank(am);
+          const uint32_t room = WF_OUT_CHUNK - outUsed;
+          const uint32_t seg1 = cntA < room ? cntA : room;
+          if (append && r < seg1) listOut[outBase + outUsed + r] = pathId;
+          outUsed += seg1;
+          if (cntA > seg1) {
+            uint32_t nb = 0;
+            if (lane == 0) nb = atomicAdd(outAlloc, WF_OUT_CHUNK);
+            nb = __builtin_amdgcn_readfirstlane(nb);
+            outBase = nb; outValid = true;
+            if (append && r >= seg1) listOut[outBase + (r - seg1)] = pathId;
+            outUsed = cntA - seg1;
+          }
+        }
+      }
+  };
+
   for (;;) {
 #if FLX_WF_CONSOLIDATE
     const long long tTail0 = COUNT ? clock64() : 0;
@@ -559,10 +620,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         const bool spread = total * (uint32_t)FLX_WF_SPREAD_DIV < 64u * waves && takers > 0u && total <= 64u * takers;
         const uint32_t share = spread ? (total + takers - 1u) / takers : 64u;
         const bool uneven = spread ? (most > share || busy > takers) : busy > (total + 63u) / 64u;
-        if (total <= suspendMax) {
-          suspendNow = true;                                   /* every wave of the workgroup reads the same total */
-        } else if (waves > 1u && uneven) {
-          /* export */
+        auto exportWalks = [&]() {                               /* every walk of the wave -> the workgroup's pool (128 B of registers each) */
           uint32_t pos0 = 0;
           if (lane == 0 && myCount) pos0 = atomicAdd(&tailCtl[TC_POOL], myCount);
           pos0 = __builtin_amdgcn_readfirstlane(pos0);
@@ -578,14 +636,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             r[6] = make_float4(__int_as_float(w.cachedTI), __int_as_float(w.tri), __int_as_float(w.hitTI), __int_as_float((int)(myRays - raysBase)));
             st = P_EMPTY;
           }
-          __syncthreads();
-          /* import: 64 walks per claim when packing; the SIMDs' takers a share each when dealing out */
-          uint32_t at = 0xffffffffu;
-          if (spread) { if (myRank != 0xffffffffu) at = myRank * share; }
-          else {
-            if (lane == 0) at = atomicAdd(&tailCtl[TC_TAKE], share);
-            at = __builtin_amdgcn_readfirstlane(at);
-          }
+        };
+        auto importWalks = [&](uint32_t at, uint32_t share) {      /* pool[at .. at + share) -> lanes 0 .. share - 1 */
           if (at != 0xffffffffu && lane < share && at + lane < total) {
             const float4 *r = pool + (size_t)(at + lane) * 8u;
             const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6];
@@ -600,6 +652,20 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             myRays = raysBase + __float_as_int(r6.w);
             if (st == P_WALKING) walkLoadEntry(sc, ldsEntries, ldsCount, (uint32_t)w.i, cur);       /* the entry the walk was about to test */
           }
+        };
+        if (total <= suspendMax) {
+          suspendNow = true;                                   /* every wave of the workgroup reads the same total */
+        } else if (waves > 1u && uneven) {
+          exportWalks();
+          __syncthreads();
+          /* import: 64 walks per claim when packing; the SIMDs' takers a share each when dealing out */
+          uint32_t at = 0xffffffffu;
+          if (spread) { if (myRank != 0xffffffffu) at = myRank * share; }
+          else {
+            if (lane == 0) at = atomicAdd(&tailCtl[TC_TAKE], share);
+            at = __builtin_amdgcn_readfirstlane(at);
+          }
+          importWalks(at, share);
           __syncthreads();
           if (lane == 0) {
             __hip_atomic_store(&tailCtl[TC_POOL], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -617,63 +683,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     if (suspendNow || walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || canRefill))) {
       if (COUNT) diagBatches++;
       long long t0 = COUNT ? clock64() : 0;
-      /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475 ------------ */
-      if (flx_ballot(st == P_DONE) != 0ull) {
-        bool append = false;
-        if (st == P_DONE) {
-          float4 *rec = wb.rec + (size_t)pathId * 8;
-          float4 q4, q5, q6, q7;
-          const float4 *pp = nullptr;
-          if (compact0) {                                     /* bounce 0, compact records: lit colour per sample, albedo per pixel */
-            uint32_t tile0, s0;
-            item_tile(fr, pathId, tile0, s0);
-            pp = wb.pix0 + (((size_t)tile0 << 6) | (pathId & 63u)) * 3;
-            q4 = wb.rec0[(size_t)pathId * 3 + 2]; q7 = pp[2];
-            q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-          } else {
-            q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
-          }
-          const bool shadowed = (flags & RF_SHADOWED_NO_WALK) || ((flags & RF_NEED_SHADOW) && w.shadowed);
-          const f3 localColor = shadowed ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
-          const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
-          const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
-          bool cont = w.tri != -1;
-          if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
-          if (cont) {
-            if (compact0) {                                   /* the path goes on: now it gets its full record (what shade0 would have written) */
-              const float4 a = wb.rec0[(size_t)pathId * 3], bq = wb.rec0[(size_t)pathId * 3 + 1], p0 = pp[0];
-              rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
-              rec[1] = make_float4(a.x, a.y, a.z, bq.w);
-              rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
-              rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-              rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
-            }
-            rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
-            rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
-            append = true;
-          } else {
-            finalize_path(fr, wb, pathId, finalColor, importancy, originalColor);
-          }
-          st = P_EMPTY;
-        }
-        const unsigned long long am = flx_ballot(append);
-        if (am != 0ull) {
-          const uint32_t cntA = (uint32_t)__popcll(am);
-          const uint32_t r = lane_rank(am);
-          const uint32_t room = WF_OUT_CHUNK - outUsed;
-          const uint32_t seg1 = cntA < room ? cntA : room;
-          if (append && r < seg1) listOut[outBase + outUsed + r] = pathId;
-          outUsed += seg1;
-          if (cntA > seg1) {
-            uint32_t nb = 0;
-            if (lane == 0) nb = atomicAdd(outAlloc, WF_OUT_CHUNK);
-            nb = __builtin_amdgcn_readfirstlane(nb);
-            outBase = nb; outValid = true;
-            if (append && r >= seg1) listOut[outBase + (r - seg1)] = pathId;
-            outUsed = cntA - seg1;
-          }
-        }
-      }
+      /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475 (foldDone, above the loop) ---- */
+      foldDone();
       long long t1 = COUNT ? clock64() : 0;
       if (COUNT) tFold += t1 - t0;
       if (suspendNow) {
