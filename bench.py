@@ -208,7 +208,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
         args.gpus = world
-    multi = world > 1
+    # FLX_BENCH_FORCE_DIST=1 with one rank: the N > 1 code path — gloo bootstrap, the communicator id handed around, ncclCommInitRank,
+    # flx_render_gathered_device in the timed loop — rehearsed on a one-GPU box with a communicator of one rank
+    multi = world > 1 or os.environ.get("FLX_BENCH_FORCE_DIST") == "1"
 
     # Counter passes first: child processes under rocprofv3, before this process touches the GPU.
     pmc = {}
@@ -227,6 +229,7 @@ def main():
     if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("gloo", rank=rank, world_size=world)      # bootstrap + barrier only; the data path is RCCL inside the library
 
     fixture, config_name = WORKLOADS[args.workload][:2]
