@@ -774,6 +774,7 @@ FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCor
 /* Primary visibility (rayTracer<true>) over the threaded copy: explicit successors, stored edges, the box test through the
  * exact reciprocal division.  The entries a ray visits, their order, the arithmetic of every test and the visit count are
  * those of rayTracer<true>; a pixel's ray changes object space a few times per walk, so that is done in place. */
+FLX_DEV bool rayCuboidFast(float l, const WalkState &w, f3 lo, f3 hi);      /* below: the interval test with the exact quotients as its fallback */
 FLX_DEV Hit primaryWalkT(const DeviceScene &sc, const Ray &ray, float viewDepthPerS, uint32_t &visits) {
   Hit hit; hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
   WalkState w;
@@ -797,7 +798,7 @@ FLX_DEV Hit primaryWalkT(const DeviceScene &sc, const Ray &ray, float viewDepthP
       reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
     }
     if ((meta & 3) == 1) {
-      link = (uint32_t)__float_as_int(rayCuboidRecip(w.minLen, w, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y)) ? e2.x : e2.y);
+      link = (uint32_t)__float_as_int(rayCuboidFast(w.minLen, w, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y)) ? e2.x : e2.y);
     } else {
       f3 suv;
       if (moellerTrumborePrimaryE(F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y), F3(e1.z, e1.w, e2.x), w.tR, w.minLen, viewDepthPerS, suv)) {
@@ -1018,17 +1019,21 @@ FLX_DEV bool rayCuboidInterval(float l, const WalkState &w, f3 minCorner, f3 max
   sure = w.fastDiv & (l >= 8.673617379884035e-19f) & (sureTrue | sureFalse);      /* (NaN anywhere: every comparison false, unsure) */
   return sureTrue;
 }
-FLX_DEV void walkBoxP(WalkState &w, const WalkEntry &cur) {
-  const f3 lo = F3(cur.e0.x, cur.e0.y, cur.e0.z), hi = F3(cur.e0.w, cur.e1.x, cur.e1.y);
+/* rayCuboid's boolean: from the interval test where it is sure, from the exact quotients where some lane of the wave is not */
+FLX_DEV bool rayCuboidFast(float l, const WalkState &w, f3 lo, f3 hi) {
 #if FLX_WF_BOX_INTERVAL
   bool sure;
-  bool hit = rayCuboidInterval(w.minLen, w, lo, hi, sure);
-  if (flx_ballot(!sure) != 0ull) {                       /* rare: some lane of the wave needs the exact quotients */
-    if (!sure) hit = rayCuboidRecip(w.minLen, w, lo, hi);
+  bool hit = rayCuboidInterval(l, w, lo, hi, sure);
+  if (flx_ballot(!sure) != 0ull) {                         /* rare */
+    if (!sure) hit = rayCuboidRecip(l, w, lo, hi);
   }
+  return hit;
 #else
-  const bool hit = rayCuboidRecip(w.minLen, w, lo, hi);
+  return rayCuboidRecip(l, w, lo, hi);
 #endif
+}
+FLX_DEV void walkBoxP(WalkState &w, const WalkEntry &cur) {
+  const bool hit = rayCuboidFast(w.minLen, w, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y));
   w.i = hit ? __float_as_int(cur.e2.x) : __float_as_int(cur.e2.y);
 }
 
