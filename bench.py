@@ -194,7 +194,7 @@ def main():
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--tile-rows", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=16, help="frames per pass of the `batched` secondary measurement (flx_render_batch_device; at most 32 and at most 2^28 paths per pass); 0 = skip it; filter frames are never batched")
+    ap.add_argument("--batch", type=int, default=16, help="frames per pass of the `batched` secondary measurement (flx_render_batch_device; at most 32 and at most 2^28 paths per pass); 0 = skip it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.achieved / traffic are then null)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal of the rank logic on a one-GPU box: every rank uses GPU 0 and the strips are gathered with torch.distributed (gloo) instead of RCCL, which refuses two ranks on one device")
@@ -254,7 +254,7 @@ def main():
         ctx.comm_init_rank(ids[0], world, rank)
 
     rows_local = ctx.tile_row_count(params)
-    F = 0 if use_filter else max(0, min(args.batch, capi.MAX_BATCH_FRAMES))
+    F = 0 if (use_filter and multi) else max(0, min(args.batch, capi.MAX_BATCH_FRAMES))      # (gathered filter frames go one by one)
     if F:
         F = max(1, min(F, (1 << 28) // max(1, (tiles.padded_rows(H, args.tile_rows, world) if multi else H) * W * full.samples)))
     frames_out = torch.zeros((max(F, 1), H, W, 4), dtype=torch.float32, device="cuda")      # whole frames (gathered when N > 1)

@@ -136,7 +136,8 @@ flx_status flx_temporal_reset(flx_context *ctx);
  * multi-GPU gather over RCCL.  Call flx_sync before reading on another stream. */
 flx_status flx_render_device(flx_context *ctx, const flx_frame_params *params, void *d_out_rgba);
 /* A batch of 1 .. 32 frames in one pass of the pipeline (the reference renders frame after frame, pathtracerWGL2.js:329
- * frameCycle; frames without filter and without temporal accumulation do not depend on each other).  The frames may differ
+ * frameCycle; frames without temporal accumulation do not depend on each other — with use_filter the trace of the batch is one
+ * pass and the denoise chain then runs frame by frame, every time from the reference's frame-0 texture state; whole frames only).  The frames may differ
  * in camera, view_matrix, ambient and random_seed only; every other field must equal params[0]'s.  Output: the frames one
  * after the other, float4[n_frames][rows][width] with rows = flx_tile_row_count(params) — each frame bit-identical to its
  * flx_render.  The kernels of the pass run once over n_frames times the paths, so the per-kernel costs that do not shrink

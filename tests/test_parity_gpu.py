@@ -157,6 +157,21 @@ def test_batch_of_frames_equals_the_frames(hip, scenes, name, w, h, spp, bounces
     assert cnt == {k: sum(c[k] for _, c, _ in singles) for k in cnt}
 
 
+@pytest.mark.parametrize("name,w,h,spp,bounces", [("cornell_obj", 160, 96, 2, 3), ("dragon", 200, 117, 1, 3)])
+def test_batch_of_filter_frames_equals_the_frames(hip, scenes, name, w, h, spp, bounces):
+    """filter frames in a batch: one trace pass over the stacked frames, the denoise chain frame by frame — each frame (a
+    different camera, seed and ambient) equal to its own flx_render"""
+    sc = scenes(name)
+    hip.update_scene(sc)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=1)
+    frames = [_moved(sc, p, i) for i in range(3)]
+    got, _ = hip.render_batch(frames)
+    for i, q in enumerate(frames):
+        want, _, _ = hip.render(q)
+        assert np.array_equal(got[i], want, equal_nan=True), "frame %d" % i
+    assert not np.array_equal(got[0], got[1])
+
+
 def test_batch_arguments(hip, scenes):
     from flexlight_hip import capi
     sc = scenes("cornell")
@@ -169,8 +184,12 @@ def test_batch_arguments(hip, scenes):
     q.samples = p.samples + 1
     with pytest.raises(capi.FlexLightHipError, match="differ in camera"):
         hip.render_batch([p, q])
-    f = sc.frame_params(width=32, height=24, use_filter=1)
+    f = sc.frame_params(width=32, height=24, use_filter=0)
+    f.is_temporal = 1
     with pytest.raises(capi.FlexLightHipError, match="cannot be batched"):
+        hip.render_batch([f, f])
+    f = sc.frame_params(width=32, height=24, use_filter=1, tile=(8, 0, 2))
+    with pytest.raises(capi.FlexLightHipError, match="whole frames"):
         hip.render_batch([f, f])
     one, _ = hip.render_batch([p])
     assert np.array_equal(one[0], hip.render(p)[0], equal_nan=True)

@@ -779,8 +779,10 @@ flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint
   if (!params || n_frames < 1 || n_frames > FLX_MAX_BATCH) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: 1 .. 32 frames per batch");
   flx_status s = flx_make_frame(ctx, params, sc, fr);
   if (s) return s;
-  if (params->use_filter || params->is_temporal)
-    return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: filter / temporal frames depend on the frame before and cannot be batched");
+  if (params->is_temporal)
+    return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: temporal frames depend on the frames before and cannot be batched");
+  if (params->use_filter && flx_tile_row_count(params) != params->height)
+    return fail(ctx, FLX_ERR_INVALID, "flx_render_batch: filter frames of a batch are whole frames (the chain reads neighbouring rows; strips go through flx_render_planes_device)");
   for (uint32_t i = 1; i < n_frames; i++) {
     const flx_frame_params &a = params[0], &b = params[i];
     if (a.width != b.width || a.height != b.height || a.samples != b.samples || a.max_reflections != b.max_reflections ||
@@ -795,6 +797,36 @@ flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint
   return FLX_OK;
 }
 
+static flx_status ensure_post_buffers(flx_context *ctx, size_t pixels, bool gbuffers, bool planes);
+
+/* A batch of filter frames: ONE trace pass over the stacked frames into the float G-buffers (the per-pixel kernel: the G-buffer
+ * accumulators carry state from sample to sample), then per frame the stores to the RGBA8 render targets and the denoise chain —
+ * which starts from the reference's frame-0 texture state every time (launch_filter_chain), so the frames of a batch do not
+ * depend on each other.  Each frame equals its own flx_render bit for bit. */
+static flx_status run_filter_batch(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, const flx_frame_params *params, float4 *d_out) {
+  const size_t per = (size_t)fr.frame_rows * fr.width, pixels = per * fr.frames;
+  flx_status s;
+  if ((s = ensure_post_buffers(ctx, pixels, true, false))) return s;
+  if ((s = ensure_post_buffers(ctx, per, false, true))) return s;
+  FilterPlanes pl;
+  for (int i = 0; i < 4; i++) { pl.R[i] = ctx->d_planes[i]; pl.Ip[i] = ctx->d_planes[4 + i]; }
+  pl.O[0] = ctx->d_planes[8]; pl.O[1] = ctx->d_planes[9]; pl.Id[0] = ctx->d_planes[10]; pl.Id[1] = ctx->d_planes[11]; pl.OId = ctx->d_planes[12];
+  GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4], nullptr };
+  if ((s = flx_run_frame(ctx, sc, fr, nullptr, gb))) return s;
+  for (uint32_t f = 0; f < fr.frames; f++) {
+    const size_t o = (size_t)f * per;
+    launch_quantize(gb.color + o, pl.R[0], per, ctx->stream);
+    launch_quantize(gb.color_ip + o, pl.Ip[0], per, ctx->stream);
+    launch_quantize(gb.original_color + o, pl.O[0], per, ctx->stream);
+    launch_quantize(gb.id + o, pl.Id[0], per, ctx->stream);
+    launch_quantize(gb.original_id + o, pl.OId, per, ctx->stream);
+    launch_filter_chain(pl, d_out + o, (int)fr.width, (int)fr.height, params->hdr, ctx->stream);
+  }
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_render_batch_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, void *d_out_rgba) {
   if (!ctx) return FLX_ERR_INVALID;
   if (!d_out_rgba) return fail(ctx, FLX_ERR_INVALID, "flx_render_batch_device: output pointer is NULL");
@@ -803,6 +835,7 @@ extern "C" flx_status flx_render_batch_device(flx_context *ctx, const flx_frame_
   flx_status s = flx_make_batch(ctx, params, n_frames, sc, fr);
   if (s) return s;
   if ((size_t)fr.rows * fr.width == 0) return empty_share(ctx);
+  if (params->use_filter) return run_filter_batch(ctx, sc, fr, params, (float4 *)d_out_rgba);
   GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   return flx_run_frame(ctx, sc, fr, (float4 *)d_out_rgba, gb);
 }
@@ -819,8 +852,12 @@ extern "C" flx_status flx_render_batch(flx_context *ctx, const flx_frame_params 
   if ((s = flx_ensure_pixels(ctx, &ctx->d_out, &ctx->out_capacity, pixels))) return s;
   const bool saved = ctx->counters_enabled;
   if (counters) ctx->counters_enabled = true;
-  GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  s = flx_run_frame(ctx, sc, fr, ctx->d_out, gb);
+  if (params->use_filter) {
+    s = run_filter_batch(ctx, sc, fr, params, ctx->d_out);
+  } else {
+    GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    s = flx_run_frame(ctx, sc, fr, ctx->d_out, gb);
+  }
   ctx->counters_enabled = saved;
   if (s) return s;
   FLX_HIP(ctx, hipMemcpyAsync(out_rgba, ctx->d_out, pixels * sizeof(float4), hipMemcpyDeviceToHost, ctx->stream));

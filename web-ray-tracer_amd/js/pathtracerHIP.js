@@ -231,11 +231,11 @@ class PathTracerHIP {
 
   /* Several frames of a camera path in ONE pass of the GPU pipeline (flx_render_batch; not in the reference, which renders frame
    * after frame): `cameras` is an array of up to 32 camera states { x, y, z, fx, fy } (missing fields default to this.camera's;
-   * fov comes from this.camera).  Frames without filter, temporal accumulation and anti-aliasing only — those depend on the frame
-   * before.  Returns { width, height, rows, frames: [Float32Array(rows*width*4), ...], frameMs, counters? }; every frame equals
+   * fov comes from this.camera).  Frames without temporal accumulation and anti-aliasing only — those depend on the frames
+   * before (filter frames are fine: their chain starts from the same state every frame).  Returns { width, height, rows, frames: [Float32Array(rows*width*4), ...], frameMs, counters? }; every frame equals
    * the renderFrame() of its camera. */
   renderBatch (cameras, options) {
-    if (this.config.filter || this.config.temporal || this._antialiasing()) throw new Error('renderBatch: filter, temporal and antialiasing frames depend on the frame before');
+    if (this.config.temporal || this._antialiasing()) throw new Error('renderBatch: temporal and antialiasing frames depend on the frames before');
     const gpu = this._uploadFrameState();
     const saved = this.camera;
     const params = cameras.map(c => {
