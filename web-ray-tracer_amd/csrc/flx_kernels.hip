@@ -21,8 +21,13 @@ __device__ __forceinline__ void tile_pixel(const DeviceFrame &fr, uint32_t &px, 
 }
 
 /* ---- v1: one thread per pixel, the whole fragment program (fragment:601-646) --------------------- */
+#ifndef FLX_TRACE_WAVES
+#define FLX_TRACE_WAVES 4                  /* waves per SIMD the register allocation of k_trace_pixels must allow: 231 VGPRs / 2 waves left to
+                                            * itself; 128 VGPRs + 376 B of scratch per lane at 4 waves is 14 % faster on the cornell.obj filter frame
+                                            * (0.969 -> 0.832 ms; 5: 0.911, 6: 0.949, 8: 1.059; profiles/r02_ab_occupancy.txt) */
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_trace_pixels(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
+__global__ __launch_bounds__(256, FLX_TRACE_WAVES) void k_trace_pixels(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
                                                       unsigned long long *__restrict__ counters) {
   uint32_t px, k;
   tile_pixel(fr, px, k);
@@ -152,7 +157,9 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
 }
 
 #ifndef FLX_PATHS_WAVES
-#define FLX_PATHS_WAVES 1
+#define FLX_PATHS_WAVES 7                  /* k_paths: 163 VGPRs / 3 waves per SIMD left to itself; theater 1080p 16 spp 6 bounces by waves per SIMD:
+                                            * 11.74 (3) 11.37 (4) 11.14 (5) 10.50 (6) 10.25 (7) 11.04 ms (8) — the shading's latency wants waves more
+                                            * than registers (profiles/r02_ab_occupancy.txt) */
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, DeviceFrame fr, const float4 *__restrict__ hits,
