@@ -70,6 +70,9 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
 #ifndef FLX_WF_WAVES_PER_EU
 #define FLX_WF_WAVES_PER_EU 4               /* occupancy the register allocation of k_wf_walk_pre must allow */
 #endif
+#ifndef FLX_WF_SHADE_WAVES
+#define FLX_WF_SHADE_WAVES 3                /* waves per SIMD the register allocation of the shade kernels must allow */
+#endif
 #ifndef FLX_TAIL_DIAG_ROUND
 #define FLX_TAIL_DIAG_ROUND 0
 #endif
@@ -88,7 +91,7 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
  * material (shadeSurface) — is computed once and the per-sample rest (shadeSample) runs `samples` times.  Every path gets the
  * record the per-path kernel would have written, bit for bit. */
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
+__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade0(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
   const uint32_t S = (uint32_t)fr.samples;
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t lane = t & 63u;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void k_wf_shade0(DeviceScene sc, DeviceFrame f
 
 /* Later rounds: one lane per live path. */
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b) {
+__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b) {
   const uint32_t n = wb.counts[b];
   const uint32_t *__restrict__ listIn = wb.live[b & 1];
   WorkCounters cnt = {};
