@@ -255,6 +255,10 @@ flx_status flx_present(flx_context *ctx, uint32_t width, uint32_t height, const 
  * Results are identical; the explicit values are for A/B timing and tests.  flx_last_pipeline: what the last frame ran. */
 flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
 flx_status flx_last_pipeline(flx_context *ctx, int *pipeline);
+/* Scenes of at most 128 entries that all stand in transform 0 (cornell, cornell.obj, the theater) are walked by the wave in
+ * lockstep over the entries in the reference's order instead of lane by lane over the threaded copy (per-pixel and persistent
+ * path kernels; same entries per ray, same arithmetic, same counters).  on = 0 switches that off, for A/B timing and tests. */
+flx_status flx_set_lockstep(flx_context *ctx, int on);
 /* Wavefront pipeline: run the bounce loop as 1..4 independent chains of screen-tile ranges on separate HIP
  * streams (default 1: more chains measured slower, profiles/r01_ab_stream_groups.txt), so that the tail of one chain's persistent walk kernel overlaps the other's work. */
 flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);

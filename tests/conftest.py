@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:                     # PyTorch-ROCm ships its own HIP / HSA runtime libraries; a process that uses both torch and
+    import torch         # libflexlight_hip.so (the tests that hand torch device pointers to the library) must load torch's
+except ImportError:      # first — the other way round torch finds "No HIP GPUs" (Build).  Test infrastructure only.
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))

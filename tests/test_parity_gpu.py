@@ -46,6 +46,29 @@ def test_radiance_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounces, 
     assert (got[..., 3] == 1).sum() == want_cnt["primary_hits"]
 
 
+@pytest.mark.parametrize("pipeline", [2, 1], ids=["persistent", "per_pixel"])
+@pytest.mark.parametrize("name,w,h,spp,bounces", [c for c in CASES if c[0] != "dragon"])
+def test_small_scenes_lane_by_lane(hip, oracle, scenes, name, w, h, spp, bounces, pipeline):
+    """cornell, cornell.obj and the theater are walked by the wave in lockstep by default (flx_set_lockstep); the lane walk
+    over the threaded copy, which larger scenes in one object space take, gives the same frame and the same counters"""
+    sc = scenes(name)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+    hip.update_scene(sc)
+    hip.set_pipeline(pipeline)
+    hip.set_lockstep(False)
+    try:
+        got, got_cnt, _ = hip.render(p, counters=True)
+    finally:
+        hip.set_lockstep(True)
+        hip.set_pipeline(0)
+    key = (name, w, h, spp, bounces)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle.render(sc, p)[:2]
+    want, want_cnt = _ORACLE_CACHE[key]
+    assert np.array_equal(got, want, equal_nan=True)
+    assert got_cnt == want_cnt
+
+
 def test_headline_frame_at_full_size(hip, oracle, scenes):
     """The configuration BASELINE.json's target is quoted on (configs[2]) at full size — dragon, 1920x1080, 8 samples,
     4 bounces, filter off, the frame bench.py times —

@@ -16,6 +16,7 @@ CASES = {
     "no_lights": dict(seed=3, n_objects=3, tris_per_object=40, n_transforms=2, n_lights=0),
     "no_terminator": dict(seed=4, n_objects=3, tris_per_object=50, n_transforms=3, n_lights=1, exact_multiple=True),
     "degenerate_untextured": dict(seed=5, n_objects=2, tris_per_object=30, n_transforms=1, n_lights=1, textured=False, degenerate=6),
+    "one_space_axis_aligned": dict(seed=7, n_objects=2, tris_per_object=24, n_transforms=1, n_lights=2, axis_aligned_view=True, width=65, height=33),
     "axis_aligned_view": dict(seed=6, n_objects=3, tris_per_object=30, n_transforms=2, n_lights=2, axis_aligned_view=True, width=65, height=33),
 }
 
@@ -38,6 +39,30 @@ def test_synthetic_scene_matches_oracle(hip, oracle, case, pipeline):
     assert got_cnt == want_cnt
     assert np.array_equal(plain, got, equal_nan=True)
     assert want_cnt["primary_hits"] > 0.3 * p.width * p.height          # the scene is actually in view
+
+
+@pytest.mark.parametrize("lockstep", [True, False], ids=["lockstep", "lanes"])
+@pytest.mark.parametrize("pipeline", [2, 1], ids=["persistent", "per_pixel"])
+@pytest.mark.parametrize("case", ["degenerate_untextured", "one_space_axis_aligned"])
+def test_small_one_space_scenes_both_walks(hip, oracle, case, pipeline, lockstep):
+    """scenes of <= 128 entries in one object space: the wave-wide lockstep walk and the lane walk, degenerate triangles and
+    rays with zero direction components (the box test's IEEE-division path) included"""
+    sc = synth_scene.make(**CASES[case])
+    assert sc.meta["textureLength"] <= 127
+    p = sc.frame_params(use_filter=0)
+    hip.update_scene(sc)
+    hip.set_pipeline(pipeline)
+    hip.set_lockstep(lockstep)
+    try:
+        got, got_cnt, _ = hip.render(p, counters=True)
+        plain, _, _ = hip.render(p)
+    finally:
+        hip.set_lockstep(True)
+        hip.set_pipeline(0)
+    want, want_cnt, _ = oracle.render(sc, p)
+    assert np.array_equal(got, want, equal_nan=True)
+    assert got_cnt == want_cnt
+    assert np.array_equal(plain, got, equal_nan=True)
 
 
 @pytest.mark.parametrize("case", ["four_transforms", "no_lights"])

@@ -85,7 +85,16 @@ struct DeviceScene {
   uint32_t walk_hot;            /* the first walk_hot entries are the shallowest ones (LDS candidates) */
   uint32_t walk_root;           /* threaded index of original entry 0 */
   uint32_t walk_fast_boxes;     /* 1: every AABB coordinate is finite with |x| <= 2^59 (precondition of rayCuboidR's fast path) */
+  /* Small scenes in one object space: the same entries once more in the reference's own order (every successor lies further
+   * on), for the wave-wide lockstep walk (walkLockPass).  lock_entries = 0: there is none. */
+  const float4 *lock;           /* 3 x float4 per entry, threaded layout; links are plain indices into `lock` (or WALK_END) */
+  uint32_t lock_entries;        /* entries in `lock`, the shared terminator (the last one) included */
+  uint32_t lock_root;           /* index of original entry 0 */
 };
+#ifndef FLX_LOCKSTEP
+#define FLX_LOCKSTEP 1
+#endif
+#define FLX_LOCK_MAX 128u       /* most entries a scene may have to be walked in lockstep */
 /* threaded entry:  AABB      e0 = min.xyz max.x | e1 = max.y max.z - - | e2 = bits(nextHit) bits(nextMiss) bits(meta) bits(origIndex)
  *                  triangle  e0 = a.xyz b.x     | e1 = b.yz c.xy      | e2 = c.z        bits(next)     bits(meta) bits(origIndex)
  *                  terminator                                           e2 = -          -              bits(meta = 0)
@@ -1049,11 +1058,71 @@ FLX_DEV void walkBoxP(WalkState &w, const WalkEntry &cur) {
 FLX_DEV bool nextBounceRuns(const DeviceFrame &fr, int i, f3 importancyFactor, f3 originalColor) {
   return (i + 1) < fr.max_reflections && length(importancyFactor * originalColor) >= fr.min_importancy * SQRT3;
 }
+/* ---- lockstep walk: small scenes in one object space (flx_api.hip: build_lockstep) --------------------------------
+ * A scene of a few dozen entries (cornell, cornell.obj, the theater) is walked by the WAVE, not by the lane: the entries
+ * stand in the reference's own order, where every successor lies further on, the wave steps through them once, and at
+ * entry i the lanes whose walk stands at i test it.  The entry is the same for all of them: it comes through scalar loads
+ * (no per-lane fetch, no address arithmetic, nothing for the next test to wait on — the loads of entry i + 1 do not depend
+ * on the test of entry i), its numbers are scalar operands of the tests, and a trip runs EITHER the box test OR the
+ * triangle test, never both under two masks.  Per ray the entries visited, their order, every arithmetic operation and the
+ * visit counts are those of walkBounce()'s lane walk (and of rayTracer / shadowTest, fragment:172-280). */
+typedef __attribute__((address_space(4))) const flx_v4f const_cf4;
+template <bool COUNT, bool CULL>
+FLX_DEV void walkLockPass(const DeviceScene &sc, bool active, const Ray &ray, float len, WalkState &w, uint32_t &visits) {
+  w.tR = ray; w.minLen = len;
+  reciprocalOfDir(sc, ray.dir, ray.origin, w.inv, w.fastDiv);
+  uint32_t nxt = active ? sc.lock_root : WALK_END;
+  const const_cf4 *L = (const const_cf4 *)sc.lock;
+  const uint32_t n = sc.lock_entries;
+  for (uint32_t i = 0; i < n; i++) {
+    const bool mine = nxt == i;
+    if (flx_ballot(mine) == 0ull) {
+      if (flx_ballot(nxt != WALK_END) == 0ull) break;        /* every walk of the wave has ended */
+      continue;
+    }
+    const uint32_t iu = __builtin_amdgcn_readfirstlane(i) * 3u;
+    const flx_v4f e0 = L[iu], e1 = L[iu + 1u], e2 = L[iu + 2u];
+    const int meta = __float_as_int(e2.z);
+    if (mine) {
+      if (COUNT) visits++;
+      if ((meta & 3) == 1) {
+        const bool hit = rayCuboidFast(w.minLen, w, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y));
+        nxt = (uint32_t)__float_as_int(hit ? e2.x : e2.y);
+      } else if ((meta & 3) == 2) {
+        f3 suv;
+        const bool hit = moellerTrumboreAny(F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y), F3(e1.z, e1.w, e2.x), w.tR, w.minLen, CULL, suv);
+        nxt = (uint32_t)__float_as_int(e2.y);
+        if (hit) {
+          if (CULL) { w.shadowed = true; nxt = WALK_END; }
+          else if (suv.x != 0.0f) {                        /* fragment:217 */
+            w.suv = suv; w.hitTI = (meta >> 2) << 1; w.tri = __float_as_int(e2.w);
+            w.minLen = suv.x;
+          }
+        }
+      } else {
+        nxt = WALK_END;                                    /* terminator: its fetch counts (fragment:208), the walk ends */
+      }
+    }
+  }
+}
+
 template <bool COUNT>
 FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, bool needClosest, const Ray &shadowRay, float shadowLen, const Ray &nextRay,
                         bool &shadowed, Hit &hit, WorkCounters &cnt) {
   WalkState w;
   walkClearResults(w);
+#if FLX_LOCKSTEP
+  if (sc.lock_entries != 0u) {
+    /* (no early return for a lane without walks: the passes are wave-wide, every lane that came here goes through them) */
+    w.cachedTI = 0;
+    if (COUNT) { if (needShadow) cnt.shadow_walks++; if (needClosest) cnt.closest_walks++; }
+    if (flx_ballot(needShadow) != 0ull) walkLockPass<COUNT, true>(sc, needShadow, shadowRay, shadowLen, w, cnt.shadow_visits);
+    if (flx_ballot(needClosest) != 0ull) walkLockPass<COUNT, false>(sc, needClosest, nextRay, POW32, w, cnt.closest_visits);
+    shadowed = w.shadowed;
+    hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri;
+    return;
+  }
+#endif
   if (!needShadow && !needClosest) {
     shadowed = false;
     hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri;

@@ -240,11 +240,22 @@ __global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex 
                                                        uint32_t *dOrig, int W, int H) {
   __shared__ uint32_t tile[5][FILTER_TW * FILTER_TW];
   const TileOrigin org = tile_origin(W);
+  int x, y;
+  const bool inImage = texel_of_thread(W, H, x, y);
+  /* Every output of this pass is centerColor.w times something, and quant() stores 0 for +-0 and for NaN alike: a texel whose
+   * colour has w = 0 — one the path-trace pass did not cover — writes zeros whatever its 36 taps hold.  A workgroup of such
+   * texels (most of a frame around a small model) skips the staging and the taps, a lone one the taps. */
+  const size_t o = inImage ? (size_t)(H - 1 - y) * W + x : 0;
+  const bool covered = inImage && rawW(fetchRaw(tColor, W, H, x, y)) != 0u;
+  if (!__syncthreads_or(covered)) {
+    if (inImage) { dColor[o] = 0u; dIp[o] = 0u; if (dOrig) dOrig[o] = 0u; }
+    return;
+  }
   stage_tile(tile[0], tColor, W, H, org); stage_tile(tile[1], tIp, W, H, org); stage_tile(tile[2], tOColor, W, H, org);
   stage_tile(tile[3], tId, W, H, org); stage_tile(tile[4], tOId, W, H, org);
   __syncthreads();
-  int x, y;
-  if (!texel_of_thread(W, H, x, y)) return;
+  if (!inImage) return;
+  if (!covered) { dColor[o] = 0u; dIp[o] = 0u; if (dOrig) dOrig[o] = 0u; return; }
   const f4 centerColor = unpack(fetchTile(tile[0], H, org, x, y));
   const f4 centerColorIp = unpack(fetchTile(tile[1], H, org, x, y));
   const f4 centerOColor = unpack(fetchTile(tile[2], H, org, x, y));
@@ -280,7 +291,6 @@ __global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex 
   const float invCount = 1.0f / count;
   const float w = centerColor.w;
   const float cx_ = color.x * invCount, cy_ = color.y * invCount, cz_ = color.z * invCount;
-  const size_t o = (size_t)(H - 1 - y) * W + x;
   dColor[o] = pack(F4(w * flx_mod(cx_, 1.0f), w * flx_mod(cy_, 1.0f), w * flx_mod(cz_, 1.0f), w * (color.w * invCount)));
   dIp[o] = pack(F4(w * (flx_floor(cx_) * INV_256), w * (flx_floor(cy_) * INV_256), w * (flx_floor(cz_) * INV_256), w * ipw));
   if (dOrig) dOrig[o] = pack(F4((w * oColor.x) / oCount, (w * oColor.y) / oCount, (w * oColor.z) / oCount, (w * oColor.w) / oCount));
@@ -289,11 +299,20 @@ __global__ __launch_bounds__(256) void k_filter_second(Tex tColor, Tex tIp, Tex 
 __global__ __launch_bounds__(256) void k_filter_final(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, float4 *out, int W, int H, int hdr) {
   __shared__ uint32_t tile[5][FILTER_TW * FILTER_TW];
   const TileOrigin org = tile_origin(W);
+  int x, y;
+  const bool inImage = texel_of_thread(W, H, x, y);
+  /* a texel whose colour has w = 0 yields vec4(0) whatever its taps hold (the last branch of the shader): workgroups of such
+   * texels skip the staging and the taps, lone ones the taps */
+  const bool covered = inImage && rawW(fetchRaw(tColor, W, H, x, y)) != 0u;
+  if (!__syncthreads_or(covered)) {
+    if (inImage) out[(size_t)(H - 1 - y) * W + x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    return;
+  }
   stage_tile(tile[0], tColor, W, H, org); stage_tile(tile[1], tIp, W, H, org); stage_tile(tile[2], tOColor, W, H, org);
   stage_tile(tile[3], tId, W, H, org); stage_tile(tile[4], tOId, W, H, org);
   __syncthreads();
-  int x, y;
-  if (!texel_of_thread(W, H, x, y)) return;
+  if (!inImage) return;
+  if (!covered) { out[(size_t)(H - 1 - y) * W + x] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); return; }
   const uint32_t rCenterColor = fetchTile(tile[0], H, org, x, y);
   const uint32_t centerIpW = rawW(fetchTile(tile[1], H, org, x, y));
   const f4 centerOColor = unpack(fetchTile(tile[2], H, org, x, y));

@@ -18,7 +18,7 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
+    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_set_lockstep", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
@@ -64,6 +64,7 @@ def _load():
         "flx_device_info": (C.c_int, [vp, C.c_char_p, u32, C.POINTER(u32)]),
         "flx_version": (C.c_char_p, []),
         "flx_set_pipeline": (C.c_int, [vp, C.c_int]),
+        "flx_set_lockstep": (C.c_int, [vp, C.c_int]),
         "flx_get_diag": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_set_wavefront_groups": (C.c_int, [vp, C.c_int]),
         "flx_last_pipeline": (C.c_int, [vp, C.POINTER(C.c_int)]),
@@ -270,6 +271,10 @@ class Context:
     def set_pipeline(self, pipeline):
         """0 auto, 1 per-pixel kernel, 2 persistent path kernel (same results)."""
         self._check(LIB.flx_set_pipeline(self._h, int(pipeline)), "flx_set_pipeline")
+
+    def set_lockstep(self, on):
+        """Small scenes: wave-wide lockstep walk (default) or the lane walk (same results)."""
+        self._check(LIB.flx_set_lockstep(self._h, int(bool(on))), "flx_set_lockstep")
 
     def get_counters(self):
         cnt = Counters()
