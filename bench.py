@@ -388,9 +388,10 @@ def main():
         k_ms = float(np.median(kernel_ms))
         frame_bytes = algorithmic_bytes(cnt, n_lights, rows_local * W, use_filter)      # this rank's share of one frame
         if pipe == 1:              # per-pixel kernel: the whole trace
-            kernel_name, kernel_sym, bytes_launch = "k_trace_pixels", "k_trace_pixels<false>", frame_bytes - (244 * rows_local * W if use_filter else 0)
+            kernel_sym = next((n for n in pmc if n.startswith("k_trace_pixels<false")), "k_trace_pixels<false, false>")      # <COUNT, LOCK>
+            kernel_name, bytes_launch = "k_trace_pixels", frame_bytes - (244 * rows_local * W if use_filter else 0)
         elif pipe == 2:            # persistent path kernel (tiny scenes): every bounce of every path, no primary walk, no output
-            kernel_name, kernel_sym = "k_paths (persistent path kernel)", "k_paths<false>"
+            kernel_name, kernel_sym = "k_paths (persistent path kernel)", next((n for n in pmc if n.startswith("k_paths<false")), "k_paths<false, false>")
             bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * cnt["shades"] + 4 * cnt["atlas_texels"]
         else:                      # the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
             visits = b0_visits if b0_visits else cnt["closest_visits"] + cnt["shadow_visits"]

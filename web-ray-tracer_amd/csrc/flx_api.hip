@@ -77,14 +77,14 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->twin) { flx_context_destroy(ctx->twin); ctx->twin = nullptr; }
   if (ctx->is_twin) {                      /* the static scene arrays belong to the primary context */
-    ctx->d_geometry = ctx->d_attributes = nullptr; ctx->d_ids = nullptr; ctx->d_walk = nullptr; ctx->d_lock = nullptr;
+    ctx->d_geometry = ctx->d_attributes = nullptr; ctx->d_ids = nullptr; ctx->d_walk = nullptr; ctx->d_fwd = nullptr;
     ctx->d_atlas[0] = ctx->d_atlas[1] = ctx->d_atlas[2] = nullptr;
   }
   (void)flx_comm_destroy(ctx);
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_send, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_lock,
+                   ctx->d_send, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -230,8 +230,10 @@ static void build_threaded(const float *geometry, uint32_t n, std::vector<float>
  * an entry lies further on — in the threaded layout, with plain indices as links and the shared terminator last.  Built for
  * scenes of at most FLX_LOCK_MAX entries whose entries all stand in transform 0, i.e. are tested with the untransformed ray
  * (fragment:174-175). */
-static void build_lockstep(const float *geometry, uint32_t n, std::vector<float> &out, uint32_t &n_out, uint32_t &root) {
+static void build_lockstep(const float *geometry, uint32_t n, std::vector<float> &out, uint32_t &n_out, uint32_t &root, uint32_t &boxes) {
   std::vector<uint32_t> order;
+  boxes = 0;
+  for (uint32_t i = 0; i < n; i++) if (geometry[(size_t)i * 12 + 10] == 1.0f) boxes++;
   for (uint32_t i = 0; i < n; i++) if (geometry[(size_t)i * 12 + 10] != 0.0f) order.push_back(i);
   const uint32_t terminator = (uint32_t)order.size();
   std::vector<uint32_t> newIndex(n, terminator);
@@ -248,11 +250,11 @@ static void build_lockstep(const float *geometry, uint32_t n, std::vector<float>
       for (int k = 0; k < 6; k++) o[k] = e[k];
       o[8] = bits(succ((uint64_t)i + 1));
       o[9] = bits(succ((uint64_t)i + 1 + (uint64_t)e[6]));
-      o[10] = bits(1u);
+      o[10] = bits(1u | ((uint32_t)e[9] << 2));
     } else {
       for (int k = 0; k < 3; k++) { o[k] = e[k]; o[3 + k] = e[3 + k] - e[k]; o[6 + k] = e[6 + k] - e[k]; }      /* as build_threaded */
       o[9] = bits(succ((uint64_t)i + 1));
-      o[10] = bits(2u);
+      o[10] = bits(2u | ((uint32_t)e[9] << 2));
     }
     o[11] = bits(i);
   }
@@ -299,14 +301,13 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
         for (int k = 0; k < 6; k++) if (!(std::fabs(e[k]) <= 5.764607523034235e17f)) bounded = false;
     }
     ctx->walk_fast_boxes = bounded ? 1u : 0u;
-    /* small scenes in one object space: the copy the wave-wide lockstep walk steps through */
-    ctx->lock_entries = 0; ctx->lock_root = 0;
-    if (max_transform == 0 && ctx->walk_entries <= FLX_LOCK_MAX) {
-      std::vector<float> lock;
-      uint32_t n_lock = 0, lock_root = 0;
-      build_lockstep(geometry, n_entries_padded, lock, n_lock, lock_root);
-      if ((s = upload(ctx, &ctx->d_lock, lock.data(), lock.size() * sizeof(float)))) return s;
-      ctx->lock_entries = n_lock; ctx->lock_root = lock_root;
+    /* the forward-ordered copy: the primary rays' walk steps through it wave by wave, and — small scenes in one object space — the
+     * bounce walks of the per-pixel and persistent path kernels do */
+    {
+      std::vector<float> fwd;
+      build_lockstep(geometry, n_entries_padded, fwd, ctx->fwd_entries, ctx->fwd_root, ctx->lock_boxes);
+      if ((s = upload(ctx, &ctx->d_fwd, fwd.data(), fwd.size() * sizeof(float)))) return s;
+      ctx->lock_ok = max_transform == 0 && ctx->fwd_entries <= FLX_LOCK_MAX;
     }
   }
   ctx->n_entries = n_entries_padded;
@@ -411,7 +412,8 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, DeviceSce
   for (int i = 0; i < 3; i++) { sc.atlas[i] = ctx->d_atlas[i]; sc.atlas_w[i] = ctx->atlas_w[i]; sc.atlas_h[i] = ctx->atlas_h[i]; }
   sc.n_entries = ctx->n_entries; sc.n_lights = ctx->n_lights; sc.n_transforms = ctx->n_transforms;
   sc.walk = ctx->d_walk; sc.walk_entries = ctx->walk_entries; sc.walk_hot = ctx->walk_hot; sc.walk_root = ctx->walk_root; sc.walk_fast_boxes = ctx->walk_fast_boxes;
-  sc.lock = ctx->d_lock; sc.lock_entries = ctx->lock_use ? ctx->lock_entries : 0u; sc.lock_root = ctx->lock_root;
+  sc.fwd = ctx->d_fwd; sc.fwd_entries = ctx->fwd_entries; sc.fwd_root = ctx->fwd_root;
+  sc.lock = ctx->d_fwd; sc.lock_entries = (ctx->lock_ok && ctx->lock_use) ? ctx->fwd_entries : 0u; sc.lock_root = ctx->fwd_root;
   uint32_t tr, ti, tc;
   tile_normalise(p, tr, ti, tc);
   fr.width = p->width; fr.height = p->height;
@@ -526,7 +528,12 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     /* persistent grid: enough workgroups to fill every CU at the kernel's occupancy; surplus ones find the queue dry */
-    launch_paths(sc, fr, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue, cus * 8u, cnt, ctx->stream);
+    /* The lockstep walk pays where a wave's lanes stand at boxes and at triangles in the same trip of the lane walk.  A nearly flat
+     * tree (the theater: 3 boxes over 20 triangles) has few such trips, and this kernel's seven waves per SIMD hide the lane walk's
+     * fetches: there the lane walk measures 2 % faster (10.70 vs 10.91 ms; cornell.obj, 13 boxes: 1.30 vs 1.19 ms). */
+    DeviceScene scPaths = sc;
+    if (ctx->lock_boxes < 8u) scPaths.lock_entries = 0u;
+    launch_paths(scPaths, fr, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue, cus * 8u, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
     launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
@@ -1042,7 +1049,7 @@ static void mirror_scene(flx_context *ctx) {
   flx_context *t = ctx->twin;
   if (!t) return;
   t->d_geometry = ctx->d_geometry; t->d_attributes = ctx->d_attributes; t->d_ids = ctx->d_ids; t->d_walk = ctx->d_walk;
-  t->d_lock = ctx->d_lock; t->lock_entries = ctx->lock_entries; t->lock_root = ctx->lock_root; t->lock_use = ctx->lock_use;
+  t->d_fwd = ctx->d_fwd; t->fwd_entries = ctx->fwd_entries; t->fwd_root = ctx->fwd_root; t->lock_ok = ctx->lock_ok; t->lock_use = ctx->lock_use; t->lock_boxes = ctx->lock_boxes;
   t->walk_entries = ctx->walk_entries; t->walk_hot = ctx->walk_hot; t->walk_root = ctx->walk_root; t->walk_fast_boxes = ctx->walk_fast_boxes;
   for (int i = 0; i < 3; i++) { t->d_atlas[i] = ctx->d_atlas[i]; t->atlas_w[i] = ctx->atlas_w[i]; t->atlas_h[i] = ctx->atlas_h[i]; }
   t->n_entries = ctx->n_entries; t->n_ids = ctx->n_ids; t->max_transform = ctx->max_transform; t->have_scene = ctx->have_scene;

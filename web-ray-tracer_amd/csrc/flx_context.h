@@ -33,8 +33,9 @@ struct flx_context {
   float4 *d_geometry = nullptr, *d_attributes = nullptr, *d_rotation = nullptr, *d_shift = nullptr;
   float4 *d_walk = nullptr;                      /* threaded hot-first copy of the skip list */
   uint32_t walk_entries = 0, walk_hot = 0, walk_root = 0, walk_fast_boxes = 0;
-  float4 *d_lock = nullptr;                      /* small scenes: the entries in the reference's order, for the lockstep walk */
-  uint32_t lock_entries = 0, lock_root = 0;
+  float4 *d_fwd = nullptr;                       /* the live entries in the reference's order (every successor further on): primary walk, lockstep walk */
+  uint32_t fwd_entries = 0, fwd_root = 0, lock_boxes = 0;
+  bool lock_ok = false;                          /* the scene is small and in one object space: its bounce walks may go in lockstep */
   bool lock_use = true;                          /* flx_set_lockstep */
   int walk_scheduler = 0;
   int32_t *d_ids = nullptr;

@@ -90,6 +90,10 @@ struct DeviceScene {
   const float4 *lock;           /* 3 x float4 per entry, threaded layout; links are plain indices into `lock` (or WALK_END) */
   uint32_t lock_entries;        /* entries in `lock`, the shared terminator (the last one) included */
   uint32_t lock_root;           /* index of original entry 0 */
+  /* Every scene: the same forward-ordered copy of ALL live entries, for the primary rays' walk (primaryWalkF) — the rays of a
+   * screen tile visit nearly the same entries, so the wave steps through them together.  (lock == fwd for the small scenes.) */
+  const float4 *fwd;
+  uint32_t fwd_entries, fwd_root;
 };
 #ifndef FLX_LOCKSTEP
 #define FLX_LOCKSTEP 1
@@ -820,6 +824,104 @@ FLX_DEV Hit primaryWalkT(const DeviceScene &sc, const Ray &ray, float viewDepthP
   return hit;
 }
 
+typedef float flx_v4f_ __attribute__((ext_vector_type(4)));
+/* Primary visibility by the wave.  The 64 rays of an 8 x 8 screen tile leave one point in nearly one direction: they visit nearly
+ * the same entries (dragon 1080p: 18 per ray, 24 per tile, tests/analysis/primary_union.py).  Over the forward-ordered copy
+ * (sc.fwd: every successor lies further on) the wave visits the lowest entry any of its rays stands at — a scalar load, one kind of
+ * test per trip, no per-lane fetch — and the rays that stand there test it.  Where the rays have spread (deep inside the
+ * dragon's tree a trip serves a handful of them) the lanes finish on their own over the same array.  Per ray: the entries,
+ * their order, the arithmetic and the visit count of primaryWalkT. */
+extern "C" __device__ unsigned int __ockl_wfred_min_u32(unsigned int);
+#ifndef FLX_PRIMARY_PREFETCH
+#define FLX_PRIMARY_PREFETCH 0       /* fetch both successors of an entry while it is tested: measured slower (k_primary 0.455 against 0.391 ms) */
+#endif
+#ifndef FLX_PRIMARY_LOCK_MIN
+#define FLX_PRIMARY_LOCK_MIN 12      /* two trips in a row that serve fewer rays than this: the lanes go on alone */
+#endif
+typedef __attribute__((address_space(4))) const flx_v4f_ fwd_cf4;
+FLX_DEV void primaryVisit(const DeviceScene &sc, const Ray &ray, float viewDepthPerS, WalkState &w, int &cachedTI, Hit &hit, uint32_t &nxt,
+                          float4 e0, float4 e1, float4 e2) {
+  const int meta = __float_as_int(e2.z);
+  if ((meta & 3) == 0) { nxt = WALK_END; return; }          /* terminator (its fetch counts, fragment:208) */
+  const int tI = (meta >> 2) << 1;
+  if (tI != cachedTI) {
+    const int iI = tI + 1;
+    const M3 rotationII = rotation_at(sc, iI);
+    cachedTI = tI;
+    w.tR.origin = mul(rotationII, ray.origin + shift_at(sc, iI));
+    w.tR.dir = mul(rotationII, ray.dir);
+    reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
+  }
+  if ((meta & 3) == 1) {
+    nxt = (uint32_t)__float_as_int(rayCuboidFast(w.minLen, w, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y)) ? e2.x : e2.y);
+  } else {
+    f3 suv;
+    if (moellerTrumborePrimaryE(F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y), F3(e1.z, e1.w, e2.x), w.tR, w.minLen, viewDepthPerS, suv)) {
+      hit.suv = suv; hit.transformId = tI; hit.triangleId = __float_as_int(e2.w);
+      w.minLen = suv.x;
+    }
+    nxt = (uint32_t)__float_as_int(e2.y);
+  }
+}
+/* every lane of the wave calls this (active = the lane has a pixel) */
+FLX_DEV Hit primaryWalkF(const DeviceScene &sc, bool active, const Ray &ray, float viewDepthPerS, uint32_t &visits) {
+  Hit hit; hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
+  WalkState w;
+  w.tR = ray; w.minLen = POW32;
+  reciprocalOfDir(sc, ray.dir, ray.origin, w.inv, w.fastDiv);
+  int cachedTI = 0;
+  uint32_t nxt = active ? sc.fwd_root : WALK_END;
+  const fwd_cf4 *L = (const fwd_cf4 *)sc.fwd;
+  uint32_t thin = 0;
+  for (;;) {
+    const uint32_t i = __builtin_amdgcn_readfirstlane(__ockl_wfred_min_u32(nxt));
+    if (i == WALK_END) return hit;
+    uint32_t iu = i;
+    asm volatile("" : "+s"(iu));                             /* (a scalar the compiler cannot trade for the lane's own `nxt`: scalar loads) */
+    const fwd_cf4 *E = L + (size_t)iu * 3u;
+    const flx_v4f_ a = E[0], b = E[1], c = E[2];
+    const bool mine = nxt == i;
+    if (mine) {
+      visits++;
+      primaryVisit(sc, ray, viewDepthPerS, w, cachedTI, hit, nxt, make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), make_float4(c.x, c.y, c.z, c.w));
+    }
+    thin = (uint32_t)__popcll(flx_ballot(mine)) < (uint32_t)FLX_PRIMARY_LOCK_MIN ? thin + 1u : 0u;
+    if (thin >= 2u) break;
+  }
+  /* The lanes on their own, over the same array.  What is left are the long walks: a ray that grazes the dragon visits several
+   * hundred entries (tests/analysis/primary_union.py: the longest ray of a tile visits 7 entries at the median, 257 at the 99th
+   * percentile, 477 at most).  Fetching both possible successors of an entry while it is tested (FLX_PRIMARY_PREFETCH) does not
+   * shorten them — measured, like the same idea in the bounce walks (profiles/r01_ab_tail_prefetch.txt). */
+#if FLX_PRIMARY_PREFETCH
+  if (nxt != WALK_END) {
+    size_t i = (size_t)nxt * 3u;
+    float4 e0 = sc.fwd[i], e1 = sc.fwd[i + 1], e2 = sc.fwd[i + 2];
+    while (nxt != WALK_END) {
+      const int meta = __float_as_int(e2.z);
+      const bool box = (meta & 3) == 1;
+      const uint32_t linkA = (uint32_t)__float_as_int(box ? e2.x : e2.y), linkB = (uint32_t)__float_as_int(e2.y);
+      /* (a terminator's links are zeros and WALK_END has no entry: entry 0 stands in, its data is not used) */
+      const size_t ia = (size_t)((meta & 3) == 0 || linkA == WALK_END ? 0u : linkA) * 3u, ib = (size_t)((meta & 3) == 0 || linkB == WALK_END ? 0u : linkB) * 3u;
+      const float4 a0 = sc.fwd[ia], a1 = sc.fwd[ia + 1], a2 = sc.fwd[ia + 2];
+      float4 b0 = a0, b1 = a1, b2 = a2;
+      if (box) { b0 = sc.fwd[ib]; b1 = sc.fwd[ib + 1]; b2 = sc.fwd[ib + 2]; }
+      visits++;
+      primaryVisit(sc, ray, viewDepthPerS, w, cachedTI, hit, nxt, e0, e1, e2);
+      const bool tookA = nxt == linkA;
+      e0 = tookA ? a0 : b0; e1 = tookA ? a1 : b1; e2 = tookA ? a2 : b2;
+    }
+  }
+#else
+  while (nxt != WALK_END) {
+    const size_t i = (size_t)nxt * 3u;
+    const float4 e0 = sc.fwd[i], e1 = sc.fwd[i + 1], e2 = sc.fwd[i + 2];
+    visits++;
+    primaryVisit(sc, ray, viewDepthPerS, w, cachedTI, hit, nxt, e0, e1, e2);
+  }
+#endif
+  return hit;
+}
+
 template <bool COUNT>
 FLX_DEV bool walkFetchT(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, WalkState &w, WalkEntry &cur, WorkCounters &cnt) {
   if ((uint32_t)w.i == WALK_END) return true;
@@ -1080,8 +1182,8 @@ FLX_DEV void walkLockPass(const DeviceScene &sc, bool active, const Ray &ray, fl
       if (flx_ballot(nxt != WALK_END) == 0ull) break;        /* every walk of the wave has ended */
       continue;
     }
-    const uint32_t iu = __builtin_amdgcn_readfirstlane(i) * 3u;
-    const flx_v4f e0 = L[iu], e1 = L[iu + 1u], e2 = L[iu + 2u];
+    const const_cf4 *E = L + (size_t)__builtin_amdgcn_readfirstlane(i) * 3u;      /* (one address, three offsets) */
+    const flx_v4f e0 = E[0], e1 = E[1], e2 = E[2];
     const int meta = __float_as_int(e2.z);
     if (mine) {
       if (COUNT) visits++;
@@ -1106,13 +1208,13 @@ FLX_DEV void walkLockPass(const DeviceScene &sc, bool active, const Ray &ray, fl
   }
 }
 
-template <bool COUNT>
+/* LOCK: the kernel variant for scenes that have the lockstep copy (sc.lock_entries != 0); the other variant does not carry its code */
+template <bool COUNT, bool LOCK>
 FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, bool needClosest, const Ray &shadowRay, float shadowLen, const Ray &nextRay,
                         bool &shadowed, Hit &hit, WorkCounters &cnt) {
   WalkState w;
   walkClearResults(w);
-#if FLX_LOCKSTEP
-  if (sc.lock_entries != 0u) {
+  if (LOCK) {
     /* (no early return for a lane without walks: the passes are wave-wide, every lane that came here goes through them) */
     w.cachedTI = 0;
     if (COUNT) { if (needShadow) cnt.shadow_walks++; if (needClosest) cnt.closest_walks++; }
@@ -1122,7 +1224,6 @@ FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, bool needClosest
     hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri;
     return;
   }
-#endif
   if (!needShadow && !needClosest) {
     shadowed = false;
     hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri;
@@ -1194,26 +1295,26 @@ FLX_DEV void bounceFinish(PixelState &ps, PathState &p, const ShadeOut &so, bool
 
 /* One full bounce iteration (fragment:476-595); false when the path ends on a miss (fragment:593). */
 /* bounce() with the surface part given: bounce 0 of a pixel's samples, which share the primary hit */
-template <bool COUNT>
+template <bool COUNT, bool LOCK>
 FLX_DEV bool bounceOn(const DeviceScene &sc, const DeviceFrame &fr, const SurfaceCtx &sf, PixelState &ps, PathState &p, f3 camera, float cosSampleN,
                       int i, WorkCounters &cnt) {
   ShadeOut so;
   shadeSample(sc, fr, sf, ps, p, camera, cosSampleN, i, so);
   bool shadowed;
-  walkBounce<COUNT>(sc, so.needShadow, nextBounceRuns(fr, i, p.importancyFactor, ps.originalColor), so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
+  walkBounce<COUNT, LOCK>(sc, so.needShadow, nextBounceRuns(fr, i, p.importancyFactor, ps.originalColor), so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
   bounceFinish(ps, p, so, shadowed);
   if (p.hit.triangleId == -1) return false;
   p.lastHitPoint = p.ray.origin;
   return true;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool LOCK>
 FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps, PathState &p, f3 camera, float cosSampleN, int i,
                     WorkCounters &cnt) {
   ShadeOut so;
   bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, i, so, cnt);
   bool shadowed;
-  walkBounce<COUNT>(sc, so.needShadow, nextBounceRuns(fr, i, p.importancyFactor, ps.originalColor), so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
+  walkBounce<COUNT, LOCK>(sc, so.needShadow, nextBounceRuns(fr, i, p.importancyFactor, ps.originalColor), so.shadowRay, so.shadowLen, p.ray, shadowed, p.hit, cnt);
   bounceFinish(ps, p, so, shadowed);
   if (p.hit.triangleId == -1) return false;
   p.lastHitPoint = p.ray.origin;

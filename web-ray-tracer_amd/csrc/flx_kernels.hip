@@ -9,6 +9,10 @@
 #include "flx_kernels.h"
 #include "flx_kernel_util.h"
 
+#ifndef FLX_PRIMARY_FWD
+#define FLX_PRIMARY_FWD 1                  /* primary rays: the wave steps through the forward-ordered copy together (primaryWalkF; k_primary 0.424 -> 0.391 ms) */
+#endif
+
 namespace flx {
 
 __device__ __forceinline__ void tile_pixel(const DeviceFrame &fr, uint32_t &px, uint32_t &k) {
@@ -26,27 +30,37 @@ __device__ __forceinline__ void tile_pixel(const DeviceFrame &fr, uint32_t &px, 
                                             * itself; 128 VGPRs + 376 B of scratch per lane at 4 waves is 14 % faster on the cornell.obj filter frame
                                             * (0.969 -> 0.832 ms; 5: 0.911, 6: 0.949, 8: 1.059; profiles/r02_ab_occupancy.txt) */
 #endif
-template <bool COUNT>
+template <bool COUNT, bool LOCK>
 __global__ __launch_bounds__(256, FLX_TRACE_WAVES) void k_trace_pixels(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
                                                       unsigned long long *__restrict__ counters) {
   uint32_t px, k;
   tile_pixel(fr, px, k);
   WorkCounters cnt = {};
-  if (px < fr.width && k < fr.rows) {
-    const uint32_t row = image_row(fr, k);
-    const uint32_t py_gl = fr.height - 1u - row;
-    PixelState ps;
+  const bool inImage = px < fr.width && k < fr.rows;
+  PixelState ps;
+  ps.ndc_x = ps.ndc_y = 0.0f;
+  float viewDepthPerS = 0.0f;
+  uint32_t frameIdx = 0;
+  f3 dir0 = F3(0.0f, 0.0f, 1.0f), camera = F3(0.0f, 0.0f, 0.0f);
+  if (inImage) {
+    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+    frameIdx = frame_index(fr, k);
+    dir0 = primary_dir(fr, frameIdx, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+    camera = frame_camera(fr, frameIdx);
+  }
+  Ray pr; pr.origin = camera; pr.dir = dir0;
+#if FLX_PRIMARY_FWD
+  Hit hit0 = primaryWalkF(sc, inImage, pr, viewDepthPerS, cnt.primary_visits);      /* the wave walks together: every lane goes in */
+#else
+  Hit hit0; hit0.suv = F3(0.0f, 0.0f, 0.0f); hit0.transformId = 0; hit0.triangleId = -1;
+  if (inImage) hit0 = primaryWalkT(sc, pr, viewDepthPerS, cnt.primary_visits);
+#endif
+  if (inImage) {
     ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
     ps.originalColor = F3(0.0f, 0.0f, 0.0f);
     ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
     ps.renderOriginalId = ps.renderId;
-    float viewDepthPerS;
-    const uint32_t frameIdx = frame_index(fr, k);
     ps.seed = fr.view[frameIdx].random_seed;
-    f3 dir0 = primary_dir(fr, frameIdx, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
-    const f3 camera = frame_camera(fr, frameIdx);
-    Ray pr; pr.origin = camera; pr.dir = dir0;
-    Hit hit0 = primaryWalkT(sc, pr, viewDepthPerS, cnt.primary_visits);
     const size_t o = (size_t)k * fr.width + px;
     float4 color = make_float4(0.f, 0.f, 0.f, 0.f), colorIp = color, origColor = color, rid = color, roid = color, loc = color;
     if (hit0.triangleId != -1) {
@@ -71,10 +85,10 @@ __global__ __launch_bounds__(256, FLX_TRACE_WAVES) void k_trace_pixels(DeviceSce
         bool alive = firstBounce;
         if (firstBounce) {
           if (COUNT) { cnt.shades += sfCnt.shades; cnt.atlas_texels += sfCnt.atlas_texels; }      /* counted per path, as when each path shades it */
-          alive = bounceOn<COUNT>(sc, fr, sf0, ps, p, camera, cosSampleN, 0, cnt);
+          alive = bounceOn<COUNT, LOCK>(sc, fr, sf0, ps, p, camera, cosSampleN, 0, cnt);
         }
         for (int i = 1; alive && i < fr.max_reflections && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3; i++) {
-          if (!bounce<COUNT>(sc, fr, ps, p, camera, cosSampleN, i, cnt)) break;
+          if (!bounce<COUNT, LOCK>(sc, fr, ps, p, camera, cosSampleN, i, cnt)) break;
         }
         finalColor = finalColor + (p.finalColor + p.importancyFactor * frame_ambient(fr, frameIdx));
       }
@@ -117,8 +131,14 @@ __global__ __launch_bounds__(256, FLX_TRACE_WAVES) void k_trace_pixels(DeviceSce
 void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *out, const GBufferPtrs &gb,
                          unsigned long long *counters, hipStream_t stream) {
   const uint32_t tiles = ((fr.width + 15u) >> 4) * ((fr.rows + 15u) >> 4);
-  if (counters) hipLaunchKernelGGL(k_trace_pixels<true>, dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
-  else hipLaunchKernelGGL(k_trace_pixels<false>, dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+  const bool lock = FLX_LOCKSTEP && sc.lock_entries != 0u;      /* small scene in one object space: the variant with the wave-wide walk */
+  if (lock) {
+    if (counters) hipLaunchKernelGGL((k_trace_pixels<true, true>), dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+    else hipLaunchKernelGGL((k_trace_pixels<false, true>), dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+  } else {
+    if (counters) hipLaunchKernelGGL((k_trace_pixels<true, false>), dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+    else hipLaunchKernelGGL((k_trace_pixels<false, false>), dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+  }
 }
 
 /* ---- v2: primary kernel + persistent path kernel with lane refill + resolve ---------------------- */
@@ -142,7 +162,25 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
   uint32_t px, k;
   tile8_pixel(fr, tile, threadIdx.x & 63u, px, k);
   WorkCounters cnt = {};
-  if (px < fr.width && k < fr.rows) {
+  const bool inImage = px < fr.width && k < fr.rows;
+#if FLX_PRIMARY_FWD
+  {   /* the wave walks together: every lane goes in, the ones without a pixel with no ray */
+    float nx, ny, viewDepthPerS = 0.0f;
+    Ray pr; pr.origin = F3(0.0f, 0.0f, 0.0f); pr.dir = F3(0.0f, 0.0f, 1.0f);
+    if (inImage) {
+      const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+      const uint32_t frameIdx = frame_index(fr, k);
+      pr.dir = primary_dir(fr, frameIdx, px, py_gl, nx, ny, viewDepthPerS);
+      pr.origin = frame_camera(fr, frameIdx);
+    }
+    Hit h = primaryWalkF(sc, inImage, pr, viewDepthPerS, cnt.primary_visits);
+    if (inImage) {
+      if (COUNT && h.triangleId != -1) cnt.primary_hits++;
+      hits[(size_t)k * fr.width + px] = make_float4(h.suv.x, h.suv.y, h.suv.z, __int_as_float(h.triangleId));
+    }
+  }
+#else
+  if (inImage) {
     const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
     float nx, ny, viewDepthPerS;
     Ray pr;
@@ -153,6 +191,7 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
     if (COUNT && h.triangleId != -1) cnt.primary_hits++;
     hits[(size_t)k * fr.width + px] = make_float4(h.suv.x, h.suv.y, h.suv.z, __int_as_float(h.triangleId));
   }
+#endif
   flush_counters<COUNT>(cnt, counters);
 }
 
@@ -161,7 +200,7 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
                                             * 11.74 (3) 11.37 (4) 11.14 (5) 10.50 (6) 10.25 (7) 11.04 ms (8) — the shading's latency wants waves more
                                             * than registers (profiles/r02_ab_occupancy.txt) */
 #endif
-template <bool COUNT>
+template <bool COUNT, bool LOCK>
 __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, DeviceFrame fr, const float4 *__restrict__ hits,
                                                float4 *__restrict__ sampleRadiance, float4 *__restrict__ lastOriginal,
                                                uint32_t *__restrict__ queue, uint32_t total_items,
@@ -251,7 +290,7 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
 
     /* -- one bounce for every live lane (fragment:475-596) ------------------------------------------ */
     if (alive) {
-      bool cont = bounce<COUNT>(sc, fr, ps, p, camera, cosSampleN, bounceIdx, cnt);
+      bool cont = bounce<COUNT, LOCK>(sc, fr, ps, p, camera, cosSampleN, bounceIdx, cnt);
       bounceIdx++;
       if (cont) cont = bounceIdx < fr.max_reflections && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3;
       if (!cont) { finishPath(); alive = false; }
@@ -299,8 +338,14 @@ void launch_primary(const DeviceScene &sc, const DeviceFrame &fr, float4 *hits, 
 void launch_paths(const DeviceScene &sc, const DeviceFrame &fr, const float4 *hits, float4 *sampleRadiance, float4 *lastOriginal,
                   uint32_t *queue, uint32_t blocks, unsigned long long *counters, hipStream_t stream) {
   const uint32_t total = path_item_count(fr);
-  if (counters) hipLaunchKernelGGL(k_paths<true>, dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
-  else hipLaunchKernelGGL(k_paths<false>, dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+  const bool lock = FLX_LOCKSTEP && sc.lock_entries != 0u;
+  if (lock) {
+    if (counters) hipLaunchKernelGGL((k_paths<true, true>), dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+    else hipLaunchKernelGGL((k_paths<false, true>), dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+  } else {
+    if (counters) hipLaunchKernelGGL((k_paths<true, false>), dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+    else hipLaunchKernelGGL((k_paths<false, false>), dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+  }
 }
 
 void launch_resolve(const DeviceFrame &fr, const float4 *hits, const float4 *sampleRadiance, const float4 *lastOriginal, float4 *out,
