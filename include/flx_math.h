@@ -58,6 +58,10 @@ FLX_HD float flx_sqrt(float x) { return __builtin_sqrtf(x); }   /* IEEE correctl
 
 /* floor for float without libm: exact. */
 FLX_HD float flx_floor(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_floorf(x);                              /* v_floor_f32: floor is exact, so this is the value computed below (NaN and
+                                                            * infinities returned as they are, -0 kept; kernels run with denormals on) */
+#endif
   uint32_t u = flx_f2u(x);
   int e = (int)((u >> 23) & 0xffu) - 127;
   if (e >= 23) return x;                       /* integral, inf or nan */
@@ -143,6 +147,9 @@ FLX_HD int flx_rem_pio2(float x, double *r, int *ok) {
   double kd = flx_floord(xd * INV_PIO2 + 0.5);
   *r = (xd - kd * PIO2_HI) - kd * PIO2_LO;
   *ok = 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)kd & 3;                                      /* |kd| < 2^20: the two low bits of the 32-bit conversion (one instruction) are those of the 64-bit one */
+#endif
   return (int)((long long)kd & 3ll);
 }
 FLX_HD float flx_sin(float x) {

@@ -25,8 +25,10 @@ def _inputs(fn, rng, n):
         a = rng.uniform(0, 8, n)
     elif fn == 7:
         a = rng.uniform(-25, 25, n)
-    elif fn == 8:
-        a = rng.uniform(-1e7, 1e7, n)
+    elif fn == 8:       # floor: wide range, around zero, integers and their neighbours, the 2^23 / 2^24 edges, denormals
+        k = rng.integers(-2 ** 24 - 4, 2 ** 24 + 4, n // 8).astype(np.float32)
+        a = np.concatenate([rng.uniform(-1e7, 1e7, n // 2), rng.uniform(-2, 2, n // 4), k, np.nextafter(k, np.float32(np.inf)),
+                            np.nextafter(k, np.float32(-np.inf)), rng.uniform(-1e-39, 1e-39, 64), rng.uniform(-3e9, 3e9, 64)])
     else:
         a = rng.uniform(0, 1e6, n)
     a = np.concatenate([a.astype(np.float32), special])
