@@ -211,17 +211,39 @@ __global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex t
     count = 1.0f;
   } else {
     const float k = 1.0f + unorm8(rawW(rCenterOColor));
-    for (int i = 0; i < 37; i++) {
-      const int cx = x + (int)(STENCIL3_37[i][0] * k * k * 3.5f);
-      const int cy = y + (int)(STENCIL3_37[i][1] * k * k * 3.5f);
-      const uint32_t id = fetchRaw(tId, W, H, cx, cy);
-      const uint32_t originalId = fetchRaw(tOId, W, H, cx, cy);
-      const int idW = (int)rawW(id);
-      const int lightNum = idW / 2;
-      const int shadow = idW % 2;
-      if (rawEq3(rCenterId, id) && rCenterOId == originalId && (centerLightNum != lightNum || centerShadow == shadow)) {
-        const f4 nextColor = unpack(fetchRaw(tColor, W, H, cx, cy));
-        const f4 nextColorIp = unpack(fetchRaw(tIp, W, H, cx, cy));
+    /* The 37 taps reach up to 42 texels from the centre — too far for an LDS tile — and each is two gathers, a decision, two more
+     * gathers.  Taken one tap after the other that is 37 round trips to L2 per texel; the taps do not depend on each other, so they
+     * go eight at a time: the sixteen id gathers in flight together, then the colours of the taps that passed (a tap that did
+     * not re-reads the centre texel: its value is not used), then the sums in tap order as the shader adds them.
+     * fetchRaw()'s "0 outside the image or from an unbound plane" as arithmetic, so that every load is unconditional: */
+    const size_t centre = (size_t)(H - 1 - y) * W + x;
+    const uint32_t *pId = tId.p ? tId.p : tColor.p, *pOId = tOId.p ? tOId.p : tColor.p, *pIp = tIp.p ? tIp.p : tColor.p;      /* (tColor is always bound) */
+    const uint32_t mId = tId.p ? ~0u : 0u, mOId = tOId.p ? ~0u : 0u, mIp = tIp.p ? ~0u : 0u;
+    constexpr int CH = 8;
+    for (int base = 0; base < 37; base += CH) {
+      size_t at[CH]; bool in[CH], pass[CH];
+      uint32_t id[CH], oid[CH], rc[CH], rip[CH];
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const int i = base + j < 37 ? base + j : 36;
+        const int cx = x + (int)(STENCIL3_37[i][0] * k * k * 3.5f);
+        const int cy = y + (int)(STENCIL3_37[i][1] * k * k * 3.5f);
+        in[j] = base + j < 37 && cx >= 0 && cy >= 0 && cx < W && cy < H;
+        at[j] = in[j] ? (size_t)(H - 1 - cy) * W + cx : centre;
+        id[j] = pId[at[j]]; oid[j] = pOId[at[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; j++) {
+        const uint32_t idj = in[j] ? id[j] & mId : 0u, oidj = in[j] ? oid[j] & mOId : 0u;
+        const int idW = (int)rawW(idj);
+        pass[j] = base + j < 37 && rawEq3(rCenterId, idj) && rCenterOId == oidj && (centerLightNum != idW / 2 || centerShadow == idW % 2);
+        const size_t a = pass[j] ? at[j] : centre;
+        rc[j] = tColor.p[a]; rip[j] = pIp[a];
+      }
+#pragma unroll
+      for (int j = 0; j < CH; j++) if (pass[j]) {
+        const f4 nextColor = unpack(in[j] ? rc[j] : 0u);
+        const f4 nextColorIp = unpack(in[j] ? rip[j] & mIp : 0u);
         color = add4(color, add4(nextColor, scale4(nextColorIp, 256.0f)));
         count += 1.0f;
       }
