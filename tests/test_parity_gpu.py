@@ -316,12 +316,17 @@ FILTER_CASES = [
     ("cornell_obj", 320, 180, 4, 3),      # BASELINE config 2 at reduced size
     ("cornell", 160, 120, 2, 3),          # textured PBR material, translucency flags off
     ("dragon", 240, 136, 2, 4),           # translucent dragon + sphere: glassFilter / vote branch of the first filter
+    ("dragon", 130, 75, 8, 5),            # eight samples, a ragged frame, glass paths of several unfiltered bounces
     ("theater", 200, 112, 1, 3),
+    ("theater", 96, 54, 16, 6),           # BASELINE config 5's samples and bounces with the filter on
+    ("cornell_obj", 100, 60, 3, 3),
+    ("cornell", 64, 40, 6, 2),
 ]
 
 
 @pytest.mark.parametrize("name,w,h,spp,bounces", FILTER_CASES)
 def test_filter_chain_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounces):
+    """filter frames: trace with G-buffers + the denoise chain"""
     sc = scenes(name)
     p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=1)
     hip.update_scene(sc)
