@@ -210,6 +210,9 @@ FLX_DEV f4 noise(float random_seed, float nx, float ny, float seed) {
 /* vote of the wave: the builtin takes the condition as it is (HIP's flx_ballot(int) first materialises it as 0 / 1 and compares
  * again: two VALU instructions per vote, and the walk kernel votes several times per entry) */
 FLX_DEV unsigned long long flx_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+/* value of `v` in lane `p` (p uniform) */
+FLX_DEV float laneF(float v, uint32_t p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)p)); }
+FLX_DEV int laneI(int v, uint32_t p) { return __builtin_amdgcn_readlane(v, (int)p); }
 
 /* RN(1 / d) without the division: v_rcp_f32 and ONE FMA correction give exactly the bits of 1.0f / d for every float with
  * 2^-60 <= |d| <= 2^60 (tools/micro/rcp_exact.hip walks all 2^32 bit patterns on the MI355X: 0 differences in that range; the
@@ -891,7 +894,9 @@ FLX_DEV Hit primaryWalkF(const DeviceScene &sc, bool active, const Ray &ray, flo
   /* The lanes on their own, over the same array.  What is left are the long walks: a ray that grazes the dragon visits several
    * hundred entries (tests/analysis/primary_union.py: the longest ray of a tile visits 7 entries at the median, 257 at the 99th
    * percentile, 477 at most).  Fetching both possible successors of an entry while it is tested (FLX_PRIMARY_PREFETCH) does not
-   * shorten them — measured, like the same idea in the bounce walks (profiles/r01_ab_tail_prefetch.txt). */
+   * shorten them — measured, like the same idea in the bounce walks (profiles/r01_ab_tail_prefetch.txt) — and neither does
+   * finishing the last walks of a wave with the whole wave, 64 consecutive entries tested per step (profiles/r02_ab_lockstep.txt):
+   * the long rays of a tile are most of its rays, not a few stragglers. */
 #if FLX_PRIMARY_PREFETCH
   if (nxt != WALK_END) {
     size_t i = (size_t)nxt * 3u;

@@ -32,9 +32,6 @@ __device__ __forceinline__ void finalize_path(const DeviceFrame &fr, const Wavef
 }
 
 
-/* value of `v` in lane `p` (p uniform) */
-FLX_DEV float laneF(float v, uint32_t p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)p)); }
-FLX_DEV int laneI(int v, uint32_t p) { return __builtin_amdgcn_readlane(v, (int)p); }
 /* flx_walkcoop.hip */
 void launch_walk_coop(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count, int b,
                       hipStream_t stream);
