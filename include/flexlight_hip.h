@@ -250,8 +250,9 @@ flx_status flx_present_device(flx_context *ctx, uint32_t width, uint32_t height,
 flx_status flx_present(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, uint8_t *out_rgba8);
 
 /* Kernel organisation of the path-trace pass.  0 = automatic: the sample-sequential per-pixel kernel when use_filter /
- * is_temporal need the cross-sample G-buffer state, else the persistent path kernel for scenes of up to 128 entries (in frames of at
- * least 2^20 paths) and the wavefront pipeline for everything else; 1 = per-pixel kernel, 2 = persistent path kernel, 3 = wavefront pipeline.
+ * is_temporal need the cross-sample G-buffer state; for scenes of up to 128 entries the per-pixel kernel too, or — from 32 bounce
+ * iterations per pixel (4 with four or more lights) in frames of at least 2^20 paths — the persistent path kernel; the wavefront
+ * pipeline for everything larger; 1 = per-pixel kernel, 2 = persistent path kernel, 3 = wavefront pipeline.
  * Results are identical; the explicit values are for A/B timing and tests.  flx_last_pipeline: what the last frame ran. */
 flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
 flx_status flx_last_pipeline(flx_context *ctx, int *pipeline);

@@ -449,7 +449,20 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
   /* automatic: tiny scenes (a Cornell box, the theater: a few dozen entries) spend the wavefront pipeline's time on its 128-byte
    * path records, not on walks — the persistent path kernel, which keeps a path in registers from bounce to bounce, is faster
    * there (tools/pipeline_crossover.py: 48 entries 1.96 vs 2.41 ms, 329 entries 4.03 vs 2.85 ms) */
-  if (pipeline == 0) pipeline = (fr.use_filter || fr.is_temporal) ? 1 : ((ctx->walk_entries <= 128u && path_item_count64(fr) >= (1u << 20)) ? 2 : 3);       /* (a 256 x 256 frame does not fill the persistent grid) */
+  if (pipeline == 0) {
+    if (fr.use_filter || fr.is_temporal) pipeline = 1;
+    else if (ctx->walk_entries <= 128u) {
+      /* Small scenes (profiles/r02_ab_lockstep.txt, 6.): the per-pixel kernel — primary hit, surface and samples in one thread —
+       * is the fastest while a pixel's thread is short (cornell 256 x 256 1 spp 1 bounce 0.057 ms against 0.144 wavefront and 0.220
+       * persistent; cornell.obj 1080p 4 spp 3 bounces 0.65 against 1.09); the persistent path kernel, which refills the lanes of
+       * dead paths, overtakes it at 32 bounce iterations per pixel (cornell.obj 8 x 6: 1.49 against 1.66 ms), with many lights
+       * to shade per bounce from 4 on (theater 4 spp 3 bounces: 3.08 against 4.19 ms).  (A frame of fewer than 2^20 paths does
+       * not fill the persistent grid.) */
+      const uint64_t work = (uint64_t)fr.samples * (uint64_t)(fr.max_reflections > 0 ? fr.max_reflections : 1);
+      const bool persistent = path_item_count64(fr) >= (1u << 20) && (work >= 32u || (ctx->n_lights >= 4u && work >= 4u));
+      pipeline = persistent ? 2 : 1;
+    } else pipeline = 3;
+  }
   if (pipeline == 3 && fr.max_reflections > WF_MAX_BOUNCES) pipeline = 2;
   ctx->last_pipeline = pipeline;
   if (pipeline != 1 && (fr.use_filter || fr.is_temporal)) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the G-buffers of filter / temporal frames");
