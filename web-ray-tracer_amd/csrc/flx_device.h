@@ -222,10 +222,22 @@ FLX_DEV float recipFast(float d) {
   const float y = __builtin_amdgcn_rcpf(d);
   return __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
 }
+#ifndef FLX_BRANCH_HINTS
+#define FLX_BRANCH_HINTS 1      /* the rare sides of three branches of the stepping loop (IEEE-division fallbacks of 1/det and of the box test, a
+                                 * change of object space) laid out of line: dragon 8.07 -> 7.95 ms; hints on the walk's end, on triangle hits
+                                 * and on the box test's slow path measured slower again (8.02) — profiles/r02_ab_walk_kernel.txt */
+#endif
+#if FLX_BRANCH_HINTS
+#define FLX_LIKELY(x) __builtin_expect(!!(x), 1)
+#define FLX_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define FLX_LIKELY(x) (x)
+#define FLX_UNLIKELY(x) (x)
+#endif
 FLX_DEV float recipOf(float d, bool needed) {
   const float a = flx_abs(d);
   const bool ok = !needed || (a >= 8.673617379884035e-19f && a <= 1.152921504606847e18f);      /* 2^-60, 2^60; NaN is not ok */
-  if (flx_ballot(!ok) == 0ull) return recipFast(d);
+  if (FLX_LIKELY(flx_ballot(!ok) == 0ull)) return recipFast(d);
   return 1.0f / d;
 }
 
@@ -770,7 +782,7 @@ FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCor
   const bool aOk = m >= (0x2b800000u << 1) - 2u;
   f3 v0, v1;
   float tmin, tmax;
-  if (w.fastDiv && aOk) {
+  if ((w.fastDiv && aOk)) {
     v0 = F3(divByRecip(a0.x, d.x, y.x), divByRecip(a0.y, d.y, y.y), divByRecip(a0.z, d.z, y.z));
     v1 = F3(divByRecip(a1.x, d.x, y.x), divByRecip(a1.y, d.y, y.y), divByRecip(a1.z, d.z, y.z));
     /* all six quotients are finite here, so GLSL min/max ((y < x) ? y : x) and the hardware's v_min/v_max agree except
@@ -987,7 +999,7 @@ FLX_DEV bool walkTriT(WalkState &w, const WalkEntry &cur) {
   const bool cull = w.mode == 0;
   const bool hit = moellerTrumboreAny(a, edge1, edge2, w.tR, w.minLen, cull, suv);
   bool ended = false;
-  if (hit) {
+  if ((hit)) {
     if (cull) { w.shadowed = true; ended = true; }
     else if (suv.x != 0.0f) {                        /* fragment:217 */
       w.suv = suv; w.hitTI = (__float_as_int(cur.e2.z) >> 2) << 1; w.tri = __float_as_int(cur.e2.w);
@@ -1051,7 +1063,7 @@ FLX_DEV void walkLoadRay(const float2 *raysGeneric, int t, WalkState &w) {
 template <bool COUNT>
 FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float2 *rays, WalkState &w, WalkEntry &cur,
                         WorkCounters &cnt) {
-  if ((uint32_t)w.i == WALK_END) return true;
+  if (((uint32_t)w.i == WALK_END)) return true;
   const uint32_t i = linkIndex((uint32_t)w.i);
 #if FLX_WF_FLAT_FETCH
   {   /* one instruction stream for both homes of an entry: a generic pointer into LDS or into the global copy (flat_load) */
@@ -1065,7 +1077,7 @@ FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
   const int meta = __float_as_int(cur.e2.z);
   const int tI = (meta >> 2) << 1;
-  if (tI != w.cachedTI) {
+  if (FLX_UNLIKELY(tI != w.cachedTI)) {
     w.cachedTI = tI;
     walkLoadRay(rays, tI >> 1, w);
   }
@@ -1140,7 +1152,7 @@ FLX_DEV bool rayCuboidFast(float l, const WalkState &w, f3 lo, f3 hi) {
 #if FLX_WF_BOX_INTERVAL
   bool sure;
   bool hit = rayCuboidInterval(l, w, lo, hi, sure);
-  if (flx_ballot(!sure) != 0ull) {                         /* rare */
+  if (FLX_UNLIKELY(flx_ballot(!sure) != 0ull)) {                         /* rare */
     if (!sure) hit = rayCuboidRecip(l, w, lo, hi);
   }
   return hit;
