@@ -638,6 +638,18 @@ static flx_status run_post_frame(flx_context *ctx, const DeviceScene &sc, const 
     }
   }
   GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5] };
+  if (filter && !temporal && !ctx->gb_float_wanted) {
+    /* nobody reads the float G-buffers of this frame (flx_render was not given `gbuffers`): the trace kernel stores the five render
+     * targets as RGBA8 itself — the values k_quantize would store — instead of 80 bytes per pixel written, read back and
+     * quantised by five more launches */
+    GBufferPtrs q = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    q.q_color = pl.R[0]; q.q_color_ip = pl.Ip[0]; q.q_original_color = pl.O[0]; q.q_id = pl.Id[0]; q.q_original_id = pl.OId;
+    if ((s = flx_run_frame(ctx, sc, fr, nullptr, q))) return s;
+    launch_filter_chain(pl, d_out, (int)fr.width, (int)fr.height, p->hdr, ctx->stream);
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+    return FLX_OK;
+  }
   if ((s = flx_run_frame(ctx, sc, fr, nullptr, gb))) return s;
   launch_quantize(gb.color, pl.R[0], pixels, ctx->stream);
   launch_quantize(gb.color_ip, pl.Ip[0], pixels, ctx->stream);
@@ -868,10 +880,10 @@ flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint
 
 static flx_status ensure_post_buffers(flx_context *ctx, size_t pixels, bool gbuffers, bool planes);
 
-/* A batch of filter frames: ONE trace pass over the stacked frames into the float G-buffers (the per-pixel kernel: the G-buffer
- * accumulators carry state from sample to sample), then per frame the stores to the RGBA8 render targets and the denoise chain —
- * which starts from the reference's frame-0 texture state every time (launch_filter_chain), so the frames of a batch do not
- * depend on each other.  Each frame equals its own flx_render bit for bit. */
+/* A batch of filter frames: ONE trace pass over the stacked frames into the RGBA8 render targets (the per-pixel kernel: the G-buffer
+ * accumulators carry state from sample to sample), then per frame the denoise chain — which starts from the reference's frame-0
+ * texture state every time (launch_filter_chain), so the frames of a batch do not depend on each other.  Each frame equals its
+ * own flx_render bit for bit. */
 static flx_status run_filter_batch(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, const flx_frame_params *params, float4 *d_out) {
   const size_t per = (size_t)fr.frame_rows * fr.width, pixels = per * fr.frames;
   flx_status s;
@@ -880,16 +892,17 @@ static flx_status run_filter_batch(flx_context *ctx, const DeviceScene &sc, cons
   FilterPlanes pl;
   for (int i = 0; i < 4; i++) { pl.R[i] = ctx->d_planes[i]; pl.Ip[i] = ctx->d_planes[4 + i]; }
   pl.O[0] = ctx->d_planes[8]; pl.O[1] = ctx->d_planes[9]; pl.Id[0] = ctx->d_planes[10]; pl.Id[1] = ctx->d_planes[11]; pl.OId = ctx->d_planes[12];
-  GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4], nullptr };
-  if ((s = flx_run_frame(ctx, sc, fr, nullptr, gb))) return s;
+  /* the trace kernel stores the five render targets of every frame as RGBA8 itself (run_post_frame), stacked frame after frame
+   * in the memory of the float G-buffers nobody reads here; each frame's chain starts from its own slices */
+  GBufferPtrs q = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  q.q_color = (uint32_t *)ctx->d_gb[0]; q.q_color_ip = (uint32_t *)ctx->d_gb[1]; q.q_original_color = (uint32_t *)ctx->d_gb[2];
+  q.q_id = (uint32_t *)ctx->d_gb[3]; q.q_original_id = (uint32_t *)ctx->d_gb[4];
+  if ((s = flx_run_frame(ctx, sc, fr, nullptr, q))) return s;
   for (uint32_t f = 0; f < fr.frames; f++) {
     const size_t o = (size_t)f * per;
-    launch_quantize(gb.color + o, pl.R[0], per, ctx->stream);
-    launch_quantize(gb.color_ip + o, pl.Ip[0], per, ctx->stream);
-    launch_quantize(gb.original_color + o, pl.O[0], per, ctx->stream);
-    launch_quantize(gb.id + o, pl.Id[0], per, ctx->stream);
-    launch_quantize(gb.original_id + o, pl.OId, per, ctx->stream);
-    launch_filter_chain(pl, d_out + o, (int)fr.width, (int)fr.height, params->hdr, ctx->stream);
+    FilterPlanes plf = pl;
+    plf.R[0] = q.q_color + o; plf.Ip[0] = q.q_color_ip + o; plf.O[0] = q.q_original_color + o; plf.Id[0] = q.q_id + o; plf.OId = q.q_original_id + o;
+    launch_filter_chain(plf, d_out + o, (int)fr.width, (int)fr.height, params->hdr, ctx->stream);
   }
   FLX_HIP(ctx, hipGetLastError());
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
@@ -974,13 +987,12 @@ extern "C" flx_status flx_render_planes_device(flx_context *ctx, const flx_frame
   if (s) return s;
   const size_t pixels = (size_t)fr.rows * fr.width;
   if (pixels == 0) return empty_share(ctx);
-  if ((s = ensure_post_buffers(ctx, pixels, true, false))) return s;
-  GBufferPtrs gb = { ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2], ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5] };
-  if ((s = flx_run_frame(ctx, sc, fr, nullptr, gb))) return s;
-  /* the reference's five render targets, stored as it stores them (RGBA8), strips packed like the radiance of a tiled frame */
+  /* the reference's five render targets, stored as it stores them (RGBA8) by the trace kernel itself, strips packed like the
+   * radiance of a tiled frame */
   uint32_t *out = (uint32_t *)d_planes;
-  const float4 *src[5] = { gb.color, gb.color_ip, gb.original_color, gb.id, gb.original_id };
-  for (int k = 0; k < 5; k++) launch_quantize(src[k], out + (size_t)k * pixels, pixels, ctx->stream);
+  GBufferPtrs q = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+  q.q_color = out; q.q_color_ip = out + pixels; q.q_original_color = out + 2 * pixels; q.q_id = out + 3 * pixels; q.q_original_id = out + 4 * pixels;
+  if ((s = flx_run_frame(ctx, sc, fr, nullptr, q))) return s;
   FLX_HIP(ctx, hipGetLastError());
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
   return FLX_OK;
@@ -1027,7 +1039,9 @@ extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *param
   const bool saved = ctx->counters_enabled;
   if (counters) ctx->counters_enabled = true;
   if (params->use_filter || params->is_temporal) {
+    ctx->gb_float_wanted = gbuffers != nullptr;
     s = run_post_frame(ctx, sc, fr, params, ctx->d_out);
+    ctx->gb_float_wanted = false;
   } else {
     GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
     s = flx_run_frame(ctx, sc, fr, ctx->d_out, gb);

@@ -37,6 +37,7 @@ struct flx_context {
   uint32_t fwd_entries = 0, fwd_root = 0, lock_boxes = 0;
   bool lock_ok = false;                          /* the scene is small and in one object space: its bounce walks may go in lockstep */
   bool lock_use = true;                          /* flx_set_lockstep */
+  bool gb_float_wanted = false;                  /* flx_render was given `gbuffers`: the filter frame keeps its float G-buffers */
   int walk_scheduler = 0;
   int32_t *d_ids = nullptr;
   float *d_lights = nullptr;

@@ -13,6 +13,7 @@
  * same cache lines.  Threads are mapped 16x16 to keep a workgroup's taps together.
  */
 #include "flx_kernels.h"
+#include "flx_kernel_util.h"
 
 namespace flx {
 
@@ -66,12 +67,8 @@ __device__ __forceinline__ uint32_t fetchTile(const uint32_t *lds, int H, TileOr
   return lds[((H - 1 - y_gl) - o.row0 + FILTER_HALO) * FILTER_TW + (x - o.x0 + FILTER_HALO)];
 }
 
-__device__ __forceinline__ uint32_t quant(float x) {
-  if (!(x > 0.0f)) return 0u;
-  if (x >= 1.0f) return 255u;
-  return (uint32_t)(x * 255.0f + 0.5f);
-}
-__device__ __forceinline__ uint32_t pack(f4 v) { return quant(v.x) | (quant(v.y) << 8) | (quant(v.z) << 16) | (quant(v.w) << 24); }
+__device__ __forceinline__ uint32_t quant(float x) { return quant_unorm8(x); }                  /* flx_kernel_util.h */
+__device__ __forceinline__ uint32_t pack(f4 v) { return pack_rgba8(v.x, v.y, v.z, v.w); }
 
 __device__ const float STENCIL3_37[37][2] = {
                               {-3, -1}, {-3, 0}, {-3, 1},

@@ -6,6 +6,16 @@
 
 namespace flx {
 
+/* A float channel as an RGBA8 render target stores it (modules/pathtracerWGL2.js:790-799): floor(clamp(x, 0, 1) * 255 + 0.5), NaN -> 0 */
+__device__ __forceinline__ uint32_t quant_unorm8(float x) {
+  if (!(x > 0.0f)) return 0u;
+  if (x >= 1.0f) return 255u;
+  return (uint32_t)(x * 255.0f + 0.5f);
+}
+__device__ __forceinline__ uint32_t pack_rgba8(float x, float y, float z, float w) {
+  return quant_unorm8(x) | (quant_unorm8(y) << 8) | (quant_unorm8(z) << 16) | (quant_unorm8(w) << 24);
+}
+
 /* 8x8 pixel tile `tile` (row-major over the context's W x rows image), lane -> pixel. */
 __device__ __forceinline__ void tile8_pixel(const DeviceFrame &fr, uint32_t tile, uint32_t lane, uint32_t &px, uint32_t &k) {
   const uint32_t tiles_x = (fr.width + 7u) >> 3;

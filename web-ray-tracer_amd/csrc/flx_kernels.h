@@ -6,7 +6,11 @@
 
 namespace flx {
 
-struct GBufferPtrs { float4 *color, *color_ip, *original_color, *id, *original_id, *location_id; };
+struct GBufferPtrs {
+  float4 *color, *color_ip, *original_color, *id, *original_id, *location_id;
+  /* the same five planes as the RGBA8 render targets the filter chain reads (stored as k_quantize would store them), or null */
+  uint32_t *q_color = nullptr, *q_color_ip = nullptr, *q_original_color = nullptr, *q_id = nullptr, *q_original_id = nullptr;
+};
 
 /* counters: 8 x u64 in flx_counters order, or nullptr (no counting code is compiled in). */
 void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *out, const GBufferPtrs &gb,

@@ -128,6 +128,12 @@ __global__ __launch_bounds__(256, FLX_TRACE_WAVES) void k_trace_pixels(DeviceSce
     if (gb.id) gb.id[o] = rid;
     if (gb.original_id) gb.original_id[o] = roid;
     if (gb.location_id) gb.location_id[o] = loc;
+    /* filter frames nobody asked the float G-buffers of: straight into the chain's RGBA8 render targets */
+    if (gb.q_color) gb.q_color[o] = pack_rgba8(color.x, color.y, color.z, color.w);
+    if (gb.q_color_ip) gb.q_color_ip[o] = pack_rgba8(colorIp.x, colorIp.y, colorIp.z, colorIp.w);
+    if (gb.q_original_color) gb.q_original_color[o] = pack_rgba8(origColor.x, origColor.y, origColor.z, origColor.w);
+    if (gb.q_id) gb.q_id[o] = pack_rgba8(rid.x, rid.y, rid.z, rid.w);
+    if (gb.q_original_id) gb.q_original_id[o] = pack_rgba8(roid.x, roid.y, roid.z, roid.w);
   }
   flush_counters<COUNT>(cnt, counters);
 }
