@@ -34,8 +34,12 @@ __device__ __forceinline__ void tile_pixel(const DeviceFrame &fr, uint32_t &px, 
                                             * itself; 128 VGPRs + 376 B of scratch per lane at 4 waves is 14 % faster on the cornell.obj filter frame
                                             * (0.969 -> 0.832 ms; 5: 0.911, 6: 0.949, 8: 1.059; profiles/r02_ab_occupancy.txt) */
 #endif
+#ifndef FLX_TRACE_WAVES_BIG
+#define FLX_TRACE_WAVES_BIG 6              /* the variant for scenes without the lockstep copy (the lane walk over the threaded copy): the dragon's
+                                            * 1080p 8 spp 4 bounces filter frame 15.26 (4) 14.24 (5) 13.68 ms (6) */
+#endif
 template <bool COUNT, bool LOCK>
-__global__ __launch_bounds__(256, FLX_TRACE_WAVES) void k_trace_pixels(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
+__global__ __launch_bounds__(256, LOCK ? FLX_TRACE_WAVES : FLX_TRACE_WAVES_BIG) void k_trace_pixels(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
                                                       unsigned long long *__restrict__ counters) {
   uint32_t px, k;
   tile_pixel(fr, px, k);
