@@ -10,10 +10,12 @@ F frames) is reported beside it as `batched`, with a different camera for every 
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload dragon|dragon_100k|dragon_4k|cornell_obj|cornell|theater]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
-environment; torch.distributed (gloo) only hands the RCCL communicator id to the ranks and provides the barrier).  The frame
-is cut into strips of --tile-rows image rows dealt round robin to the ranks: total work is fixed as N grows
--> "scaling": "strong".
+N > 1: one rank per GPU.  Under torch.distributed.run the ranks are there already (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from
+the environment); started plainly — `python bench.py --gpus 8` — this process launches the N ranks itself as child processes
+(before it touches a GPU: it never does) and relays rank 0's line.  torch.distributed (gloo) only hands the RCCL communicator
+id to the ranks and provides the barrier.  The frame is cut into strips of --tile-rows image rows dealt round robin to the
+ranks: total work is fixed as N grows -> "scaling": "strong".  The gathered frame is verified against one
+context's frame (bit for bit) and the line says how it was exchanged and over how many RCCL ranks.
 
 Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of a frame — the walk kernel of bounce 0 — by the
 limit that binds it: VALU issue (wave-instructions per second against 256 CUs x 4 SIMDs x 1/2 per cycle x 2.4 GHz), from
@@ -27,6 +29,8 @@ import glob
 import json
 import os
 import shutil
+import signal
+import socket
 import subprocess
 import sys
 import tempfile
@@ -66,50 +70,136 @@ def algorithmic_bytes(cnt, n_lights, pixels, use_filter):
     return b
 
 
-def collect_pmc(args):
-    """rocprofv3 --pmc passes over tools/pmc_pass.py (the same workload, one frame per launch, through the same library),
-    run as child processes BEFORE this process initialises the GPU.  Returns {kernel name: {counter: mean per dispatch}},
-    plus "_meta"; {} with a reason when rocprofv3 is missing or a pass fails (the bench line then carries nulls)."""
+def _run_group(cmd, cwd, env, timeout):
+    """run a child in its own process group; on timeout the WHOLE group is killed and waited for (rocprofv3's grandchild would
+    otherwise keep running on the GPU beside the timed region).  -> (returncode or None on timeout, stderr tail)"""
+    p = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+    try:
+        _, err = p.communicate(timeout=timeout)
+        return p.returncode, err.decode(errors="replace")[-300:]
+    except subprocess.TimeoutExpired:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                p.communicate(timeout=20)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        if p.poll() is None:
+            raise SystemExit("bench.py: a rocprofv3 pass hung and did not die when killed; not touching the GPU after it")
+        return None, "timed out after %d s (process group killed)" % timeout
+
+
+def collect_pmc(args, tile=None):
+    """rocprofv3 --pmc passes over tools/pmc_pass.py (the same workload — a rank's strips of it when `tile` = (rows, index, count) —
+    one frame per launch, through the same library) plus one --kernel-trace --stats pass for the kernels' average durations, run as
+    child processes BEFORE this process initialises the GPU.  Returns {kernel name: {counter: mean per dispatch}}, plus "_meta";
+    {} with a reason when rocprofv3 is missing or a pass fails (the bench line then carries nulls)."""
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not exe:
         return {"_meta": {"error": "rocprofv3 not found"}}
     acc, commands = {}, []
     work = tempfile.mkdtemp(prefix="flx_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):          # the profiled child is a plain one-GPU program
+        env.pop(k, None)
+    child = ["--workload", args.workload, "--frames", "3"]
+    if args.width:
+        child += ["--width", str(args.width)]
+    if args.height:
+        child += ["--height", str(args.height)]
+    if tile:
+        child += ["--tile-rows", str(tile[0]), "--tile-index", str(tile[1]), "--tile-count", str(tile[2])]
+
+    def clean(name):
+        return name.split("(")[0].replace("void ", "").replace("flx::", "").strip()
     try:
-        for i, counters in enumerate(PMC_PASSES):
+        passes = [list(c) for c in PMC_PASSES]
+        i = 0
+        while i < len(passes):
+            counters = passes[i]
             out = os.path.join(work, "p%d" % i)
-            child = ["--workload", args.workload, "--frames", "3"]
-            if args.width:
-                child += ["--width", str(args.width)]
-            if args.height:
-                child += ["--height", str(args.height)]
+            shutil.rmtree(out, ignore_errors=True)
             cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_pass.py")] + child
-            commands.append("rocprofv3 --pmc %s --output-format csv -d <dir> -- python3 tools/pmc_pass.py %s" % (" ".join(counters), " ".join(child)))
-            try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, timeout=420, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            except subprocess.TimeoutExpired:
-                return {"_meta": {"error": "pmc pass %d timed out" % i, "commands": commands}}
+            line = "rocprofv3 --pmc %s --output-format csv -d <dir> -- python3 tools/pmc_pass.py %s" % (" ".join(counters), " ".join(child))
+            rc, err = _run_group(cmd, "/tmp", env, 420)
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                if i == 0 and "SQ_THREAD_CYCLES_VALU" in counters:       # a counter this rocprofv3 does not know: retry the pass without it
-                    PMC_PASSES[0] = [c for c in counters if c != "SQ_THREAD_CYCLES_VALU"]
-                    return collect_pmc(args)
-                return {"_meta": {"error": "pmc pass %d failed (rc %d): %s" % (i, r.returncode, r.stderr.decode(errors="replace")[-300:]), "commands": commands}}
+            if rc != 0 or not files:
+                if i == 0 and "SQ_THREAD_CYCLES_VALU" in counters:       # a counter this rocprofv3 does not know: the pass once more without it
+                    passes[0] = [c for c in counters if c != "SQ_THREAD_CYCLES_VALU"]
+                    continue
+                commands.append(line)
+                return {"_meta": {"error": "pmc pass %d failed (rc %s): %s" % (i, rc, err), "commands": commands}}
+            commands.append(line)
             per = {}
             for path in files:
                 with open(path) as fh:
                     for row in csv.DictReader(fh):
-                        name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("flx::", "").strip()
-                        per.setdefault(name, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+                        per.setdefault(clean(row["Kernel_Name"]), {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
             for name, ctrs in per.items():
                 for c, v in ctrs.items():
                     acc.setdefault(name, {})[c] = sum(v) / len(v)
                     acc[name]["dispatches"] = len(v)
+            i += 1
+        # the kernels' average durations as rocprofv3's kernel trace sees them (beside the HIP-event time of the timed run)
+        out = os.path.join(work, "kt")
+        kt_child = [c if c != "3" else "10" for c in child]
+        cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_pass.py")] + kt_child
+        rc, err = _run_group(cmd, "/tmp", env, 420)
+        files = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
+        if rc == 0 and files:
+            commands.append("rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python3 tools/pmc_pass.py %s" % " ".join(kt_child))
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    acc.setdefault(clean(row["Name"]), {})["kernel_trace_avg_ms"] = float(row["AverageNs"]) / 1e6
     finally:
         shutil.rmtree(work, ignore_errors=True)
-    acc["_meta"] = {"commands": commands, "collected": "by this bench.py run, before its timed region, one frame per launch"}
+    acc["_meta"] = {"commands": commands, "collected": "by this bench.py run, before its timed region, one frame per launch" + (" (rank 0's strips: tile %s)" % (tile,) if tile else "")}
     return acc
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without torch.distributed.run around it: this process — which never touches a GPU — runs rank 0's
+    counter passes, then starts the N ranks as fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays
+    rank 0's JSON line and exits with the worst exit code."""
+    n = args.gpus
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env0 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n), FLX_BENCH_SELF_LAUNCHED="1")
+    pmc_file = None
+    if not args.no_pmc:
+        pmc = collect_pmc(args, tile=(args.tile_rows, 0, n))
+        fd, pmc_file = tempfile.mkstemp(prefix="flx_pmc_", suffix=".json", dir="/tmp")
+        with os.fdopen(fd, "w") as fh:
+            json.dump(pmc, fh)
+        env0["FLX_BENCH_PMC_JSON"] = pmc_file
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+        out, _ = procs[0].communicate()
+        rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        if pmc_file:
+            try:
+                os.unlink(pmc_file)
+            except OSError:
+                pass
+    sys.stdout.write(out.decode(errors="replace"))
+    sys.stdout.flush()
+    worst = max((abs(rc) for rc in rcs), default=0)
+    if worst:
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+    raise SystemExit(1 if worst else 0)
 
 
 def usable_cores():
@@ -198,24 +288,30 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.achieved / traffic are then null)")
     ap.add_argument("--one-device", action="store_true", help="rehearsal of the rank logic on a one-GPU box: every rank uses GPU 0 and the strips are gathered with torch.distributed (gloo) instead of RCCL, which refuses two ranks on one device")
-    ap.add_argument("--verify", action="store_true", help="after the run, rank 0 renders the whole frame on its own and compares the gathered frame with it (bit for bit)")
+    ap.add_argument("--verify", action="store_true", help="rank 0 renders the whole frame on its own after the run and compares the gathered frame with it, bit for bit (the default for N > 1)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: root = only rank 0, which presents the frame, receives the strips (ncclSend / ncclRecv; the reference presents from its one context); all = ncclAllGather, every rank ends up with the frame")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                   # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     # FLX_BENCH_FORCE_DIST=1 with one rank: the N > 1 code path — gloo bootstrap, the communicator id handed around, ncclCommInitRank,
     # flx_render_gathered_device in the timed loop — rehearsed on a one-GPU box with a communicator of one rank
     multi = world > 1 or os.environ.get("FLX_BENCH_FORCE_DIST") == "1"
 
     # Counter passes first: child processes under rocprofv3, before this process touches the GPU.
     pmc = {}
-    if not args.no_pmc and not multi:
-        pmc = collect_pmc(args)
+    if not args.no_pmc and rank == 0:
+        if os.environ.get("FLX_BENCH_PMC_JSON"):               # collected by the launching process (launch_ranks) before any rank existed
+            with open(os.environ["FLX_BENCH_PMC_JSON"]) as fh:
+                pmc = json.load(fh)
+        else:                                                    # N = 1, or rank 0 under torch.distributed.run (the other ranks wait at the rendezvous)
+            pmc = collect_pmc(args, tile=(args.tile_rows, 0, world) if world > 1 else None)
+    verify = (args.verify or multi) and not args.no_verify
 
     import numpy as np
     import torch
@@ -230,7 +326,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("gloo", rank=rank, world_size=world)      # bootstrap + barrier only; the data path is RCCL inside the library
+        import datetime
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=30))      # bootstrap + barrier only; the data path is RCCL inside the library
 
     fixture, config_name = WORKLOADS[args.workload][:2]
     if len(WORKLOADS[args.workload]) > 2 and args.width is None and args.height is None:
@@ -248,6 +345,7 @@ def main():
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
     rccl = multi and not args.one_device
+    to_root = rccl and args.gather == "root"
     if rccl:
         ids = [capi.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -283,7 +381,9 @@ def main():
 
     def render(plist):
         """the frames of plist in ONE pass: whole frames land in frames_out (device memory), nothing waits on the host"""
-        if rccl:
+        if rccl and to_root:
+            ctx.render_gathered_root_device(plist, 0, frames_out.data_ptr())
+        elif rccl:
             ctx.render_gathered_device(plist, frames_out.data_ptr())
         elif multi:
             gather_gloo(plist)
@@ -315,7 +415,7 @@ def main():
         elapsed = float(t.item())
 
     verified = None
-    if args.verify and multi and rank == 0:
+    if verify and multi and rank == 0:
         torch.cuda.synchronize()
         whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
         ctx.render_device(full, whole.data_ptr())
@@ -333,22 +433,30 @@ def main():
     # two frames in flight (flx_frame_begin / flx_frame_end with two lanes: what the JavaScript frame loop runs): still one frame per
     # pass and frames complete in order, but frame k + 1's kernels fill the CUs the tails of frame k's kernels leave idle
     pipelined = None
-    if not multi:
+    if not multi or rccl:
         lat = []
         for phase in range(2):               # 0 = warm-up (the second lane sizes its workspace), 1 = timed
             n = 6 if phase == 0 else max(args.steps, 20)
             fence()
             t1 = time.perf_counter()
             for i in range(n):
-                ctx.frame_begin(params, device=True)
+                if rccl:                     # the same loop over the communicator: every lane gathers over its own (flx_frame_begin_gathered)
+                    ctx.frame_begin_gathered(params, root=0 if to_root else -1)
+                else:
+                    ctx.frame_begin(params, device=True)
                 if ctx.frames_in_flight() == 2:
                     lat.append(ctx.frame_end()[1])
             while ctx.frames_in_flight():
                 lat.append(ctx.frame_end()[1])
             fence()
             dtp = time.perf_counter() - t1
+            if multi:
+                t = torch.tensor([dtp], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtp = float(t.item())
         pipelined = {"frames_in_flight": 2, "ms_per_frame": dtp / n * 1e3, "frames": n, "frame_gpu_ms_median": float(np.median(lat[-n:])),
-                     "note": "flx_frame_begin / flx_frame_end, pixels left in device memory: one frame per pass, frames complete in order; a frame completes every ms_per_frame, its own GPU time (first kernel .. last, overlapped with its neighbours) is frame_gpu_ms_median"}
+                     "note": ("flx_frame_begin_gathered / flx_frame_end on every rank, each of the two lanes gathering over its own communicator" if rccl else "flx_frame_begin / flx_frame_end") +
+                             ", pixels left in device memory: one frame per pass, frames complete in order; a frame completes every ms_per_frame, its own GPU time (first kernel .. last, overlapped with its neighbours) is frame_gpu_ms_median"}
     batched = None
     if F > 1:
         passes = max(2, (args.steps + F - 1) // F)
@@ -368,7 +476,7 @@ def main():
     # work counters of ONE frame (this rank's share), a counted launch
     ctx.set_counters_enabled(True)
     if rccl:
-        ctx.render_gathered_device([params], frames_out.data_ptr())
+        render([params])
     else:
         local1 = torch.zeros((max(rows_local, 1), W, 4), dtype=torch.float32, device="cuda")
         ctx.render_device(params, local1.data_ptr())
@@ -404,6 +512,9 @@ def main():
         lane_util = None
         if k.get("SQ_THREAD_CYCLES_VALU") and k.get("SQ_ACTIVE_INST_VALU"):
             lane_util = k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"])
+        frac = achieved / VALU_ISSUE_PEAK if achieved else None
+        walks = cnt["closest_walks"] + cnt["shadow_walks"]
+        segments = walks + cnt["primary_hits"]                 # rays actually traced through the tree: bounce walks + the primary rays that hit
         line = {
             "metric": "Mray/s at 1080p (spp x bounces x pixels / s)", "value": value, "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -411,7 +522,7 @@ def main():
             "config": {
                 "workload": config_name, "width": W, "height": H, "spp": spp, "bounces": bounces, "filter": bool(use_filter),
                 "scene_entries": int(scene.meta["textureLength"]),
-                "parallelism": ("row-strip tiles x%d, %d rows/strip, %s" % (world, args.tile_rows, "ncclAllGather + reassembly kernel inside libflexlight_hip.so (flx_render_gathered_device)" if rccl else "REHEARSAL: strips gathered over gloo on one device")) if multi else "single GPU",
+                "parallelism": ("row-strip tiles x%d, %d rows/strip, %s" % (world, args.tile_rows, (("ncclSend / ncclRecv to rank 0 (flx_render_gathered_root_device)" if to_root else "ncclAllGather (flx_render_gathered_device)") + " + reassembly kernel inside libflexlight_hip.so") if rccl else "REHEARSAL: strips gathered over gloo on one device")) if multi else "single GPU",
                 "rays_per_frame": rays, "frames_per_pass": 1,
                 "frames": "one frame per pass, frame after frame (the static camera of the BASELINE config, as in the reference's frame loop); every frame is traced in full, nothing is reused between frames",
             },
@@ -419,8 +530,12 @@ def main():
                              "note": "HIP events on the launch stream around one frame: first kernel .. last byte of the (gathered) frame on this rank"},
             "roofline": {
                 "bound": "valu_issue", "kernel": kernel_name, "achieved": achieved, "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s",
-                "frac": achieved / VALU_ISSUE_PEAK if achieved else None,
-                "traffic": traffic, "kernel_ms": k_ms,
+                "frac": frac,
+                "frac_is": "VALU wave-instructions issued per second over the part's issue rate (NOT SURVEY.md 8d's HBM form: see survey_8d_frac)",
+                "effective_lane_frac": frac * lane_util if frac and lane_util else None,      # frac x the share of lanes an executed vector instruction has switched on
+                "survey_8d_frac": bytes_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "survey_8d_frac_note": "SURVEY.md 8d's figure (48 B x entries visited / kernel time / 8 TB/s): not physical when it nears or exceeds 1 — the scene is LDS / L2 resident, the visits never reach HBM (hbm_measured is what does)",
+                "traffic": traffic, "kernel_ms": k_ms, "kernel_ms_rocprofv3_kernel_trace": k.get("kernel_trace_avg_ms"),
                 "valu_insts_per_launch": valu, "valu_lane_utilisation": lane_util,
                 "hbm_measured": {"bytes_per_launch": traffic, "GBps": traffic / (k_ms * 1e-3) / 1e9 if traffic else None, "peak_GBps": HBM_PEAK_GBS,
                                  "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
@@ -433,6 +548,9 @@ def main():
                 "pmc": dict(pmc.get("_meta", {"error": "not collected (--no-pmc or N > 1)"}), counters_per_launch=k),
             },
             "counters": cnt,
+            "traced": {"walks_per_frame": walks, "walks_per_s": walks / (ms_per_step * 1e-3) * (1 if not multi else 1), "segments_per_frame": segments,
+                       "Gsegments_per_s": segments / (ms_per_step * 1e-3) / 1e9, "scope": "this rank's share of the frame" if multi else "the frame",
+                       "note": "`value` counts nominal rays (spp x bounces x pixels); these are the rays the frame really traces (its own work counters: closest-hit walks + shadow walks + primary rays that hit), paths that left the scene or fell below minImportancy trace none"},
         }
         if pipelined:
             pipelined["value"] = rays / (pipelined["ms_per_frame"] * 1e-3) / 1e6
@@ -442,6 +560,9 @@ def main():
             batched["value"] = rays / (batched["ms_per_frame"] * 1e-3) / 1e6
             batched["unit"] = "Mray/s"
             line["batched"] = batched
+        if multi:
+            line["gather"] = {"exchange": ("root" if to_root else "all_gather") if rccl else "gloo rehearsal", "uses_rccl": bool(rccl), "rccl_ranks": ctx.comm_count() if rccl else 0,
+                              "launched_by": "bench.py itself (child processes)" if os.environ.get("FLX_BENCH_SELF_LAUNCHED") else "torch.distributed.run"}
         if verified is not None:
             line["gathered_frame_equals_single_context_frame"] = verified
         if not args.no_cpu_baseline:

@@ -168,6 +168,11 @@ flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_ker
 #define FLX_FRAME_DEVICE 2     /* float32 RGBA left in device memory: flx_frame_end hands out a device pointer (no copy to the host) */
 flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *params, int format);
 flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_t *bytes, float *gpu_ms);
+/* The pinned host buffers behind flx_frame_end's `pixels` (FLX_FRAME_FLOAT / FLX_FRAME_RGBA8): slots[0..1] the first lane's,
+ * slots[2..3] the second lane's (NULL where none is allocated); *last_begun (may be NULL) = index in `slots` of the buffer the
+ * frame begun last will be copied into, -1 if that frame stays in device memory or none was begun.  For bindings that hand the
+ * buffers out as zero-copy views and must retire a view when its memory is re-used or re-allocated (napi/flexlight_napi.cc). */
+flx_status flx_frame_host_slots(flx_context *ctx, const void *slots[4], int *last_begun);
 /* frames begun and not yet ended (0 .. 2) */
 int flx_frames_in_flight(const flx_context *ctx);
 /* 2 (default): the two frames in flight run on two lanes — two streams with a workspace each (+2 GB at 1080p x 8 spp), the static
@@ -208,6 +213,19 @@ flx_status flx_comm_destroy(flx_context *ctx);          /* also done by flx_cont
  * same on every rank and bit-identical to the frames one context renders.  Everything is enqueued on the context's stream
  * without a host synchronisation; flx_last_frame_ms then spans first kernel .. last byte of the gathered frame. */
 flx_status flx_render_gathered_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, void *d_frames);
+/* The same with ONE receiver — the rank that presents the frame.  ncclGroupStart, one ncclSend per rank to `root`, n ncclRecv on
+ * `root`, ncclGroupEnd: a 1080p frame is 33 MB (a 4K frame 133 MB) that the other n - 1 ranks no longer receive; `root`
+ * reassembles (and runs the denoise chain of a filter frame), the others are done when their strips are sent.  d_frames is read
+ * on `root` only (may be NULL elsewhere).  The reference presents from its one context (pathtracerWGL2.js:60-68, 552-553). */
+flx_status flx_render_gathered_root_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames);
+/* ranks of the context's communicator as RCCL reports them (ncclCommCount); 0: the context belongs to none */
+int flx_comm_count(const flx_context *ctx);
+/* The frame loop (flx_frame_begin / flx_frame_end) over the communicator: every rank begins the same frame with its own
+ * tile_index; the frames alternate between the context's two lanes, the second lane gathering over a communicator of its own
+ * (ncclCommSplit of the first, made by flx_comm_init_rank), so that frame k + 1's kernels fill the CUs the tails of frame k's
+ * kernels leave idle on every rank.  root < 0: flx_frame_end hands out the whole frame on every rank; root >= 0: on that rank
+ * (0 bytes elsewhere).  Frames complete in order; at most two in flight. */
+flx_status flx_frame_begin_gathered(flx_context *ctx, const flx_frame_params *params, int format, int root);
 
 /* One process, n GPUs (the JavaScript host: Node is one process): n contexts, one RCCL communicator each (ncclCommInitAll).
  * `devices` may name one GPU more than once — a rehearsal on a one-GPU box, where RCCL refuses two ranks on a device: the
@@ -218,6 +236,9 @@ void flx_group_destroy(flx_group *group);
 const char *flx_group_last_error(const flx_group *group);   /* group may be NULL: last creation error */
 int flx_group_size(const flx_group *group);
 int flx_group_uses_rccl(const flx_group *group);
+/* to_root = 1: only context 0 — the one flx_group_render hands the frame out from — receives the strips (ncclSend / ncclRecv, or
+ * copies into context 0 alone); 0 (default): all-gather, every context ends up with the frame. */
+flx_status flx_group_set_gather(flx_group *group, int to_root);
 flx_context *flx_group_context(flx_group *group, int rank);          /* owned by the group; for per-context settings and timings */
 /* the uploads of a context, applied to every context of the group (the scene is replicated) */
 flx_status flx_group_scene_upload(flx_group *group, const float *geometry, const float *attributes, uint32_t n_entries_padded,
@@ -275,6 +296,9 @@ flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
 #define FLX_WALK_QUEUES 1
 #define FLX_WALK_LANES_FINISHER 2
 flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, uint32_t suspend_walks);
+/* 1 when the library carries the experimental schedulers above (`make EXPERIMENTS=1`: libflexlight_hip_experiments.so); the
+ * shipped library returns 0 and its flx_set_walk_scheduler accepts (FLX_WALK_LANES, 0) only. */
+int flx_has_experiments(void);
 
 /* ---- native scene import (host only, needs no GPU and no context) ---------------------------------
  * One imported object: Scene.importMtl + Scene.importObj of the reference (modules/scene.js:330-487) including the

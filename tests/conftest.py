@@ -16,6 +16,22 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+    config.addinivalue_line("markers", "experiments: walk schedulers that are not in the shipped library; run against `make EXPERIMENTS=1`'s "
+                            "libflexlight_hip_experiments.so (FLX_LIB=...), skipped otherwise")
+
+
+def pytest_collection_modifyitems(config, items):
+    try:
+        from flexlight_hip import capi
+        have = capi.has_experiments()
+    except Exception:
+        have = False
+    if have:
+        return
+    skip = pytest.mark.skip(reason="the loaded library has no experimental walk schedulers (make -C web-ray-tracer_amd/csrc EXPERIMENTS=1; FLX_LIB=.../libflexlight_hip_experiments.so)")
+    for item in items:
+        if "experiments" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -52,6 +52,28 @@ def test_bench_rccl_path_with_one_rank():
     flx_render_gathered_device (trace, ncclAllGather, reassembly in the library) in the timed loop — with a communicator of one rank"""
     env = dict(os.environ, FLX_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29703")
     d = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "4", "--verify"] + SMALL, timeout=900, env=env, stderr=subprocess.DEVNULL))
-    assert d["n_gpus"] == 1 and d["value"] > 0 and "ncclAllGather" in d["config"]["parallelism"]
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "ncclSend / ncclRecv to rank 0" in d["config"]["parallelism"]
     assert d["gathered_frame_equals_single_context_frame"] is True
     assert d["batched"]["frames_per_pass"] == 4
+    assert d["gather"] == {"exchange": "root", "uses_rccl": True, "rccl_ranks": 1, "launched_by": "torch.distributed.run"} or d["gather"]["rccl_ranks"] == 1
+    assert d["pipelined"]["frames_in_flight"] == 2 and "communicator" in d["pipelined"]["note"]      # the frame loop over the communicator
+    e = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "0", "--gather", "all", "--no-pmc"] + SMALL, timeout=900, env=env, stderr=subprocess.DEVNULL))
+    assert "ncclAllGather" in e["config"]["parallelism"] and e["gathered_frame_equals_single_context_frame"] is True and e["gather"]["exchange"] == "all_gather"
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with nothing around it: bench.py starts the two ranks itself (child processes, before it touches a
+    GPU), collects rank 0's counter passes for its strips, verifies the gathered frame by default and says how the frame was
+    exchanged — the N = 1 line's schema plus `gather` and the verification flag"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--batch", "4"] + SMALL, timeout=1200, env=env, stderr=subprocess.DEVNULL)
+    d = _last_json(out)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0
+    assert d["gathered_frame_equals_single_context_frame"] is True            # verified without --verify
+    assert d["gather"]["launched_by"].startswith("bench.py itself") and d["gather"]["uses_rccl"] is False
+    one = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "4", "--no-pmc"] + SMALL, timeout=900, env=env, stderr=subprocess.DEVNULL))
+    assert set(one) - {"pipelined"} <= set(d), sorted(set(one) - set(d))    # the N = 1 schema is a subset of the N > 1 line's (`pipelined` needs RCCL lanes)
+    assert set(one["roofline"]) == set(d["roofline"])
+    r = d["roofline"]
+    if "error" not in r["pmc"]:                                               # rank 0's strips under rocprofv3: the line has a roofline for N > 1 too
+        assert r["achieved"] > 0 and 0 < r["frac"] <= 1 and "tile" in r["pmc"]["collected"]

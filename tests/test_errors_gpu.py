@@ -185,3 +185,30 @@ def test_frame_loop_lanes_keep_their_own_lights(hip, oracle, scenes):
         want, _, _ = oracle.render(sci, p)
         assert np.array_equal(got[i], want, equal_nan=True), "frame %d" % i
     hip.update_scene(sc)
+
+
+def test_a_scene_change_between_frames_in_flight(hip, oracle, scenes):
+    """flx_scene_upload / flx_atlas_upload while frames are in flight on BOTH lanes of the frame loop: the static scene arrays are
+    shared between the lanes, so the upload waits for the second lane's frame (which must finish on the old scene) and the next
+    frame of either lane sees the new arrays complete — small scenes, whose uploads go through the asynchronous staging ring, in
+    both directions (a larger scene into the smaller one's buffers and back).  Every frame equals the oracle's frame of the scene
+    it was begun on."""
+    a, b = scenes("cornell"), scenes("theater")                 # 48 and 32 entries: staged copies; different atlases
+    pa = a.frame_params(width=160, height=96, samples=2, max_reflections=3, use_filter=0)
+    pb = b.frame_params(width=160, height=96, samples=2, max_reflections=3, use_filter=0)
+    want = {"a": oracle.render(a, pa)[0], "b": oracle.render(b, pb)[0]}
+    hip.update_scene(a)
+    hip.frame_begin(pa)
+    hip.frame_begin(pa)                                           # second lane
+    assert np.array_equal(hip.frame_end()[0], want["a"], equal_nan=True)
+    order = []
+    for k in range(6):                                            # one frame stays in flight across every scene change
+        sc, p, key = (b, pb, "b") if k % 2 == 0 else (a, pa, "a")
+        hip.update_scene(sc)                                      # the frame in flight was begun on the other scene
+        hip.frame_begin(p)
+        order.append(key)
+        got = hip.frame_end()[0]
+        prev = "a" if k == 0 else order[k - 1]
+        assert np.array_equal(got, want[prev], equal_nan=True), "frame before change %d" % k
+    assert np.array_equal(hip.frame_end()[0], want[order[-1]], equal_nan=True)
+    assert hip.frames_in_flight() == 0

@@ -115,6 +115,92 @@ def test_rccl_gather_with_a_communicator_of_one_rank(hip, scenes):
         ctx.close()
 
 
+def test_gather_to_root_on_repeated_devices_and_with_one_rank(hip, scenes):
+    """only the presenting rank receives the strips (flx_group_set_gather / flx_render_gathered_root_device: ncclSend + ncclRecv
+    inside one ncclGroupStart / End): the same frame as the all-gather, radiance and filter frames, groups on one device (copies
+    into context 0 alone) and a communicator of one rank (the RCCL calls themselves)"""
+    import torch
+    from flexlight_hip import capi
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=224, height=126, samples=2, max_reflections=3, use_filter=0)
+    f = sc.frame_params(width=224, height=126, samples=1, max_reflections=2, use_filter=1)
+    want, want_cnt, _ = hip.render(p, counters=True)
+    want_f = hip.render(f)[0]
+    with capi.Group([0] * 3) as g:
+        g.update_scene(sc)
+        g.set_gather(True)
+        for _ in range(2):                                    # twice: the send buffers are reused while only context 0 copies
+            got, cnt = g.render(p, tile_rows=8, counters=True)
+            assert np.array_equal(got[0], want, equal_nan=True) and cnt == want_cnt
+        assert np.array_equal(g.render(f, tile_rows=8)[0][0], want_f, equal_nan=True)
+        g.set_gather(False)
+        assert np.array_equal(g.render(p, tile_rows=8)[0][0], want, equal_nan=True)
+    ctx = capi.Context(0)
+    try:
+        ctx.update_scene(sc)
+        assert ctx.comm_count() == 0
+        ctx.comm_init_rank(capi.comm_unique_id(), 1, 0)
+        assert ctx.comm_count() == 1                          # ncclCommCount of the communicator the frames go through
+        out = torch.zeros((126, 224, 4), dtype=torch.float32, device="cuda")
+        pt = sc.frame_params(width=224, height=126, samples=2, max_reflections=3, use_filter=0, tile=(8, 0, 1))
+        ctx.render_gathered_root_device([pt], 0, out.data_ptr())
+        ctx.sync()
+        assert np.array_equal(out.cpu().numpy(), want, equal_nan=True)
+        ft = sc.frame_params(width=224, height=126, samples=1, max_reflections=2, use_filter=1, tile=(8, 0, 1))
+        ctx.render_gathered_root_device([ft], 0, out.data_ptr())
+        ctx.sync()
+        assert np.array_equal(out.cpu().numpy(), want_f, equal_nan=True)
+        with pytest.raises(capi.FlexLightHipError, match="root"):
+            ctx.render_gathered_root_device([pt], 1, out.data_ptr())
+        with pytest.raises(capi.FlexLightHipError, match="root"):
+            ctx.render_gathered_root_device([pt], -1, out.data_ptr())
+    finally:
+        ctx.close()
+
+
+def test_frame_loop_over_a_communicator(hip, scenes):
+    """flx_frame_begin_gathered: the frames of a camera move alternate between the two lanes, each lane gathering over its own
+    communicator (the second is an ncclCommSplit of the first); every frame taken equals its own render — with a communicator of
+    one rank, which is what one GPU can run"""
+    import torch  # noqa: F401  (device memory is read back through torch below)
+    from flexlight_hip import capi
+    sc = scenes("dragon")
+    ctx = capi.Context(0)
+    try:
+        ctx.update_scene(sc)
+        p = sc.frame_params(width=240, height=136, samples=2, max_reflections=3, use_filter=0, tile=(8, 0, 1))
+        with pytest.raises(capi.FlexLightHipError, match="no communicator"):
+            ctx.frame_begin_gathered(p)
+        ctx._pending.clear()
+        ctx.comm_init_rank(capi.comm_unique_id(), 1, 0)
+        frames = [_moved(sc, p, i) for i in range(5)]
+        got = []
+
+        import ctypes as C
+        hipMemcpy = C.CDLL("libamdhip64.so").hipMemcpy
+        hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+        def take():
+            ptr, ms = ctx.frame_end()                          # the gathered whole frame, in device memory
+            host = np.empty((136, 240, 4), np.float32)
+            assert hipMemcpy(host.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), host.nbytes, 2) == 0      # hipMemcpyDeviceToHost
+            assert ms > 0
+            got.append(host)
+        for q in frames:
+            ctx.frame_begin_gathered(q, root=0)
+            if ctx.frames_in_flight() == 2:
+                take()
+        while ctx.frames_in_flight():
+            take()
+        for i, q in enumerate(frames):
+            q.tile_rows = q.tile_index = q.tile_count = 0
+            assert np.array_equal(got[i], hip_render(hip, sc, q), equal_nan=True), "frame %d" % i
+        ctx.comm_destroy()
+    finally:
+        ctx.close()
+
+
 def hip_render(hip, sc, p):
     hip.update_scene(sc)
     return hip.render(p)[0]

@@ -295,6 +295,7 @@ def test_wavefront_groups_do_not_change_the_frame(hip, oracle, scenes, name, w, 
         hip.set_wavefront_groups(1)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize("scheduler,suspend", [(0, 128), (0, 16), (1, 0), (2, 16), (2, 128), (0, 0)])
 @pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 480, 270, 2, 4), ("cornell_obj", 128, 96, 2, 5), ("theater", 96, 64, 1, 1)])
 def test_walk_schedulers_do_not_change_the_frame(hip, oracle, scenes, name, w, h, spp, bounces, scheduler, suspend):
@@ -324,6 +325,11 @@ def test_walk_scheduler_arguments(hip):
     for args in ((3, 0), (-1, 0), (0, 513), (1, 8)):
         with pytest.raises(capi.FlexLightHipError):
             hip.set_walk_scheduler(*args)
+    hip.set_walk_scheduler(0, 0)
+    if not capi.has_experiments():                                # the shipped library carries the default scheduler only
+        for args in ((1, 0), (2, 16), (0, 16)):
+            with pytest.raises(capi.FlexLightHipError, match="EXPERIMENTS"):
+                hip.set_walk_scheduler(*args)
 
 
 def test_errors_are_reported_not_thrown(hip, scenes):

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="frames per launch (flx_render_batch) instead of one")
     ap.add_argument("--scheduler", type=int, default=0, help="flx_set_walk_scheduler: 0 lanes, 1 queues, 2 lanes + cooperative finisher")
     ap.add_argument("--suspend", type=int, default=0, help="walks a walk workgroup may hand over (flx_set_walk_scheduler)")
+    ap.add_argument("--tile-rows", type=int, default=0, help="with --tile-count N: render rank --tile-index's strips of the frame (what one of N ranks traces)")
+    ap.add_argument("--tile-index", type=int, default=0)
+    ap.add_argument("--tile-count", type=int, default=0)
     args = ap.parse_args()
     from flexlight_hip import capi
     from flexlight_hip.scene_io import Scene
@@ -31,7 +34,8 @@ def main():
     if len(w) > 2 and args.width is None and args.height is None:
         args.width, args.height = w[2:]
     scene = Scene.golden(w[0])
-    p = scene.frame_params(width=args.width, height=args.height)
+    tile = (args.tile_rows, args.tile_index, args.tile_count) if args.tile_count > 1 else (0, 0, 0)
+    p = scene.frame_params(width=args.width, height=args.height, tile=tile)
     with capi.Context(0) as ctx:
         ctx.update_scene(scene)
         ctx.set_walk_scheduler(args.scheduler, args.suspend)

@@ -21,6 +21,10 @@
 
 using namespace flx;
 
+#ifndef FLX_EXPERIMENTS
+#define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 */
+#endif
+
 thread_local std::string g_create_error;
 
 flx_status flx_fail(flx_context *ctx, flx_status code, const char *msg) {
@@ -116,6 +120,21 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
  * buffer is not retained. */
 constexpr size_t STAGE_SLOT_BYTES = 64 * 1024;
 constexpr int STAGE_SLOTS = 8;
+
+/* The static scene arrays (geometry, attributes, ids, the threaded and forward-ordered copies, atlases) are SHARED with the
+ * frame loop's second lane (mirror_scene): its frames read them on another stream.  An upload of one of them therefore first
+ * waits for the twin's frames in flight (they must not see the array change under them, nor new metadata over old contents)
+ * and ends with the copy complete, so that the twin's next frame — enqueued on its own stream, which does not order itself after
+ * the primary's — finds the new contents.  Scene and atlas uploads are per scene, not per frame; what changes per frame
+ * (lights, transforms) lives in per-lane buffers and stays asynchronous. */
+static flx_status shared_upload_begin(flx_context *ctx) {
+  if (ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
+  return FLX_OK;
+}
+static flx_status shared_upload_end(flx_context *ctx) {
+  if (ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FLX_OK;
+}
 
 template <typename T>
 static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t bytes) {
@@ -267,7 +286,6 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
   if (n_ids && !ids) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: ids is NULL");
   if (n_entries_padded > LINK_INDEX) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: more than 2^28 - 1 entries");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
-  ctx->have_scene = false;
   /* Validate the skip list on the host: a skip that leaves the array would make the walk read out of
    * bounds on the GPU (the shader's texelFetch would be robust-access clamped; we refuse instead). */
   uint32_t max_transform = 0;
@@ -286,6 +304,8 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
     }
   }
   flx_status s;
+  if ((s = shared_upload_begin(ctx))) return s;
+  ctx->have_scene = false;
   if ((s = upload(ctx, &ctx->d_geometry, geometry, (size_t)n_entries_padded * 48))) return s;
   if ((s = upload(ctx, &ctx->d_attributes, attributes, (size_t)n_entries_padded * 112))) return s;
   if ((s = upload(ctx, &ctx->d_ids, ids, (size_t)n_ids * 4))) return s;
@@ -313,6 +333,7 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
   ctx->n_entries = n_entries_padded;
   ctx->n_ids = n_ids;
   ctx->max_transform = max_transform;
+  if ((s = shared_upload_end(ctx))) return s;
   ctx->have_scene = true;
   return FLX_OK;
 }
@@ -351,10 +372,11 @@ extern "C" flx_status flx_atlas_upload(flx_context *ctx, int which, const uint8_
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   size_t bytes = rgba ? (size_t)width * height * 4 : 0;
   flx_status s;
+  if ((s = shared_upload_begin(ctx))) return s;
   if ((s = upload(ctx, &ctx->d_atlas[which], rgba, bytes))) return s;
   ctx->atlas_w[which] = bytes ? width : 0;
   ctx->atlas_h[which] = bytes ? height : 0;
-  return FLX_OK;
+  return shared_upload_end(ctx);
 }
 
 extern "C" flx_status flx_scene_upload_view(flx_context *ctx, const flx_scene_view *v) {
@@ -802,10 +824,16 @@ extern "C" flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, ui
   if (scheduler < FLX_WALK_LANES || scheduler > FLX_WALK_LANES_FINISHER) return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: scheduler 0 lanes, 1 queues, 2 lanes + finisher");
   if (suspend_walks > WF_STRAG_MAX) return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: suspend_walks 0..512");
   if (scheduler == FLX_WALK_QUEUES && suspend_walks != 0u) return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: the queue scheduler does not suspend walks");
+#if !FLX_EXPERIMENTS
+  if (scheduler != FLX_WALK_LANES || suspend_walks != 0u)
+    return fail(ctx, FLX_ERR_INVALID, "flx_set_walk_scheduler: this library was built without the experimental walk schedulers (make EXPERIMENTS=1 builds libflexlight_hip_experiments.so)");
+#endif
   ctx->walk_scheduler = scheduler;
   ctx->walk_suspend = suspend_walks;
   return FLX_OK;
 }
+
+extern "C" int flx_has_experiments(void) { return FLX_EXPERIMENTS; }
 
 extern "C" flx_status flx_last_pipeline(flx_context *ctx, int *pipeline) {
   if (!ctx || !pipeline) return FLX_ERR_INVALID;
@@ -1082,11 +1110,15 @@ static void mirror_scene(flx_context *ctx) {
   t->n_entries = ctx->n_entries; t->n_ids = ctx->n_ids; t->max_transform = ctx->max_transform; t->have_scene = ctx->have_scene;
 }
 
-static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *params, int format, int *slot) {
+constexpr int NOT_GATHERED = -2;      /* frame_begin_on's `gather`: this context's own frame; -1: gathered on every rank; >= 0: on that rank */
+static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *params, int format, int gather, int *slot) {
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
   flx_status s = flx_make_frame(ctx, params, sc, fr);
   if (s) return s;
+  const bool gathered = gather != NOT_GATHERED;
+  const bool receiver = !gathered || gather < 0 || gather == ctx->comm_rank;
+  if (gathered) { fr.rows = receiver ? params->height : 0u; }      /* the slot holds the WHOLE frame on a rank that receives it, nothing elsewhere */
   const int k = (int)(ctx->frames_begun & 1u);
   if (!ctx->copy_stream) {
     FLX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -1112,7 +1144,11 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
     ctx->h_slot_capacity[k] = bytes;
   }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_start[k], ctx->stream));
-  if (pixels) {
+  if (gathered) {
+    /* this rank's strips, the exchange over the lane's communicator and the reassembly, all on the lane's stream */
+    if ((s = flx_gather_enqueue(ctx, params, 1, gather, receiver ? ctx->d_slot[k] : nullptr))) return s;
+    if (pixels && format == FLX_FRAME_RGBA8) { launch_quantize(ctx->d_slot[k], ctx->d_slot8[k], pixels, ctx->stream); FLX_HIP(ctx, hipGetLastError()); }
+  } else if (pixels) {
     if (params->use_filter || params->is_temporal) {
       s = run_post_frame(ctx, sc, fr, params, ctx->d_slot[k]);
     } else {
@@ -1148,11 +1184,15 @@ extern "C" flx_status flx_set_frame_lanes(flx_context *ctx, int lanes) {
   return FLX_OK;
 }
 
-extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *params, int format) {
-  if (!ctx) return FLX_ERR_INVALID;
+static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, int format, int gather) {
   if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_RGBA8 && format != FLX_FRAME_DEVICE) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: format is FLX_FRAME_FLOAT, FLX_FRAME_RGBA8 or FLX_FRAME_DEVICE");
   if (ctx->fifo_n >= 2) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: two frames are in flight already, take one with flx_frame_end first");
   if (!params) return fail(ctx, FLX_ERR_INVALID, "frame params are NULL");
+  if (gather != NOT_GATHERED) {
+    if (!ctx->comm) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: the context belongs to no communicator (flx_comm_init_rank)");
+    if (params->is_temporal) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: temporal frames keep their history in one context and are not sharded");
+    if (ctx->frame_lanes == 2 && !ctx->comm_twin) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: the second lane has no communicator (contexts of a flx_group render through flx_group_render)");
+  }
   flx_context *lane = ctx;
   if (ctx->frame_lanes == 2 && !params->is_temporal && (ctx->lane_next & 1u)) {
     FLX_HIP(ctx, hipSetDevice(ctx->device));
@@ -1163,6 +1203,7 @@ extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *
       ctx->twin_dyn_version = 0;
     }
     flx_context *t = ctx->twin;
+    t->comm = ctx->comm_twin; t->comm_rank = ctx->comm_rank; t->comm_size = ctx->comm_size; t->comm_owned = false;      /* (the primary owns and destroys both) */
     mirror_scene(ctx);
     t->pipeline = ctx->pipeline; t->wf_groups = ctx->wf_groups; t->walk_scheduler = ctx->walk_scheduler; t->walk_suspend = ctx->walk_suspend;
     if (ctx->twin_dyn_version != ctx->dyn_version) {          /* lights / transforms changed since the twin's last frame: its own copies, on its stream */
@@ -1174,11 +1215,25 @@ extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *
     lane = t;
   }
   int slot = 0;
-  flx_status s = frame_begin_on(lane, params, format, &slot);
+  flx_status s = frame_begin_on(lane, params, format, gather, &slot);
   if (s) { if (lane != ctx) ctx->err = lane->err; return s; }
   ctx->fifo[ctx->fifo_n].lane = lane; ctx->fifo[ctx->fifo_n].slot = slot; ctx->fifo_n++;
   if (!params->is_temporal) ctx->lane_next++;
   return FLX_OK;
+}
+
+extern "C" flx_status flx_frame_begin(flx_context *ctx, const flx_frame_params *params, int format) {
+  if (!ctx) return FLX_ERR_INVALID;
+  return frame_begin(ctx, params, format, NOT_GATHERED);
+}
+
+/* The frame loop over a communicator: every rank begins the same frame (its own tile_index of tile_count = the communicator's
+ * size); frames alternate between the two lanes like flx_frame_begin's, each lane gathering over its own communicator, so the
+ * kernels of frame k + 1 fill the CUs that the tails of frame k's kernels leave idle ON EVERY RANK.  root < 0: every rank's
+ * flx_frame_end hands out the whole frame; root >= 0: that rank's does, the others get 0 bytes. */
+extern "C" flx_status flx_frame_begin_gathered(flx_context *ctx, const flx_frame_params *params, int format, int root) {
+  if (!ctx) return FLX_ERR_INVALID;
+  return frame_begin(ctx, params, format, root < 0 ? -1 : root);
 }
 
 extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_t *bytes, float *gpu_ms) {
@@ -1193,6 +1248,19 @@ extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_
   if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, lane->ev_slot_start[k], lane->ev_slot_traced[k])); *gpu_ms = ms; }
   if (pixels) *pixels = lane->slot_host[k] ? lane->h_slot[k] : (const void *)lane->d_slot[k];
   if (bytes) *bytes = lane->slot_bytes[k];
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_frame_host_slots(flx_context *ctx, const void *slots[4], int *last_begun) {
+  if (!ctx || !slots) return FLX_ERR_INVALID;
+  for (int i = 0; i < 2; i++) { slots[i] = ctx->h_slot[i]; slots[2 + i] = ctx->twin ? ctx->twin->h_slot[i] : nullptr; }
+  if (last_begun) {
+    *last_begun = -1;
+    if (ctx->fifo_n > 0) {
+      const auto &f = ctx->fifo[ctx->fifo_n - 1];
+      if (f.lane->slot_host[f.slot]) *last_begun = (f.lane == ctx ? 0 : 2) + f.slot;
+    }
+  }
   return FLX_OK;
 }
 

@@ -91,6 +91,8 @@ struct flx_context {
   bool timed = false;
   /* several GPUs (flx_group.hip): this context's RCCL communicator and the buffers of the gather */
   flx_nccl_comm comm = nullptr;
+  flx_nccl_comm comm_twin = nullptr;             /* a second communicator over the same ranks (ncclCommSplit) for the frame loop's second lane */
+  int last_gather_root = -1;                     /* how the last gathered frame was exchanged: -1 all-gather, else the receiving rank */
   int comm_rank = 0, comm_size = 1;
   bool comm_owned = false;                       /* made by flx_comm_init_rank (else by a group's ncclCommInitAll) */
   float4 *d_send = nullptr, *d_recv = nullptr;   /* this rank's packed strips; every rank's */
@@ -139,6 +141,10 @@ struct flx_context {
 
 flx_status flx_fail(flx_context *ctx, flx_status code, const char *msg);
 
+
+/* flx_group.hip: this context's strips traced, exchanged over its communicator (root < 0: all-gather; else only `root` receives) and
+ * put in image order, all enqueued on its stream */
+flx_status flx_gather_enqueue(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames);
 
 /* flx_api.hip */
 flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, flx::DeviceScene &sc, flx::DeviceFrame &fr);

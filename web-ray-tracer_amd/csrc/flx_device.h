@@ -210,6 +210,13 @@ FLX_DEV f4 noise(float random_seed, float nx, float ny, float seed) {
 /* vote of the wave: the builtin takes the condition as it is (HIP's flx_ballot(int) first materialises it as 0 / 1 and compares
  * again: two VALU instructions per vote, and the walk kernel votes several times per entry) */
 FLX_DEV unsigned long long flx_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+/* does any lane of the wave hold p?  As a SCALAR test (s_cmp_lg_u64 + s_cbranch_scc): the mask goes through an empty asm so the
+ * compiler cannot turn `ballot(p) != 0` back into a vector condition (which it materialises as v_cndmask 0/1 + v_cmp + a vcc branch) */
+FLX_DEV bool flx_any(bool p) {
+  unsigned long long m = __builtin_amdgcn_ballot_w64(p);
+  asm volatile("" : "+s"(m));
+  return m != 0ull;
+}
 /* value of `v` in lane `p` (p uniform) */
 FLX_DEV float laneF(float v, uint32_t p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)p)); }
 FLX_DEV int laneI(int v, uint32_t p) { return __builtin_amdgcn_readlane(v, (int)p); }
@@ -281,11 +288,7 @@ FLX_DEV bool moellerTrumboreCull(f3 a, f3 b, f3 c, const Ray &ray, float l) {
 }
 
 /* Primary-visibility triangle rule: front faces only, inclusive edges, near plane. */
-FLX_DEV bool moellerTrumborePrimaryE(f3 a, f3 edge1, f3 edge2, const Ray &ray, float l, float viewDepthPerS, f3 &suv);
-FLX_DEV bool moellerTrumborePrimary(f3 a, f3 b, f3 c, const Ray &ray, float l, float viewDepthPerS, f3 &suv) {
-  return moellerTrumborePrimaryE(a, b - a, c - a, ray, l, viewDepthPerS, suv);
-}
-/* the same with the edges b - a, c - a given (the threaded copy stores them) */
+/* (the edges b - a, c - a are given: the threaded copy stores them) */
 FLX_DEV bool moellerTrumborePrimaryE(f3 a, f3 edge1, f3 edge2, const Ray &ray, float l, float viewDepthPerS, f3 &suv) {
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
@@ -310,68 +313,6 @@ FLX_DEV bool rayCuboid(float l, const Ray &ray, f3 minCorner, f3 maxCorner) {
   float tmin = flx_max(flx_max(flx_min(v0.x, v1.x), flx_min(v0.y, v1.y)), flx_min(v0.z, v1.z));
   float tmax = flx_min(flx_min(flx_max(v0.x, v1.x), flx_max(v0.y, v1.y)), flx_max(v0.z, v1.z));
   return tmax >= flx_max(tmin, BIAS) && tmin < l;
-}
-
-/* fragment:172-227 (PRIMARY = false) and the primary-visibility walk (PRIMARY = true). */
-template <bool PRIMARY>
-FLX_DEV Hit rayTracer(const DeviceScene &sc, const Ray &ray, float viewDepthPerS, uint32_t &visits) {
-  Ray tR = ray;
-  int cachedTI = 0;
-  Hit hit; hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
-  float minLen = POW32;
-  const int size = (int)sc.n_entries;
-  for (int i = 0; i < size; i++) {
-    float4 e0 = sc.geometry[3 * i], e1 = sc.geometry[3 * i + 1], e2 = sc.geometry[3 * i + 2];
-    visits++;
-    int tI = (int)e2.y << 1;
-    if (tI != cachedTI) {
-      int iI = tI + 1;
-      M3 rotationII = rotation_at(sc, iI);
-      cachedTI = tI;
-      tR.origin = mul(rotationII, ray.origin + shift_at(sc, iI));
-      tR.dir = mul(rotationII, ray.dir);
-    }
-    if (e2.z == 0.0f) return hit;
-    if (e2.z == 1.0f) {
-      if (!rayCuboid(minLen, tR, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y))) i += (int)e1.z;
-    } else {
-      f3 suv;
-      f3 a = F3(e0.x, e0.y, e0.z), b = F3(e0.w, e1.x, e1.y), c = F3(e1.z, e1.w, e2.x);
-      bool h = PRIMARY ? moellerTrumborePrimary(a, b, c, tR, minLen, viewDepthPerS, suv) : moellerTrumbore(a, b, c, tR, minLen, suv);
-      if (h) {
-        hit.suv = suv; hit.transformId = tI; hit.triangleId = i;
-        minLen = suv.x;
-      }
-    }
-  }
-  return hit;
-}
-
-/* fragment:231-280 */
-FLX_DEV bool shadowTest(const DeviceScene &sc, const Ray &ray, float l, uint32_t &visits) {
-  Ray tR = ray;
-  int cachedTI = 0;
-  const float minLen = l;
-  const int size = (int)sc.n_entries;
-  for (int i = 0; i < size; i++) {
-    float4 e0 = sc.geometry[3 * i], e1 = sc.geometry[3 * i + 1], e2 = sc.geometry[3 * i + 2];
-    visits++;
-    int tI = (int)e2.y << 1;
-    if (tI != cachedTI) {
-      int iI = tI + 1;
-      M3 rotationII = rotation_at(sc, iI);
-      cachedTI = tI;
-      tR.origin = mul(rotationII, ray.origin + shift_at(sc, iI));
-      tR.dir = normalize(mul(rotationII, ray.dir));
-    }
-    if (e2.z == 0.0f) return false;
-    if (e2.z == 1.0f) {
-      if (!rayCuboid(minLen, tR, F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y))) i += (int)e1.z;
-    } else {
-      if (moellerTrumboreCull(F3(e0.x, e0.y, e0.z), F3(e0.w, e1.x, e1.y), F3(e1.z, e1.w, e2.x), tR, minLen)) return true;
-    }
-  }
-  return false;
 }
 
 /* fragment:282-302 */
@@ -622,7 +563,7 @@ struct WalkState {
   int i;              /* next entry */
   int cachedTI;
   int mode;           /* 0 shadowTest, 1 rayTracer, 2 finished */
-  bool shadowed;      /* result of the shadow walk */
+  int shadowed;       /* result of the shadow walk (0 / 1; an int so that a select, not a mask round trip, updates it) */
   f3 suv;             /* closest hit so far */
   int tri, hitTI;     /* entry index (-1: none) and 2 * transform number of the closest hit */
   f3 inv;             /* RN(1 / tR.dir), for the threaded walk's box test */
@@ -674,50 +615,8 @@ FLX_DEV bool walkStep(const DeviceScene &sc, WalkState &w, WorkCounters &cnt) {
   return endWalk || next >= (int)sc.n_entries;
 }
 
-/* walkStep() split by entry type, for schedulers that want all lanes of a wave to run the SAME test:
- * the current entry is held in registers (WalkEntry), walkFetch() loads entry w.i and applies the
- * transform-change rule, walkBox() / walkTri() do the test of fragment:210-223 / :270-276 and set w.i.
- * Entry order, arithmetic and visit counts per ray are those of walkStep(). */
+/* The current entry of a walk, held in registers. */
 struct WalkEntry { float4 e0, e1, e2; };
-
-/* Returns true when the walk ends here (loop bound reached or terminator entry, fragment:184,208). */
-template <bool COUNT>
-FLX_DEV bool walkFetch(const DeviceScene &sc, WalkState &w, WalkEntry &cur, WorkCounters &cnt) {
-  if (w.i >= (int)sc.n_entries) return true;
-  cur.e0 = sc.geometry[3 * w.i]; cur.e1 = sc.geometry[3 * w.i + 1]; cur.e2 = sc.geometry[3 * w.i + 2];
-  if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
-  int tI = (int)cur.e2.y << 1;
-  if (tI != w.cachedTI) {
-    int iI = tI + 1;
-    M3 rotationII = rotation_at(sc, iI);
-    w.cachedTI = tI;
-    w.tR.origin = mul(rotationII, w.src.origin + shift_at(sc, iI));
-    f3 d = mul(rotationII, w.src.dir);
-    w.tR.dir = (w.mode == 0) ? normalize(d) : d;
-  }
-  return cur.e2.z == 0.0f;
-}
-FLX_DEV void walkBox(WalkState &w, const WalkEntry &cur) {
-  int next = w.i + 1;
-  if (!rayCuboid(w.minLen, w.tR, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y))) next += (int)cur.e1.z;
-  w.i = next;
-}
-/* Returns true when the (shadow) walk ends on this triangle. */
-FLX_DEV bool walkTri(WalkState &w, const WalkEntry &cur) {
-  f3 a = F3(cur.e0.x, cur.e0.y, cur.e0.z), b = F3(cur.e0.w, cur.e1.x, cur.e1.y), c = F3(cur.e1.z, cur.e1.w, cur.e2.x);
-  bool ended = false;
-  if (w.mode == 0) {
-    if (moellerTrumboreCull(a, b, c, w.tR, w.minLen)) { w.shadowed = true; ended = true; }
-  } else {
-    f3 suv;
-    if (moellerTrumbore(a, b, c, w.tR, w.minLen, suv)) {
-      w.suv = suv; w.hitTI = (int)cur.e2.y << 1; w.tri = w.i;
-      w.minLen = suv.x;
-    }
-  }
-  w.i = w.i + 1;
-  return ended;
-}
 
 /* ---- the same walk over the threaded copy (DeviceScene::walk) ---------------------------------------
  * w.i is a threaded index; `lds` holds the first ldsCount entries (3 float4 each) or is null. */
@@ -799,9 +698,9 @@ FLX_DEV bool rayCuboidRecip(float l, const WalkState &w, f3 minCorner, f3 maxCor
   return tmax >= flx_max(tmin, BIAS) && tmin < l;
 }
 
-/* Primary visibility (rayTracer<true>) over the threaded copy: explicit successors, stored edges, the box test through the
+/* Primary visibility (the walk of fragment:172-227 with the primary triangle rule) over the threaded copy: explicit successors, stored edges, the box test through the
  * exact reciprocal division.  The entries a ray visits, their order, the arithmetic of every test and the visit count are
- * those of rayTracer<true>; a pixel's ray changes object space a few times per walk, so that is done in place. */
+ * those of the shader's loop; a pixel's ray changes object space a few times per walk, so that is done in place. */
 FLX_DEV bool rayCuboidFast(float l, const WalkState &w, f3 lo, f3 hi);      /* below: the interval test with the exact quotients as its fallback */
 FLX_DEV Hit primaryWalkT(const DeviceScene &sc, const Ray &ray, float viewDepthPerS, uint32_t &visits) {
   Hit hit; hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
@@ -1163,6 +1062,103 @@ FLX_DEV bool rayCuboidFast(float l, const WalkState &w, f3 lo, f3 hi) {
 FLX_DEV void walkBoxP(WalkState &w, const WalkEntry &cur) {
   const bool hit = rayCuboidFast(w.minLen, w, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y));
   w.i = hit ? __float_as_int(cur.e2.x) : __float_as_int(cur.e2.y);
+}
+
+/* ---- one trip of the walk kernel's stepping loop as ONE straight-line stream (round 3) -------------------------------------
+ * walkIsBoxT / walkBoxP / walkTriT / walkFetchP above run a trip as `if (box) ... else ...; if (!ended) fetch` per lane: on a wave whose
+ * lanes stand at boxes and at triangles at once — nearly every trip — the hardware executes both sides anyway, each under a saved
+ * and restored execution mask, and a third of the trip's instructions were that bookkeeping (s_and_saveexec / s_xor / s_or exec /
+ * s_cbranch_execz around every test, every hit update, the fetch and the transform change; profiles/r02_ab_walk_kernel.txt:
+ * 0.38 % of the kernel per scalar instruction of a trip).  Here every lane of the wave executes the box test AND the triangle
+ * test on whatever its entry registers hold, unmasked; what a lane keeps is chosen by selects from three predicates (the lane
+ * walks, its entry is a box, the test's boolean).  Wave-uniform branches remain only around the rare paths: the exact-quotient
+ * box test when the interval test is unsure, IEEE 1/det outside recipFast's range, a change of object space.  A lane that is not
+ * walking computes on stale registers and keeps none of it; its fetch reads entry 0 (the shared terminator, a broadcast LDS read).
+ * Per ray: the entries visited, their order, every arithmetic operation and the visit counts of the functions above.
+ * Returns whether the lane's walk ended in this trip (meaningful for walking lanes). */
+#ifndef FLX_WF_FUSED_TRIP
+#define FLX_WF_FUSED_TRIP 0      /* measured slower than the branched trip (profiles/r03_ab_fused_trip.txt): off */
+#endif
+#ifndef FLX_WF_FUSED_SKIP
+#define FLX_WF_FUSED_SKIP 1      /* the wave skips the box (triangle) arithmetic when no walk of it stands at a box (triangle) */
+#endif
+template <bool COUNT>
+FLX_DEV bool walkTripFused(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float2 *rays, bool walking, WalkState &w, WalkEntry &cur,
+                           WorkCounters &cnt) {
+  const int meta = __float_as_int(cur.e2.z);
+  const bool isBox = (meta & 3) == 1;
+  const bool cull = w.mode == 0;
+  const f3 p0 = F3(cur.e0.x, cur.e0.y, cur.e0.z), p1 = F3(cur.e0.w, cur.e1.x, cur.e1.y), p2 = F3(cur.e1.z, cur.e1.w, cur.e2.x);
+  const bool boxLane = walking & isBox, triLane = walking & !isBox;
+  /* box (min = p0, max = p1): rayCuboidFast.  Skipped by the wave when none of its walks stands at a box (a thin wave at the end of
+   * a kernel, a wave deep in the leaves): a uniform branch, nothing is masked inside. */
+  bool boxHit = false;
+#if FLX_WF_FUSED_SKIP
+  if (flx_any(boxLane))
+#endif
+  {
+    bool sure;
+    boxHit = rayCuboidInterval(w.minLen, w, p0, p1, sure);
+    const bool boxSlow = boxLane & !sure;
+    if (FLX_UNLIKELY(flx_any(boxSlow))) {
+      if (boxSlow) boxHit = rayCuboidRecip(w.minLen, w, p0, p1);
+    }
+  }
+  /* triangle (a = p0, b - a = p1, c - a = p2): moellerTrumboreAny, with recipOf's range test reduced to what can fail — a lane
+   * that reads 1/det has |det| >= BIAS = 2^-16 (or is NaN), so only the upper bound and NaN send the wave to the division */
+  bool shadowHit = false;
+#if FLX_WF_FUSED_SKIP
+  if (flx_any(triLane))
+#endif
+  {
+    const f3 pvec = cross(w.tR.dir, p2);
+    const float det = dot(p1, pvec);
+    const bool detBad = cull ? (det < BIAS) : (flx_abs(det) < BIAS);
+    float inv_det = recipFast(det);
+    const bool divSlow = triLane & !detBad & !(flx_abs(det) <= 1.152921504606847e18f);
+    if (FLX_UNLIKELY(flx_any(divSlow))) {
+      if (divSlow) inv_det = 1.0f / det;
+    }
+    const f3 tvec = w.tR.origin - p0;
+    const float u = dot(tvec, pvec) * inv_det;
+    const f3 qvec = cross(tvec, p1);
+    const float v = dot(w.tR.dir, qvec) * inv_det;
+    const float uvSum = u + v;
+    const float s = dot(p2, qvec) * inv_det;
+    const bool uBad = (u < BIAS) | (u > 1.0f);
+    const bool vBad = (v < BIAS) | (uvSum > 1.0f);
+    /* the cull rule is (s <= l) && (s > BIAS), the two-sided one !(s > l) && !(s <= BIAS) = ((s <= l) || unordered(s, l)) &&
+     * ((s > BIAS) || s is NaN): one pair of comparisons for both, the unordered cases added for the two-sided walks */
+    const bool sLe = (s <= w.minLen) | (!cull & __builtin_isunordered(s, w.minLen));
+    const bool sGt = (s > BIAS) | (!cull & (s != s));
+    const bool triHit = triLane & !detBad & !uBad & !vBad & sLe & sGt;
+    shadowHit = triHit & cull;
+    const bool upd = triHit & !cull & (s != 0.0f);                       /* fragment:217 */
+    w.shadowed = shadowHit ? 1 : w.shadowed;
+    w.suv.x = upd ? s : w.suv.x; w.suv.y = upd ? u : w.suv.y; w.suv.z = upd ? v : w.suv.z;
+    w.tri = upd ? __float_as_int(cur.e2.w) : w.tri;
+    w.minLen = upd ? s : w.minLen;
+  }
+  /* successor: a box's next-on-hit is e2.x, its next-on-miss and a triangle's next are both e2.y */
+  const uint32_t next = (uint32_t)__float_as_int((isBox & boxHit) ? cur.e2.x : cur.e2.y);
+  bool ended = shadowHit | (next == WALK_END);
+  const bool go = walking & !ended;
+  w.i = (int)next;
+  const uint32_t idx = go ? linkIndex(next) : 0u;
+  {
+    const float4 *src = (idx < ldsCount) ? lds + 3u * idx : sc.walk + 3 * (size_t)idx;
+    cur.e0 = src[0]; cur.e1 = src[1]; cur.e2 = src[2];
+  }
+  if (COUNT) { if (go) { if (cull) cnt.shadow_visits++; else cnt.closest_visits++; } }
+  const int meta2 = __float_as_int(cur.e2.z);
+  const int tI = (meta2 >> 2) << 1;
+  const bool term = (meta2 & 3) == 0;
+  const bool xf = go & !term & (tI != w.cachedTI);
+  if (FLX_UNLIKELY(flx_any(xf))) {
+    if (xf) { w.cachedTI = tI; walkLoadRay(rays, tI >> 1, w); }
+  }
+  ended |= go & term;
+  return ended;
 }
 
 /* The two traversals of one bounce in ONE loop: shadowTest (fragment:231-280) on so.shadowRay, then

@@ -154,7 +154,19 @@ extern "C" flx_status flx_comm_init_rank(flx_context *ctx, const uint8_t *id, in
   ncclComm_t comm = nullptr;
   FLX_NCCL(ctx, ncclCommInitRank(&comm, n_ranks, u, rank));
   ctx->comm = (flx_nccl_comm)comm; ctx->comm_rank = rank; ctx->comm_size = n_ranks; ctx->comm_owned = true;
+  /* a second communicator over the same ranks for the frame loop's second lane (flx_frame_begin_gathered): two frames in flight
+   * gather on two streams, and collectives of ONE communicator must not be in flight on two streams at once.  ncclCommSplit is
+   * collective: every rank makes it here, in the same order. */
+  ncclComm_t second = nullptr;
+  FLX_NCCL(ctx, ncclCommSplit(comm, 0, rank, &second, nullptr));
+  ctx->comm_twin = (flx_nccl_comm)second;
   return FLX_OK;
+}
+
+extern "C" int flx_comm_count(const flx_context *ctx) {
+  if (!ctx || !ctx->comm) return 0;
+  int n = 0;
+  return ncclCommCount((ncclComm_t)ctx->comm, &n) == ncclSuccess ? n : -1;
 }
 
 extern "C" flx_status flx_comm_destroy(flx_context *ctx) {
@@ -162,26 +174,60 @@ extern "C" flx_status flx_comm_destroy(flx_context *ctx) {
   if (ctx->comm && ctx->comm_owned) {
     FLX_HIP(ctx, hipSetDevice(ctx->device));
     FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->twin) { FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream)); ctx->twin->comm = nullptr; }
+    if (ctx->comm_twin) FLX_NCCL(ctx, ncclCommDestroy((ncclComm_t)ctx->comm_twin));
     FLX_NCCL(ctx, ncclCommDestroy((ncclComm_t)ctx->comm));
   }
-  ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_size = 1; ctx->comm_owned = false;
+  ctx->comm = nullptr; ctx->comm_twin = nullptr; ctx->comm_rank = 0; ctx->comm_size = 1; ctx->comm_owned = false;
   return FLX_OK;
 }
 
-extern "C" flx_status flx_render_gathered_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, void *d_frames) {
-  if (!ctx) return FLX_ERR_INVALID;
-  if (!d_frames) return flx_fail(ctx, FLX_ERR_INVALID, "flx_render_gathered_device: output pointer is NULL");
-  if (!ctx->comm) return flx_fail(ctx, FLX_ERR_INVALID, "flx_render_gathered_device: the context belongs to no communicator (flx_comm_init_rank)");
+/* trace, exchange, reassembly — all enqueued on the context's stream, nothing waits on the host.  root < 0: ncclAllGather, every rank
+ * ends up with the frames.  root >= 0: only that rank receives (one ncclSend per rank and n ncclRecv on the root inside one
+ * ncclGroupStart / End: 1/n of the all-gather's bytes on every link but the root's), reassembles and — filter frames — runs the
+ * denoise chain; the other ranks are done when their strips are sent. */
+flx_status flx_gather_enqueue(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames) {
+  if (!ctx->comm) return flx_fail(ctx, FLX_ERR_INVALID, "gathered render: the context belongs to no communicator (flx_comm_init_rank)");
+  if (root >= ctx->comm_size) return flx_fail(ctx, FLX_ERR_INVALID, "gathered render: root is not a rank of the communicator");
+  const bool receiver = root < 0 || root == ctx->comm_rank;
+  if (receiver && !d_frames) return flx_fail(ctx, FLX_ERR_INVALID, "gathered render: output pointer is NULL on a rank that receives the frames");
   Share sh;
   flx_status s = check_params(ctx, params, n_frames, ctx->comm_rank, ctx->comm_size, sh);
   if (s) return s;
   if ((s = trace_share(ctx, params, sh))) return s;
-  FLX_NCCL(ctx, ncclAllGather(ctx->d_send, ctx->d_recv, sh.slot * 4u, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
+  ncclComm_t comm = (ncclComm_t)ctx->comm;
+  if (root < 0) {
+    FLX_NCCL(ctx, ncclAllGather(ctx->d_send, ctx->d_recv, sh.slot * 4u, ncclFloat, comm, ctx->stream));
+  } else {
+    FLX_NCCL(ctx, ncclGroupStart());
+    ncclResult_t rc = ncclSend(ctx->d_send, sh.slot * 4u, ncclFloat, root, comm, ctx->stream);
+    if (receiver)
+      for (int r = 0; r < ctx->comm_size && rc == ncclSuccess; r++) rc = ncclRecv(ctx->d_recv + (size_t)r * sh.slot, sh.slot * 4u, ncclFloat, r, comm, ctx->stream);
+    const ncclResult_t rc2 = ncclGroupEnd();
+    if (rc != ncclSuccess || rc2 != ncclSuccess) { ctx->err = std::string("ncclSend / ncclRecv: ") + ncclGetErrorString(rc != ncclSuccess ? rc : rc2); return FLX_ERR_DEVICE; }
+  }
+  ctx->last_gather_root = root;
+  if (!receiver) {
+    FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+    return FLX_OK;
+  }
   return finish_share(ctx, params, sh, d_frames);
+}
+
+extern "C" flx_status flx_render_gathered_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, void *d_frames) {
+  if (!ctx) return FLX_ERR_INVALID;
+  return flx_gather_enqueue(ctx, params, n_frames, -1, d_frames);
+}
+
+extern "C" flx_status flx_render_gathered_root_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (root < 0) return flx_fail(ctx, FLX_ERR_INVALID, "flx_render_gathered_root_device: root must be a rank (flx_render_gathered_device gathers on every rank)");
+  return flx_gather_enqueue(ctx, params, n_frames, root, d_frames);
 }
 
 /* ---- one process, several GPUs ------------------------------------------------------------------------------------------- */
 struct flx_group {
+  int gather_root = -1;                 /* -1: every context receives the strips (all-gather); 0: only context 0, the one that hands the frame out */
   std::vector<flx_context *> ctx;
   std::vector<ncclComm_t> comms;        /* empty: the contexts share a device, strips are exchanged by copies */
   std::vector<hipEvent_t> traced;       /* per context: its strips are in d_send */
@@ -243,6 +289,11 @@ extern "C" flx_status flx_group_create(int n, const int *devices, flx_group **ou
 extern "C" int flx_group_size(const flx_group *g) { return g ? (int)g->ctx.size() : 0; }
 extern "C" flx_context *flx_group_context(flx_group *g, int rank) { return (g && rank >= 0 && rank < (int)g->ctx.size()) ? g->ctx[rank] : nullptr; }
 extern "C" int flx_group_uses_rccl(const flx_group *g) { return g && !g->comms.empty(); }
+extern "C" flx_status flx_group_set_gather(flx_group *g, int to_root) {
+  if (!g) return FLX_ERR_INVALID;
+  g->gather_root = to_root ? 0 : -1;
+  return FLX_OK;
+}
 
 #define FLX_GROUP_EACH(g, call)                                                           \
   do {                                                                                    \
@@ -289,17 +340,21 @@ extern "C" flx_status flx_group_render(flx_group *g, const flx_frame_params *par
     if (hipEventRecord(g->traced[r], c->stream) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
   }
   /* 2. the exchange: one all-gather over RCCL, or (contexts on one device) plain copies ordered by events */
+  const bool toRoot = g->gather_root == 0;      /* only context 0 hands the frame out: the others need not receive anything */
   if (!g->comms.empty()) {
     ncclResult_t rc = ncclGroupStart();
     for (int r = 0; r < n && rc == ncclSuccess; r++) {
       flx_context *c = g->ctx[r];
       (void)hipSetDevice(c->device);
-      rc = ncclAllGather(c->d_send, c->d_recv, sh[r].slot * 4u, ncclFloat, g->comms[r], c->stream);
+      if (!toRoot) { rc = ncclAllGather(c->d_send, c->d_recv, sh[r].slot * 4u, ncclFloat, g->comms[r], c->stream); continue; }
+      rc = ncclSend(c->d_send, sh[r].slot * 4u, ncclFloat, 0, g->comms[r], c->stream);
+      if (r == 0)
+        for (int q = 0; q < n && rc == ncclSuccess; q++) rc = ncclRecv(c->d_recv + (size_t)q * sh[0].slot, sh[0].slot * 4u, ncclFloat, q, g->comms[0], c->stream);
     }
     ncclResult_t rc2 = ncclGroupEnd();
-    if (rc != ncclSuccess || rc2 != ncclSuccess) { g->err = std::string("ncclAllGather: ") + ncclGetErrorString(rc != ncclSuccess ? rc : rc2); return FLX_ERR_DEVICE; }
+    if (rc != ncclSuccess || rc2 != ncclSuccess) { g->err = std::string(toRoot ? "ncclSend / ncclRecv: " : "ncclAllGather: ") + ncclGetErrorString(rc != ncclSuccess ? rc : rc2); return FLX_ERR_DEVICE; }
   } else {
-    for (int r = 0; r < n; r++) {
+    for (int r = 0; r < (toRoot ? 1 : n); r++) {
       flx_context *c = g->ctx[r];
       (void)hipSetDevice(c->device);
       for (int q = 0; q < n; q++) {
@@ -309,8 +364,8 @@ extern "C" flx_status flx_group_render(flx_group *g, const flx_frame_params *par
       }
       if (hipEventRecord(g->gathered[r], c->stream) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
     }
-    /* a context's d_send may be overwritten by its next frame only after every peer has copied it */
-    for (int r = 0; r < n; r++) for (int q = 0; q < n; q++) if (q != r && hipStreamWaitEvent(g->ctx[r]->stream, g->gathered[q], 0) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
+    /* a context's d_send may be overwritten by its next frame only after every receiving peer has copied it */
+    for (int r = 0; r < n; r++) for (int q = 0; q < (toRoot ? 1 : n); q++) if (q != r && hipStreamWaitEvent(g->ctx[r]->stream, g->gathered[q], 0) != hipSuccess) return gfail(nullptr, FLX_ERR_DEVICE);
   }
   /* 3. context 0 puts the rows in image order (and runs the denoise chain of a filter frame); the frames go to the host */
   flx_context *c0 = g->ctx[0];

@@ -82,6 +82,9 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
 #ifndef FLX_DIAG_PAD_VALU
 #define FLX_DIAG_PAD_VALU 0
 #endif
+#ifndef FLX_EXPERIMENTS
+#define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 adds the queue scheduler, the cooperative finisher and walk suspension */
+#endif
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
 #endif
@@ -421,6 +424,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
    * the walk kernel of the next round takes them up first: the kernel no longer waits for its longest walk, the paths held
    * up run one round behind the others (every path's record carries its own bounce index) — or, with the cooperative
    * finisher (flx_walkcoop.hip, resumePrev == 0), are completed right after this kernel, a wave per walk. */
+#if !FLX_EXPERIMENTS
+  suspendMax = 0u; resumePrev = 0u;        /* the shipped library does not suspend walks (Makefile: EXPERIMENTS): constants, so that code folds away */
+#endif
   const uint32_t nStrag = (resumePrev && b > 0) ? wb.stragCount[b - 1] : 0u;     /* with the cooperative finisher nothing is carried over */
   const uint32_t nList = FIRST ? total_items : wb.counts[b];
   const bool compact0 = FIRST && wb.rec0 != nullptr;         /* bounce 0 reads the compact records (flx_kernels.h) */
@@ -824,12 +830,21 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #pragma unroll FLX_WF_UNROLL
     for (int it = 0; it < FLX_WF_INNER; it++) {
       if (COUNT) diagIters++;
+#if FLX_WF_FUSED_TRIP
+      {
+        const bool walkingNow = st == P_WALKING;
+        if (flx_ballot(walkingNow) == 0ull) break;
+        const bool ended = walkTripFused<COUNT>(sc, ldsEntries, ldsCount, myRays, walkingNow, w, cur, cnt);
+        st = (walkingNow & ended) ? ((w.mode == 0) ? P_SWITCH : P_DONE) : st;
+      }
+#else
       if (st == P_WALKING) {
         bool ended = false;
         if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
         if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
         if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
       }
+#endif
 #if FLX_DIAG_PAD_SALU        /* diagnostic builds: what do N more scalar / vector instructions per trip cost? (profiles/r02_issue_sensitivity.txt) */
       { uint32_t a = 1, b = 2, c = 3, d = 4;
         for (int k = 0; k < FLX_DIAG_PAD_SALU / 4; k++) asm volatile("s_mov_b32 %0, %1\n s_mov_b32 %1, %2\n s_mov_b32 %2, %3\n s_mov_b32 %3, %0" : "+s"(a), "+s"(b), "+s"(c), "+s"(d) : : "scc"); }      /* (s_mov leaves SCC alone; an s_add here without the clobber corrupts the loop's compare and the kernel never ends) */
@@ -895,6 +910,9 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   /* Suspension needs the kernel that can take a walk up again (k_wf_walk_pre), at least two bounces to gain anything, and
    * as many extra rounds as a path can be held up: one per regular round.  The extra rounds find their lists empty
    * almost always and return at once. */
+#if !FLX_EXPERIMENTS
+  walk_scheduler = 0; suspend_max = 0u;                     /* (flx_set_walk_scheduler refuses anything else in this build) */
+#endif
   const bool finisher = (walk_scheduler & 2) != 0;          /* suspended walks go to k_wf_walk_coop instead of the next round */
   const bool lanes = (walk_scheduler & 1) == 0;             /* one walk per lane (not the queue scheduler) */
   const bool suspend = suspend_max > 0u && pre && lanes && (bounces >= 2 || finisher) && FLX_WF_CONSOLIDATE;
@@ -915,7 +933,9 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
     if (r == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
     const uint32_t smax = (suspend && r < bounces) ? suspend_max : 0u;
     if (!lanes) {
+#if FLX_EXPERIMENTS
       launch_walk_queue(sc, fr, wb, compute_units, count, r, total, stream);
+#endif
     } else if (pre) {
       if (r == 0) {
         if (count) hipLaunchKernelGGL((k_wf_walk_pre<true, true>), dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount, T, smax, finisher ? 0u : 1u);
@@ -929,7 +949,9 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
       else hipLaunchKernelGGL(k_wf_walk<false>, dim3(walkBlocks), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, sc, fr, wb, r, total, ldsCount);
     }
     if (r == 0 && walk0_end) (void)hipEventRecord(walk0_end, stream);
+#if FLX_EXPERIMENTS
     if (suspend && finisher) launch_walk_coop(sc, fr, wb, compute_units, count, r, stream);
+#endif
   }
 }
 

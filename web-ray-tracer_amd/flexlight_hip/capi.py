@@ -24,6 +24,7 @@ EXPORTS = [
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
     "flx_group_create", "flx_group_destroy", "flx_group_last_error", "flx_group_size", "flx_group_uses_rccl", "flx_group_context",
     "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag",
+    "flx_render_gathered_root_device", "flx_comm_count", "flx_frame_begin_gathered", "flx_group_set_gather", "flx_frame_host_slots", "flx_has_experiments",
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
 ]
 
@@ -101,6 +102,12 @@ def _load():
         "flx_comm_init_rank": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
         "flx_comm_destroy": (C.c_int, [vp]),
         "flx_render_gathered_device": (C.c_int, [vp, C.POINTER(FrameParams), u32, vp]),
+        "flx_render_gathered_root_device": (C.c_int, [vp, C.POINTER(FrameParams), u32, C.c_int, vp]),
+        "flx_comm_count": (C.c_int, [vp]),
+        "flx_frame_begin_gathered": (C.c_int, [vp, C.POINTER(FrameParams), C.c_int, C.c_int]),
+        "flx_group_set_gather": (C.c_int, [vp, C.c_int]),
+        "flx_frame_host_slots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
+        "flx_has_experiments": (C.c_int, []),
         "flx_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
         "flx_group_destroy": (None, [vp]),
         "flx_group_last_error": (C.c_char_p, [vp]),
@@ -121,6 +128,11 @@ def _load():
 
 
 LIB = _load()
+
+
+def has_experiments():
+    """the loaded library carries the experimental walk schedulers (`make EXPERIMENTS=1`)"""
+    return bool(LIB.flx_has_experiments())
 
 
 def _fp(a):
@@ -229,6 +241,22 @@ class Context:
         n = len(params_list)
         arr = (FrameParams * n)(*params_list)
         self._check(LIB.flx_render_gathered_device(self._h, arr, n, C.c_void_p(device_ptr)), "flx_render_gathered_device")
+
+    def render_gathered_root_device(self, params_list, root, device_ptr):
+        """the same with one receiver: ncclSend / ncclRecv to rank `root`, which alone gets float4[n][H][W] at device_ptr (0 elsewhere)"""
+        n = len(params_list)
+        arr = (FrameParams * n)(*params_list)
+        self._check(LIB.flx_render_gathered_root_device(self._h, arr, n, int(root), C.c_void_p(device_ptr or 0)), "flx_render_gathered_root_device")
+
+    def comm_count(self):
+        """ranks of this context's RCCL communicator (ncclCommCount); 0 without one"""
+        return int(LIB.flx_comm_count(self._h))
+
+    def frame_begin_gathered(self, params, root=-1):
+        """flx_frame_begin over the communicator: the gathered whole frame stays in device memory (frame_end -> its pointer)"""
+        self._pending = getattr(self, "_pending", [])
+        self._check(LIB.flx_frame_begin_gathered(self._h, C.byref(params), 2, int(root)), "flx_frame_begin_gathered")
+        self._pending.append((params.height, params.width, False, True))
 
     # -- the frame loop: two frames in flight, pixels out of pinned host memory (flx_frame_begin / flx_frame_end) --------
     def set_frame_lanes(self, lanes):
@@ -421,6 +449,10 @@ class Group:
     @property
     def uses_rccl(self):
         return bool(LIB.flx_group_uses_rccl(self._h))
+
+    def set_gather(self, to_root):
+        """True: only context 0 (which hands the frame out) receives the strips; False (default): all-gather"""
+        self._check(LIB.flx_group_set_gather(self._h, 1 if to_root else 0), "flx_group_set_gather")
 
     def context(self, rank):
         h = LIB.flx_group_context(self._h, rank)

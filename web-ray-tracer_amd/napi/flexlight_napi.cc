@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "flexlight_hip.h"
 
@@ -36,12 +37,36 @@ static bool get_args(napi_env env, napi_callback_info info, size_t want, napi_va
   return true;
 }
 
-static flx_context *get_ctx(napi_env env, napi_value v) {
+/* What a context handle points to: the context and the ArrayBuffers handed out over its pinned frame slots (frameEnd).  Those
+ * buffers are views of memory the LIBRARY owns — freed by halt(), re-allocated when a larger frame needs a bigger slot, re-used
+ * by the frame after the next — so the box keeps a weak reference to each and DETACHES it (length 0, no pointer) the moment its
+ * memory stops being that frame's: a JavaScript holder of an old frame then reads an empty array, never freed memory. */
+struct CtxBox {
+  flx_context *ctx = nullptr;              /* first member: a handle also reads as flx_context ** */
+  struct View { const void *ptr; napi_ref ref; };
+  std::vector<View> views;
+};
+static void detach_view(napi_env env, CtxBox::View &v) {
+  napi_value buf = nullptr;
+  if (napi_get_reference_value(env, v.ref, &buf) == napi_ok && buf) (void)napi_detach_arraybuffer(env, buf);      /* (collected already: nothing to do) */
+  napi_delete_reference(env, v.ref);
+}
+/* detach the views for which keep(ptr) is false */
+template <typename Keep> static void detach_views(napi_env env, CtxBox *box, Keep keep) {
+  size_t n = 0;
+  for (auto &v : box->views) { if (keep(v.ptr)) box->views[n++] = v; else detach_view(env, v); }
+  box->views.resize(n);
+}
+static CtxBox *get_box(napi_env env, napi_value v) {
   void *p = nullptr;
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a context handle"); return nullptr; }
-  flx_context *ctx = *static_cast<flx_context **>(p);
-  if (!ctx) napi_throw_error(env, nullptr, "context was halted");
-  return ctx;
+  CtxBox *box = static_cast<CtxBox *>(p);
+  if (!box->ctx) { napi_throw_error(env, nullptr, "context was halted"); return nullptr; }
+  return box;
+}
+static flx_context *get_ctx(napi_env env, napi_value v) {
+  CtxBox *box = get_box(env, v);
+  return box ? box->ctx : nullptr;
 }
 
 /* typed array -> pointer + element count; null / undefined -> nullptr, 0 */
@@ -90,10 +115,11 @@ static bool floats(napi_env env, napi_value obj, const char *key, float *dst, si
   return true;
 }
 
-static void finalize_ctx(napi_env, void *data, void *) {
-  flx_context **slot = static_cast<flx_context **>(data);
-  if (*slot) flx_context_destroy(*slot);
-  delete slot;
+static void finalize_ctx(napi_env env, void *data, void *) {
+  CtxBox *box = static_cast<CtxBox *>(data);
+  for (auto &v : box->views) napi_delete_reference(env, v.ref);      /* (finalizers may not touch JS values; whoever still holds a view keeps the handle alive through its frame object) */
+  if (box->ctx) flx_context_destroy(box->ctx);
+  delete box;
 }
 
 /* createContext(device) -> handle */
@@ -106,7 +132,9 @@ static napi_value CreateContext(napi_env env, napi_callback_info info) {
   flx_status rc = flx_context_create(device, &ctx);
   if (rc != FLX_OK) return fail(env, nullptr, "flx_context_create", rc);
   napi_value ext;
-  NAPI_OK(env, napi_create_external(env, new flx_context *(ctx), finalize_ctx, nullptr, &ext));
+  CtxBox *box = new CtxBox();
+  box->ctx = ctx;
+  NAPI_OK(env, napi_create_external(env, box, finalize_ctx, nullptr, &ext));
   return ext;
 }
 
@@ -116,8 +144,9 @@ static napi_value DestroyContext(napi_env env, napi_callback_info info) {
   if (!get_args(env, info, 1, argv)) return nullptr;
   void *p = nullptr;
   if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
-    flx_context **slot = static_cast<flx_context **>(p);
-    if (*slot) { flx_context_destroy(*slot); *slot = nullptr; }
+    CtxBox *box = static_cast<CtxBox *>(p);
+    detach_views(env, box, [](const void *) { return false; });      /* the pinned slots are about to be freed */
+    if (box->ctx) { flx_context_destroy(box->ctx); box->ctx = nullptr; }
   }
   return nullptr;
 }
@@ -504,18 +533,29 @@ static napi_value PackTransforms(napi_env env, napi_callback_info info) {
 
 
 /* ---- the frame loop: frameBegin(handle, params, rgba8) / frameEnd(handle) -> { pixels, gpuMs } ---------------------------
- * `pixels` is a typed array over the context's pinned host buffer (no copy): valid until the second frameBegin after the one
- * that made it, or halt(). */
+ * `pixels` is a typed array over the context's pinned host buffer (no copy).  It belongs to that frame until the library re-uses
+ * or frees the buffer — the frameBegin that will copy a newer frame into it (with two lanes: the fourth after the one that made
+ * it; with one lane the second), a frameBegin that re-allocates it for a larger frame, or halt() — at which point the addon
+ * DETACHES it: `pixels.length` becomes 0 instead of the array showing another frame or freed memory. */
 static napi_value FrameBegin(napi_env env, napi_callback_info info) {
   napi_value argv[3];
   if (!get_args(env, info, 3, argv)) return nullptr;
-  flx_context *ctx = get_ctx(env, argv[0]);
-  if (!ctx) return nullptr;
+  CtxBox *box = get_box(env, argv[0]);
+  if (!box) return nullptr;
+  flx_context *ctx = box->ctx;
   flx_frame_params p;
   if (!read_params(env, argv[1], &p)) return nullptr;
   bool rgba8 = false;
   napi_get_value_bool(env, argv[2], &rgba8);
   flx_status rc = flx_frame_begin(ctx, &p, rgba8 ? FLX_FRAME_RGBA8 : FLX_FRAME_FLOAT);
+  /* a larger frame (canvas or renderQuality changed) made the library re-allocate a pinned slot: the views over the old one go
+   * (no JavaScript has run since the free — this is one native call) */
+  const void *slots[4] = { nullptr, nullptr, nullptr, nullptr };
+  int begun = -1;
+  (void)flx_frame_host_slots(ctx, slots, &begun);
+  /* ... and the slot the frame just begun will be copied into stops being the older frame's that was handed out over it */
+  const void *reused = (rc == FLX_OK && begun >= 0) ? slots[begun] : nullptr;
+  detach_views(env, box, [&](const void *q) { return q != reused && (q == slots[0] || q == slots[1] || q == slots[2] || q == slots[3]); });
   if (rc != FLX_OK) return fail(env, ctx, "flx_frame_begin", rc);
   return nullptr;
 }
@@ -523,8 +563,9 @@ static void no_free(napi_env, void *, void *) {}
 static napi_value FrameEnd(napi_env env, napi_callback_info info) {
   napi_value argv[2];
   if (!get_args(env, info, 2, argv)) return nullptr;
-  flx_context *ctx = get_ctx(env, argv[0]);
-  if (!ctx) return nullptr;
+  CtxBox *box = get_box(env, argv[0]);
+  if (!box) return nullptr;
+  flx_context *ctx = box->ctx;
   bool rgba8 = false;
   napi_get_value_bool(env, argv[1], &rgba8);
   const void *pixels = nullptr; size_t bytes = 0; float ms = 0.f;
@@ -532,7 +573,14 @@ static napi_value FrameEnd(napi_env env, napi_callback_info info) {
   if (rc != FLX_OK) return fail(env, ctx, "flx_frame_end", rc);
   napi_value res, buf, arr, v;
   NAPI_OK(env, napi_create_object(env, &res));
+  /* the slot now holds THIS frame: an older frame's view of the same memory (two frames back on this lane) is detached */
+  detach_views(env, box, [&](const void *q) { return q != pixels; });
   NAPI_OK(env, napi_create_external_arraybuffer(env, const_cast<void *>(pixels), bytes, no_free, nullptr, &buf));
+  {
+    CtxBox::View view = { pixels, nullptr };
+    NAPI_OK(env, napi_create_reference(env, buf, 0, &view.ref));      /* weak: the view lives as long as JavaScript holds it */
+    box->views.push_back(view);
+  }
   if (rgba8) NAPI_OK(env, napi_create_typedarray(env, napi_uint8_clamped_array, bytes, buf, 0, &arr));
   else NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, bytes / 4, buf, 0, &arr));
   napi_set_named_property(env, res, "pixels", arr);
