@@ -501,7 +501,12 @@ def main():
         elif pipe == 2:            # persistent path kernel (tiny scenes): every bounce of every path, no primary walk, no output
             kernel_name, kernel_sym = "k_paths (persistent path kernel)", next((n for n in pmc if n.startswith("k_paths<false")), "k_paths<false, false>")
             bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * cnt["shades"] + 4 * cnt["atlas_texels"]
-        else:                      # the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
+        elif "k_wf_frame<false>" in pmc or (b0_visits and b0_visits == cnt["closest_visits"] + cnt["shadow_visits"] and bounces > 1):
+            # the frame kernel (its tally holds EVERY bounce's visits): all bounce walks of the frame and the shading of bounces >= 1 in one persistent launch
+            later_shades = max(0, cnt["shades"] - spp * cnt["primary_hits"])
+            kernel_name, kernel_sym = "k_wf_frame<false> (frame kernel: all bounce walks + shading of bounces >= 1)", "k_wf_frame<false>"
+            bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * later_shades
+        else:                      # rounds: the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
             visits = b0_visits if b0_visits else cnt["closest_visits"] + cnt["shadow_visits"]
             kernel_name, kernel_sym, bytes_launch = "k_wf_walk_pre<false, true> (walk kernel of bounce 0)", "k_wf_walk_pre<false, true>", 48 * visits
         k = pmc.get(kernel_sym, {})

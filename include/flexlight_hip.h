@@ -284,6 +284,11 @@ flx_status flx_set_lockstep(flx_context *ctx, int on);
 /* Wavefront pipeline: run the bounce loop as 1..4 independent chains of screen-tile ranges on separate HIP
  * streams (default 1: more chains measured slower, profiles/r01_ab_stream_groups.txt), so that the tail of one chain's persistent walk kernel overlaps the other's work. */
 flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
+/* Wavefront pipeline: how the bounce loop is laid out on the GPU.  0 (default): automatic — ONE persistent launch for all bounces
+ * (k_wf_frame: the walk waves and shade waves of a workgroup pass paths to each other through LDS rings; no kernel boundary, hence no
+ * tail, between the bounces) where the scene's object spaces leave room in LDS, rounds otherwise; 1: rounds, a shade + walk kernel
+ * pair per bounce (the round-1/2 organisation); 2: the frame kernel where it fits.  Frames and work counters are identical. */
+flx_status flx_set_wavefront_organisation(flx_context *ctx, int organisation);
 /* Wavefront pipeline: how the bounce walks are scheduled.  Every mode walks every ray through the same entries with the
  * same arithmetic (frames and work counters are identical); they differ in speed and exist for A/B measurements
  * (profiles/r01_ab_tail_schedulers.txt).

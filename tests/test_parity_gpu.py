@@ -295,6 +295,35 @@ def test_wavefront_groups_do_not_change_the_frame(hip, oracle, scenes, name, w, 
         hip.set_wavefront_groups(1)
 
 
+@pytest.mark.parametrize("organisation", [1, 2], ids=["rounds", "frame_kernel"])
+@pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 480, 270, 2, 4), ("dragon", 333, 187, 3, 2), ("dragon", 640, 360, 8, 6), ("cornell_obj", 128, 96, 2, 5),
+                                                  ("theater", 96, 64, 2, 3), ("cornell", 64, 64, 1, 1), ("dragon", 64, 36, 1, 4)])
+def test_both_organisations_of_the_bounce_loop_equal_the_oracle(hip, oracle, scenes, name, w, h, spp, bounces, organisation):
+    """the wavefront pipeline as rounds (a shade + walk kernel pair per bounce) and as ONE persistent launch (k_wf_frame: walk waves and
+    shade waves of a workgroup hand paths to each other through LDS rings): the same frame and the same work counters as the oracle —
+    frames of a few waves (where most workgroups find the item queue dry at once) and frames that fill the machine"""
+    sc = scenes(name)
+    hip.update_scene(sc)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+    key = (name, w, h, spp, bounces)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle.render(sc, p)[:2]
+    want, want_cnt = _ORACLE_CACHE[key]
+    try:
+        hip.set_pipeline(3)
+        hip.set_wavefront_organisation(organisation)
+        for _ in range(2):
+            got, cnt, _ = hip.render(p, counters=True)
+            assert np.array_equal(got, want, equal_nan=True)
+            assert cnt == want_cnt
+        for _ in range(3):
+            got, _, _ = hip.render(p)                               # the build without counters
+            assert np.array_equal(got, want, equal_nan=True)
+    finally:
+        hip.set_pipeline(0)
+        hip.set_wavefront_organisation(0)
+
+
 @pytest.mark.experiments
 @pytest.mark.parametrize("scheduler,suspend", [(0, 128), (0, 16), (1, 0), (2, 16), (2, 128), (0, 0)])
 @pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 480, 270, 2, 4), ("cornell_obj", 128, 96, 2, 5), ("theater", 96, 64, 1, 1)])

@@ -28,16 +28,19 @@ def test_synthetic_scene_matches_oracle(hip, oracle, case, pipeline):
     p = sc.frame_params(use_filter=0)
     hip.update_scene(sc)
     hip.set_pipeline(pipeline)
+    want, want_cnt, _ = oracle.render(sc, p)
     try:
-        got, got_cnt, _ = hip.render(p, counters=True)
-        plain, _, _ = hip.render(p)
+        for organisation in ((2, 1) if pipeline == 3 else (0,)):         # the wavefront pipeline as one persistent launch and as rounds
+            hip.set_wavefront_organisation(organisation)
+            got, got_cnt, _ = hip.render(p, counters=True)
+            plain, _, _ = hip.render(p)
+            rms, mism = assert_parity(got, want, case)
+            assert mism == 0, "%s (organisation %d): %d of %d floats differ (rms %s)" % (case, organisation, mism, got.size, rms)
+            assert got_cnt == want_cnt, organisation
+            assert np.array_equal(plain, got, equal_nan=True)
     finally:
         hip.set_pipeline(0)
-    want, want_cnt, _ = oracle.render(sc, p)
-    rms, mism = assert_parity(got, want, case)
-    assert mism == 0, "%s: %d of %d floats differ (rms %s)" % (case, mism, got.size, rms)
-    assert got_cnt == want_cnt
-    assert np.array_equal(plain, got, equal_nan=True)
+        hip.set_wavefront_organisation(0)
     assert want_cnt["primary_hits"] > 0.3 * p.width * p.height          # the scene is actually in view
 
 

@@ -1,0 +1,22 @@
+#!/usr/bin/env python3
+"""Debug aid for the frame kernel (k_wf_frame): render one counted frame and print the control words a wave left behind if its
+watchdog tripped (never in a healthy frame).  argv: width height [spp bounces]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+from flexlight_hip import capi
+from flexlight_hip.scene_io import Scene
+sc = Scene.golden("dragon")
+ctx = capi.Context(0)
+ctx.update_scene(sc)
+ctx.set_pipeline(3); ctx.set_wavefront_organisation(2)
+w, h = int(sys.argv[1]), int(sys.argv[2])
+spp, b = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (2, 4)
+p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=b, use_filter=0)
+t0 = time.time()
+_, cnt, _ = ctx.render(p, counters=True)
+print("frame %dx%d spp %d bounces %d: %.3f s" % (w, h, spp, b, time.time() - t0), cnt)
+t = ctx.get_tail_diag()
+names = ["alive", "dry", "sq_tail", "sq_head", "sq_avail", "wq_tail", "wq_head", "wq_avail"]
+print("shade waves that gave up:", t[8], {n: t[k] - 1 for k, n in enumerate(names) if t[k]})
+print("walk waves that gave up: ", t[18], {n: t[10 + k] - 1 for k, n in enumerate(names) if t[10 + k]})

@@ -24,6 +24,9 @@ using namespace flx;
 #ifndef FLX_EXPERIMENTS
 #define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 */
 #endif
+#ifndef FLX_WF_ORGANISATION_DEFAULT
+#define FLX_WF_ORGANISATION_DEFAULT 0       /* A/B builds: force rounds (1) or the frame kernel (2) whatever the context says */
+#endif
 
 thread_local std::string g_create_error;
 
@@ -88,7 +91,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_send, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd,
+                   ctx->d_send, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -577,6 +580,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t), ctx->stream));
     /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
     if (!ctx->d_tail_pool) FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
+    if (!ctx->d_frame_rings) FLX_HIP(ctx, hipMalloc(&ctx->d_frame_rings, (size_t)WF_MAX_GROUPS * cus * 2u * WF_FRAME_RING * sizeof(uint32_t)));
     launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     /* The bounce loop runs as `groups` independent chains (contiguous ranges of screen tiles), group 0 on the
@@ -596,6 +600,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       WavefrontBuffers wb;
       wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
+      wb.frameRings = ctx->d_frame_rings + (size_t)g * cus * 2u * WF_FRAME_RING;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
       wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
@@ -603,7 +608,8 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;
       wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
       hipStream_t st = g == 0 ? ctx->stream : ctx->aux_stream[g - 1];
-      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend, g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
+      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend, FLX_WF_ORGANISATION_DEFAULT ? FLX_WF_ORGANISATION_DEFAULT : ctx->wf_organisation,
+                       g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
       FLX_HIP(ctx, hipGetLastError());
       if (g > 0) {
         FLX_HIP(ctx, hipEventRecord(ctx->ev_join[g - 1], st));
@@ -845,6 +851,13 @@ extern "C" flx_status flx_set_pipeline(flx_context *ctx, int pipeline) {
   if (!ctx) return FLX_ERR_INVALID;
   if (pipeline < 0 || pipeline > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_pipeline: 0 auto, 1 per-pixel, 2 persistent paths, 3 wavefront");
   ctx->pipeline = pipeline;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_set_wavefront_organisation(flx_context *ctx, int organisation) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (organisation < 0 || organisation > 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_wavefront_organisation: 0 automatic, 1 rounds (a kernel pair per bounce), 2 frame kernel (one persistent launch)");
+  ctx->wf_organisation = organisation;
   return FLX_OK;
 }
 
@@ -1205,7 +1218,7 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
     flx_context *t = ctx->twin;
     t->comm = ctx->comm_twin; t->comm_rank = ctx->comm_rank; t->comm_size = ctx->comm_size; t->comm_owned = false;      /* (the primary owns and destroys both) */
     mirror_scene(ctx);
-    t->pipeline = ctx->pipeline; t->wf_groups = ctx->wf_groups; t->walk_scheduler = ctx->walk_scheduler; t->walk_suspend = ctx->walk_suspend;
+    t->pipeline = ctx->pipeline; t->wf_groups = ctx->wf_groups; t->wf_organisation = ctx->wf_organisation; t->walk_scheduler = ctx->walk_scheduler; t->walk_suspend = ctx->walk_suspend;
     if (ctx->twin_dyn_version != ctx->dyn_version) {          /* lights / transforms changed since the twin's last frame: its own copies, on its stream */
       flx_status s;
       if (ctx->have_transforms && (s = flx_transforms_upload(t, ctx->h_rotation.data(), ctx->h_shift.data(), ctx->n_transforms))) return fail(ctx, s, flx_last_error(t));

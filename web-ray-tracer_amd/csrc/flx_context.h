@@ -35,6 +35,8 @@ struct flx_context {
   uint32_t walk_entries = 0, walk_hot = 0, walk_root = 0, walk_fast_boxes = 0;
   float4 *d_fwd = nullptr;                       /* the live entries in the reference's order (every successor further on): primary walk, lockstep walk */
   uint32_t fwd_entries = 0, fwd_root = 0, lock_boxes = 0;
+  uint32_t *d_frame_rings = nullptr;             /* k_wf_frame: per chain and workgroup two rings of WF_FRAME_RING path ids */
+  int wf_organisation = 0;                       /* wavefront pipeline: 0 automatic, 1 rounds, 2 frame kernel (flx_set_wavefront_organisation) */
   bool lock_ok = false;                          /* the scene is small and in one object space: its bounce walks may go in lockstep */
   bool lock_use = true;                          /* flx_set_lockstep */
   bool gb_float_wanted = false;                  /* flx_render was given `gbuffers`: the filter frame keeps its float G-buffers */

@@ -183,6 +183,48 @@ __global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade0(DeviceSce
   flush_counters<COUNT>(cnt, wb.counters);
 }
 
+/* One path's shading for its next bounce (fragment:476-589): the record the last walk left -> the record the next walk reads. */
+template <bool COUNT>
+FLX_DEV void shade_path(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t pathId, WorkCounters &cnt) {
+  float4 *rec = wb.rec + (size_t)pathId * 8;
+  uint32_t px, k, s;
+  item_pixel(fr, pathId, px, k, s);
+  const uint32_t frameIdx = frame_index(fr, k);
+  const f3 camera = frame_camera(fr, frameIdx);
+  PathState p;
+  PixelState ps;
+  ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
+  ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+  ps.renderOriginalId = ps.renderId;
+  const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q6 = rec[6], q7 = rec[7];
+  const int pb = __float_as_int(q3.w) + 1;            /* the bounce this path is at (its record carries the last one shaded) */
+  p.ray.origin = F3(q0.x, q0.y, q0.z);
+  p.lastHitPoint = p.ray.origin;                      /* fragment:595 */
+  p.ray.dir = F3(q1.x, q1.y, q1.z);
+  p.hit.suv = F3(q2.x, q2.y, q2.z);
+  p.hit.triangleId = __float_as_int(q2.w);
+  p.hit.transformId = (int)sc.geometry[3 * p.hit.triangleId + 2].y << 1;
+  p.dontFilter = (__float_as_int(q0.w) & RF_DONT_FILTER) != 0;
+  p.importancyFactor = F3(q6.x, q6.y, q6.z);
+  ps.originalColor = F3(q7.x, q7.y, q7.z);
+  const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+  float viewDepthPerS;
+  (void)primary_dir(fr, frameIdx, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+  ps.seed = fr.view[frameIdx].random_seed;
+  const float cosSampleN = flx_cos((float)s);
+  ShadeOut so;
+  bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, pb, so, cnt);
+  const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0) |
+                    (nextBounceRuns(fr, pb, p.importancyFactor, ps.originalColor) ? 0 : RF_NO_CLOSEST);
+  rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
+  rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
+  rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
+  rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, __int_as_float(pb));
+  rec[4] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
+  rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
+  rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
+}
+
 /* Later rounds: one lane per live path. */
 template <bool COUNT>
 __global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b) {
@@ -192,43 +234,7 @@ __global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade(DeviceScen
   for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
     const uint32_t pathId = listIn[j];
     if (pathId == WF_INVALID) continue;
-    float4 *rec = wb.rec + (size_t)pathId * 8;
-    uint32_t px, k, s;
-    item_pixel(fr, pathId, px, k, s);
-    const uint32_t frameIdx = frame_index(fr, k);
-    const f3 camera = frame_camera(fr, frameIdx);
-    PathState p;
-    PixelState ps;
-    ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
-    ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
-    ps.renderOriginalId = ps.renderId;
-    const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q6 = rec[6], q7 = rec[7];
-    const int pb = __float_as_int(q3.w) + 1;            /* the bounce this path is at (its record carries the last one shaded) */
-    p.ray.origin = F3(q0.x, q0.y, q0.z);
-    p.lastHitPoint = p.ray.origin;                      /* fragment:595 */
-    p.ray.dir = F3(q1.x, q1.y, q1.z);
-    p.hit.suv = F3(q2.x, q2.y, q2.z);
-    p.hit.triangleId = __float_as_int(q2.w);
-    p.hit.transformId = (int)sc.geometry[3 * p.hit.triangleId + 2].y << 1;
-    p.dontFilter = (__float_as_int(q0.w) & RF_DONT_FILTER) != 0;
-    p.importancyFactor = F3(q6.x, q6.y, q6.z);
-    ps.originalColor = F3(q7.x, q7.y, q7.z);
-    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
-    float viewDepthPerS;
-    (void)primary_dir(fr, frameIdx, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
-    ps.seed = fr.view[frameIdx].random_seed;
-    const float cosSampleN = flx_cos((float)s);
-    ShadeOut so;
-    bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, pb, so, cnt);
-    const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0) |
-                      (nextBounceRuns(fr, pb, p.importancyFactor, ps.originalColor) ? 0 : RF_NO_CLOSEST);
-    rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
-    rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
-    rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
-    rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, __int_as_float(pb));
-    rec[4] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
-    rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
-    rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
+    shade_path<COUNT>(sc, fr, wb, pathId, cnt);
   }
   flush_counters<COUNT>(cnt, wb.counters);
 }
@@ -879,9 +885,388 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   }
 }
 
+/* ---- the frame kernel: every bounce of every path in ONE persistent launch (round 3) ---------------------------------------------
+ * k_wf_shade / k_wf_walk_pre run the bounce loop as rounds, one kernel pair per bounce, and every walk kernel ends in a tail set by its
+ * longest walk: rounds 1 - 3 of the dragon frame spend 25 / 39 / 65 % of their kernels after their queue has run dry, at 0.79 / 0.66 /
+ * 0.58 lane utilisation, and a rank's eighth of the frame pays the same four tails for an eighth of the work
+ * (profiles/r02_ab_walk_kernel.txt).  The rounds are not a dependency of the algorithm — a path's bounce b + 1 needs ITS bounce b, not
+ * everybody's (the shader's loop, fragment:475-596, runs per pixel) — so here the barrier between rounds is gone: a workgroup keeps
+ * the paths it has drawn until they end, and its waves are specialised:
+ *
+ *   walk waves   k_wf_walk_pre's stepping loop unchanged.  A lane whose closest-hit walk found a surface and whose path goes on pushes
+ *                the path to the workgroup's shade queue (a ring of path ids in LDS) instead of a global list for the next round; free
+ *                lanes are refilled from the workgroup's walk queue first (paths of any bounce that came back from shading), then from
+ *                the frame's item queue (fresh bounce-0 paths, whose first shading k_wf_shade0 did for all pixels beforehand).
+ *   shade waves  (FLX_FRAME_SHADERS of the 16) pop 64 paths, run one bounce's shading (shade_path: what k_wf_shade runs) densely,
+ *                push them to the walk queue.  While the frame's item queue has work they wait for full batches; once it is dry they
+ *                take what is there, so that the last paths are not held up.
+ *
+ * Hand-over between the waves of a workgroup needs no device-wide fence: the record is written with plain stores, a workgroup-scope
+ * release / acquire pair around the LDS ring makes it visible to the other waves of the same CU (they share its L1), and nothing
+ * crosses workgroups until the kernel ends.  The workgroup counts its live paths in LDS (optimistically at every draw, corrected when
+ * an item turns out dead or a path ends); a wave leaves when the item queue is dry and that count is zero.  A draw that would take
+ * the count past FQ_ALIVE_MAX is not made, so the rings cannot overflow; and a wave does not draw while FQ_LIMIT paths or more wait
+ * for shading (the shade waves are behind: walking more new paths would only lengthen their queue).
+ * Per path nothing changes — the same records, the same arithmetic in the same order, its radiance in its own slot — so frames and
+ * work counters are bit-identical to the rounds (tests/test_parity_gpu.py: both organisations against the oracle). */
+#ifndef FLX_FRAME_SHADERS
+#define FLX_FRAME_SHADERS 2                 /* shade waves of a frame-kernel workgroup (dragon 1080p: 1 -> 7.27, 2 -> 6.87, 3 -> 7.16 ms per frame) */
+#endif
+#ifndef FLX_FRAME_AUTO_MAX_ITEMS
+#define FLX_FRAME_AUTO_MAX_ITEMS (64u << 20)
+#endif
+constexpr uint32_t FQ_SIZE = WF_FRAME_RING;   /* ids per ring (the rings live in HBM-backed memory private to the workgroup, their counts in LDS) */
+#ifndef FLX_FQ_LIMIT
+#define FLX_FQ_LIMIT 4096
+#endif
+constexpr uint32_t FQ_LIMIT = FLX_FQ_LIMIT; /* paths waiting for shading beyond which the walk waves stop drawing new ones (a policy: the shade waves are behind) */
+constexpr uint32_t FQ_ALIVE_MAX = FQ_SIZE - 256u;     /* live paths of a workgroup, enforced at every draw (the rings' capacity) */
+#ifndef FLX_FQ_WATCHDOG_LOG2
+#define FLX_FQ_WATCHDOG_LOG2 24
+#endif
+constexpr uint32_t FQ_WATCHDOG = 1u << FLX_FQ_WATCHDOG_LOG2;  /* polls (~500 cycles each) after which a wave that waits gives up: a seconds-long guard against a hung GPU, never reached by a frame */
+enum { FC_ALIVE = 0, FC_DRY = 1, FC_SQ = 2 /* tail, head, avail */, FC_WQ = 5 /* tail, head, avail */, FC_WORDS = 16 };
+
+FLX_DEV uint32_t fq_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+/* the lanes of `mine` append their `id` to the ring (ctl: tail, head, avail) */
+FLX_DEV void fq_push(uint32_t *ring, uint32_t *ctl, bool mine, uint32_t id, uint32_t lane) {
+  const unsigned long long m = flx_ballot(mine);
+  if (m == 0ull) return;
+  const uint32_t c = (uint32_t)__popcll(m);
+  uint32_t pos0 = 0;
+  if (lane == 0) pos0 = atomicAdd(&ctl[0], c);
+  pos0 = __builtin_amdgcn_readfirstlane(pos0);
+  if (mine) __hip_atomic_store(&ring[(pos0 + lane_rank(m)) & (FQ_SIZE - 1u)], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          /* the path's record (plain global stores) and the slot, before the count */
+  if (lane == 0) atomicAdd(&ctl[2], c);
+}
+/* up to `want` ids (none unless at least `atLeast` are there) for the lanes of `takers`, lowest lanes first; returns how many (uniform) */
+FLX_DEV uint32_t fq_pop(uint32_t *ring, uint32_t *ctl, unsigned long long takers, uint32_t want, uint32_t atLeast, uint32_t lane, uint32_t &id) {
+  uint32_t n = 0, pos0 = 0;
+  if (lane == 0) {
+    uint32_t a = fq_load(&ctl[2]);
+    while (a != 0u && a >= atLeast) {
+      const uint32_t take = a < want ? a : want;
+      const uint32_t seen = atomicCAS(&ctl[2], a, a - take);
+      if (seen == a) { n = take; pos0 = atomicAdd(&ctl[1], take); break; }
+      a = seen;
+    }
+  }
+  n = __builtin_amdgcn_readfirstlane(n);
+  pos0 = __builtin_amdgcn_readfirstlane(pos0);
+  if (n == 0u) return 0u;
+  const uint32_t r = lane_rank(takers);
+  if (((takers >> lane) & 1ull) != 0ull && r < n) {
+    uint32_t *slot = &ring[(pos0 + r) & (FQ_SIZE - 1u)];
+    uint32_t v, spins = 0;
+    do { v = fq_load(slot); } while (v == WF_INVALID && ++spins < FQ_WATCHDOG);      /* (pushes are counted in the order they finish, not in slot order: the slot says when it is filled) */
+    __hip_atomic_store(slot, WF_INVALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    id = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return n;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_frame(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items,
+                                                                                    uint32_t ldsCount, uint32_t nTransforms) {
+  const uint32_t n = total_items;
+  if (n == 0u) return;
+  constexpr uint32_t WALK_WAVES = FLX_WF_WALK_THREADS / 64u - FLX_FRAME_SHADERS;
+  const bool compactRecs = wb.rec0 != nullptr;                /* bounce 0 comes with compact records (flx_kernels.h) */
+  /* LDS: [tree top][inverse transforms][control words][per walk thread: nTransforms x 40 B of rays]; the two rings of path ids are this
+   * workgroup's slice of wb.frameRings (a few lanes touch them per fold / refill, not per trip: they need no LDS) */
+  extern __shared__ float4 ldsAll[];
+  float4 *ldsEntries = ldsAll;
+  float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u;
+  uint32_t *ctl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);
+  uint32_t *shadeRing = wb.frameRings + (size_t)blockIdx.x * 2u * FQ_SIZE, *walkRing = shadeRing + FQ_SIZE;
+  float2 *raysBase = (float2 *)(ctl + FC_WORDS);
+  for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
+  for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
+    const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
+    ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
+  }
+  if (threadIdx.x < (uint32_t)FC_WORDS) ctl[threadIdx.x] = 0u;
+  for (uint32_t t = threadIdx.x; t < 2u * FQ_SIZE; t += FLX_WF_WALK_THREADS) shadeRing[t] = WF_INVALID;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  WorkCounters cnt = {};
+
+  if (wave >= WALK_WAVES) {
+    /* ================================ shade wave ================================ */
+    uint32_t idle = 0;
+    for (;;) {
+      const bool dry = fq_load(&ctl[FC_DRY]) != 0u;
+      uint32_t id = WF_INVALID;
+      const uint32_t got = fq_pop(shadeRing, ctl + FC_SQ, ~0ull, 64u, dry ? 1u : 64u, lane, id);
+      if (got == 0u) {
+        if (dry && fq_load(&ctl[FC_ALIVE]) == 0u) break;
+        if (++idle > FQ_WATCHDOG) {                               /* never in a healthy frame; counted builds leave the control words behind (flx_get_tail_diag) */
+          if (COUNT && lane == 0) { for (uint32_t k = 0; k < 8u; k++) atomicMax(wb.counters + 40 + k, (unsigned long long)fq_load(&ctl[k]) + 1ull); atomicAdd(wb.counters + 48, 1ull); }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        continue;
+      }
+      idle = 0;
+      const bool mine = lane < got && id != WF_INVALID;
+      if (mine) shade_path<COUNT>(sc, fr, wb, id, cnt);
+      fq_push(walkRing, ctl + FC_WQ, mine, id, lane);
+    }
+    flush_counters<COUNT>(cnt, wb.counters);
+    return;
+  }
+
+  /* ================================ walk wave ================================ */
+  float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
+  uint32_t *__restrict__ queue = wb.walkQueue;
+  const uint32_t nWaves = gridDim.x * WALK_WAVES;
+  uint32_t lastBase = 0;
+  uint32_t inChunk = n / (nWaves * FLX_WF_DRAWS_PER_WAVE);
+  inChunk = inChunk < 64u ? 64u : (inChunk > WF_IN_CHUNK ? WF_IN_CHUNK : inChunk);
+
+  int st = P_EMPTY;
+  uint32_t pathId = 0;
+  int flags = 0;
+  int pathBounce = 0;
+  float base = 0.0f;
+  Ray nextRay; nextRay.origin = F3(0.f, 0.f, 0.f); nextRay.dir = nextRay.origin;
+  Ray shadowRay = nextRay;
+  float shadowLen = 0.0f;
+  WalkState w;
+  walkClearResults(w);
+  w.src = nextRay; w.tR = nextRay; w.minLen = 0.0f; w.i = 0; w.cachedTI = 0;
+  w.mode = 2;
+  WalkEntry cur;
+  cur.e0 = cur.e1 = cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t chunkNext = 0, chunkEnd = 0;
+  bool itemsLeft = true;
+  uint32_t idleSpins = 0;
+
+  auto pixPart = [&](uint32_t id) -> const float4 * {
+    uint32_t tile0, s0;
+    item_tile(fr, id, tile0, s0);
+    return wb.pix0 + (((size_t)tile0 << 6) | (id & 63u)) * 3;
+  };
+
+  for (;;) {
+    const unsigned long long walking = flx_ballot(st == P_WALKING);
+    if (walking != 0ull) idleSpins = 0;
+    const unsigned long long workMask = flx_ballot(st == P_DONE || st == P_SWITCH);
+    const uint32_t parked = 64u - (uint32_t)__popcll(walking);
+    const bool mayRefill = itemsLeft || chunkNext != chunkEnd || fq_load(&ctl[FC_WQ + 2]) != 0u;
+    if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
+      /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475; a path that goes on is handed to the shade waves ---- */
+      if (flx_ballot(st == P_DONE) != 0ull) {
+        bool toShade = false, ended = false;
+        if (st == P_DONE) {
+          float4 *rec = wb.rec + (size_t)pathId * 8;
+          const bool compact = compactRecs && pathBounce == 0;
+          float4 q4, q5, q6, q7;
+          const float4 *pp = nullptr;
+          if (compact) {
+            pp = pixPart(pathId);
+            q4 = wb.rec0[(size_t)pathId * 3 + 2]; q7 = pp[2];
+            q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+          } else {
+            q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
+          }
+          const bool shadowed = (flags & RF_SHADOWED_NO_WALK) || ((flags & RF_NEED_SHADOW) && w.shadowed);
+          const f3 localColor = shadowed ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
+          const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
+          const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
+          bool cont = w.tri != -1;
+          if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+          if (cont) {
+            if (compact) {                                    /* the path goes on: now it gets its full record (what shade0 would have written) */
+              const float4 a = wb.rec0[(size_t)pathId * 3], bq = wb.rec0[(size_t)pathId * 3 + 1], p0 = pp[0];
+              rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
+              rec[1] = make_float4(a.x, a.y, a.z, bq.w);
+              rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+              rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+              rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
+            }
+            rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
+            rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
+            toShade = true;
+          } else {
+            finalize_path(fr, wb, pathId, finalColor, importancy, originalColor);
+            ended = true;
+          }
+          st = P_EMPTY;
+        }
+        fq_push(shadeRing, ctl + FC_SQ, toShade, pathId, lane);
+        const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
+        if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
+      }
+      /* ---- refill the free lanes: paths that came back from shading first, then fresh ones from the frame's item queue ---- */
+      for (;;) {
+        const unsigned long long idle = flx_ballot(st == P_EMPTY);
+        if (idle == 0ull) break;
+        const uint32_t nIdle = (uint32_t)__popcll(idle);
+        uint32_t id = WF_INVALID;
+        bool fresh = false;                                    /* a bounce-0 item: compact record, may be dead */
+        const uint32_t back = fq_pop(walkRing, ctl + FC_WQ, idle, nIdle, 1u, lane, id);
+        if (back == 0u) {
+          if (chunkNext == chunkEnd) {
+            if (!itemsLeft) break;
+            if (fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT) break;  /* the shade waves are behind: no new paths for now */
+            uint32_t want = (n - lastBase) / (nWaves * 2u);    /* guided self-scheduling: draws shrink as the queue empties */
+            want = want < 64u ? 64u : (want > inChunk ? inChunk : want);
+            /* The workgroup's live paths are counted BEFORE they are drawn (the count never runs behind) and never exceed FQ_ALIVE_MAX: a
+             * path is in one place at a time — a lane, a ring, a shade wave's batch — so neither ring can hold more than that, and a slot
+             * is read and cleared before its position comes round again. */
+            uint32_t base0 = 0, room = 1;
+            if (lane == 0) {
+              const uint32_t before = atomicAdd(&ctl[FC_ALIVE], want);
+              if (before + want > FQ_ALIVE_MAX) { atomicSub(&ctl[FC_ALIVE], want); room = 0; }
+              else base0 = atomicAdd(queue, want);
+            }
+            room = __builtin_amdgcn_readfirstlane(room);
+            if (room == 0u) break;                              /* as many live paths as the rings hold: no new ones until some end */
+            base0 = __builtin_amdgcn_readfirstlane(base0);
+            if (base0 >= n) {
+              if (lane == 0) { atomicSub(&ctl[FC_ALIVE], want); __hip_atomic_store(&ctl[FC_DRY], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+              itemsLeft = false;
+              break;
+            }
+            const uint32_t have = (base0 + want < n) ? want : n - base0;
+            if (have < want && lane == 0) atomicSub(&ctl[FC_ALIVE], want - have);
+            lastBase = base0;
+            chunkNext = base0; chunkEnd = base0 + have;
+          }
+          const uint32_t avail = chunkEnd - chunkNext;
+          const uint32_t take = nIdle < avail ? nIdle : avail;
+          const uint32_t r = lane_rank(idle);
+          if (st == P_EMPTY && r < take) { id = wb.item_base + chunkNext + r; fresh = true; }
+          chunkNext += take;
+        }
+        bool dead = false;
+        if (id != WF_INVALID) {
+          const float4 *rec = wb.rec + (size_t)id * 8;
+          float4 q0, q1, q2, q3;
+          if (fresh && compactRecs) {
+            const float4 *pp = pixPart(id);
+            const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
+            const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+            q0 = make_float4(p0.x, p0.y, p0.z, a.w);
+            q1 = make_float4(a.x, a.y, a.z, bq.w);
+            q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
+            q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+          } else {
+            q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+          }
+          const int fl = __float_as_int(q0.w);
+          if (fl & RF_DEAD) {
+            dead = true;
+          } else {
+            pathId = id; flags = fl; base = q2.w; pathBounce = __float_as_int(q3.w);
+            nextRay.origin = F3(q0.x, q0.y, q0.z);
+            nextRay.dir = F3(q1.x, q1.y, q1.z);
+            shadowRay.origin = F3(q2.x, q2.y, q2.z);
+            shadowRay.dir = F3(q3.x, q3.y, q3.z);
+            shadowLen = q1.w;
+            walkClearResults(w);
+            w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
+            if (COUNT) { if (w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
+            st = (w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;      /* nothing to walk: straight to the fold */
+          }
+        }
+        const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
+        if (nDead != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nDead);
+      }
+      /* ---- set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended ---- */
+      if (st == P_SWITCH) {
+        if (flags & RF_NO_CLOSEST) st = P_DONE;
+        else { w.mode = 1; st = P_SETUP; }
+      }
+      if (flx_ballot(st == P_SETUP) != 0ull) {
+        if (st == P_SETUP) {
+          const bool shadowMode = w.mode == 0;
+          const Ray src = shadowMode ? shadowRay : nextRay;
+          walkSetupRays(sc, nTransforms, ldsXf, myRays, src, shadowMode);
+          w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
+          reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);
+          st = P_WALKING;
+          if (walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
+        }
+      }
+      if (flx_ballot(st == P_WALKING) == 0ull) {
+        if (flx_ballot(st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
+        /* nothing in this wave: done when the item queue is dry and no path of the workgroup is alive; else wait for the shade waves */
+        if (!itemsLeft && chunkNext == chunkEnd && fq_load(&ctl[FC_ALIVE]) == 0u) break;
+        if (fq_load(&ctl[FC_WQ + 2]) == 0u && !(itemsLeft && fq_load(&ctl[FC_SQ + 2]) < FQ_LIMIT && fq_load(&ctl[FC_ALIVE]) + 256u <= FQ_ALIVE_MAX)) {
+          if (++idleSpins > FQ_WATCHDOG) {
+            if (COUNT && lane == 0) { for (uint32_t k = 0; k < 8u; k++) atomicMax(wb.counters + 50 + k, (unsigned long long)fq_load(&ctl[k]) + 1ull); atomicAdd(wb.counters + 58, 1ull); }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        continue;
+      }
+    }
+    /* ---- FLX_WF_INNER entries for every walking lane ---- */
+#pragma unroll FLX_WF_UNROLL
+    for (int it = 0; it < FLX_WF_INNER; it++) {
+      if (st == P_WALKING) {
+        bool ended = false;
+        if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
+        if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
+        if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
+      }
+    }
+  }
+  if (COUNT && (cnt.closest_visits | cnt.shadow_visits) != 0u) atomicAdd(wb.counters + 23, (unsigned long long)cnt.closest_visits + cnt.shadow_visits);
+  flush_counters<COUNT>(cnt, wb.counters);
+}
+
+/* Can the frame kernel take this frame?  Its LDS holds the rays of its walk threads, the staged transforms, the two rings and
+ * at least a little of the tree's top. */
+static bool frame_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes) {
+  const uint32_t T = sc.n_transforms;
+  const uint32_t walkThreads = FLX_WF_WALK_THREADS - 64u * FLX_FRAME_SHADERS;
+  const uint32_t fixed = walkThreads * T * 40u + T * 64u + FC_WORDS * 4u;
+  if (!FLX_WF_PRETRANSFORM || fixed + 4096u > (uint32_t)FLX_WF_LDS_TOTAL) return false;
+  ldsCount = ((uint32_t)FLX_WF_LDS_TOTAL - fixed) / 48u;
+  if (ldsCount > sc.walk_hot) ldsCount = sc.walk_hot;
+  ldsBytes = ldsCount * 48u + fixed;
+  return true;
+}
+
 void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wbIn, uint32_t compute_units, bool count,
-                      int walk_scheduler, uint32_t suspend_max, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
+                      int walk_scheduler, uint32_t suspend_max, int organisation, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
   WavefrontBuffers wb = wbIn;
+#if !FLX_EXPERIMENTS
+  walk_scheduler = 0; suspend_max = 0u;                     /* (flx_set_walk_scheduler refuses anything else in this build) */
+#endif
+  /* ---- one persistent launch for the whole bounce loop (k_wf_frame), where it fits ---- */
+  {
+    uint32_t ldsCountF = 0, ldsBytesF = 0;
+    /* automatic: the frame kernel while the pass is small enough for the rounds' tails to matter — measured crossover at ~66 M paths
+     * (a 4K frame at 8 spp, or four 1080p frames per pass: tools/organisation_time.py, profiles/r03_organisation_crossover.txt); beyond
+     * it the rounds' sixteen walk waves per CU beat fourteen walk + two shade waves */
+    const bool wanted = organisation == 2 || (organisation == 0 && wb.item_count <= (uint32_t)FLX_FRAME_AUTO_MAX_ITEMS);
+    if (wanted && walk_scheduler == 0 && suspend_max == 0u && fr.max_reflections >= 1 && wb.frameRings != nullptr && frame_kernel_fits(sc, ldsCountF, ldsBytesF)) {
+      static bool attrSetF = false;
+      if (!attrSetF) {
+        (void)hipFuncSetAttribute((const void *)k_wf_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_wf_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attrSetF = true;
+      }
+      const uint32_t total = wb.item_count;
+      const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);
+      const uint32_t shadeBlocks = (pixels + 255u) / 256u;
+      if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
+      else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
+      if (walk0_begin) (void)hipEventRecord(walk0_begin, stream);
+      if (count) hipLaunchKernelGGL(k_wf_frame<true>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms);
+      else hipLaunchKernelGGL(k_wf_frame<false>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms);
+      if (walk0_end) (void)hipEventRecord(walk0_end, stream);
+      return;
+    }
+  }
   const uint32_t total = wb.item_count;                 /* items of this group (all of the frame when there is one group) */
   const uint32_t maxBlocks = compute_units * 8u;
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
@@ -910,9 +1295,6 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   /* Suspension needs the kernel that can take a walk up again (k_wf_walk_pre), at least two bounces to gain anything, and
    * as many extra rounds as a path can be held up: one per regular round.  The extra rounds find their lists empty
    * almost always and return at once. */
-#if !FLX_EXPERIMENTS
-  walk_scheduler = 0; suspend_max = 0u;                     /* (flx_set_walk_scheduler refuses anything else in this build) */
-#endif
   const bool finisher = (walk_scheduler & 2) != 0;          /* suspended walks go to k_wf_walk_coop instead of the next round */
   const bool lanes = (walk_scheduler & 1) == 0;             /* one walk per lane (not the queue scheduler) */
   const bool suspend = suspend_max > 0u && pre && lanes && (bounces >= 2 || finisher) && FLX_WF_CONSOLIDATE;
