@@ -717,6 +717,31 @@ void flx_oracle_forward_trace(const float m[9], const float light_dir[3], float 
   v3 r = forwardTrace(mat, V3(light_dir[0], light_dir[1], light_dir[2]), strength, V3(n[0], n[1], n[2]), V3(v[0], v[1], v[2]));
   out[0] = r.x; out[1] = r.y; out[2] = r.z;
 }
+/* reservoirSample (fragment:400-461) on its own, for the literal known-answer table (tests/golden/shading_kat.json): the lights of
+ * `lights` (6 floats each), an empty scene behind them (the shadow ray finds nothing), out = the returned colour and renderId.w. */
+void flx_oracle_reservoir_sample(const float *lights, uint32_t n_lights, float random_seed, const float m[9], const float origin[3], const float unit_dir[3],
+                                 const float random_vec[4], const float n[3], const float smooth_normal[3], float geometry_offset, int dont_filter, int i,
+                                 float out[4]) {
+  static const float no_geometry[12 * 256] = { 0.0f };
+  static const float identity_rot[24] = { 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0 };
+  static const float zero_shift[8] = { 0.0f };
+  flx_scene_view sc;
+  memset(&sc, 0, sizeof sc);
+  sc.geometry = no_geometry; sc.attributes = no_geometry; sc.n_entries_padded = 256;
+  sc.rotation = identity_rot; sc.shift = zero_shift; sc.n_transforms = 1;
+  sc.lights = lights; sc.n_lights = n_lights;
+  flx_frame_params fp;
+  memset(&fp, 0, sizeof fp);
+  fp.random_seed = random_seed;
+  Frag f;
+  memset(&f, 0, sizeof f);
+  f.sc = &sc; f.fp = &fp;
+  Material mat = { V3(m[0], m[1], m[2]), V3(m[3], m[4], m[5]), V3(m[6], m[7], m[8]) };
+  Ray ray = { V3(origin[0], origin[1], origin[2]), V3(unit_dir[0], unit_dir[1], unit_dir[2]) };
+  v4 rv = { random_vec[0], random_vec[1], random_vec[2], random_vec[3] };
+  v3 c = reservoirSample(&f, mat, ray, rv, V3(n[0], n[1], n[2]), V3(smooth_normal[0], smooth_normal[1], smooth_normal[2]), geometry_offset, dont_filter, i);
+  out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = f.renderId.w;
+}
 void flx_oracle_ray_tracer(const flx_scene_view *scene, const float origin[3], const float dir[3], float hit_suv[3],
                            int *transform_id, int *triangle_id, uint64_t *visits) {
   uint64_t v = 0;

@@ -291,3 +291,38 @@ def test_present_kat():
     f[0, :, 0] = [0.0, 1.0, 0.5, -3.0, 7.0, np.nan, 1.0 / 255.0, 0.999]
     got = flx_oracle.present(f)[0, :, 0].tolist()
     assert got[:5] == [0, 255, 128, 0, 255] and got[6] == 1 and got[7] == 255
+
+
+def test_shading_literal_known_answers(oracle):
+    """tests/golden/shading_kat.json: forwardTrace (with its GGX / Smith / Schlick helpers, fragment:282-334) and reservoirSample
+    (fragment:400-461, incl. its two noise() chains, the showColor / showShadow exits and renderId.w) evaluated from the shader's
+    text in float32 arithmetic with a 70-digit sine (tests/analysis/make_shading_kat.py) — not through flx_math.h or the oracle.
+    The oracle must return every stored bit; the GPU frames equal the oracle's, so the table holds the kernels too."""
+    import json
+    from shading_kat_util import oracle_forward_trace, oracle_reservoir
+    table = json.load(open(os.path.join(ROOT, "tests", "golden", "shading_kat.json")))
+    assert len(table["forward_trace"]) >= 160 and len(table["reservoir"]) >= 96
+    for k, row in enumerate(table["forward_trace"]):
+        assert oracle_forward_trace(row[:16]) == row[16:], "forwardTrace row %d" % k
+    exits = set()
+    for k, row in enumerate(table["reservoir"]):
+        assert oracle_reservoir(row) == row["out"], "reservoirSample row %d" % k
+        exits.add(len(row["lights"]))
+    assert {0, 1, 2, 9} <= exits                                 # no light at all, one, two, many
+
+
+@pytest.mark.parametrize("key", ["configs[0] cornell 256x256 1spp 1b", "configs[1] cornell_obj 1080p 4spp 3b filter", "configs[2] dragon 1080p 8spp 4b",
+                                 "configs[3] dragon 4K 8spp 4b", "configs[4] theater 1080p 16spp 6b"])
+def test_fullsize_frames_keep_their_hashes(oracle, key):
+    """the oracle's frame of every BASELINE.json configuration at FULL size hashes to tests/golden/oracle_fullsize.json, counters
+    included: the fixed point that oracle and kernels — one hand, one flx_math.h — cannot leave together unnoticed (the GPU suite
+    asserts the same hashes of the GPU frames)"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "analysis"))
+    import make_fullsize_hashes as fs
+    want = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_fullsize.json")))[key]
+    got = fs.oracle_record(key)
+    assert got["counters"] == want["counters"]
+    assert got["frame"] == want["frame"]
+    assert got.get("gbuffers") == want.get("gbuffers")

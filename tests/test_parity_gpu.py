@@ -4,6 +4,8 @@ Inputs are the arrays the reference's own scene.js emits for the BASELINE scenes
 Bar: per-channel RMS <= 1e-4 (BASELINE.json north_star); because both sides share include/flx_math.h
 and are compiled without FMA contraction we additionally expect — and assert — bit equality, and
 identical work counters (entries visited, shades, walks)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -25,6 +27,20 @@ CASES = [
 _ORACLE_CACHE = {}
 
 
+def _assert_fullsize_hash(key, frame, counters, gbuffers=None):
+    """the GPU frame of a BASELINE.json configuration at full size against tests/golden/oracle_fullsize.json (committed hashes of the
+    oracle's frames: tests/analysis/make_fullsize_hashes.py) — beside the comparison with the oracle run next to it"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "analysis"))
+    import make_fullsize_hashes as fs
+    want = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_fullsize.json")))[key]
+    assert counters == want["counters"], key
+    assert fs.sha(frame) == want["frame"], key
+    if gbuffers is not None:
+        assert {k: fs.sha(v) for k, v in gbuffers.items()} == want["gbuffers"], key
+
+
 @pytest.mark.parametrize("pipeline", [3, 2, 1], ids=["wavefront", "persistent", "per_pixel"])
 @pytest.mark.parametrize("name,w,h,spp,bounces", CASES)
 def test_radiance_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounces, pipeline):
@@ -44,6 +60,8 @@ def test_radiance_matches_oracle(hip, oracle, scenes, name, w, h, spp, bounces, 
     assert mism == 0, "%s: %d of %d floats differ in bits (rms %s)" % (name, mism, got.size, rms)
     assert got_cnt == want_cnt
     assert (got[..., 3] == 1).sum() == want_cnt["primary_hits"]
+    if (name, w, h, spp, bounces) == ("cornell", 256, 256, 1, 1):
+        _assert_fullsize_hash("configs[0] cornell 256x256 1spp 1b", got, got_cnt)
 
 
 @pytest.mark.parametrize("pipeline", [2, 1], ids=["persistent", "per_pixel"])
@@ -83,6 +101,7 @@ def test_headline_frame_at_full_size(hip, oracle, scenes):
     assert np.array_equal(got, want, equal_nan=True)
     assert got_cnt == want_cnt
     assert hip.last_pipeline() == 3
+    _assert_fullsize_hash("configs[2] dragon 1080p 8spp 4b", got, got_cnt)
     whole = np.full_like(got, np.nan)
     for rank in range(8):
         p.tile_rows, p.tile_index, p.tile_count = 8, rank, 8
@@ -141,6 +160,7 @@ def test_multi_gpu_configs_at_full_size(hip, oracle, scenes, name, w, h, spp, bo
     want, want_cnt = oracle.render(sc, p, threads=0)[:2]
     assert np.array_equal(got, want, equal_nan=True)
     assert got_cnt == want_cnt
+    _assert_fullsize_hash({"dragon": "configs[3] dragon 4K 8spp 4b", "theater": "configs[4] theater 1080p 16spp 6b"}[name], got, got_cnt)
 
 
 def _moved(sc, p, i):
@@ -420,6 +440,7 @@ def test_filter_frame_at_full_size(hip, oracle, scenes):
     assert np.array_equal(got, want, equal_nan=True)
     assert got_cnt == want_cnt
     assert hip.last_pipeline() == 1
+    _assert_fullsize_hash("configs[1] cornell_obj 1080p 4spp 3b filter", got, got_cnt, got_gb)
 
 
 def test_filter_refuses_tiles(hip, scenes):
