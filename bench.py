@@ -513,7 +513,9 @@ def main():
         valu = k.get("SQ_INSTS_VALU")
         achieved = valu / (k_ms * 1e-3) if valu else None
         fetch_kb, write_kb = k.get("FETCH_SIZE"), k.get("WRITE_SIZE")
-        traffic = (fetch_kb + write_kb) * 1024.0 if fetch_kb is not None and write_kb is not None else None
+        # gfx950: FETCH_SIZE tallies the L2's 128-byte fabric read requests at 64 B each (MI355X_MICROARCH.md, HBM; confirmed for this kernel's
+        # record pieces by TCC_EA0_RDREQ_128B x 128 B = 2 x FETCH_SIZE, profiles/r03_pmc_cache.txt): doubled.  WRITE_SIZE is exact.
+        traffic = (2.0 * fetch_kb + write_kb) * 1024.0 if fetch_kb is not None and write_kb is not None else None
         lane_util = None
         if k.get("SQ_THREAD_CYCLES_VALU") and k.get("SQ_ACTIVE_INST_VALU"):
             lane_util = k["SQ_THREAD_CYCLES_VALU"] / (64.0 * k["SQ_ACTIVE_INST_VALU"])
@@ -544,7 +546,7 @@ def main():
                 "valu_insts_per_launch": valu, "valu_lane_utilisation": lane_util,
                 "hbm_measured": {"bytes_per_launch": traffic, "GBps": traffic / (k_ms * 1e-3) / 1e9 if traffic else None, "peak_GBps": HBM_PEAK_GBS,
                                  "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
-                                 "note": "FETCH_SIZE + WRITE_SIZE (KB, separate rocprofv3 passes of this run); FETCH_SIZE is taken 1:1 — the walk kernel reads 16-byte pieces of per-lane 128-byte records, the access pattern profiles/r01_hbm_traffic.json calibrated at 1:1 (the guide's x2 is for wide coalesced streams)"},
+                                 "note": "2 x FETCH_SIZE + WRITE_SIZE (KB, separate rocprofv3 passes of this run): on gfx950 FETCH_SIZE counts 64 B per 128-byte fabric read request (guide's HBM section; TCC_EA0_RDREQ_128B of this kernel in profiles/r03_pmc_cache.txt); Infinity-Cache hits are included, so HBM proper is at most this"},
                 "algorithmic": {"bytes_per_launch": bytes_launch, "GBps": bytes_launch / (k_ms * 1e-3) / 1e9,
                                 "frame_bytes": frame_bytes, "frame_GBps": frame_bytes / (ms_per_step * 1e-3) / 1e9,
                                 "note": "SURVEY.md 8d: 48 B x entries visited (+ 160 B x shades + 24 B x lights x shades + 4 B x texels + 16 B x pixels for the frame), from this frame's work counters; the <= 12 MB scene is LDS / L2 resident, so this is NOT a fraction of HBM bandwidth — the kernel is bound by VALU issue, not by memory"},
