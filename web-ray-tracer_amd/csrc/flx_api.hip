@@ -91,7 +91,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_send, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings,
+                   ctx->d_send, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings, ctx->d_qbatch,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -508,7 +508,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       size_t grow = 0, freed = 0;
       for (auto &b : w) if (b.need > b.have) { grow += b.need * sizeof(float4); freed += b.have * sizeof(float4); }
       if (pipeline == 3) {
-        const size_t live = wavefront_live_capacity(fr, cus) * (size_t)WF_MAX_GROUPS;
+        const size_t live = wavefront_live_capacity(fr, cus) * (size_t)(ctx->wf_groups < 1 ? 1 : (ctx->wf_groups > WF_MAX_GROUPS ? WF_MAX_GROUPS : ctx->wf_groups));      /* what the allocation below asks for */
         if (live > ctx->live_capacity) { grow += 2 * live * sizeof(uint32_t); freed += 2 * ctx->live_capacity * sizeof(uint32_t); }
       }
       size_t memFree = 0, memTotal = 0;
@@ -928,16 +928,30 @@ static flx_status ensure_post_buffers(flx_context *ctx, size_t pixels, bool gbuf
 static flx_status run_filter_batch(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, const flx_frame_params *params, float4 *d_out) {
   const size_t per = (size_t)fr.frame_rows * fr.width, pixels = per * fr.frames;
   flx_status s;
-  if ((s = ensure_post_buffers(ctx, pixels, true, false))) return s;
+  /* the five RGBA8 render targets of every frame of the batch: 20 bytes per pixel (not the float G-buffers' 96), refused with
+   * advice when they do not fit */
+  if (ctx->qbatch_capacity < pixels) {
+    const size_t need = 5 * pixels * sizeof(uint32_t);
+    size_t memFree = 0, memTotal = 0;
+    if (hipMemGetInfo(&memFree, &memTotal) == hipSuccess && need > memFree + 5 * ctx->qbatch_capacity * sizeof(uint32_t)) {
+      char msg[200];
+      snprintf(msg, sizeof msg, "the render targets of this batch of filter frames need %.1f GB of device memory, %.1f GB are free: render fewer frames per batch", need / 1e9, memFree / 1e9);
+      return fail(ctx, FLX_ERR_DEVICE, msg);
+    }
+    ctx->qbatch_capacity = 0;
+    if (ctx->d_qbatch) { FLX_HIP(ctx, hipFree(ctx->d_qbatch)); ctx->d_qbatch = nullptr; }
+    FLX_HIP(ctx, hipMalloc(&ctx->d_qbatch, need));
+    ctx->qbatch_capacity = pixels;
+  }
   if ((s = ensure_post_buffers(ctx, per, false, true))) return s;
   FilterPlanes pl;
   for (int i = 0; i < 4; i++) { pl.R[i] = ctx->d_planes[i]; pl.Ip[i] = ctx->d_planes[4 + i]; }
   pl.O[0] = ctx->d_planes[8]; pl.O[1] = ctx->d_planes[9]; pl.Id[0] = ctx->d_planes[10]; pl.Id[1] = ctx->d_planes[11]; pl.OId = ctx->d_planes[12];
   /* the trace kernel stores the five render targets of every frame as RGBA8 itself (run_post_frame), stacked frame after frame
-   * in the memory of the float G-buffers nobody reads here; each frame's chain starts from its own slices */
+   * in planes of their own; each frame's chain starts from its own slices */
   GBufferPtrs q = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
-  q.q_color = (uint32_t *)ctx->d_gb[0]; q.q_color_ip = (uint32_t *)ctx->d_gb[1]; q.q_original_color = (uint32_t *)ctx->d_gb[2];
-  q.q_id = (uint32_t *)ctx->d_gb[3]; q.q_original_id = (uint32_t *)ctx->d_gb[4];
+  q.q_color = ctx->d_qbatch; q.q_color_ip = ctx->d_qbatch + pixels; q.q_original_color = ctx->d_qbatch + 2 * pixels;
+  q.q_id = ctx->d_qbatch + 3 * pixels; q.q_original_id = ctx->d_qbatch + 4 * pixels;
   if ((s = flx_run_frame(ctx, sc, fr, nullptr, q))) return s;
   for (uint32_t f = 0; f < fr.frames; f++) {
     const size_t o = (size_t)f * per;

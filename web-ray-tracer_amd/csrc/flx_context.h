@@ -54,6 +54,8 @@ struct flx_context {
   float4 *d_gb[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
   size_t gb_capacity = 0;
   uint32_t *d_planes[13] = {};                   /* the filter chain's RGBA8 render targets */
+  uint32_t *d_qbatch = nullptr;                  /* batches of filter frames: the five render targets of every frame, 5 x pixels */
+  size_t qbatch_capacity = 0;                    /* pixels */
   size_t planes_capacity = 0;
   /* temporal history: rings of RGBA8 planes (colour, colour ip, location id, original id), newest at ring_head */
   uint32_t *d_ring[4][16] = {};

@@ -1020,6 +1020,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   }
 
   /* ================================ walk wave ================================ */
+  const long long tStart = COUNT ? clock64() : 0;
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
   uint32_t *__restrict__ queue = wb.walkQueue;
   const uint32_t nWaves = gridDim.x * WALK_WAVES;
@@ -1128,7 +1129,15 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             if (room == 0u) break;                              /* as many live paths as the rings hold: no new ones until some end */
             base0 = __builtin_amdgcn_readfirstlane(base0);
             if (base0 >= n) {
-              if (lane == 0) { atomicSub(&ctl[FC_ALIVE], want); __hip_atomic_store(&ctl[FC_DRY], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+              if (lane == 0) {
+                atomicSub(&ctl[FC_ALIVE], want);
+                const uint32_t was = atomicExch(&ctl[FC_DRY], 1u);
+                if (COUNT && was == 0u) {                       /* frame-kernel profile (flx_get_tail_diag 20..): when did this workgroup find the item queue dry, with how many paths alive */
+                  const unsigned long long now = (unsigned long long)(clock64() - tStart);
+                  atomicAdd(wb.counters + 60, now); atomicMax(wb.counters + 61, now); atomicAdd(wb.counters + 62, 1ull);
+                  atomicAdd(wb.counters + 63, (unsigned long long)fq_load(&ctl[FC_ALIVE]));
+                }
+              }
               itemsLeft = false;
               break;
             }
@@ -1219,6 +1228,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     }
   }
   if (COUNT && (cnt.closest_visits | cnt.shadow_visits) != 0u) atomicAdd(wb.counters + 23, (unsigned long long)cnt.closest_visits + cnt.shadow_visits);
+  if (COUNT && lane == 0) {                                     /* wave lifetimes: sum / max / count (flx_get_tail_diag 24..26) */
+    const unsigned long long life = (unsigned long long)(clock64() - tStart);
+    atomicAdd(wb.counters + 64, life); atomicMax(wb.counters + 65, life); atomicAdd(wb.counters + 66, 1ull);
+  }
   flush_counters<COUNT>(cnt, wb.counters);
 }
 
