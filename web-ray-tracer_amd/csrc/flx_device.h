@@ -210,13 +210,6 @@ FLX_DEV f4 noise(float random_seed, float nx, float ny, float seed) {
 /* vote of the wave: the builtin takes the condition as it is (HIP's flx_ballot(int) first materialises it as 0 / 1 and compares
  * again: two VALU instructions per vote, and the walk kernel votes several times per entry) */
 FLX_DEV unsigned long long flx_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-/* does any lane of the wave hold p?  As a SCALAR test (s_cmp_lg_u64 + s_cbranch_scc): the mask goes through an empty asm so the
- * compiler cannot turn `ballot(p) != 0` back into a vector condition (which it materialises as v_cndmask 0/1 + v_cmp + a vcc branch) */
-FLX_DEV bool flx_any(bool p) {
-  unsigned long long m = __builtin_amdgcn_ballot_w64(p);
-  asm volatile("" : "+s"(m));
-  return m != 0ull;
-}
 /* value of `v` in lane `p` (p uniform) */
 FLX_DEV float laneF(float v, uint32_t p) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), (int)p)); }
 FLX_DEV int laneI(int v, uint32_t p) { return __builtin_amdgcn_readlane(v, (int)p); }
@@ -870,6 +863,9 @@ FLX_DEV void walkBoxT(WalkState &w, const WalkEntry &cur) {
  * copy (build_threaded).  The shader's early returns have no side effects, so evaluating all of it
  * and combining the predicates at the end gives the same accept/reject and the same (s,u,v), NaNs
  * included: two-sided accepts unless (s > l || s <= BIAS), cull accepts only if (s <= l && s > BIAS). */
+#ifndef FLX_MT_BRANCHFREE
+#define FLX_MT_BRANCHFREE 1      /* dragon frame kernel 5.90 -> 5.86 ms, the other workloads unchanged (profiles/r03_ab_fused_trip.txt) */
+#endif
 FLX_DEV bool moellerTrumboreAny(f3 a, f3 edge1, f3 edge2, const Ray &ray, float l, bool cull, f3 &suv) {
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
@@ -883,9 +879,19 @@ FLX_DEV bool moellerTrumboreAny(f3 a, f3 edge1, f3 edge2, const Ray &ray, float 
   float s = dot(edge2, qvec) * inv_det;
   bool uBad = (u < BIAS) || (u > 1.0f);
   bool vBad = (v < BIAS) || (uvSum > 1.0f);
+#if FLX_MT_BRANCHFREE
+  /* the cull rule is (s <= l) && (s > BIAS), the two-sided one !(s > l) && !(s <= BIAS) = ((s <= l) || unordered(s, l)) && ((s > BIAS) || s is NaN):
+   * one pair of comparisons for both kinds of walk, the unordered cases added for the two-sided ones — no execution-mask branch on `cull` */
+  const bool sLe = (s <= l) | (!cull & __builtin_isunordered(s, l));
+  const bool sGt = (s > BIAS) | (!cull & (s != s));
+  const bool sOk = sLe & sGt;
+  suv = F3(s, u, v);
+  return !detBad & !uBad & !vBad & sOk;
+#else
   bool sOk = cull ? ((s <= l) && (s > BIAS)) : (!(s > l) && !(s <= BIAS));
   suv = F3(s, u, v);
   return !detBad && !uBad && !vBad && sOk;
+#endif
 }
 #ifndef FLX_WF_FLAT_FETCH
 #define FLX_WF_FLAT_FETCH 1      /* entry fetch through one generic pointer (flat_load) instead of an LDS branch and a global branch: nine
@@ -1062,103 +1068,6 @@ FLX_DEV bool rayCuboidFast(float l, const WalkState &w, f3 lo, f3 hi) {
 FLX_DEV void walkBoxP(WalkState &w, const WalkEntry &cur) {
   const bool hit = rayCuboidFast(w.minLen, w, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y));
   w.i = hit ? __float_as_int(cur.e2.x) : __float_as_int(cur.e2.y);
-}
-
-/* ---- one trip of the walk kernel's stepping loop as ONE straight-line stream (round 3) -------------------------------------
- * walkIsBoxT / walkBoxP / walkTriT / walkFetchP above run a trip as `if (box) ... else ...; if (!ended) fetch` per lane: on a wave whose
- * lanes stand at boxes and at triangles at once — nearly every trip — the hardware executes both sides anyway, each under a saved
- * and restored execution mask, and a third of the trip's instructions were that bookkeeping (s_and_saveexec / s_xor / s_or exec /
- * s_cbranch_execz around every test, every hit update, the fetch and the transform change; profiles/r02_ab_walk_kernel.txt:
- * 0.38 % of the kernel per scalar instruction of a trip).  Here every lane of the wave executes the box test AND the triangle
- * test on whatever its entry registers hold, unmasked; what a lane keeps is chosen by selects from three predicates (the lane
- * walks, its entry is a box, the test's boolean).  Wave-uniform branches remain only around the rare paths: the exact-quotient
- * box test when the interval test is unsure, IEEE 1/det outside recipFast's range, a change of object space.  A lane that is not
- * walking computes on stale registers and keeps none of it; its fetch reads entry 0 (the shared terminator, a broadcast LDS read).
- * Per ray: the entries visited, their order, every arithmetic operation and the visit counts of the functions above.
- * Returns whether the lane's walk ended in this trip (meaningful for walking lanes). */
-#ifndef FLX_WF_FUSED_TRIP
-#define FLX_WF_FUSED_TRIP 0      /* measured slower than the branched trip (profiles/r03_ab_fused_trip.txt): off */
-#endif
-#ifndef FLX_WF_FUSED_SKIP
-#define FLX_WF_FUSED_SKIP 1      /* the wave skips the box (triangle) arithmetic when no walk of it stands at a box (triangle) */
-#endif
-template <bool COUNT>
-FLX_DEV bool walkTripFused(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float2 *rays, bool walking, WalkState &w, WalkEntry &cur,
-                           WorkCounters &cnt) {
-  const int meta = __float_as_int(cur.e2.z);
-  const bool isBox = (meta & 3) == 1;
-  const bool cull = w.mode == 0;
-  const f3 p0 = F3(cur.e0.x, cur.e0.y, cur.e0.z), p1 = F3(cur.e0.w, cur.e1.x, cur.e1.y), p2 = F3(cur.e1.z, cur.e1.w, cur.e2.x);
-  const bool boxLane = walking & isBox, triLane = walking & !isBox;
-  /* box (min = p0, max = p1): rayCuboidFast.  Skipped by the wave when none of its walks stands at a box (a thin wave at the end of
-   * a kernel, a wave deep in the leaves): a uniform branch, nothing is masked inside. */
-  bool boxHit = false;
-#if FLX_WF_FUSED_SKIP
-  if (flx_any(boxLane))
-#endif
-  {
-    bool sure;
-    boxHit = rayCuboidInterval(w.minLen, w, p0, p1, sure);
-    const bool boxSlow = boxLane & !sure;
-    if (FLX_UNLIKELY(flx_any(boxSlow))) {
-      if (boxSlow) boxHit = rayCuboidRecip(w.minLen, w, p0, p1);
-    }
-  }
-  /* triangle (a = p0, b - a = p1, c - a = p2): moellerTrumboreAny, with recipOf's range test reduced to what can fail — a lane
-   * that reads 1/det has |det| >= BIAS = 2^-16 (or is NaN), so only the upper bound and NaN send the wave to the division */
-  bool shadowHit = false;
-#if FLX_WF_FUSED_SKIP
-  if (flx_any(triLane))
-#endif
-  {
-    const f3 pvec = cross(w.tR.dir, p2);
-    const float det = dot(p1, pvec);
-    const bool detBad = cull ? (det < BIAS) : (flx_abs(det) < BIAS);
-    float inv_det = recipFast(det);
-    const bool divSlow = triLane & !detBad & !(flx_abs(det) <= 1.152921504606847e18f);
-    if (FLX_UNLIKELY(flx_any(divSlow))) {
-      if (divSlow) inv_det = 1.0f / det;
-    }
-    const f3 tvec = w.tR.origin - p0;
-    const float u = dot(tvec, pvec) * inv_det;
-    const f3 qvec = cross(tvec, p1);
-    const float v = dot(w.tR.dir, qvec) * inv_det;
-    const float uvSum = u + v;
-    const float s = dot(p2, qvec) * inv_det;
-    const bool uBad = (u < BIAS) | (u > 1.0f);
-    const bool vBad = (v < BIAS) | (uvSum > 1.0f);
-    /* the cull rule is (s <= l) && (s > BIAS), the two-sided one !(s > l) && !(s <= BIAS) = ((s <= l) || unordered(s, l)) &&
-     * ((s > BIAS) || s is NaN): one pair of comparisons for both, the unordered cases added for the two-sided walks */
-    const bool sLe = (s <= w.minLen) | (!cull & __builtin_isunordered(s, w.minLen));
-    const bool sGt = (s > BIAS) | (!cull & (s != s));
-    const bool triHit = triLane & !detBad & !uBad & !vBad & sLe & sGt;
-    shadowHit = triHit & cull;
-    const bool upd = triHit & !cull & (s != 0.0f);                       /* fragment:217 */
-    w.shadowed = shadowHit ? 1 : w.shadowed;
-    w.suv.x = upd ? s : w.suv.x; w.suv.y = upd ? u : w.suv.y; w.suv.z = upd ? v : w.suv.z;
-    w.tri = upd ? __float_as_int(cur.e2.w) : w.tri;
-    w.minLen = upd ? s : w.minLen;
-  }
-  /* successor: a box's next-on-hit is e2.x, its next-on-miss and a triangle's next are both e2.y */
-  const uint32_t next = (uint32_t)__float_as_int((isBox & boxHit) ? cur.e2.x : cur.e2.y);
-  bool ended = shadowHit | (next == WALK_END);
-  const bool go = walking & !ended;
-  w.i = (int)next;
-  const uint32_t idx = go ? linkIndex(next) : 0u;
-  {
-    const float4 *src = (idx < ldsCount) ? lds + 3u * idx : sc.walk + 3 * (size_t)idx;
-    cur.e0 = src[0]; cur.e1 = src[1]; cur.e2 = src[2];
-  }
-  if (COUNT) { if (go) { if (cull) cnt.shadow_visits++; else cnt.closest_visits++; } }
-  const int meta2 = __float_as_int(cur.e2.z);
-  const int tI = (meta2 >> 2) << 1;
-  const bool term = (meta2 & 3) == 0;
-  const bool xf = go & !term & (tI != w.cachedTI);
-  if (FLX_UNLIKELY(flx_any(xf))) {
-    if (xf) { w.cachedTI = tI; walkLoadRay(rays, tI >> 1, w); }
-  }
-  ended |= go & term;
-  return ended;
 }
 
 /* The two traversals of one bounce in ONE loop: shadowTest (fragment:231-280) on so.shadowRay, then

@@ -836,21 +836,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #pragma unroll FLX_WF_UNROLL
     for (int it = 0; it < FLX_WF_INNER; it++) {
       if (COUNT) diagIters++;
-#if FLX_WF_FUSED_TRIP
-      {
-        const bool walkingNow = st == P_WALKING;
-        if (flx_ballot(walkingNow) == 0ull) break;
-        const bool ended = walkTripFused<COUNT>(sc, ldsEntries, ldsCount, myRays, walkingNow, w, cur, cnt);
-        st = (walkingNow & ended) ? ((w.mode == 0) ? P_SWITCH : P_DONE) : st;
-      }
-#else
       if (st == P_WALKING) {
         bool ended = false;
         if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
         if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
         if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
       }
-#endif
 #if FLX_DIAG_PAD_SALU        /* diagnostic builds: what do N more scalar / vector instructions per trip cost? (profiles/r02_issue_sensitivity.txt) */
       { uint32_t a = 1, b = 2, c = 3, d = 4;
         for (int k = 0; k < FLX_DIAG_PAD_SALU / 4; k++) asm volatile("s_mov_b32 %0, %1\n s_mov_b32 %1, %2\n s_mov_b32 %2, %3\n s_mov_b32 %3, %0" : "+s"(a), "+s"(b), "+s"(c), "+s"(d) : : "scc"); }      /* (s_mov leaves SCC alone; an s_add here without the clobber corrupts the loop's compare and the kernel never ends) */
