@@ -24,6 +24,9 @@ using namespace flx;
 #ifndef FLX_EXPERIMENTS
 #define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 */
 #endif
+#ifndef FLX_COMM_RESERVED_CUS
+#define FLX_COMM_RESERVED_CUS 8u            /* CUs a context with two gathering lanes leaves free of persistent walk workgroups */
+#endif
 #ifndef FLX_WF_ORGANISATION_DEFAULT
 #define FLX_WF_ORGANISATION_DEFAULT 0       /* A/B builds: force rounds (1) or the frame kernel (2) whatever the context says */
 #endif
@@ -608,7 +611,11 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       wb.item_base = t0 * perTile; wb.item_count = (t1 - t0) * perTile;
       wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = cnt;
       hipStream_t st = g == 0 ? ctx->stream : ctx->aux_stream[g - 1];
-      launch_wavefront(sc, fr, wb, cus, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend, FLX_WF_ORGANISATION_DEFAULT ? FLX_WF_ORGANISATION_DEFAULT : ctx->wf_organisation,
+      /* Two lanes gathering over a communicator (flx_frame_begin_gathered): the persistent walk workgroups of one lane's frame hold every
+       * CU until they end, and the other lane's RCCL kernel — a handful of workgroups that carry the finished frame's strips — would wait
+       * behind them for a whole frame.  Such a context leaves a few CUs to the exchange. */
+      const uint32_t cusWalk = (ctx->comm && (ctx->twin || ctx->is_twin) && cus > 4u * FLX_COMM_RESERVED_CUS) ? cus - FLX_COMM_RESERVED_CUS : cus;
+      launch_wavefront(sc, fr, wb, cusWalk, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend, FLX_WF_ORGANISATION_DEFAULT ? FLX_WF_ORGANISATION_DEFAULT : ctx->wf_organisation,
                        g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
       FLX_HIP(ctx, hipGetLastError());
       if (g > 0) {
