@@ -742,6 +742,39 @@ void flx_oracle_reservoir_sample(const float *lights, uint32_t n_lights, float r
   v3 c = reservoirSample(&f, mat, ray, rv, V3(n[0], n[1], n[2]), V3(smooth_normal[0], smooth_normal[1], smooth_normal[2]), geometry_offset, dont_filter, i);
   out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = f.renderId.w;
 }
+/* One whole iteration of lightTrace's bounce loop (fragment:464-599 with bounces = 1) on a scene of ONE triangle under transform
+ * `rotation / shift` (24 + 8 floats: forward then inverse, as the scene arrays hold them) and `n_lights` lights, for the literal
+ * known-answer table (tests/golden/shading_kat.json "bounce"): the primary ray leaves `camera` in `dir0`, hits the triangle at `suv`,
+ * the bounce is shaded, the shadow ray and the next ray meet the triangle or nothing.  out[0..2] the returned colour, [3..5]
+ * originalColor, [6..9] renderId, [10..13] renderOriginalId, [14] originalRMEx, [15] originalTPOx, [16] glassFilter. */
+void flx_oracle_light_trace_bounce(const float geometry[12], const float attributes[28], const float *rotation, const float *shift, int transform,
+                                   const float *lights, uint32_t n_lights, const float ambient[3], float random_seed, float min_importancy,
+                                   const float ndc[2], const float camera[3], const float dir0[3], const float suv[3], float cos_sample_n, float out[17]) {
+  static float geo[12 * 256], att[28 * 256];
+  memset(geo, 0, sizeof geo); memset(att, 0, sizeof att);
+  memcpy(geo, geometry, 12 * sizeof(float)); memcpy(att, attributes, 28 * sizeof(float));
+  flx_scene_view sc;
+  memset(&sc, 0, sizeof sc);
+  sc.geometry = geo; sc.attributes = att; sc.n_entries_padded = 256;
+  sc.rotation = rotation; sc.shift = shift; sc.n_transforms = (uint32_t)transform + 1u;
+  sc.lights = lights; sc.n_lights = n_lights;
+  flx_frame_params fp;
+  memset(&fp, 0, sizeof fp);
+  fp.random_seed = random_seed; fp.min_importancy = min_importancy; fp.texture_width = 1;
+  fp.ambient[0] = ambient[0]; fp.ambient[1] = ambient[1]; fp.ambient[2] = ambient[2];
+  Frag f;
+  memset(&f, 0, sizeof f);
+  f.sc = &sc; f.fp = &fp;
+  f.firstRayLength = 1.0f;
+  f.ndc = V3(ndc[0], ndc[1], 1.0f);
+  Hit hit = { V3(suv[0], suv[1], suv[2]), transform << 1, 0 };
+  v3 c = lightTrace(&f, hit, V3(dir0[0], dir0[1], dir0[2]), V3(camera[0], camera[1], camera[2]), cos_sample_n, 1);
+  out[0] = c.x; out[1] = c.y; out[2] = c.z;
+  out[3] = f.originalColor.x; out[4] = f.originalColor.y; out[5] = f.originalColor.z;
+  out[6] = f.renderId.x; out[7] = f.renderId.y; out[8] = f.renderId.z; out[9] = f.renderId.w;
+  out[10] = f.renderOriginalId.x; out[11] = f.renderOriginalId.y; out[12] = f.renderOriginalId.z; out[13] = f.renderOriginalId.w;
+  out[14] = f.originalRMEx; out[15] = f.originalTPOx; out[16] = f.glassFilter;
+}
 void flx_oracle_ray_tracer(const flx_scene_view *scene, const float origin[3], const float dir[3], float hit_suv[3],
                            int *transform_id, int *triangle_id, uint64_t *visits) {
   uint64_t v = 0;

@@ -169,6 +169,207 @@ def reservoir_sample(lights, randomSeed, albedo, rme, origin, unitDirection, ran
     return add(localColor, baseLuminance) + [renderIdW]      # the shadow ray meets nothing
 
 
+# ---- helpers for the whole bounce: fragment:91-105, 143-158, 231-280 (one triangle), GLSL reflect / refract / sign / clamp ----
+from make_math_kat import dacos, datan2, dcos      # noqa: E402
+
+
+def f_acos(x):
+    x = min(max(float(x), -1.0), 1.0)                      # (pinned: acos clamps its argument)
+    return round_f32(dacos(Decimal(x)))
+
+
+def f_tan(x):
+    d = Decimal(float(x))
+    return round_f32(dsin(d) / dcos(d))
+
+
+def f_atan2(y, x):
+    return round_f32(datan2(Decimal(float(y)), Decimal(float(x))))
+
+
+def to_uint(x):                                            # uint(x): truncation; negative / NaN -> 0 (pinned)
+    return int(x) if x > 0 else 0
+
+
+def to4bit(a, b):
+    aui = to_uint(f32(a * f32(255.0))) & 240
+    bui = (to_uint(f32(b * f32(255.0))) & 240) >> 4
+    return f32(f32(aui | bui) * INV_255)
+
+
+def normal_to_spherical(n):
+    phi = f32(f32(f32(f_atan2(n[2], n[0]) * INV_PI) * f32(0.5)) + f32(0.5))
+    theta = f32(f32(f32(f_atan2(n[0], n[1]) * INV_PI) * f32(0.5)) + f32(0.5))
+    return to4bit(phi, theta)
+
+
+def cross(a, b):
+    return [f32(f32(a[1] * b[2]) - f32(b[1] * a[2])), f32(f32(a[2] * b[0]) - f32(b[2] * a[0])), f32(f32(a[0] * b[1]) - f32(b[0] * a[1]))]
+
+
+def matvec(cols, v):                                       # GLSL mat3 * vec3, columns cols[0..2]
+    return [f32(f32(f32(cols[0][k] * v[0]) + f32(cols[1][k] * v[1])) + f32(cols[2][k] * v[2])) for k in range(3)]
+
+
+def distance(a, b):
+    return length(sub(a, b))
+
+
+def mix3(a, b, t):
+    return [mix(x, y, t) for x, y in zip(a, b)]
+
+
+def gsign(x):
+    return ONE if x > ZERO else (f32(-1.0) if x < ZERO else ZERO)
+
+
+def clamp01(x):
+    return gmax(x, ZERO) if not (gmax(x, ZERO) > ONE) else ONE       # clamp(x, 0, 1) = min(max(x, 0), 1)
+
+
+def reflect(I, N):
+    return sub(I, scale(N, f32(f32(2.0) * dot(N, I))))
+
+
+def refract(I, N, eta):
+    d = dot(N, I)
+    k = f32(ONE - f32(f32(eta * eta) * f32(ONE - f32(d * d))))
+    if k < ZERO:
+        return [ZERO, ZERO, ZERO]
+    return sub(scale(I, eta), scale(N, f32(f32(eta * d) + f32(np.sqrt(k)))))
+
+
+def mt_cull(a, b, c, origin, d, l):                        # fragment:143-158
+    edge1, edge2 = sub(b, a), sub(c, a)
+    pvec = cross(d, edge2)
+    det = dot(edge1, pvec)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        invDet = f32(ONE / det)
+    if det < BIAS:
+        return False
+    tvec = sub(origin, a)
+    u = f32(dot(tvec, pvec) * invDet)
+    if u < BIAS or u > ONE:
+        return False
+    qvec = cross(tvec, edge1)
+    v = f32(dot(d, qvec) * invDet)
+    if v < BIAS or f32(u + v) > ONE:
+        return False
+    s = f32(dot(edge2, qvec) * invDet)
+    return bool(s <= l and s > BIAS)
+
+
+def shadow_test_one_triangle(tri, rot_inv, shift_inv, transform, origin, d, l):
+    """fragment:231-280 over a scene of one triangle (entry 0) and the terminator: the ray goes into the triangle's object space when
+    the triangle's transform is not number 0 (cachedTI starts at 0 with the untransformed ray)"""
+    o, dd = origin, d
+    if transform != 0:
+        o = matvec(rot_inv, add(origin, shift_inv))
+        dd = normalize(matvec(rot_inv, d))
+    return mt_cull(tri[0:3], tri[3:6], tri[6:9], o, dd, l)
+
+
+def light_trace_bounce(geometry, attributes, rot, rot_inv, shift, shift_inv, transform, lights, ambient, randomSeed, ndc, camera, dir0, suv, cosSampleN):
+    """fragment:464-599 for bounces = 1 (one iteration, i = 0; the loop guard holds: importancyFactor = originalColor = 1)"""
+    g, t = geometry, attributes
+    dontFilter = True
+    finalColor = [ZERO, ZERO, ZERO]
+    importancyFactor = [ONE, ONE, ONE]
+    originalColor = [ONE, ONE, ONE]
+    origin, unitDirection = camera, dir0
+    lastHitPoint = camera
+    fi = ZERO
+    origin = add(scale(unitDirection, suv[0]), origin)
+    uvw = [f32(f32(ONE - suv[1]) - suv[2]), suv[1], suv[2]]
+    tri = [matvec(rot, g[0:3]), matvec(rot, g[3:6]), matvec(rot, g[6:9])]
+    offsetRayTarget = sub(origin, shift)
+    geometryNormal = normalize(cross(sub(tri[0], tri[1]), sub(tri[0], tri[2])))
+    diffs = [distance(offsetRayTarget, tri[0]), distance(offsetRayTarget, tri[1]), distance(offsetRayTarget, tri[2])]
+    normals = [matvec(rot, t[0:3]), matvec(rot, t[3:6]), matvec(rot, t[6:9])]
+    smoothNormal = normalize(matvec(normals, uvw))
+    angles = [f_acos(abs(dot(geometryNormal, n))) for n in normals]          # geometryNormal * normals
+    angleTan = [clamp01(f_tan(a)) for a in angles]
+    geometryOffset = dot(mul(diffs, angleTan), uvw)
+    assert t[15] == f32(-1.0) and t[16] == f32(-1.0) and t[17] == f32(-1.0)   # no textures: fetchTexVal returns the defaults
+    albedo, rme, tpo = t[18:21], t[21:24], t[24:27]
+    unitDirection = normalize(sub(origin, lastHitPoint))
+    signDir = gsign(dot(unitDirection, smoothNormal))
+    smoothNormal = scale(smoothNormal, f32(-signDir))
+    randomVec = noise(ndc[0], ndc[1], f32(fi + cosSampleN), randomSeed)
+    randomSpheareVec = normalize(add(smoothNormal, normalize(randomVec[0:3])))
+    BRDF = mix(ONE, f32(abs(dot(smoothNormal, unitDirection))), rme[1])
+    roughnessBRDF = f32(rme[0] * BRDF)
+    roughNormal = normalize(mix3(smoothNormal, randomSpheareVec, roughnessBRDF))
+    H = normalize(sub(roughNormal, unitDirection))
+    VdotH = gmax(dot(neg(unitDirection), H), ZERO)
+    F0 = scale(albedo, BRDF)
+    fr = fresnel(F0, VdotH)
+    fresnelReflect = gmax(fr[0], gmax(fr[1], fr[2]))
+    isSolid = bool(f32(tpo[0] * fresnelReflect) <= f32(abs(randomVec[3])))
+    renderId = [ZERO] * 4
+    renderOriginalId = [ZERO] * 4
+    originalRMEx, originalTPOx, glassFilter = ZERO, ZERO, ZERO
+    if dontFilter:
+        originalTPOx = tpo[0]
+        originalColor = mul(originalColor, albedo)
+        originalRMEx = f32(originalRMEx + rme[0])
+        sc = ONE                                                           # pow(2.0, -0.0)
+        cn = [normal_to_spherical(smoothNormal), rme[0], to4bit(rme[1], rme[2])]
+        upd = [f32(sc * cn[0]), f32(sc * cn[1]), f32(sc * cn[2]), f32(sc * ZERO)]
+        renderId = [f32(a + b) for a, b in zip(renderId, upd)]
+        renderOriginalId = [f32(a + b) for a, b in zip(renderOriginalId, upd)]
+        dontFilter = (rme[0] < f32(0.01) and isSolid) or not isSolid
+        if isSolid and tpo[0] > f32(0.01):
+            glassFilter = f32(glassFilter + ONE)
+            dontFilter = False
+    else:
+        importancyFactor = mul(importancyFactor, albedo)
+    # reservoirSample(material, ray, randomVec, -signDir * roughNormal, -signDir * smoothNormal, geometryOffset, dontFilter, i) with its shadowTest
+    N = scale(roughNormal, f32(-signDir))
+    sN = scale(smoothNormal, f32(-signDir))
+    localColor = [ZERO, ZERO, ZERO]
+    reservoirLength = totalWeight = reservoirWeight = ZERO
+    reservoirNum = 0
+    reservoirLightDir = [ZERO, ZERO, ZERO]
+    lastRandom = noise(randomVec[2], randomVec[3], BIAS, randomSeed)[0:2]
+    for j, lt in enumerate(lights):
+        if lt[3] <= ZERO:
+            continue
+        reservoirLength = f32(reservoirLength + ONE)
+        light = add(lt[0:3], scale(randomVec[0:3], lt[4]))
+        dirv = sub(light, origin)
+        colorForLight = forward_trace(albedo, rme, dirv, lt[3], N, neg(unitDirection))
+        localColor = add(localColor, colorForLight)
+        weight = length(colorForLight)
+        totalWeight = f32(totalWeight + weight)
+        if f32(abs(lastRandom[1]) * totalWeight) <= weight:
+            reservoirNum, reservoirWeight, reservoirLightDir = j, weight, dirv
+        lastRandom = noise(lastRandom[0], lastRandom[1], BIAS, randomSeed)[2:4]
+    unitLightDir = normalize(reservoirLightDir)
+    showColor = reservoirLength == ZERO or reservoirWeight == ZERO
+    with np.errstate(invalid="ignore"):
+        showShadow = bool(dot(sN, unitLightDir) <= BIAS)
+    baseLuminance = [rme[2]] * 3
+    mark = dontFilter                                                      # (dontFilter || i == 0) with i = 0: always
+    renderId[3] = f32(f32((reservoirNum % 128) << 1) * INV_255)
+    if showColor:
+        local = add(localColor, baseLuminance)
+    elif showShadow:
+        renderId[3] = f32(renderId[3] + INV_255)
+        local = baseLuminance
+    else:
+        offsetTarget = add(origin, scale(sN, geometryOffset))
+        if shadow_test_one_triangle(g, rot_inv, shift_inv, transform, offsetTarget, unitLightDir, length(reservoirLightDir)):
+            renderId[3] = f32(renderId[3] + INV_255)
+            local = baseLuminance
+        else:
+            local = add(localColor, baseLuminance)
+    finalColor = add(finalColor, mul(local, importancyFactor))
+    # (the next direction is computed and the loop ends: bounces = 1; nothing of it reaches an output)
+    out = add(finalColor, mul(importancyFactor, ambient))
+    return out + originalColor + renderId + renderOriginalId + [originalRMEx, originalTPOx, glassFilter]
+
+
 def unit(rng):
     v = rng.normal(size=3)
     return [f32(x) for x in v / np.linalg.norm(v)]
@@ -217,6 +418,55 @@ def main():
             "lights": [[bits(x) for x in lt] for lt in lights], "random_seed": bits(randomSeed),
             "in": [bits(x) for x in albedo + rme + origin + unitDirection + randomVec + N + smoothNormal + [geometryOffset]],
             "dont_filter": dontFilter, "i": i, "out": [bits(x) for x in out]})
+    # ---- one whole bounce on one triangle under a rotated, shifted transform with two lights ----
+    table["bounce"] = []
+    for k in range(64):
+        transform = int(k % 3 != 0)                               # transform 0 (identity) for a third of the rows, a real one else
+        ang = rng.uniform(0, 6.28, 3)
+        cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
+        R = np.array([[cy * cz, -cy * sz, sy], [sx * sy * cz + cx * sz, -sx * sy * sz + cx * cz, -sx * cy], [-cx * sy * cz + sx * sz, cx * sy * sz + sx * cz, cx * cy]])
+        if transform == 0:
+            R = np.eye(3)
+        pos = rng.uniform(-1, 1, 3) if transform else np.zeros(3)
+        rot = [[f32(R[r][c]) for r in range(3)] for c in range(3)]                       # columns
+        Ri = np.linalg.inv(np.array([[float(rot[c][r]) for c in range(3)] for r in range(3)]))
+        rot_inv = [[f32(Ri[r][c]) for r in range(3)] for c in range(3)]
+        shift, shift_inv = [f32(x) for x in pos], [f32(-x) for x in pos]
+        a, b, c = rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3), rng.uniform(-1, 1, 3)
+        geometry = [f32(x) for x in np.concatenate([a, b, c])] + [ZERO, f32(2.0), ZERO]                 # (transform number, type 2: the walk reads them, the shading not)
+        geometry[9] = f32(transform)
+        nrm = np.cross(b - a, c - a); nrm /= np.linalg.norm(nrm)
+        ns = [nrm + rng.normal(size=3) * 0.15 for _ in range(3)]
+        ns = [n / np.linalg.norm(n) for n in ns]
+        attributes = [f32(x) for x in np.concatenate(ns)] + [f32(x) for x in rng.uniform(0, 1, 6)] + [f32(-1.0)] * 3
+        attributes += [f32(x) for x in rng.uniform(0.05, 1, 3)]                                         # albedo
+        attributes += [f32(rng.choice([0.005, 0.3, 0.9])), f32(rng.choice([0.0, 0.5, 1.0])), f32(rng.choice([0.0, 0.2]))]      # rme
+        attributes += [f32(rng.choice([0.0, 0.0, 0.8])), ZERO, f32(1.5)] + [ZERO]                       # tpo + padding
+        suv_uv = rng.dirichlet([1, 1, 1])
+        hit_obj = a * suv_uv[0] + b * suv_uv[1] + c * suv_uv[2]
+        hit_world = np.array([[float(rot[cc][r]) for cc in range(3)] for r in range(3)]) @ hit_obj + pos
+        side = 1.0 if k % 5 else -1.0
+        n_world = np.array([[float(rot[cc][r]) for cc in range(3)] for r in range(3)]) @ nrm
+        camera = hit_world + side * n_world * rng.uniform(1.5, 4) + rng.normal(size=3) * 0.5
+        d0 = hit_world - camera
+        dist = np.linalg.norm(d0)
+        camera = [f32(x) for x in camera]
+        dir0 = normalize([f32(x) for x in d0])
+        suv = [f32(dist), f32(suv_uv[1]), f32(suv_uv[2])]
+        lside = -side if k % 7 == 3 else side                     # every seventh row: both lights behind the surface (the showShadow exit)
+        lights = [[f32(x) for x in hit_world + lside * n_world * rng.uniform(1, 5) + rng.normal(size=3) * (0.3 if k % 7 == 3 else 1.5)] + [f32(rng.choice([60.0, 300.0])), f32(rng.choice([0.0, 0.3])), ZERO] for _ in range(2)]
+        ambient = [f32(x) for x in rng.uniform(0, 0.2, 3)]
+        randomSeed = f32(rng.integers(0, 3))
+        ndc = [f32(x) for x in rng.uniform(-1, 1, 2)]
+        cosSampleN = round_f32(dcos(Decimal(int(rng.integers(0, 8)))))
+        out = light_trace_bounce(geometry, attributes, rot, rot_inv, shift, shift_inv, transform, lights, ambient, randomSeed, ndc, camera, dir0, suv, cosSampleN)
+        table["bounce"].append({
+            "geometry": [bits(x) for x in geometry], "attributes": [bits(x) for x in attributes + [ZERO] * (28 - len(attributes))],
+            "rotation": [bits(x) for col in rot for x in col], "rotation_inv": [bits(x) for col in rot_inv for x in col],
+            "shift": [bits(x) for x in shift], "shift_inv": [bits(x) for x in shift_inv], "transform": transform,
+            "lights": [[bits(x) for x in lt] for lt in lights], "ambient": [bits(x) for x in ambient], "random_seed": bits(randomSeed),
+            "ndc": [bits(x) for x in ndc], "camera": [bits(x) for x in camera], "dir0": [bits(x) for x in dir0], "suv": [bits(x) for x in suv],
+            "cos_sample_n": bits(cosSampleN), "out": [bits(x) for x in out]})
     with open(os.path.join(ROOT, "tests", "golden", "shading_kat.json"), "w") as fh:
         json.dump(table, fh, separators=(",", ":"))
     # how does today's oracle compare?  (informational; the test is what binds)
@@ -224,7 +474,9 @@ def main():
     from shading_kat_util import oracle_forward_trace, oracle_reservoir
     bad_ft = sum(1 for row in table["forward_trace"] if oracle_forward_trace(row[:16]) != row[16:])
     bad_rs = sum(1 for row in table["reservoir"] if oracle_reservoir(row) != row["out"])
-    print({k: len(v) for k, v in table.items()}, "oracle disagrees on: forward_trace %d, reservoir %d" % (bad_ft, bad_rs))
+    from shading_kat_util import oracle_bounce
+    bad_b = [k for k, row in enumerate(table["bounce"]) if oracle_bounce(row) != row["out"]]
+    print({k: len(v) for k, v in table.items()}, "oracle disagrees on: forward_trace %d, reservoir %d, bounce %d %s" % (bad_ft, bad_rs, len(bad_b), bad_b[:8]))
 
 
 if __name__ == "__main__":

@@ -309,6 +309,13 @@ def test_shading_literal_known_answers(oracle):
         assert oracle_reservoir(row) == row["out"], "reservoirSample row %d" % k
         exits.add(len(row["lights"]))
     assert {0, 1, 2, 9} <= exits                                 # no light at all, one, two, many
+    # one whole iteration of lightTrace's bounce loop (fragment:464-599) on a single triangle under a rotated, shifted transform with two
+    # lights: hit point, normals (acos / tan of their deviation), material, noise, Fresnel choice, the G-buffer accumulators (atan in the
+    # normal's 4-bit code), reservoirSample with its shadow test against the triangle, the returned colour — 17 outputs per row
+    from shading_kat_util import oracle_bounce
+    assert len(table["bounce"]) >= 64
+    for k, row in enumerate(table["bounce"]):
+        assert oracle_bounce(row) == row["out"], "lightTrace bounce row %d" % k
 
 
 @pytest.mark.parametrize("key", ["configs[0] cornell 256x256 1spp 1b", "configs[1] cornell_obj 1080p 4spp 3b filter", "configs[2] dragon 1080p 8spp 4b",
