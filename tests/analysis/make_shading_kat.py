@@ -420,7 +420,11 @@ def main():
             "dont_filter": dontFilter, "i": i, "out": [bits(x) for x in out]})
     # ---- one whole bounce on one triangle under a rotated, shifted transform with two lights ----
     table["bounce"] = []
-    for k in range(64):
+    grazing_found = 0
+    k = -1
+    while len(table["bounce"]) < 72:
+        k += 1
+        grazing = k >= 64                                         # after the 64 regular rows: lights near the surface's horizon, until 8 rows take the showShadow exit
         transform = int(k % 3 != 0)                               # transform 0 (identity) for a third of the rows, a real one else
         ang = rng.uniform(0, 6.28, 3)
         cx, sx, cy, sy, cz, sz = np.cos(ang[0]), np.sin(ang[0]), np.cos(ang[1]), np.sin(ang[1]), np.cos(ang[2]), np.sin(ang[2])
@@ -453,13 +457,22 @@ def main():
         camera = [f32(x) for x in camera]
         dir0 = normalize([f32(x) for x in d0])
         suv = [f32(dist), f32(suv_uv[1]), f32(suv_uv[2])]
-        lside = -side if k % 7 == 3 else side                     # every seventh row: both lights behind the surface (the showShadow exit)
+        lside = -side if k % 7 == 3 else side                     # every seventh row: both lights behind the surface (weight 0: the showColor exit)
         lights = [[f32(x) for x in hit_world + lside * n_world * rng.uniform(1, 5) + rng.normal(size=3) * (0.3 if k % 7 == 3 else 1.5)] + [f32(rng.choice([60.0, 300.0])), f32(rng.choice([0.0, 0.3])), ZERO] for _ in range(2)]
+        if grazing:                                               # in the surface's plane, a little to either side of it
+            tangent = np.cross(n_world, rng.normal(size=3)); tangent /= np.linalg.norm(tangent)
+            lights = [[f32(x) for x in hit_world + tangent * rng.uniform(2, 4) + n_world * rng.uniform(-0.08, 0.08)] + [f32(300.0), ZERO, ZERO] for _ in range(2)]
+            attributes[21] = f32(0.9)
         ambient = [f32(x) for x in rng.uniform(0, 0.2, 3)]
         randomSeed = f32(rng.integers(0, 3))
         ndc = [f32(x) for x in rng.uniform(-1, 1, 2)]
         cosSampleN = round_f32(dcos(Decimal(int(rng.integers(0, 8)))))
         out = light_trace_bounce(geometry, attributes, rot, rot_inv, shift, shift_inv, transform, lights, ambient, randomSeed, ndc, camera, dir0, suv, cosSampleN)
+        if grazing:
+            odd = int(round(float(out[9]) * 255.0)) & 1           # renderId.w carries + 1/255 when the sample is shadowed (showShadow, or a hit of the shadow ray)
+            if not odd and k < 3000:
+                continue
+            grazing_found += odd
         table["bounce"].append({
             "geometry": [bits(x) for x in geometry], "attributes": [bits(x) for x in attributes + [ZERO] * (28 - len(attributes))],
             "rotation": [bits(x) for col in rot for x in col], "rotation_inv": [bits(x) for col in rot_inv for x in col],
@@ -476,7 +489,7 @@ def main():
     bad_rs = sum(1 for row in table["reservoir"] if oracle_reservoir(row) != row["out"])
     from shading_kat_util import oracle_bounce
     bad_b = [k for k, row in enumerate(table["bounce"]) if oracle_bounce(row) != row["out"]]
-    print({k: len(v) for k, v in table.items()}, "oracle disagrees on: forward_trace %d, reservoir %d, bounce %d %s" % (bad_ft, bad_rs, len(bad_b), bad_b[:8]))
+    print({k: len(v) for k, v in table.items()}, "oracle disagrees on: forward_trace %d, reservoir %d, bounce %d %s; bounce rows through the shadowed exits: %d" % (bad_ft, bad_rs, len(bad_b), bad_b[:8], grazing_found))
 
 
 if __name__ == "__main__":

@@ -313,7 +313,7 @@ def test_shading_literal_known_answers(oracle):
     # lights: hit point, normals (acos / tan of their deviation), material, noise, Fresnel choice, the G-buffer accumulators (atan in the
     # normal's 4-bit code), reservoirSample with its shadow test against the triangle, the returned colour — 17 outputs per row
     from shading_kat_util import oracle_bounce
-    assert len(table["bounce"]) >= 64
+    assert len(table["bounce"]) >= 72
     for k, row in enumerate(table["bounce"]):
         assert oracle_bounce(row) == row["out"], "lightTrace bounce row %d" % k
 
