@@ -344,6 +344,33 @@ def test_both_organisations_of_the_bounce_loop_equal_the_oracle(hip, oracle, sce
         hip.set_wavefront_organisation(0)
 
 
+def test_frame_kernel_hands_paths_over_the_same_way_every_time(hip, oracle, scenes):
+    """the frame kernel's walk waves and shade waves pass paths to each other through rings with workgroup-scope release / acquire:
+    eighty renders of one frame, alternating with a frame of another size (other buffers, other ring contents), all equal the
+    oracle's frame bit for bit (tools/soak_framekernel.py does 645 full-size frames the same way)"""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=640, height=360, samples=8, max_reflections=6, use_filter=0)
+    q = sc.frame_params(width=333, height=187, samples=3, max_reflections=4, use_filter=0)
+    key = ("dragon", 640, 360, 8, 6)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle.render(sc, p)[:2]
+    want, _ = _ORACLE_CACHE[key]
+    want_q = None
+    try:
+        hip.set_pipeline(3)
+        hip.set_wavefront_organisation(2)
+        for i in range(80):
+            assert np.array_equal(hip.render(p)[0], want, equal_nan=True), "frame %d" % i
+            if i % 8 == 0:
+                got_q = hip.render(q)[0]
+                want_q = got_q if want_q is None else want_q
+                assert np.array_equal(got_q, want_q, equal_nan=True), "small frame %d" % i
+    finally:
+        hip.set_pipeline(0)
+        hip.set_wavefront_organisation(0)
+
+
 @pytest.mark.experiments
 @pytest.mark.parametrize("scheduler,suspend", [(0, 128), (0, 16), (1, 0), (2, 16), (2, 128), (0, 0)])
 @pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 480, 270, 2, 4), ("cornell_obj", 128, 96, 2, 5), ("theater", 96, 64, 1, 1)])
