@@ -236,8 +236,8 @@ void flx_group_destroy(flx_group *group);
 const char *flx_group_last_error(const flx_group *group);   /* group may be NULL: last creation error */
 int flx_group_size(const flx_group *group);
 int flx_group_uses_rccl(const flx_group *group);
-/* to_root = 1: only context 0 — the one flx_group_render hands the frame out from — receives the strips (ncclSend / ncclRecv, or
- * copies into context 0 alone); 0 (default): all-gather, every context ends up with the frame. */
+/* to_root = 1 (default): only context 0 — the one flx_group_render hands the frame out from — receives the strips (ncclSend / ncclRecv,
+ * or copies into context 0 alone); 0: all-gather, every context ends up with the frame. */
 flx_status flx_group_set_gather(flx_group *group, int to_root);
 flx_context *flx_group_context(flx_group *group, int rank);          /* owned by the group; for per-context settings and timings */
 /* the uploads of a context, applied to every context of the group (the scene is replicated) */

@@ -129,8 +129,7 @@ def test_gather_to_root_on_repeated_devices_and_with_one_rank(hip, scenes):
     want_f = hip.render(f)[0]
     with capi.Group([0] * 3) as g:
         g.update_scene(sc)
-        g.set_gather(True)
-        for _ in range(2):                                    # twice: the send buffers are reused while only context 0 copies
+        for _ in range(2):                                    # the default: only context 0 receives; twice: the send buffers are reused while only context 0 copies
             got, cnt = g.render(p, tile_rows=8, counters=True)
             assert np.array_equal(got[0], want, equal_nan=True) and cnt == want_cnt
         assert np.array_equal(g.render(f, tile_rows=8)[0][0], want_f, equal_nan=True)

@@ -227,7 +227,7 @@ extern "C" flx_status flx_render_gathered_root_device(flx_context *ctx, const fl
 
 /* ---- one process, several GPUs ------------------------------------------------------------------------------------------- */
 struct flx_group {
-  int gather_root = -1;                 /* -1: every context receives the strips (all-gather); 0: only context 0, the one that hands the frame out */
+  int gather_root = 0;                  /* 0 (default): only context 0, the one that hands the frame out, receives the strips; -1: every context (all-gather) */
   std::vector<flx_context *> ctx;
   std::vector<ncclComm_t> comms;        /* empty: the contexts share a device, strips are exchanged by copies */
   std::vector<hipEvent_t> traced;       /* per context: its strips are in d_send */

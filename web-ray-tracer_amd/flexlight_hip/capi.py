@@ -456,7 +456,7 @@ class Group:
         return bool(LIB.flx_group_uses_rccl(self._h))
 
     def set_gather(self, to_root):
-        """True: only context 0 (which hands the frame out) receives the strips; False (default): all-gather"""
+        """True (default): only context 0 (which hands the frame out) receives the strips; False: all-gather"""
         self._check(LIB.flx_group_set_gather(self._h, 1 if to_root else 0), "flx_group_set_gather")
 
     def context(self, rank):
