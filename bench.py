@@ -484,6 +484,7 @@ def main():
     cnt = ctx.get_counters()
     b0_visits = ctx.get_diag()[15] if not use_filter else 0      # entries the round-0 walk kernel visited (its own tally; 0 when another kernel walked)
     pipe = ctx.last_pipeline()
+    organisation = ctx.last_organisation()                      # wavefront pipeline: 1 rounds, 2 frame kernel, 3 frame kernel with the front of the frame inside
     ctx.set_counters_enabled(False)
     torch.cuda.synchronize()
 
@@ -501,11 +502,16 @@ def main():
         elif pipe == 2:            # persistent path kernel (tiny scenes): every bounce of every path, no primary walk, no output
             kernel_name, kernel_sym = "k_paths (persistent path kernel)", next((n for n in pmc if n.startswith("k_paths<false")), "k_paths<false, false>")
             bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * cnt["shades"] + 4 * cnt["atlas_texels"]
-        elif "k_wf_frame<false>" in pmc or (b0_visits and b0_visits == cnt["closest_visits"] + cnt["shadow_visits"] and bounces > 1):
-            # the frame kernel (its tally holds EVERY bounce's visits): all bounce walks of the frame and the shading of bounces >= 1 in one persistent launch
-            later_shades = max(0, cnt["shades"] - spp * cnt["primary_hits"])
-            kernel_name, kernel_sym = "k_wf_frame<false> (frame kernel: all bounce walks + shading of bounces >= 1)", "k_wf_frame<false>"
-            bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * later_shades
+        elif organisation >= 2:
+            # the frame kernel (its tally holds EVERY bounce's visits), <COUNT, FRONT>: all bounce walks of the frame and the shading of bounces >= 1 in one
+            # persistent launch — and, with the front of the frame inside it, the primary rays and the bounce-0 shading as well
+            if organisation == 3:
+                kernel_name, kernel_sym = "k_wf_frame<false, true> (frame kernel: primary rays, every bounce's shading, all bounce walks)", "k_wf_frame<false, true>"
+                bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"] + cnt["primary_visits"]) + (160 + 24 * n_lights) * cnt["shades"]
+            else:
+                later_shades = max(0, cnt["shades"] - spp * cnt["primary_hits"])
+                kernel_name, kernel_sym = "k_wf_frame<false, false> (frame kernel: all bounce walks + shading of bounces >= 1)", "k_wf_frame<false, false>"
+                bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * later_shades
         else:                      # rounds: the bounce-0 walk kernel's share of B_frame: the 48-byte entries its walks visit
             visits = b0_visits if b0_visits else cnt["closest_visits"] + cnt["shadow_visits"]
             kernel_name, kernel_sym, bytes_launch = "k_wf_walk_pre<false, true> (walk kernel of bounce 0)", "k_wf_walk_pre<false, true>", 48 * visits

@@ -315,13 +315,14 @@ def test_wavefront_groups_do_not_change_the_frame(hip, oracle, scenes, name, w, 
         hip.set_wavefront_groups(1)
 
 
-@pytest.mark.parametrize("organisation", [1, 2], ids=["rounds", "frame_kernel"])
+@pytest.mark.parametrize("organisation,front", [(1, 0), (2, 0), (2, 2)], ids=["rounds", "frame_kernel", "frame_kernel_with_its_front"])
 @pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 480, 270, 2, 4), ("dragon", 333, 187, 3, 2), ("dragon", 640, 360, 8, 6), ("cornell_obj", 128, 96, 2, 5),
                                                   ("theater", 96, 64, 2, 3), ("cornell", 64, 64, 1, 1), ("dragon", 64, 36, 1, 4)])
-def test_both_organisations_of_the_bounce_loop_equal_the_oracle(hip, oracle, scenes, name, w, h, spp, bounces, organisation):
+def test_both_organisations_of_the_bounce_loop_equal_the_oracle(hip, oracle, scenes, name, w, h, spp, bounces, organisation, front):
     """the wavefront pipeline as rounds (a shade + walk kernel pair per bounce) and as ONE persistent launch (k_wf_frame: walk waves and
-    shade waves of a workgroup hand paths to each other through LDS rings): the same frame and the same work counters as the oracle —
-    frames of a few waves (where most workgroups find the item queue dry at once) and frames that fill the machine"""
+    shade waves of a workgroup hand paths to each other through LDS rings) — with k_primary and k_wf_shade0 in front of it, and with the
+    primary rays and the bounce-0 shading made by its own shade waves (flx_set_frame_front): the same frame and the same work counters as
+    the oracle — frames of a few waves (where most workgroups find the item queue dry at once) and frames that fill the machine"""
     sc = scenes(name)
     hip.update_scene(sc)
     p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
@@ -332,6 +333,7 @@ def test_both_organisations_of_the_bounce_loop_equal_the_oracle(hip, oracle, sce
     try:
         hip.set_pipeline(3)
         hip.set_wavefront_organisation(organisation)
+        hip.set_frame_front(front)
         for _ in range(2):
             got, cnt, _ = hip.render(p, counters=True)
             assert np.array_equal(got, want, equal_nan=True)
@@ -342,6 +344,46 @@ def test_both_organisations_of_the_bounce_loop_equal_the_oracle(hip, oracle, sce
     finally:
         hip.set_pipeline(0)
         hip.set_wavefront_organisation(0)
+        hip.set_frame_front(1)
+
+
+def test_the_front_inside_the_frame_kernel_at_its_edges(hip, oracle, scenes):
+    """flx_set_frame_front(2): more samples than a wave has lanes (a tile's units are handed over 64 at a time), so many samples that a tile would not
+    fit the workgroup's rings (the front stays outside: refused quietly, same frame), a rank's strips of a tiled frame, a batch of moved cameras —
+    against the same frames with k_primary and k_wf_shade0 in front (which the tests above hold against the oracle), bit for bit with equal counters"""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    try:
+        hip.set_pipeline(3)
+        hip.set_wavefront_organisation(2)
+        cases = [sc.frame_params(width=160, height=90, samples=70, max_reflections=3, use_filter=0),
+                 sc.frame_params(width=96, height=56, samples=130, max_reflections=2, use_filter=0),
+                 sc.frame_params(width=333, height=187, samples=5, max_reflections=4, use_filter=0, tile=(8, 1, 3)),
+                 sc.frame_params(width=640, height=360, samples=4, max_reflections=4, use_filter=0, tile=(16, 0, 2))]
+        for p in cases:
+            hip.set_frame_front(0)
+            want, want_cnt, _ = hip.render(p, counters=True)
+            hip.set_frame_front(2)
+            for _ in range(2):
+                got, cnt, _ = hip.render(p, counters=True)
+                assert np.array_equal(got, want, equal_nan=True) and cnt == want_cnt, (p.width, p.height, p.samples)
+            assert np.array_equal(hip.render(p)[0], want, equal_nan=True)
+        batch = []
+        for i in range(3):
+            q = sc.frame_params(width=320, height=180, samples=4, max_reflections=4, use_filter=0)
+            q.camera[0] += 0.4 * i
+            q.random_seed = float(i)
+            batch.append(q)
+        hip.set_frame_front(0)
+        want, want_cnt = hip.render_batch(batch, counters=True)
+        hip.set_frame_front(2)
+        got, cnt = hip.render_batch(batch, counters=True)
+        assert np.array_equal(got, want, equal_nan=True) and cnt == want_cnt
+        assert np.array_equal(hip.render_batch(batch)[0], want, equal_nan=True)
+    finally:
+        hip.set_pipeline(0)
+        hip.set_wavefront_organisation(0)
+        hip.set_frame_front(1)
 
 
 def test_frame_kernel_hands_paths_over_the_same_way_every_time(hip, oracle, scenes):
@@ -361,6 +403,7 @@ def test_frame_kernel_hands_paths_over_the_same_way_every_time(hip, oracle, scen
         hip.set_pipeline(3)
         hip.set_wavefront_organisation(2)
         for i in range(80):
+            hip.set_frame_front(2 if i % 2 else 0)                  # (the front of the frame inside the launch: a third ring, the same scopes)
             assert np.array_equal(hip.render(p)[0], want, equal_nan=True), "frame %d" % i
             if i % 8 == 0:
                 got_q = hip.render(q)[0]
@@ -369,6 +412,7 @@ def test_frame_kernel_hands_paths_over_the_same_way_every_time(hip, oracle, scen
     finally:
         hip.set_pipeline(0)
         hip.set_wavefront_organisation(0)
+        hip.set_frame_front(1)
 
 
 @pytest.mark.experiments

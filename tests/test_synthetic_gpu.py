@@ -30,8 +30,10 @@ def test_synthetic_scene_matches_oracle(hip, oracle, case, pipeline):
     hip.set_pipeline(pipeline)
     want, want_cnt, _ = oracle.render(sc, p)
     try:
-        for organisation in ((2, 1) if pipeline == 3 else (0,)):         # the wavefront pipeline as one persistent launch and as rounds
+        # the wavefront pipeline as one persistent launch (with the front of the frame inside it, and in front of it) and as rounds
+        for organisation, front in (((2, 2), (2, 0), (1, 0)) if pipeline == 3 else ((0, 1),)):
             hip.set_wavefront_organisation(organisation)
+            hip.set_frame_front(front)
             got, got_cnt, _ = hip.render(p, counters=True)
             plain, _, _ = hip.render(p)
             rms, mism = assert_parity(got, want, case)
@@ -41,6 +43,7 @@ def test_synthetic_scene_matches_oracle(hip, oracle, case, pipeline):
     finally:
         hip.set_pipeline(0)
         hip.set_wavefront_organisation(0)
+        hip.set_frame_front(1)
     assert want_cnt["primary_hits"] > 0.3 * p.width * p.height          # the scene is actually in view
 
 

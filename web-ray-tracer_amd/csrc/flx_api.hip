@@ -24,6 +24,9 @@ using namespace flx;
 #ifndef FLX_EXPERIMENTS
 #define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 */
 #endif
+#ifndef FLX_FRONT_MIN_TILES_PER_CU
+#define FLX_FRONT_MIN_TILES_PER_CU 48
+#endif
 #ifndef FLX_COMM_RESERVED_CUS
 #define FLX_COMM_RESERVED_CUS 8u            /* CUs a context with two gathering lanes leaves free of persistent walk workgroups */
 #endif
@@ -493,6 +496,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
   }
   if (pipeline == 3 && fr.max_reflections > WF_MAX_BOUNCES) pipeline = 2;
   ctx->last_pipeline = pipeline;
+  ctx->last_organisation = 0;
   if (pipeline != 1 && (fr.use_filter || fr.is_temporal)) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the G-buffers of filter / temporal frames");
   const size_t P = (size_t)fr.rows * fr.width;
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
@@ -583,8 +587,16 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t), ctx->stream));
     /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
     if (!ctx->d_tail_pool) FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
-    if (!ctx->d_frame_rings) FLX_HIP(ctx, hipMalloc(&ctx->d_frame_rings, (size_t)WF_MAX_GROUPS * cus * 2u * WF_FRAME_RING * sizeof(uint32_t)));
-    launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
+    if (!ctx->d_frame_rings) FLX_HIP(ctx, hipMalloc(&ctx->d_frame_rings, (size_t)WF_MAX_GROUPS * cus * WF_FRAME_RINGS * WF_FRAME_RING * sizeof(uint32_t)));
+    /* the frame kernel can trace the primary rays and shade bounce 0 itself (one chain, all of the frame in it) */
+    const int organisationNow = FLX_WF_ORGANISATION_DEFAULT ? FLX_WF_ORGANISATION_DEFAULT : ctx->wf_organisation;
+    /* (automatic: from FLX_FRONT_MIN_TILES_PER_CU screen tiles per workgroup on — the fresh paths of a tile stay with the workgroup that made them, and a
+     * workgroup with a dozen tiles, a rank's eighth of a 1080p frame, may have drawn the dragon or the sky: tools/front_time.py, profiles/r03_ab_front.txt) */
+    const uint32_t frameTiles = path_item_count(fr) / ((uint32_t)fr.samples * 64u);
+    const bool front = ctx->frame_front != 0 && wf_chains == 1 && ctx->d_rec0 != nullptr &&
+                       (ctx->frame_front == 2 || frameTiles >= (uint32_t)FLX_FRONT_MIN_TILES_PER_CU * cus) &&
+                       wavefront_front_in_kernel(sc, fr, path_item_count(fr), ctx->walk_scheduler, ctx->walk_suspend, organisationNow);
+    if (!front) launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     /* The bounce loop runs as `groups` independent chains (contiguous ranges of screen tiles), group 0 on the
      * context's stream and the others on auxiliary streams: every persistent walk kernel ends in a tail set by
@@ -603,7 +615,8 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       WavefrontBuffers wb;
       wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
-      wb.frameRings = ctx->d_frame_rings + (size_t)g * cus * 2u * WF_FRAME_RING;
+      wb.frameRings = ctx->d_frame_rings + (size_t)g * cus * WF_FRAME_RINGS * WF_FRAME_RING;
+      wb.front = front ? 1u : 0u;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
       wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
@@ -615,9 +628,11 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
        * CU until they end, and the other lane's RCCL kernel — a handful of workgroups that carry the finished frame's strips — would wait
        * behind them for a whole frame.  Such a context leaves a few CUs to the exchange. */
       const uint32_t cusWalk = (ctx->comm && (ctx->twin || ctx->is_twin) && cus > 4u * FLX_COMM_RESERVED_CUS) ? cus - FLX_COMM_RESERVED_CUS : cus;
-      launch_wavefront(sc, fr, wb, cusWalk, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend, FLX_WF_ORGANISATION_DEFAULT ? FLX_WF_ORGANISATION_DEFAULT : ctx->wf_organisation,
-                       g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
+      const int ran = launch_wavefront(sc, fr, wb, cusWalk, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend, organisationNow,
+                                       g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
       FLX_HIP(ctx, hipGetLastError());
+      if (ran < 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the frame kernel was to trace the primary rays but does not take this frame");
+      ctx->last_organisation = ran;
       if (g > 0) {
         FLX_HIP(ctx, hipEventRecord(ctx->ev_join[g - 1], st));
         FLX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[g - 1], 0));
@@ -848,6 +863,12 @@ extern "C" flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, ui
 
 extern "C" int flx_has_experiments(void) { return FLX_EXPERIMENTS; }
 
+extern "C" flx_status flx_last_organisation(flx_context *ctx, int *organisation) {
+  if (!ctx || !organisation) return FLX_ERR_INVALID;
+  *organisation = ctx->last_organisation;
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_last_pipeline(flx_context *ctx, int *pipeline) {
   if (!ctx || !pipeline) return FLX_ERR_INVALID;
   *pipeline = ctx->last_pipeline;
@@ -865,6 +886,14 @@ extern "C" flx_status flx_set_wavefront_organisation(flx_context *ctx, int organ
   if (!ctx) return FLX_ERR_INVALID;
   if (organisation < 0 || organisation > 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_wavefront_organisation: 0 automatic, 1 rounds (a kernel pair per bounce), 2 frame kernel (one persistent launch)");
   ctx->wf_organisation = organisation;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_set_frame_front(flx_context *ctx, int mode) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (mode < 0 || mode > 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_front: 0 never, 1 automatic, 2 wherever the frame kernel runs");
+  ctx->frame_front = mode;
+  if (ctx->twin) ctx->twin->frame_front = ctx->frame_front;
   return FLX_OK;
 }
 
@@ -1239,7 +1268,7 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
     flx_context *t = ctx->twin;
     t->comm = ctx->comm_twin; t->comm_rank = ctx->comm_rank; t->comm_size = ctx->comm_size; t->comm_owned = false;      /* (the primary owns and destroys both) */
     mirror_scene(ctx);
-    t->pipeline = ctx->pipeline; t->wf_groups = ctx->wf_groups; t->wf_organisation = ctx->wf_organisation; t->walk_scheduler = ctx->walk_scheduler; t->walk_suspend = ctx->walk_suspend;
+    t->pipeline = ctx->pipeline; t->wf_groups = ctx->wf_groups; t->wf_organisation = ctx->wf_organisation; t->frame_front = ctx->frame_front; t->walk_scheduler = ctx->walk_scheduler; t->walk_suspend = ctx->walk_suspend;
     if (ctx->twin_dyn_version != ctx->dyn_version) {          /* lights / transforms changed since the twin's last frame: its own copies, on its stream */
       flx_status s;
       if (ctx->have_transforms && (s = flx_transforms_upload(t, ctx->h_rotation.data(), ctx->h_shift.data(), ctx->n_transforms))) return fail(ctx, s, flx_last_error(t));

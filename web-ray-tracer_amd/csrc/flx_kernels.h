@@ -46,9 +46,11 @@ struct WavefrontBuffers {
    * kernel reads, 0.9 GB per 1080p x 8 frame instead of 2.1; the walk kernel's fold writes a full record for the paths
    * that go on (a fifth of them). */
   float4 *rec0, *pix0;
-  uint32_t *frameRings;         /* the frame kernel's rings of path ids: 2 x WF_FRAME_RING per walk workgroup (k_wf_frame), or nullptr */
+  uint32_t *frameRings;         /* the frame kernel's rings of path ids: WF_FRAME_RINGS x WF_FRAME_RING per walk workgroup (k_wf_frame), or nullptr */
+  uint32_t front;               /* frame kernel: 1 = it also traces the primary rays and shades bounce 0 (hits need not be there, item_base must be 0) */
 };
 constexpr uint32_t WF_FRAME_RING = 16384;
+constexpr uint32_t WF_FRAME_RINGS = 3;       /* to shade, to walk, fresh (tile, sample) units */
 constexpr size_t WF_TAIL_POOL_F4 = 1024 * 8;
 constexpr uint32_t WF_STRAG_F4 = 5;
 constexpr int WF_MAX_ROUNDS = 2 * WF_MAX_BOUNCES;    /* regular rounds + the rounds that drain suspended walks */
@@ -59,8 +61,10 @@ size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units);
 /* organisation: 0 automatic — the whole bounce loop in ONE persistent launch (k_wf_frame: walk waves and shade waves of a workgroup
  * hand paths to each other through LDS rings, no barrier between bounces) where the scene's transforms leave room in LDS, else
  * rounds; 1 = rounds (one k_wf_shade + k_wf_walk_pre pair per bounce); 2 = the frame kernel (rounds if it does not fit). */
-void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
-                      int walk_scheduler, uint32_t suspend_max, int organisation, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
+bool wavefront_front_in_kernel(const DeviceScene &sc, const DeviceFrame &fr, uint32_t item_count, int walk_scheduler, uint32_t suspend_max, int organisation);
+/* -> what ran: 1 rounds, 2 the frame kernel, 3 the frame kernel with the front of the frame inside it; -1: wb.front set but the frame kernel cannot run */
+int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
+                     int walk_scheduler, uint32_t suspend_max, int organisation, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
 /* denoise chain (flx_filter.hip): 13 RGBA8 planes = the reference's RenderTexture[0..3], IpRenderTexture[0..3],
  * OriginalRenderTexture[0..1], IdRenderTexture[0..1], OriginalIdRenderTexture (pathtracerWGL2.js:224-252). */
 struct FilterPlanes { uint32_t *R[4], *Ip[4], *O[2], *Id[2], *OId; };

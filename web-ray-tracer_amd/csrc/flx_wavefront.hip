@@ -99,23 +99,16 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
  * knows before it draws a random number — triangle and attribute fetch, normals, the acos / tan of the normal deviation,
  * material (shadeSurface) — is computed once and the per-sample rest (shadeSample) runs `samples` times.  Every path gets the
  * record the per-path kernel would have written, bit for bit. */
+/* (the lane's pixel of screen tile `tile`; h = its primary hit: suv + triangle id as bits, -1 for none; returns whether the pixel's paths run) */
 template <bool COUNT>
-__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade0(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
+FLX_DEV bool shade0_tile(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t tile, uint32_t lane, float4 h, WorkCounters &cnt) {
   const uint32_t S = (uint32_t)fr.samples;
-  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-  const uint32_t lane = t & 63u;
-  const uint32_t tileLocal = t >> 6;
-  if (tileLocal * S * 64u >= total_items) return;
-  const uint32_t tile = wb.item_base / (S * 64u) + tileLocal;
-  WorkCounters cnt = {};
   uint32_t px, k;
   tile8_pixel(fr, tile, lane, px, k);
   const bool inFrame = px < fr.width && k < fr.rows;
   const uint32_t frameIdx = inFrame ? frame_index(fr, k) : 0u;
   const f3 camera = frame_camera(fr, frameIdx);
-  int tri = -1;
-  float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (inFrame) { h = wb.hits[(size_t)k * fr.width + px]; tri = __float_as_int(h.w); }
+  const int tri = inFrame ? __float_as_int(h.w) : -1;
   /* loop guard of fragment:475 before the first bounce (importancy and originalColor are 1) */
   const bool alive = tri != -1 && fr.max_reflections > 0 && length(F3(1.0f, 1.0f, 1.0f) * F3(1.0f, 1.0f, 1.0f)) >= fr.min_importancy * SQRT3;
   SurfaceCtx sf;
@@ -186,7 +179,48 @@ __global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade0(DeviceSce
     rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
     rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
   }
+  return alive;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade0(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
+  const uint32_t S = (uint32_t)fr.samples;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lane = t & 63u;
+  const uint32_t tileLocal = t >> 6;
+  if (tileLocal * S * 64u >= total_items) return;
+  const uint32_t tile = wb.item_base / (S * 64u) + tileLocal;
+  WorkCounters cnt = {};
+  uint32_t px, k;
+  tile8_pixel(fr, tile, lane, px, k);
+  float4 h = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+  if (px < fr.width && k < fr.rows) h = wb.hits[(size_t)k * fr.width + px];
+  (void)shade0_tile<COUNT>(sc, fr, wb, tile, lane, h, cnt);
   flush_counters<COUNT>(cnt, wb.counters);
+}
+
+/* The primary ray of the lane's pixel of screen tile `tile` (what k_primary does for it, flx_kernels.hip): the wave walks the forward-ordered copy
+ * together.  -> suv + triangle id as bits (-1: no hit, or no pixel), also stored for k_resolve. */
+template <bool COUNT>
+FLX_DEV float4 primary_tile(const DeviceScene &sc, const DeviceFrame &fr, float4 *__restrict__ hits, uint32_t tile, uint32_t lane, WorkCounters &cnt) {
+  uint32_t px, k;
+  tile8_pixel(fr, tile, lane, px, k);
+  const bool inImage = px < fr.width && k < fr.rows;
+  float nx, ny, viewDepthPerS = 0.0f;
+  Ray pr; pr.origin = F3(0.0f, 0.0f, 0.0f); pr.dir = F3(0.0f, 0.0f, 1.0f);
+  if (inImage) {
+    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+    const uint32_t frameIdx = frame_index(fr, k);
+    pr.dir = primary_dir(fr, frameIdx, px, py_gl, nx, ny, viewDepthPerS);
+    pr.origin = frame_camera(fr, frameIdx);
+  }
+  const Hit hp = primaryWalkF(sc, inImage, pr, viewDepthPerS, cnt.primary_visits);
+  float4 h = make_float4(hp.suv.x, hp.suv.y, hp.suv.z, __int_as_float(inImage ? hp.triangleId : -1));
+  if (inImage) {
+    if (COUNT && hp.triangleId != -1) cnt.primary_hits++;
+    hits[(size_t)k * fr.width + px] = h;
+  }
+  return h;
 }
 
 /* One path's shading for its next bounce (fragment:476-589): the record the last walk left -> the record the next walk reads. */
@@ -909,8 +943,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #ifndef FLX_FRAME_SHADERS
 #define FLX_FRAME_SHADERS 2                 /* shade waves of a frame-kernel workgroup (dragon 1080p: 1 -> 7.27, 2 -> 6.87, 3 -> 7.16 ms per frame) */
 #endif
+#ifndef FLX_FRAME_SHADERS_FRONT
+#define FLX_FRAME_SHADERS_FRONT 3           /* ... when they also make the fresh paths (WavefrontBuffers::front) */
+#endif
 #ifndef FLX_FRAME_AUTO_MAX_ITEMS
 #define FLX_FRAME_AUTO_MAX_ITEMS (64u << 20)
+#endif
+#ifndef FLX_FRAME_AUTO_MAX_ITEMS_FRONT
+#define FLX_FRAME_AUTO_MAX_ITEMS_FRONT (128u << 20)
 #endif
 constexpr uint32_t FQ_SIZE = WF_FRAME_RING;   /* ids per ring (the rings live in HBM-backed memory private to the workgroup, their counts in LDS) */
 #ifndef FLX_FQ_LIMIT
@@ -922,7 +962,10 @@ constexpr uint32_t FQ_ALIVE_MAX = FQ_SIZE - 256u;     /* live paths of a workgro
 #define FLX_FQ_WATCHDOG_LOG2 24
 #endif
 constexpr uint32_t FQ_WATCHDOG = 1u << FLX_FQ_WATCHDOG_LOG2;  /* polls (~500 cycles each) after which a wave that waits gives up: a seconds-long guard against a hung GPU, never reached by a frame */
-enum { FC_ALIVE = 0, FC_DRY = 1, FC_SQ = 2 /* tail, head, avail */, FC_WQ = 5 /* tail, head, avail */, FC_WORDS = 16 };
+enum { FC_ALIVE = 0, FC_DRY = 1, FC_SQ = 2 /* tail, head, avail */, FC_WQ = 5 /* tail, head, avail */, FC_RQ = 8 /* tail, head, avail */, FC_FRONT_DONE = 11, FC_WORDS = 16 };
+#ifndef FLX_FRAME_READY_UNITS
+#define FLX_FRAME_READY_UNITS 32            /* front in the kernel: (tile, sample) units of 64 fresh paths a workgroup keeps ready for its walk waves before its shade waves stop making more */
+#endif
 
 FLX_DEV uint32_t fq_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 /* the lanes of `mine` append their `id` to the ring (ctl: tail, head, avail) */
@@ -964,12 +1007,12 @@ FLX_DEV uint32_t fq_pop(uint32_t *ring, uint32_t *ctl, unsigned long long takers
   return n;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool FRONT>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_frame(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items,
-                                                                                    uint32_t ldsCount, uint32_t nTransforms) {
+                                                                                    uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves) {
   const uint32_t n = total_items;
   if (n == 0u) return;
-  constexpr uint32_t WALK_WAVES = FLX_WF_WALK_THREADS / 64u - FLX_FRAME_SHADERS;
+  const uint32_t WALK_WAVES = FLX_WF_WALK_THREADS / 64u - shadeWaves;
   const bool compactRecs = wb.rec0 != nullptr;                /* bounce 0 comes with compact records (flx_kernels.h) */
   /* LDS: [tree top][inverse transforms][control words][per walk thread: nTransforms x 40 B of rays]; the two rings of path ids are this
    * workgroup's slice of wb.frameRings (a few lanes touch them per fold / refill, not per trip: they need no LDS) */
@@ -977,7 +1020,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   float4 *ldsEntries = ldsAll;
   float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u;
   uint32_t *ctl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);
-  uint32_t *shadeRing = wb.frameRings + (size_t)blockIdx.x * 2u * FQ_SIZE, *walkRing = shadeRing + FQ_SIZE;
+  uint32_t *shadeRing = wb.frameRings + (size_t)blockIdx.x * WF_FRAME_RINGS * FQ_SIZE, *walkRing = shadeRing + FQ_SIZE, *readyRing = walkRing + FQ_SIZE;
+  /* The front of the frame inside the launch (wb.front): the shade waves also make the fresh paths — primary ray and bounce-0 shading of one 8 x 8 screen
+   * tile at a time (what k_primary and k_wf_shade0 do in front of the launch otherwise) — and hand them to the walk waves as (tile, sample) units of 64
+   * through a third ring; the frame's queue then counts screen tiles. */
+  constexpr bool front = FRONT;                /* (a kernel of its own: the front's code costs the other one registers) */
+  const uint32_t perTile = (uint32_t)fr.samples * 64u;
   float2 *raysBase = (float2 *)(ctl + FC_WORDS);
   for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
   for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
@@ -985,19 +1033,61 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
   }
   if (threadIdx.x < (uint32_t)FC_WORDS) ctl[threadIdx.x] = 0u;
-  for (uint32_t t = threadIdx.x; t < 2u * FQ_SIZE; t += FLX_WF_WALK_THREADS) shadeRing[t] = WF_INVALID;
+  for (uint32_t t = threadIdx.x; t < WF_FRAME_RINGS * FQ_SIZE; t += FLX_WF_WALK_THREADS) shadeRing[t] = WF_INVALID;
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   WorkCounters cnt = {};
 
+  /* The front of the frame, one 8 x 8 screen tile: primary rays (the wave walks together), bounce-0 shading, and the tile's (tile, sample) units into
+   * the ready ring.  0: not now (the walk waves have enough ready, or the workgroup holds as many paths as its rings take), 1: a tile made, 2: the
+   * frame has no more tiles.  Every item of a tile counts as alive from before it is drawn until a walk wave has met it (the dead pixels' items are
+   * taken off the count there); a tile none of whose pixels goes on is not handed over at all. */
+  const uint32_t nTiles = n / perTile;
+  auto makeTile = [&]() -> uint32_t {
+    if (!FRONT) return 2u;
+    uint32_t take = 0, tile = 0;
+    if (lane == 0 && fq_load(&ctl[FC_RQ + 2]) < (uint32_t)FLX_FRAME_READY_UNITS) {
+      const uint32_t before = atomicAdd(&ctl[FC_ALIVE], perTile);
+      if (before + perTile > FQ_ALIVE_MAX) atomicSub(&ctl[FC_ALIVE], perTile);
+      else { tile = atomicAdd(wb.walkQueue, 1u); take = 1; }
+    }
+    take = __builtin_amdgcn_readfirstlane(take);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (take == 0u) return 0u;
+    if (tile >= nTiles) {
+      if (lane == 0) atomicSub(&ctl[FC_ALIVE], perTile);
+      return 2u;
+    }
+    tile += wb.item_base / perTile;
+    const float4 h = primary_tile<COUNT>(sc, fr, const_cast<float4 *>(wb.hits), tile, lane, cnt);
+    const bool runs = shade0_tile<COUNT>(sc, fr, wb, tile, lane, h, cnt);
+    if (flx_ballot(runs) == 0ull) {
+      if (lane == 0) atomicSub(&ctl[FC_ALIVE], perTile);
+    } else {
+      for (uint32_t s0 = 0; s0 < (uint32_t)fr.samples; s0 += 64u)
+        fq_push(readyRing, ctl + FC_RQ, s0 + lane < (uint32_t)fr.samples, tile * (uint32_t)fr.samples + s0 + lane, lane);
+    }
+    return 1u;
+  };
+
   if (wave >= WALK_WAVES) {
     /* ================================ shade wave ================================ */
     uint32_t idle = 0;
+    bool frontDone = !front;                                 /* this wave has found the frame's tile queue dry */
     for (;;) {
       const bool dry = fq_load(&ctl[FC_DRY]) != 0u;
       uint32_t id = WF_INVALID;
       const uint32_t got = fq_pop(shadeRing, ctl + FC_SQ, ~0ull, 64u, dry ? 1u : 64u, lane, id);
+      if (got == 0u && !frontDone) {
+        /* no full batch to shade: make fresh paths */
+        const uint32_t made = makeTile();
+        if (made == 2u) {                                     /* the frame has no more tiles: the last shade wave to find that says so */
+          if (lane == 0 && atomicAdd(&ctl[FC_FRONT_DONE], 1u) + 1u == shadeWaves) atomicExch(&ctl[FC_DRY], 1u);
+          frontDone = true;
+        }
+        if (made != 0u) { idle = 0; continue; }
+      }
       if (got == 0u) {
         if (dry && fq_load(&ctl[FC_ALIVE]) == 0u) break;
         if (++idle > FQ_WATCHDOG) {                               /* never in a healthy frame; counted builds leave the control words behind (flx_get_tail_diag) */
@@ -1017,6 +1107,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   }
 
   /* ================================ walk wave ================================ */
+  /* with the front in the kernel nothing is there to walk when it starts: every walk wave first makes fresh paths too, until the workgroup has enough
+   * ready (a tile each, all at once — for a rank's thin share of a frame that is every tile it has) */
+  if (front) while (makeTile() == 1u) {}
   const long long tStart = COUNT ? clock64() : 0;
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
   uint32_t *__restrict__ queue = wb.walkQueue;
@@ -1054,7 +1147,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     if (walking != 0ull) idleSpins = 0;
     const unsigned long long workMask = flx_ballot(st == P_DONE || st == P_SWITCH);
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
-    const bool mayRefill = itemsLeft || chunkNext != chunkEnd || fq_load(&ctl[FC_WQ + 2]) != 0u;
+    const bool mayRefill = (front ? fq_load(&ctl[FC_RQ + 2]) != 0u : itemsLeft) || chunkNext != chunkEnd || fq_load(&ctl[FC_WQ + 2]) != 0u;
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
       /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475; a path that goes on is handed to the shade waves ---- */
       if (flx_ballot(st == P_DONE) != 0ull) {
@@ -1108,7 +1201,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         bool fresh = false;                                    /* a bounce-0 item: compact record, may be dead */
         const uint32_t back = fq_pop(walkRing, ctl + FC_WQ, idle, nIdle, 1u, lane, id);
         if (back == 0u) {
-          if (chunkNext == chunkEnd) {
+          if (chunkNext == chunkEnd && front) {
+            /* fresh paths come from this workgroup's shade waves: one (tile, sample) unit of 64 at a time (they are counted alive already) */
+            if (fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT) break;
+            uint32_t unit = WF_INVALID;
+            if (fq_pop(readyRing, ctl + FC_RQ, 1ull, 1u, 1u, lane, unit) == 0u) break;
+            unit = __builtin_amdgcn_readfirstlane(unit);
+            chunkNext = unit << 6; chunkEnd = chunkNext + 64u;
+          } else if (chunkNext == chunkEnd) {
             if (!itemsLeft) break;
             if (fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT) break;  /* the shade waves are behind: no new paths for now */
             uint32_t want = (n - lastBase) / (nWaves * 2u);    /* guided self-scheduling: draws shrink as the queue empties */
@@ -1146,7 +1246,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           const uint32_t avail = chunkEnd - chunkNext;
           const uint32_t take = nIdle < avail ? nIdle : avail;
           const uint32_t r = lane_rank(idle);
-          if (st == P_EMPTY && r < take) { id = wb.item_base + chunkNext + r; fresh = true; }
+          if (st == P_EMPTY && r < take) { id = (front ? 0u : wb.item_base) + chunkNext + r; fresh = true; }
           chunkNext += take;
         }
         bool dead = false;
@@ -1202,8 +1302,11 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       if (flx_ballot(st == P_WALKING) == 0ull) {
         if (flx_ballot(st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
         /* nothing in this wave: done when the item queue is dry and no path of the workgroup is alive; else wait for the shade waves */
-        if (!itemsLeft && chunkNext == chunkEnd && fq_load(&ctl[FC_ALIVE]) == 0u) break;
-        if (fq_load(&ctl[FC_WQ + 2]) == 0u && !(itemsLeft && fq_load(&ctl[FC_SQ + 2]) < FQ_LIMIT && fq_load(&ctl[FC_ALIVE]) + 256u <= FQ_ALIVE_MAX)) {
+        if (front) {
+          if (fq_load(&ctl[FC_DRY]) != 0u && chunkNext == chunkEnd && fq_load(&ctl[FC_ALIVE]) == 0u) break;
+        } else if (!itemsLeft && chunkNext == chunkEnd && fq_load(&ctl[FC_ALIVE]) == 0u) break;
+        if (fq_load(&ctl[FC_WQ + 2]) == 0u && (front ? (fq_load(&ctl[FC_RQ + 2]) == 0u || fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT)
+                                                     : !(itemsLeft && fq_load(&ctl[FC_SQ + 2]) < FQ_LIMIT && fq_load(&ctl[FC_ALIVE]) + 256u <= FQ_ALIVE_MAX))) {
           if (++idleSpins > FQ_WATCHDOG) {
             if (COUNT && lane == 0) { for (uint32_t k = 0; k < 8u; k++) atomicMax(wb.counters + 50 + k, (unsigned long long)fq_load(&ctl[k]) + 1ull); atomicAdd(wb.counters + 58, 1ull); }
             break;
@@ -1245,8 +1348,27 @@ static bool frame_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_
   return true;
 }
 
-void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wbIn, uint32_t compute_units, bool count,
-                      int walk_scheduler, uint32_t suspend_max, int organisation, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
+/* Will launch_wavefront run these items as ONE frame kernel? */
+static bool frame_kernel_wanted(const DeviceScene &sc, const DeviceFrame &fr, uint32_t item_count, int walk_scheduler, uint32_t suspend_max, int organisation,
+                                bool withFront, uint32_t &ldsCountF, uint32_t &ldsBytesF) {
+#if !FLX_EXPERIMENTS
+  walk_scheduler = 0; suspend_max = 0u;                     /* (flx_set_walk_scheduler refuses anything else in this build) */
+#endif
+  /* automatic: the frame kernel while the pass is small enough for the rounds' tails to matter — measured crossover at ~66 M paths
+   * (a 4K frame at 8 spp, or four 1080p frames per pass: tools/organisation_time.py, profiles/r03_organisation_crossover.txt), with the front of
+   * the frame inside the launch somewhere between 66 M (3.7 % ahead) and 265 M (2.7 % behind); beyond it the rounds' sixteen walk waves per CU beat
+   * fourteen walk + two shade waves */
+  const bool wanted = organisation == 2 || (organisation == 0 && item_count <= (withFront ? (uint32_t)FLX_FRAME_AUTO_MAX_ITEMS_FRONT : (uint32_t)FLX_FRAME_AUTO_MAX_ITEMS));
+  return wanted && walk_scheduler == 0 && suspend_max == 0u && fr.max_reflections >= 1 && frame_kernel_fits(sc, ldsCountF, ldsBytesF);
+}
+/* May the frame kernel also take the front of the frame (primary rays, bounce-0 shading: WavefrontBuffers::front)?  Then launch_primary is not needed. */
+bool wavefront_front_in_kernel(const DeviceScene &sc, const DeviceFrame &fr, uint32_t item_count, int walk_scheduler, uint32_t suspend_max, int organisation) {
+  uint32_t a = 0, b = 0;
+  return frame_kernel_wanted(sc, fr, item_count, walk_scheduler, suspend_max, organisation, true, a, b) && (uint32_t)fr.samples * 64u * 2u <= FQ_ALIVE_MAX;
+}
+
+int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wbIn, uint32_t compute_units, bool count,
+                     int walk_scheduler, uint32_t suspend_max, int organisation, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
   WavefrontBuffers wb = wbIn;
 #if !FLX_EXPERIMENTS
   walk_scheduler = 0; suspend_max = 0u;                     /* (flx_set_walk_scheduler refuses anything else in this build) */
@@ -1254,29 +1376,36 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
   /* ---- one persistent launch for the whole bounce loop (k_wf_frame), where it fits ---- */
   {
     uint32_t ldsCountF = 0, ldsBytesF = 0;
-    /* automatic: the frame kernel while the pass is small enough for the rounds' tails to matter — measured crossover at ~66 M paths
-     * (a 4K frame at 8 spp, or four 1080p frames per pass: tools/organisation_time.py, profiles/r03_organisation_crossover.txt); beyond
-     * it the rounds' sixteen walk waves per CU beat fourteen walk + two shade waves */
-    const bool wanted = organisation == 2 || (organisation == 0 && wb.item_count <= (uint32_t)FLX_FRAME_AUTO_MAX_ITEMS);
-    if (wanted && walk_scheduler == 0 && suspend_max == 0u && fr.max_reflections >= 1 && wb.frameRings != nullptr && frame_kernel_fits(sc, ldsCountF, ldsBytesF)) {
+    if (wb.frameRings != nullptr && frame_kernel_wanted(sc, fr, wb.item_count, walk_scheduler, suspend_max, organisation, wb.front != 0u, ldsCountF, ldsBytesF)) {
       static bool attrSetF = false;
       if (!attrSetF) {
-        (void)hipFuncSetAttribute((const void *)k_wf_frame<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_wf_frame<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_wf_frame<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_wf_frame<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_wf_frame<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)k_wf_frame<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attrSetF = true;
       }
       const uint32_t total = wb.item_count;
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);
       const uint32_t shadeBlocks = (pixels + 255u) / 256u;
-      if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
+      if (wb.front) { /* the frame kernel shades bounce 0 itself */ }
+      else if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
       else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
       if (walk0_begin) (void)hipEventRecord(walk0_begin, stream);
-      if (count) hipLaunchKernelGGL(k_wf_frame<true>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms);
-      else hipLaunchKernelGGL(k_wf_frame<false>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms);
+      const uint32_t shadeWaves = wb.front ? (uint32_t)FLX_FRAME_SHADERS_FRONT : (uint32_t)FLX_FRAME_SHADERS;
+      const dim3 grid(compute_units), block(FLX_WF_WALK_THREADS);
+      if (wb.front) {
+        if (count) hipLaunchKernelGGL((k_wf_frame<true, true>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves);
+        else hipLaunchKernelGGL((k_wf_frame<false, true>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves);
+      } else {
+        if (count) hipLaunchKernelGGL((k_wf_frame<true, false>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves);
+        else hipLaunchKernelGGL((k_wf_frame<false, false>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves);
+      }
       if (walk0_end) (void)hipEventRecord(walk0_end, stream);
-      return;
+      return wb.front ? 3 : 2;
     }
   }
+  if (wb.front) return -1;                              /* the caller left the primary rays to a frame kernel that does not run (wavefront_front_in_kernel said it would) */
   const uint32_t total = wb.item_count;                 /* items of this group (all of the frame when there is one group) */
   const uint32_t maxBlocks = compute_units * 8u;
   /* walk kernel: one big workgroup per CU.  LDS first holds every thread's pre-transformed rays
@@ -1345,6 +1474,7 @@ void launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefr
     if (suspend && finisher) launch_walk_coop(sc, fr, wb, compute_units, count, r, stream);
 #endif
   }
+  return 1;
 }
 
 size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units) {

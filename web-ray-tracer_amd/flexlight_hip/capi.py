@@ -24,7 +24,7 @@ EXPORTS = [
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
     "flx_group_create", "flx_group_destroy", "flx_group_last_error", "flx_group_size", "flx_group_uses_rccl", "flx_group_context",
     "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag",
-    "flx_render_gathered_root_device", "flx_comm_count", "flx_frame_begin_gathered", "flx_group_set_gather", "flx_frame_host_slots", "flx_has_experiments", "flx_set_wavefront_organisation",
+    "flx_render_gathered_root_device", "flx_comm_count", "flx_frame_begin_gathered", "flx_group_set_gather", "flx_frame_host_slots", "flx_has_experiments", "flx_set_wavefront_organisation", "flx_set_frame_front", "flx_last_organisation",
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
 ]
 
@@ -109,6 +109,8 @@ def _load():
         "flx_frame_host_slots": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_int)]),
         "flx_has_experiments": (C.c_int, []),
         "flx_set_wavefront_organisation": (C.c_int, [vp, C.c_int]),
+        "flx_set_frame_front": (C.c_int, [vp, C.c_int]),
+        "flx_last_organisation": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "flx_group_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(vp)]),
         "flx_group_destroy": (None, [vp]),
         "flx_group_last_error": (C.c_char_p, [vp]),
@@ -356,6 +358,16 @@ class Context:
     def set_wavefront_organisation(self, organisation):
         """0 automatic, 1 rounds (a shade + walk kernel pair per bounce), 2 the frame kernel (all bounces in one persistent launch)"""
         self._check(LIB.flx_set_wavefront_organisation(self._h, int(organisation)), "flx_set_wavefront_organisation")
+
+    def last_organisation(self):
+        """what the wavefront pipeline ran for the last frame: 1 rounds, 2 frame kernel, 3 frame kernel with the front inside; 0 another pipeline"""
+        v = C.c_int()
+        self._check(LIB.flx_last_organisation(self._h, C.byref(v)), "flx_last_organisation")
+        return v.value
+
+    def set_frame_front(self, mode):
+        """frame kernel: 2 it also traces the primary rays and shades bounce 0; 0 k_primary and k_wf_shade0 in front of it; 1 (default) automatic"""
+        self._check(LIB.flx_set_frame_front(self._h, int(mode)), "flx_set_frame_front")
 
     def set_walk_scheduler(self, scheduler, suspend_walks=0):
         """0 one walk per lane (default), 1 LDS test queues, 2 lanes + cooperative finisher; identical results"""
