@@ -946,6 +946,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #ifndef FLX_FRAME_SHADERS_FRONT
 #define FLX_FRAME_SHADERS_FRONT 3           /* ... when they also make the fresh paths (WavefrontBuffers::front) */
 #endif
+#ifndef FLX_FRAME_PROLOGUE_WAVES
+#define FLX_FRAME_PROLOGUE_WAVES 2
+#endif
 #ifndef FLX_FRAME_AUTO_MAX_ITEMS
 #define FLX_FRAME_AUTO_MAX_ITEMS (64u << 20)
 #endif
@@ -1107,9 +1110,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   }
 
   /* ================================ walk wave ================================ */
-  /* with the front in the kernel nothing is there to walk when it starts: every walk wave first makes fresh paths too, until the workgroup has enough
-   * ready (a tile each, all at once — for a rank's thin share of a frame that is every tile it has) */
-  if (front) while (makeTile() == 1u) {}
+  /* with the front in the kernel nothing is there to walk when it starts: the first walk waves make a tile each as well, before any walk state is
+   * live that the tile's code would have to spill around (dragon 1080p by the number of such waves: 0 -> 6.62, 1 -> 6.44, 2 -> 6.42, 3 -> 6.45, all 13 -> 6.55 ms:
+   * the more tiles are bound to the workgroup at once, the worse the frame's balance) */
+  if (front && wave < (uint32_t)FLX_FRAME_PROLOGUE_WAVES) while (makeTile() == 1u) {}
   const long long tStart = COUNT ? clock64() : 0;
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
   uint32_t *__restrict__ queue = wb.walkQueue;
