@@ -360,6 +360,20 @@ def test_the_front_inside_the_frame_kernel_at_its_edges(hip, oracle, scenes):
                  sc.frame_params(width=96, height=56, samples=130, max_reflections=2, use_filter=0),
                  sc.frame_params(width=333, height=187, samples=5, max_reflections=4, use_filter=0, tile=(8, 1, 3)),
                  sc.frame_params(width=640, height=360, samples=4, max_reflections=4, use_filter=0, tile=(16, 0, 2))]
+        # a view that hits nothing (the camera far outside the scene's room, looking away from it): no tile is handed over at all
+        from flexlight_hip import scene_io
+        cam = sc.meta["camera"]
+        away = None
+        for dy, fy in ((1.0e3, 1.4), (1.0e3, -1.4), (-1.0e3, 1.4), (-1.0e3, -1.4)):
+            q = sc.frame_params(width=256, height=144, samples=4, max_reflections=3, use_filter=0)
+            q.camera[1] += dy
+            q.view_matrix[:] = scene_io.view_matrix(cam["fx"], fy, cam["fov"], q.width, q.height).tolist()
+            hip.set_frame_front(0)
+            if hip.render(q, counters=True)[1]["primary_hits"] == 0:
+                away = q
+                break
+        assert away is not None
+        cases.append(away)
         for p in cases:
             hip.set_frame_front(0)
             want, want_cnt, _ = hip.render(p, counters=True)
