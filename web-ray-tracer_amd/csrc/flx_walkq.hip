@@ -25,6 +25,7 @@
  * one cell or in the hands of exactly one wave, so a ring of capacity >= number of walks never overflows.
  * Every wait is bounded (FLX_WQ_MAX_TRIPS): a kernel that loses a walk raises the error word and ends.
  */
+#include <atomic>
 #include <cstdio>
 #include "flx_wavefront_common.h"
 
@@ -432,13 +433,15 @@ void launch_walk_queue(const DeviceScene &sc, const DeviceFrame &fr, const Wavef
                        uint32_t total, hipStream_t stream) {
   const uint32_t nSlots = walk_queue_slots();
   const uint32_t ldsBytes = (uint32_t)sizeof(WqCtl) + Q_COUNT * WQ_CAP * 4u + nSlots * WQ_SLOT_F4 * 16u;
-  static bool attrSet = false;
-  if (!attrSet) {
+  static std::atomic<uint64_t> attrDone{0};                  /* (per device: see launch_wavefront) */
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if ((attrDone.fetch_or(bit) & bit) == 0ull) {
     (void)hipFuncSetAttribute((const void *)k_wf_walk_queue<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk_queue<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk_queue<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk_queue<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attrSet = true;
   }
   const dim3 grid(compute_units), block(FLX_WQ_THREADS);
   if (b == 0) {

@@ -29,6 +29,7 @@
  *                 hand paths to each other through rings until every path it drew has ended (round 3; the default up to 64 M paths
  *                 per pass: dragon 1080p 7.87 -> 6.83 ms per frame, a rank's eighth of the frame 2.94 -> 1.67 ms).
  */
+#include <atomic>
 #include <cstdio>
 #include "flx_kernels.h"
 #include "flx_kernel_util.h"
@@ -939,7 +940,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
  * the count past FQ_ALIVE_MAX is not made, so the rings cannot overflow; and a wave does not draw while FQ_LIMIT paths or more wait
  * for shading (the shade waves are behind: walking more new paths would only lengthen their queue).
  * Per path nothing changes — the same records, the same arithmetic in the same order, its radiance in its own slot — so frames and
- * work counters are bit-identical to the rounds (tests/test_parity_gpu.py: both organisations against the oracle). */
+ * work counters are bit-identical to the rounds (tests/test_parity_gpu.py: both organisations against the oracle).
+ *
+ * FRONT = true: the front of the frame is inside the launch as well (profiles/r03_ab_front.txt).  The shade waves — three of them then — also
+ * make the fresh paths, one 8 x 8 screen tile at a time (makeTile: primary_tile = what a wave of k_primary does, shade0_tile = the body of
+ * k_wf_shade0), and hand them to the walk waves as (tile, sample) units of 64 paths through a third ring; the frame's queue counts screen
+ * tiles; k_primary and k_wf_shade0 are not launched.  The fresh paths of a tile stay with the workgroup that made them, so a frame needs
+ * enough tiles per workgroup to balance (flx_api.hip: automatic from 48 on); FRONT = false is the kernel described above, register for
+ * register. */
 #ifndef FLX_FRAME_SHADERS
 #define FLX_FRAME_SHADERS 2                 /* shade waves of a frame-kernel workgroup (dragon 1080p: 1 -> 7.27, 2 -> 6.87, 3 -> 7.16 ms per frame) */
 #endif
@@ -947,7 +955,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #define FLX_FRAME_SHADERS_FRONT 3           /* ... when they also make the fresh paths (WavefrontBuffers::front) */
 #endif
 #ifndef FLX_FRAME_PROLOGUE_WAVES
-#define FLX_FRAME_PROLOGUE_WAVES 2
+#define FLX_FRAME_PROLOGUE_WAVES 2          /* walk waves that make a first tile before their loop (FRONT) */
 #endif
 #ifndef FLX_FRAME_AUTO_MAX_ITEMS
 #define FLX_FRAME_AUTO_MAX_ITEMS (64u << 20)
@@ -1352,6 +1360,16 @@ static bool frame_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_
   return true;
 }
 
+/* A kernel's dynamic-LDS limit (hipFuncSetAttribute) belongs to the device it is set on: once per device and kernel family, whichever context launches there
+ * first (a group of contexts on several GPUs lives in one process). */
+static bool first_launch_on_this_device(int family) {
+  static std::atomic<uint64_t> done[2];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  const uint64_t bit = 1ull << dev;
+  return (done[family].fetch_or(bit) & bit) == 0ull;
+}
+
 /* Will launch_wavefront run these items as ONE frame kernel? */
 static bool frame_kernel_wanted(const DeviceScene &sc, const DeviceFrame &fr, uint32_t item_count, int walk_scheduler, uint32_t suspend_max, int organisation,
                                 bool withFront, uint32_t &ldsCountF, uint32_t &ldsBytesF) {
@@ -1381,13 +1399,11 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
   {
     uint32_t ldsCountF = 0, ldsBytesF = 0;
     if (wb.frameRings != nullptr && frame_kernel_wanted(sc, fr, wb.item_count, walk_scheduler, suspend_max, organisation, wb.front != 0u, ldsCountF, ldsBytesF)) {
-      static bool attrSetF = false;
-      if (!attrSetF) {
+      if (first_launch_on_this_device(0)) {
         (void)hipFuncSetAttribute((const void *)k_wf_frame<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_wf_frame<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_wf_frame<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)k_wf_frame<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attrSetF = true;
       }
       const uint32_t total = wb.item_count;
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);
@@ -1424,15 +1440,13 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
   uint32_t perCu = (160u * 1024u) / (ldsBytes > 20480u ? ldsBytes : 20480u);
   if (perCu > 8u) perCu = 8u;
   const uint32_t walkBlocks = compute_units * perCu;
-  static bool attrSet = false;
-  if (!attrSet) {
+  if (first_launch_on_this_device(1)) {
     (void)hipFuncSetAttribute((const void *)k_wf_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attrSet = true;
   }
   const int bounces = fr.max_reflections > 0 ? fr.max_reflections : 1;   /* 0 bounces: shade(0) only finalises */
   /* Suspension needs the kernel that can take a walk up again (k_wf_walk_pre), at least two bounces to gain anything, and
