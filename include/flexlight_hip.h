@@ -291,7 +291,7 @@ flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
 flx_status flx_set_wavefront_organisation(flx_context *ctx, int organisation);
 /* Frame kernel: who traces the primary rays and shades bounce 0.  2: the persistent launch itself — its shade waves make the fresh paths one 8 x 8
  * screen tile at a time while its walk waves walk the earlier ones (k_primary and k_wf_shade0 are not launched); 0: those two kernels run in front of it, as
- * they do in front of the rounds; 1 (default): automatic, the launch itself where a workgroup gets at least 48 screen tiles (a whole 1080p frame: yes, a
+ * they do in front of the rounds; 1 (default): automatic, the launch itself where a workgroup gets at least 32 screen tiles (a whole 1080p frame: yes, a
  * rank's eighth of one: no).  Frames and work counters are identical. */
 flx_status flx_set_frame_front(flx_context *ctx, int mode);
 /* What the wavefront pipeline ran for the last frame: 1 rounds, 2 the frame kernel, 3 the frame kernel with the front of the frame inside it;

@@ -25,7 +25,7 @@ using namespace flx;
 #define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 */
 #endif
 #ifndef FLX_FRONT_MIN_TILES_PER_CU
-#define FLX_FRONT_MIN_TILES_PER_CU 48
+#define FLX_FRONT_MIN_TILES_PER_CU 32
 #endif
 #ifndef FLX_COMM_RESERVED_CUS
 #define FLX_COMM_RESERVED_CUS 8u            /* CUs a context with two gathering lanes leaves free of persistent walk workgroups */

@@ -946,7 +946,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
  * make the fresh paths, one 8 x 8 screen tile at a time (makeTile: primary_tile = what a wave of k_primary does, shade0_tile = the body of
  * k_wf_shade0), and hand them to the walk waves as (tile, sample) units of 64 paths through a third ring; the frame's queue counts screen
  * tiles; k_primary and k_wf_shade0 are not launched.  The fresh paths of a tile stay with the workgroup that made them, so a frame needs
- * enough tiles per workgroup to balance (flx_api.hip: automatic from 48 on); FRONT = false is the kernel described above, register for
+ * enough tiles per workgroup to balance (flx_api.hip: automatic from 32 on); FRONT = false is the kernel described above, register for
  * register. */
 #ifndef FLX_FRAME_SHADERS
 #define FLX_FRAME_SHADERS 2                 /* shade waves of a frame-kernel workgroup (dragon 1080p: 1 -> 7.27, 2 -> 6.87, 3 -> 7.16 ms per frame) */
@@ -975,7 +975,7 @@ constexpr uint32_t FQ_ALIVE_MAX = FQ_SIZE - 256u;     /* live paths of a workgro
 constexpr uint32_t FQ_WATCHDOG = 1u << FLX_FQ_WATCHDOG_LOG2;  /* polls (~500 cycles each) after which a wave that waits gives up: a seconds-long guard against a hung GPU, never reached by a frame */
 enum { FC_ALIVE = 0, FC_DRY = 1, FC_SQ = 2 /* tail, head, avail */, FC_WQ = 5 /* tail, head, avail */, FC_RQ = 8 /* tail, head, avail */, FC_FRONT_DONE = 11, FC_WORDS = 16 };
 #ifndef FLX_FRAME_READY_UNITS
-#define FLX_FRAME_READY_UNITS 32            /* front in the kernel: (tile, sample) units of 64 fresh paths a workgroup keeps ready for its walk waves before its shade waves stop making more */
+#define FLX_FRAME_READY_UNITS 32            /* front in the kernel: the most (tile, sample) units of 64 fresh paths a workgroup keeps ready (launch_wavefront: readyUnits) */
 #endif
 
 FLX_DEV uint32_t fq_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -1020,7 +1020,7 @@ FLX_DEV uint32_t fq_pop(uint32_t *ring, uint32_t *ctl, unsigned long long takers
 
 template <bool COUNT, bool FRONT>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_frame(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items,
-                                                                                    uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves) {
+                                                                                    uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves, uint32_t readyUnits) {
   const uint32_t n = total_items;
   if (n == 0u) return;
   const uint32_t WALK_WAVES = FLX_WF_WALK_THREADS / 64u - shadeWaves;
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   auto makeTile = [&]() -> uint32_t {
     if (!FRONT) return 2u;
     uint32_t take = 0, tile = 0;
-    if (lane == 0 && fq_load(&ctl[FC_RQ + 2]) < (uint32_t)FLX_FRAME_READY_UNITS) {
+    if (lane == 0 && fq_load(&ctl[FC_RQ + 2]) < readyUnits) {
       const uint32_t before = atomicAdd(&ctl[FC_ALIVE], perTile);
       if (before + perTile > FQ_ALIVE_MAX) atomicSub(&ctl[FC_ALIVE], perTile);
       else { tile = atomicAdd(wb.walkQueue, 1u); take = 1; }
@@ -1414,12 +1414,19 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
       if (walk0_begin) (void)hipEventRecord(walk0_begin, stream);
       const uint32_t shadeWaves = wb.front ? (uint32_t)FLX_FRAME_SHADERS_FRONT : (uint32_t)FLX_FRAME_SHADERS;
       const dim3 grid(compute_units), block(FLX_WF_WALK_THREADS);
+      /* front inside: (tile, sample) units of 64 fresh paths a workgroup keeps ready for its walk waves before its shade waves stop making more.  What is
+       * ready is bound to the workgroup, so the fewer tiles a workgroup gets the less it may hoard: FLX_FRAME_READY_UNITS from 48 tiles per workgroup on, below
+       * that half a unit per tile it can expect but FLX_FRAME_READY_UNITS / 4 at the least (whole 1080p frame, 127 tiles per workgroup: 16 -> 6.61, 32 -> 6.43, 64 -> 6.49 ms; a quarter of
+       * it, 31 tiles: 8 -> 2.40, 16 -> 2.33, 32 -> 2.57 ms; an eighth: 8 -> 1.76, 16 -> 1.83, 32 -> 2.0 ms) */
+      const uint32_t tilesPerGroup = (total / ((uint32_t)fr.samples * 64u)) / compute_units;
+      uint32_t readyUnits = tilesPerGroup >= 48u ? (uint32_t)FLX_FRAME_READY_UNITS : tilesPerGroup / 2u;
+      readyUnits = readyUnits < (uint32_t)FLX_FRAME_READY_UNITS / 4u ? (uint32_t)FLX_FRAME_READY_UNITS / 4u : (readyUnits > (uint32_t)FLX_FRAME_READY_UNITS ? (uint32_t)FLX_FRAME_READY_UNITS : readyUnits);
       if (wb.front) {
-        if (count) hipLaunchKernelGGL((k_wf_frame<true, true>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves);
-        else hipLaunchKernelGGL((k_wf_frame<false, true>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves);
+        if (count) hipLaunchKernelGGL((k_wf_frame<true, true>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
+        else hipLaunchKernelGGL((k_wf_frame<false, true>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
       } else {
-        if (count) hipLaunchKernelGGL((k_wf_frame<true, false>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves);
-        else hipLaunchKernelGGL((k_wf_frame<false, false>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves);
+        if (count) hipLaunchKernelGGL((k_wf_frame<true, false>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
+        else hipLaunchKernelGGL((k_wf_frame<false, false>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
       }
       if (walk0_end) (void)hipEventRecord(walk0_end, stream);
       return wb.front ? 3 : 2;
