@@ -1086,6 +1086,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     /* ================================ shade wave ================================ */
     uint32_t idle = 0;
     bool frontDone = !front;                                 /* this wave has found the frame's tile queue dry */
+    const long long tStartShade = COUNT ? clock64() : 0;
     for (;;) {
       const bool dry = fq_load(&ctl[FC_DRY]) != 0u;
       uint32_t id = WF_INVALID;
@@ -1094,7 +1095,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         /* no full batch to shade: make fresh paths */
         const uint32_t made = makeTile();
         if (made == 2u) {                                     /* the frame has no more tiles: the last shade wave to find that says so */
-          if (lane == 0 && atomicAdd(&ctl[FC_FRONT_DONE], 1u) + 1u == shadeWaves) atomicExch(&ctl[FC_DRY], 1u);
+          if (lane == 0 && atomicAdd(&ctl[FC_FRONT_DONE], 1u) + 1u == shadeWaves) {
+            atomicExch(&ctl[FC_DRY], 1u);
+            if (COUNT) {                                        /* frame-kernel profile (flx_get_tail_diag 20..), as where the walk waves find the item queue dry */
+              const unsigned long long now = (unsigned long long)(clock64() - tStartShade);
+              atomicAdd(wb.counters + 60, now); atomicMax(wb.counters + 61, now); atomicAdd(wb.counters + 62, 1ull);
+              atomicAdd(wb.counters + 63, (unsigned long long)fq_load(&ctl[FC_ALIVE]));
+            }
+          }
           frontDone = true;
         }
         if (made != 0u) { idle = 0; continue; }
@@ -1121,8 +1129,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   /* with the front in the kernel nothing is there to walk when it starts: the first walk waves make a tile each as well, before any walk state is
    * live that the tile's code would have to spill around (dragon 1080p by the number of such waves: 0 -> 6.62, 1 -> 6.44, 2 -> 6.42, 3 -> 6.45, all 13 -> 6.55 ms:
    * the more tiles are bound to the workgroup at once, the worse the frame's balance) */
-  if (front && wave < (uint32_t)FLX_FRAME_PROLOGUE_WAVES) while (makeTile() == 1u) {}
   const long long tStart = COUNT ? clock64() : 0;
+  if (front && wave < (uint32_t)FLX_FRAME_PROLOGUE_WAVES) while (makeTile() == 1u) {}
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
   uint32_t *__restrict__ queue = wb.walkQueue;
   const uint32_t nWaves = gridDim.x * WALK_WAVES;
