@@ -400,6 +400,37 @@ def test_the_front_inside_the_frame_kernel_at_its_edges(hip, oracle, scenes):
         hip.set_frame_front(1)
 
 
+def test_random_frames_agree_between_the_organisations(hip, scenes):
+    """a hundred random frames — odd sizes, one to eleven samples, one to seven bounces, whole frames and a rank's strips of every width — rendered as rounds (which the
+    tests above hold against the oracle), as the frame kernel, and as the frame kernel with the front of the frame inside it: the same bits and the same work counters"""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    rng = np.random.default_rng(20261004)
+    try:
+        hip.set_pipeline(3)
+        for case in range(100):
+            w, h = int(rng.integers(1, 700)), int(rng.integers(1, 400))
+            spp, bounces = int(rng.integers(1, 12)), int(rng.integers(1, 8))
+            tile = (0, 0, 0)
+            if rng.random() < 0.5:
+                count = int(rng.integers(2, 9))
+                tile = (int(rng.choice([1, 3, 8, 16])), int(rng.integers(0, count)), count)
+            p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0, tile=tile)
+            p.random_seed = float(case)
+            hip.set_wavefront_organisation(1)
+            want, want_cnt, _ = hip.render(p, counters=True)
+            for front in (0, 2):
+                hip.set_wavefront_organisation(2)
+                hip.set_frame_front(front)
+                got, cnt, _ = hip.render(p, counters=True)
+                assert np.array_equal(got, want, equal_nan=True) and cnt == want_cnt, (case, w, h, spp, bounces, tile, front)
+                assert np.array_equal(hip.render(p)[0], want, equal_nan=True), (case, w, h, spp, bounces, tile, front)
+    finally:
+        hip.set_pipeline(0)
+        hip.set_wavefront_organisation(0)
+        hip.set_frame_front(1)
+
+
 def test_frame_kernel_hands_paths_over_the_same_way_every_time(hip, oracle, scenes):
     """the frame kernel's walk waves and shade waves pass paths to each other through rings with workgroup-scope release / acquire:
     eighty renders of one frame, alternating with a frame of another size (other buffers, other ring contents), all equal the
