@@ -289,10 +289,11 @@ flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
  * tail, between the bounces) where the scene's object spaces leave room in LDS, rounds otherwise; 1: rounds, a shade + walk kernel
  * pair per bounce (the round-1/2 organisation); 2: the frame kernel where it fits.  Frames and work counters are identical. */
 flx_status flx_set_wavefront_organisation(flx_context *ctx, int organisation);
-/* Frame kernel: who traces the primary rays and shades bounce 0.  2: the persistent launch itself — its shade waves make the fresh paths one 8 x 8
- * screen tile at a time while its walk waves walk the earlier ones (k_primary and k_wf_shade0 are not launched); 0: those two kernels run in front of it, as
- * they do in front of the rounds; 1 (default): automatic, the launch itself where a workgroup gets at least 32 screen tiles (a whole 1080p frame: yes, a
- * rank's eighth of one: no).  Frames and work counters are identical. */
+/* Wavefront pipeline: who traces the primary rays and shades bounce 0.  0: two kernels in front of the bounce loop (k_primary, k_wf_shade0); 3: ONE kernel in
+ * front (k_wf_front: a wave traces the primary rays of its 8 x 8 screen tile and shades it straight away); 2: the frame kernel itself wherever it runs — its shade waves
+ * make the fresh paths one screen tile at a time while its walk waves walk the earlier ones — and one kernel in front elsewhere; 1 (default): automatic — the frame
+ * kernel itself where a workgroup gets at least 32 screen tiles (a whole 1080p frame: yes, a rank's eighth of one: no), else one kernel in front up to 128 M paths
+ * a pass, two beyond.  Frames and work counters are identical. */
 flx_status flx_set_frame_front(flx_context *ctx, int mode);
 /* What the wavefront pipeline ran for the last frame: 1 rounds, 2 the frame kernel, 3 the frame kernel with the front of the frame inside it;
  * 0 when another pipeline rendered it (flx_last_pipeline). */

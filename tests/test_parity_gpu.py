@@ -315,14 +315,15 @@ def test_wavefront_groups_do_not_change_the_frame(hip, oracle, scenes, name, w, 
         hip.set_wavefront_groups(1)
 
 
-@pytest.mark.parametrize("organisation,front", [(1, 0), (2, 0), (2, 2)], ids=["rounds", "frame_kernel", "frame_kernel_with_its_front"])
+@pytest.mark.parametrize("organisation,front", [(1, 0), (2, 0), (2, 2), (1, 3), (2, 3)],
+                         ids=["rounds", "frame_kernel", "frame_kernel_with_its_front", "rounds_one_front_kernel", "frame_kernel_one_front_kernel"])
 @pytest.mark.parametrize("name,w,h,spp,bounces", [("dragon", 480, 270, 2, 4), ("dragon", 333, 187, 3, 2), ("dragon", 640, 360, 8, 6), ("cornell_obj", 128, 96, 2, 5),
                                                   ("theater", 96, 64, 2, 3), ("cornell", 64, 64, 1, 1), ("dragon", 64, 36, 1, 4)])
 def test_both_organisations_of_the_bounce_loop_equal_the_oracle(hip, oracle, scenes, name, w, h, spp, bounces, organisation, front):
     """the wavefront pipeline as rounds (a shade + walk kernel pair per bounce) and as ONE persistent launch (k_wf_frame: walk waves and
     shade waves of a workgroup hand paths to each other through LDS rings) — with k_primary and k_wf_shade0 in front of it, and with the
-    primary rays and the bounce-0 shading made by its own shade waves (flx_set_frame_front): the same frame and the same work counters as
-    the oracle — frames of a few waves (where most workgroups find the item queue dry at once) and frames that fill the machine"""
+    primary rays and the bounce-0 shading made by its own shade waves, or by ONE kernel in front (k_wf_front) instead of two (flx_set_frame_front):
+    the same frame and the same work counters as the oracle — frames of a few waves (where most workgroups find the item queue dry at once) and frames that fill the machine"""
     sc = scenes(name)
     hip.update_scene(sc)
     p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
@@ -402,7 +403,8 @@ def test_the_front_inside_the_frame_kernel_at_its_edges(hip, oracle, scenes):
 
 def test_random_frames_agree_between_the_organisations(hip, scenes):
     """a hundred random frames — odd sizes, one to eleven samples, one to seven bounces, whole frames and a rank's strips of every width — rendered as rounds (which the
-    tests above hold against the oracle), as the frame kernel, and as the frame kernel with the front of the frame inside it: the same bits and the same work counters"""
+    tests above hold against the oracle), as the frame kernel, as the frame kernel with the front of the frame inside it, and with one kernel in front of either:
+    the same bits and the same work counters"""
     sc = scenes("dragon")
     hip.update_scene(sc)
     rng = np.random.default_rng(20261004)
@@ -418,9 +420,10 @@ def test_random_frames_agree_between_the_organisations(hip, scenes):
             p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0, tile=tile)
             p.random_seed = float(case)
             hip.set_wavefront_organisation(1)
+            hip.set_frame_front(0)
             want, want_cnt, _ = hip.render(p, counters=True)
-            for front in (0, 2):
-                hip.set_wavefront_organisation(2)
+            for organisation, front in ((2, 0), (2, 2), (2, 3), (1, 3)):
+                hip.set_wavefront_organisation(organisation)
                 hip.set_frame_front(front)
                 got, cnt, _ = hip.render(p, counters=True)
                 assert np.array_equal(got, want, equal_nan=True) and cnt == want_cnt, (case, w, h, spp, bounces, tile, front)

@@ -31,7 +31,7 @@ def test_synthetic_scene_matches_oracle(hip, oracle, case, pipeline):
     want, want_cnt, _ = oracle.render(sc, p)
     try:
         # the wavefront pipeline as one persistent launch (with the front of the frame inside it, and in front of it) and as rounds
-        for organisation, front in (((2, 2), (2, 0), (1, 0)) if pipeline == 3 else ((0, 1),)):
+        for organisation, front in (((2, 2), (2, 0), (1, 0), (1, 3)) if pipeline == 3 else ((0, 1),)):
             hip.set_wavefront_organisation(organisation)
             hip.set_frame_front(front)
             got, got_cnt, _ = hip.render(p, counters=True)

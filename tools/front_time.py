@@ -19,7 +19,7 @@ extra = dict(samples=int(os.environ["FLX_SPP"])) if "FLX_SPP" in os.environ else
 shares = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
 print("%-22s" % "front of the frame" + "".join("   1/%-2d share  " % n for n in shares) + "  (ms per frame: median of 20, min)")
 frames, counters = {}, {}
-for front in (0, 2, 0, 2):
+for front in (0, 2, 3, 0, 2, 3):
     ctx.set_frame_front(front)
     row = []
     for n in shares:
@@ -35,7 +35,7 @@ for front in (0, 2, 0, 2):
         row.append("%6.3f (%5.3f)" % (float(np.median(ms)), min(ms)))
         frames.setdefault(n, []).append(np.asarray(img).copy())
         counters.setdefault(n, []).append(ctx.render(p, counters=True)[1])
-    print("%-22s" % {2: "inside the launch", 0: "kernels in front"}[front] + " ".join(row))
+    print("%-22s" % {2: "inside the launch", 0: "kernels in front", 3: "ONE kernel in front"}[front] + " ".join(row))
 for n, f in frames.items():
     print("1/%d share: same frame: %s   same counters: %s" % (n, all(np.array_equal(f[0].view(np.uint32), g.view(np.uint32)) for g in f[1:]),
                                                                all(c == counters[n][0] for c in counters[n][1:])))

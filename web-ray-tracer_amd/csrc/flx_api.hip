@@ -24,6 +24,9 @@ using namespace flx;
 #ifndef FLX_EXPERIMENTS
 #define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 */
 #endif
+#ifndef FLX_FRONT_FUSED_MAX_ITEMS
+#define FLX_FRONT_FUSED_MAX_ITEMS (128u << 20)
+#endif
 #ifndef FLX_FRONT_MIN_TILES_PER_CU
 #define FLX_FRONT_MIN_TILES_PER_CU 32
 #endif
@@ -588,15 +591,18 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
     if (!ctx->d_tail_pool) FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
     if (!ctx->d_frame_rings) FLX_HIP(ctx, hipMalloc(&ctx->d_frame_rings, (size_t)WF_MAX_GROUPS * cus * WF_FRAME_RINGS * WF_FRAME_RING * sizeof(uint32_t)));
-    /* the frame kernel can trace the primary rays and shade bounce 0 itself (one chain, all of the frame in it) */
+    /* Who traces the primary rays and shades bounce 0 (flx_set_frame_front; one chain, all of the frame in it — several chains keep the two kernels):
+     * the frame kernel itself from FLX_FRONT_MIN_TILES_PER_CU screen tiles per workgroup on (the fresh paths of a tile stay with the workgroup that made them,
+     * and a workgroup with a dozen tiles, a rank's eighth of a 1080p frame, may have drawn the dragon or the sky: tools/front_time.py, profiles/r03_ab_front.txt);
+     * below that ONE kernel in front (k_wf_front: a wave traces its tile and shades it straight away), which beats k_primary + k_wf_shade0 up to ~128 M paths a pass. */
     const int organisationNow = FLX_WF_ORGANISATION_DEFAULT ? FLX_WF_ORGANISATION_DEFAULT : ctx->wf_organisation;
-    /* (automatic: from FLX_FRONT_MIN_TILES_PER_CU screen tiles per workgroup on — the fresh paths of a tile stay with the workgroup that made them, and a
-     * workgroup with a dozen tiles, a rank's eighth of a 1080p frame, may have drawn the dragon or the sky: tools/front_time.py, profiles/r03_ab_front.txt) */
     const uint32_t frameTiles = path_item_count(fr) / ((uint32_t)fr.samples * 64u);
-    const bool front = ctx->frame_front != 0 && wf_chains == 1 && ctx->d_rec0 != nullptr &&
-                       (ctx->frame_front == 2 || frameTiles >= (uint32_t)FLX_FRONT_MIN_TILES_PER_CU * cus) &&
+    const int frontMode = wf_chains == 1 ? ctx->frame_front : 0;
+    const bool front = (frontMode == 1 || frontMode == 2) && ctx->d_rec0 != nullptr &&
+                       (frontMode == 2 || frameTiles >= (uint32_t)FLX_FRONT_MIN_TILES_PER_CU * cus) &&
                        wavefront_front_in_kernel(sc, fr, path_item_count(fr), ctx->walk_scheduler, ctx->walk_suspend, organisationNow);
-    if (!front) launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
+    const bool fusedFront = !front && (frontMode == 2 || frontMode == 3 || (frontMode == 1 && path_item_count(fr) <= (uint32_t)FLX_FRONT_FUSED_MAX_ITEMS));
+    if (!front && !fusedFront) launch_primary(sc, fr, ctx->d_hits, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     /* The bounce loop runs as `groups` independent chains (contiguous ranges of screen tiles), group 0 on the
      * context's stream and the others on auxiliary streams: every persistent walk kernel ends in a tail set by
@@ -616,7 +622,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
       wb.frameRings = ctx->d_frame_rings + (size_t)g * cus * WF_FRAME_RINGS * WF_FRAME_RING;
-      wb.front = front ? 1u : 0u;
+      wb.front = front ? 1u : (fusedFront ? 2u : 0u);
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
       wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
@@ -891,7 +897,7 @@ extern "C" flx_status flx_set_wavefront_organisation(flx_context *ctx, int organ
 
 extern "C" flx_status flx_set_frame_front(flx_context *ctx, int mode) {
   if (!ctx) return FLX_ERR_INVALID;
-  if (mode < 0 || mode > 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_front: 0 never, 1 automatic, 2 wherever the frame kernel runs");
+  if (mode < 0 || mode > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_front: 0 k_primary + k_wf_shade0, 1 automatic, 2 inside the frame kernel wherever it runs, 3 one kernel in front");
   ctx->frame_front = mode;
   if (ctx->twin) ctx->twin->frame_front = ctx->frame_front;
   return FLX_OK;

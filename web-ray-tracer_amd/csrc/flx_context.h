@@ -36,7 +36,7 @@ struct flx_context {
   float4 *d_fwd = nullptr;                       /* the live entries in the reference's order (every successor further on): primary walk, lockstep walk */
   uint32_t fwd_entries = 0, fwd_root = 0, lock_boxes = 0;
   int last_organisation = 0;                     /* flx_last_organisation: what launch_wavefront ran for the last frame (0: another pipeline) */
-  int frame_front = 1;                           /* flx_set_frame_front: the frame kernel traces the primary rays and shades bounce 0 itself (0 never, 1 automatic, 2 always) */
+  int frame_front = 1;                           /* flx_set_frame_front: the frame kernel traces the primary rays and shades bounce 0 itself (0 two kernels in front, 1 automatic, 2 inside wherever the frame kernel runs, 3 one kernel in front) */
   uint32_t *d_frame_rings = nullptr;             /* k_wf_frame: per chain and workgroup two rings of WF_FRAME_RING path ids */
   int wf_organisation = 0;                       /* wavefront pipeline: 0 automatic, 1 rounds, 2 frame kernel (flx_set_wavefront_organisation) */
   bool lock_ok = false;                          /* the scene is small and in one object space: its bounce walks may go in lockstep */

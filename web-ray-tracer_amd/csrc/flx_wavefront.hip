@@ -224,6 +224,22 @@ FLX_DEV float4 primary_tile(const DeviceScene &sc, const DeviceFrame &fr, float4
   return h;
 }
 
+/* k_primary and k_wf_shade0 in one launch: a wave traces the primary rays of its screen tile and shades bounce 0 for it straight away (the hits go through
+ * registers; they are still stored for k_resolve), so that the slowest primary ray of the frame holds up its own tile's shading only. */
+template <bool COUNT>
+__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_front(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
+  const uint32_t S = (uint32_t)fr.samples;
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lane = t & 63u;
+  const uint32_t tileLocal = t >> 6;
+  if (tileLocal * S * 64u >= total_items) return;
+  const uint32_t tile = wb.item_base / (S * 64u) + tileLocal;
+  WorkCounters cnt = {};
+  const float4 h = primary_tile<COUNT>(sc, fr, const_cast<float4 *>(wb.hits), tile, lane, cnt);
+  (void)shade0_tile<COUNT>(sc, fr, wb, tile, lane, h, cnt);
+  flush_counters<COUNT>(cnt, wb.counters);
+}
+
 /* One path's shading for its next bounce (fragment:476-589): the record the last walk left -> the record the next walk reads. */
 template <bool COUNT>
 FLX_DEV void shade_path(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t pathId, WorkCounters &cnt) {
@@ -1400,6 +1416,8 @@ bool wavefront_front_in_kernel(const DeviceScene &sc, const DeviceFrame &fr, uin
 int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wbIn, uint32_t compute_units, bool count,
                      int walk_scheduler, uint32_t suspend_max, int organisation, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream) {
   WavefrontBuffers wb = wbIn;
+  const bool fused = wb.front == 2u;                        /* no hits yet: primary rays and bounce-0 shading in one launch (k_wf_front) in front of whatever walks */
+  if (fused) wb.front = 0u;
 #if !FLX_EXPERIMENTS
   walk_scheduler = 0; suspend_max = 0u;                     /* (flx_set_walk_scheduler refuses anything else in this build) */
 #endif
@@ -1417,6 +1435,7 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);
       const uint32_t shadeBlocks = (pixels + 255u) / 256u;
       if (wb.front) { /* the frame kernel shades bounce 0 itself */ }
+      else if (fused) { if (count) hipLaunchKernelGGL(k_wf_front<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total); else hipLaunchKernelGGL(k_wf_front<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total); }
       else if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
       else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
       if (walk0_begin) (void)hipEventRecord(walk0_begin, stream);
@@ -1477,7 +1496,8 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
     if (r == 0) {
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);        /* 64 per screen tile */
       const uint32_t shadeBlocks = (pixels + 255u) / 256u;
-      if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
+      if (fused) { if (count) hipLaunchKernelGGL(k_wf_front<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total); else hipLaunchKernelGGL(k_wf_front<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total); }
+      else if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
       else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
     } else {
       const uint32_t shadeBlocks = maxBlocks * 2u;

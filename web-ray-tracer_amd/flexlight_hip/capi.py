@@ -366,7 +366,7 @@ class Context:
         return v.value
 
     def set_frame_front(self, mode):
-        """frame kernel: 2 it also traces the primary rays and shades bounce 0; 0 k_primary and k_wf_shade0 in front of it; 1 (default) automatic"""
+        """primary rays and bounce-0 shading: 0 k_primary + k_wf_shade0 in front, 3 one kernel in front, 2 inside the frame kernel wherever it runs, 1 (default) automatic"""
         self._check(LIB.flx_set_frame_front(self._h, int(mode)), "flx_set_frame_front")
 
     def set_walk_scheduler(self, scheduler, suspend_walks=0):
