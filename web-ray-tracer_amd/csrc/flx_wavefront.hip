@@ -28,6 +28,8 @@
  *   frame kernel  k_wf_shade0, then k_wf_frame: ONE persistent launch in which the walk waves and the shade waves of a workgroup
  *                 hand paths to each other through rings until every path it drew has ended (round 3; the default up to 64 M paths
  *                 per pass: dragon 1080p 7.87 -> 6.83 ms per frame, a rank's eighth of the frame 2.94 -> 1.67 ms).
+ * In front of either: k_primary + k_wf_shade0, or both as one kernel (k_wf_front); or, frame kernel only, nothing — its shade waves trace
+ * the primary rays and shade bounce 0 themselves (k_wf_frame<COUNT, true>: dragon 1080p 6.83 -> 6.40 ms).
  */
 #include <atomic>
 #include <cstdio>
