@@ -82,6 +82,9 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
 #ifndef FLX_WF_SHADE_WAVES
 #define FLX_WF_SHADE_WAVES 3                /* waves per SIMD the register allocation of the shade kernels must allow */
 #endif
+#ifndef FLX_WF_FRONT_WAVES
+#define FLX_WF_FRONT_WAVES 3                /* waves per SIMD the register allocation of k_wf_front must allow */
+#endif
 #ifndef FLX_TAIL_DIAG_ROUND
 #define FLX_TAIL_DIAG_ROUND 0
 #endif
@@ -229,7 +232,7 @@ FLX_DEV float4 primary_tile(const DeviceScene &sc, const DeviceFrame &fr, float4
 /* k_primary and k_wf_shade0 in one launch: a wave traces the primary rays of its screen tile and shades bounce 0 for it straight away (the hits go through
  * registers; they are still stored for k_resolve), so that the slowest primary ray of the frame holds up its own tile's shading only. */
 template <bool COUNT>
-__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_front(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
+__global__ __launch_bounds__(256, FLX_WF_FRONT_WAVES) void k_wf_front(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
   const uint32_t S = (uint32_t)fr.samples;
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t lane = t & 63u;
