@@ -351,6 +351,13 @@ flx_status flx_transforms_pack(uint32_t n_transforms, const double *matrices, co
  * functions); used by tests to prove CPU/GPU bit equality.  fn: 0 sin 1 cos 2 tan 3 acos 4 atan2
  * 5 exp 6 pow 7 tanh 8 floor 9 sqrt 10 div. */
 flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, const float *b, float *out, uint32_t n);
+/* Evaluate one of the intersection routines on the GPU, AS THE KERNELS CALL IT, for n rows; used by tests to hold the device code against literal
+ * answers computed from the shader text (tests/golden/intersect_kat.json.gz).  fn 0: moellerTrumbore (fragment:123-140) through the walk kernels'
+ * routine over stored edges (exact 1/det from v_rcp_f32, branch-free acceptance), 1: moellerTrumboreCull (:143-158) through the same routine, 2: rayCuboid
+ * (:161-167) through the walk kernels' box test (interval test, exact quotients by reciprocal, IEEE division where their preconditions fail); 3, 4, 5: the
+ * same three as the per-pixel kernel calls them.  Rows: triangles 16 floats (a, b, c, origin, direction, l), boxes 13 (l, origin, direction, min, max);
+ * out: 3 floats per row for fn 0 and 3 ((s, u, v) of a hit, zeros otherwise), else one float 0 / 1. */
+flx_status flx_debug_intersect(flx_context *ctx, int fn, const float *in, float *out, uint32_t n);
 /* Scheduler statistics of the last counted frame (wavefront pipeline): for bounce b = 0..3 (3 = all
  * later ones) out[2b] = wave-iterations of the walk kernel, out[2b+1] = fold/refill batches. */
 flx_status flx_get_diag(flx_context *ctx, uint64_t out[32]);   /* out[8..12]: bounce-0 walk kernel stamps: fold, refill, step cycles, wave lifetime, waves; out[16+3b..]: per bounce sum / count / max of wave lifetimes */

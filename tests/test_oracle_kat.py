@@ -293,6 +293,27 @@ def test_present_kat():
     assert got[:5] == [0, 255, 128, 0, 255] and got[6] == 1 and got[7] == 255
 
 
+def test_intersection_literal_known_answers(lib):
+    """tests/golden/intersect_kat.json.gz: moellerTrumbore, moellerTrumboreCull and rayCuboid evaluated from the shader text one float32 operation at a
+    time (tests/analysis/make_intersect_kat.py: not through oracle/ nor include/flx_math.h) on 1 500 random and edge cases each — the oracle's routines
+    give the same bits"""
+    import gzip
+    import json
+    import struct
+    data = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "intersect_kat.json.gz"), "rt"))
+    fl = lambda words: [struct.unpack("<f", struct.pack("<I", w))[0] for w in words]
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    assert len(data["moeller_trumbore"]) >= 1000 and sum(1 for r in data["moeller_trumbore"] if r[16:] != [0, 0, 0]) >= 200
+    for r in data["moeller_trumbore"]:
+        out = F3()
+        lib.flx_oracle_moeller_trumbore(F9(*fl(r[0:9])), F3(*fl(r[9:12])), F3(*fl(r[12:15])), fl(r[15:16])[0], out)
+        assert [bits(x) for x in out] == r[16:19], r
+    for r in data["moeller_trumbore_cull"]:
+        assert lib.flx_oracle_moeller_trumbore_cull(F9(*fl(r[0:9])), F3(*fl(r[9:12])), F3(*fl(r[12:15])), fl(r[15:16])[0]) == r[16], r
+    for r in data["ray_cuboid"]:
+        assert lib.flx_oracle_ray_cuboid(fl(r[0:1])[0], F3(*fl(r[1:4])), F3(*fl(r[4:7])), F3(*fl(r[7:10])), F3(*fl(r[10:13]))) == r[13], r
+
+
 def test_shading_literal_known_answers(oracle):
     """tests/golden/shading_kat.json: forwardTrace (with its GGX / Smith / Schlick helpers, fragment:282-334) and reservoirSample
     (fragment:400-461, incl. its two noise() chains, the showColor / showShadow exits and renderId.w) evaluated from the shader's

@@ -1426,6 +1426,24 @@ extern "C" flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, c
   return FLX_OK;
 }
 
+extern "C" flx_status flx_debug_intersect(flx_context *ctx, int fn, const float *in, float *out, uint32_t n) {
+  if (!ctx || !in || !out) return FLX_ERR_INVALID;
+  if (fn < 0 || fn > 5) return fail(ctx, FLX_ERR_INVALID, "flx_debug_intersect: fn 0 .. 5");
+  if (n == 0) return FLX_OK;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t nin = (size_t)n * ((fn == 2 || fn == 5) ? 13u : 16u), nout = (size_t)n * ((fn == 0 || fn == 3) ? 3u : 1u);
+  float *d_in = nullptr, *d_out = nullptr;
+  FLX_HIP(ctx, hipMalloc(&d_in, nin * 4));
+  FLX_HIP(ctx, hipMalloc(&d_out, nout * 4));
+  FLX_HIP(ctx, hipMemcpy(d_in, in, nin * 4, hipMemcpyHostToDevice));
+  launch_debug_intersect(fn, d_in, d_out, n, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FLX_HIP(ctx, hipMemcpy(out, d_out, nout * 4, hipMemcpyDeviceToHost));
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_device_info(flx_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units) {
   if (!ctx) return FLX_ERR_INVALID;
   if (name && name_len) { snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName); }

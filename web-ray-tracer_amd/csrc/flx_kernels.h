@@ -81,6 +81,7 @@ struct TemporalRings { const uint32_t *c[16], *ip[16], *id[16], *oid[16]; int n;
 void launch_temporal(const TemporalRings &rings, int W, int H, int hdr, int use_filter, uint32_t *dColor, uint32_t *dIp, float4 *out,
                      hipStream_t stream);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, uint32_t n, hipStream_t stream);
+void launch_debug_intersect(int fn, const float *in, float *out, uint32_t n, hipStream_t stream);
 
 }  // namespace flx
 #endif

@@ -390,6 +390,43 @@ __global__ void k_debug_math(int fn, const float *__restrict__ a, const float *_
   out[i] = r;
 }
 
+/* ---- diagnostics: the intersection routines as the kernels call them, one row per thread (flx_debug_intersect) ---- */
+__global__ void k_debug_intersect(int fn, const float *__restrict__ in, float *__restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  DeviceScene sc = {};
+  sc.walk_fast_boxes = 1u;                                    /* the rows' boxes are small: the precondition of the reciprocal box test holds */
+  if (fn == 2 || fn == 5) {                                   /* rayCuboid: l, origin, dir, min, max */
+    const float *r = in + (size_t)i * 13u;
+    WalkState w;
+    w.tR.origin = F3(r[1], r[2], r[3]); w.tR.dir = F3(r[4], r[5], r[6]);
+    reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
+    const f3 lo = F3(r[7], r[8], r[9]), hi = F3(r[10], r[11], r[12]);
+    out[i] = (fn == 2 ? rayCuboidFast(r[0], w, lo, hi) : rayCuboid(r[0], w.tR, lo, hi)) ? 1.0f : 0.0f;
+    return;
+  }
+  const float *r = in + (size_t)i * 16u;                      /* triangles: a, b, c, origin, dir, l */
+  const f3 a = F3(r[0], r[1], r[2]), b = F3(r[3], r[4], r[5]), c = F3(r[6], r[7], r[8]);
+  Ray ray; ray.origin = F3(r[9], r[10], r[11]); ray.dir = F3(r[12], r[13], r[14]);
+  const float l = r[15];
+  f3 suv = F3(0.0f, 0.0f, 0.0f);
+  bool hit;
+  switch (fn) {
+    case 0: hit = moellerTrumboreAny(a, b - a, c - a, ray, l, false, suv); break;      /* the walk kernels' routine over the stored edges */
+    case 1: hit = moellerTrumboreAny(a, b - a, c - a, ray, l, true, suv); break;
+    case 3: hit = moellerTrumbore(a, b, c, ray, l, suv); break;                         /* the per-pixel kernel's */
+    default: hit = moellerTrumboreCull(a, b, c, ray, l); break;
+  }
+  if (fn == 0 || fn == 3) {
+    float *o = out + (size_t)i * 3u;
+    o[0] = hit ? suv.x : 0.0f; o[1] = hit ? suv.y : 0.0f; o[2] = hit ? suv.z : 0.0f;
+  } else out[i] = hit ? 1.0f : 0.0f;
+}
+
+void launch_debug_intersect(int fn, const float *in, float *out, uint32_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(k_debug_intersect, dim3((n + 63u) / 64u), dim3(64), 0, stream, fn, in, out, n);
+}
+
 void launch_debug_math(int fn, const float *a, const float *b, float *out, uint32_t n, hipStream_t stream) {
   hipLaunchKernelGGL(k_debug_math, dim3((n + 255u) / 256u), dim3(256), 0, stream, fn, a, b, out, n);
 }

@@ -18,7 +18,7 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_set_lockstep", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
+    "flx_last_frame_ms", "flx_debug_math", "flx_debug_intersect", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_set_lockstep", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
@@ -69,6 +69,7 @@ def _load():
         "flx_get_diag": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_set_wavefront_groups": (C.c_int, [vp, C.c_int]),
         "flx_last_pipeline": (C.c_int, [vp, C.POINTER(C.c_int)]),
+        "flx_debug_intersect": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32]),
         "flx_temporal_reset": (C.c_int, [vp]),
         "flx_set_walk_scheduler": (C.c_int, [vp, C.c_int, C.c_uint32]),
         "flx_render_batch": (C.c_int, [vp, C.POINTER(FrameParams), u32, fp, C.POINTER(Counters)]),
@@ -314,6 +315,14 @@ class Context:
 
     def temporal_reset(self):
         self._check(LIB.flx_temporal_reset(self._h), "flx_temporal_reset")
+
+    def debug_intersect(self, fn, rows):
+        """flx_debug_intersect: rows [n, 16] (triangles: fn 0, 1, 3, 4) or [n, 13] (boxes: fn 2, 5) float32 -> [n, 3] (fn 0, 3) or [n] float32"""
+        rows = np.ascontiguousarray(rows, np.float32)
+        n = rows.shape[0]
+        out = np.zeros((n, 3) if fn in (0, 3) else (n,), np.float32)
+        self._check(LIB.flx_debug_intersect(self._h, int(fn), _fp(rows), _fp(out), n), "flx_debug_intersect")
+        return out
 
     def last_pipeline(self):
         v = C.c_int()
