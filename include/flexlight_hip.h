@@ -358,6 +358,13 @@ flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, const float 
  * same three as the per-pixel kernel calls them.  Rows: triangles 16 floats (a, b, c, origin, direction, l), boxes 13 (l, origin, direction, min, max);
  * out: 3 floats per row for fn 0 and 3 ((s, u, v) of a hit, zeros otherwise), else one float 0 / 1. */
 flx_status flx_debug_intersect(flx_context *ctx, int fn, const float *in, float *out, uint32_t n);
+/* Walk n rays through the uploaded scene on the GPU, AS THE KERNELS DO, one ray per lane: rayTracer (fragment:172-227) and shadowTest (:230-279) of each ray;
+ * used by tests to hold the device walks against literal answers computed from the shader text (tests/golden/walk_kat.json.gz).  variant 0: the wavefront
+ * pipeline's lane walk over the threaded, hot-first copy with the rays pre-transformed into every object space; 1: the per-pixel / persistent kernels' lane
+ * walk; 2: their wave-wide lockstep walk (scenes of at most 128 entries in one object space).  rays: 7 floats each (origin, direction, shadowTest's l);
+ * out: 8 floats each: s, u, v, 2 x transform number and entry index of the closest hit (zeros and -1 for none), entries that walk fetched, shadowTest's
+ * answer (0 / 1), entries the shadow walk fetched. */
+flx_status flx_debug_walk(flx_context *ctx, int variant, const float *rays, float *out, uint32_t n);
 /* Scheduler statistics of the last counted frame (wavefront pipeline): for bounce b = 0..3 (3 = all
  * later ones) out[2b] = wave-iterations of the walk kernel, out[2b+1] = fold/refill batches. */
 flx_status flx_get_diag(flx_context *ctx, uint64_t out[32]);   /* out[8..12]: bounce-0 walk kernel stamps: fold, refill, step cycles, wave lifetime, waves; out[16+3b..]: per bounce sum / count / max of wave lifetimes */

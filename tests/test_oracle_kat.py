@@ -314,6 +314,35 @@ def test_intersection_literal_known_answers(lib):
         assert lib.flx_oracle_ray_cuboid(fl(r[0:1])[0], F3(*fl(r[1:4])), F3(*fl(r[4:7])), F3(*fl(r[7:10])), F3(*fl(r[10:13]))) == r[13], r
 
 
+@pytest.mark.parametrize("name", ["cornell", "cornell_obj", "theater", "dragon"])
+def test_walk_literal_known_answers(oracle, scenes, name):
+    """tests/golden/walk_kat.json.gz: rayTracer and shadowTest (fragment:172-279) transcribed statement by statement over the arrays the reference's scene.js emits
+    (tests/analysis/make_walk_kat.py, with make_intersect_kat.py's float32 intersection routines: not through oracle/) — camera rays, rays from the surface points they
+    find, zero direction components, the dragon's 73 694 entries: the oracle's walks find the same hit to the last bit, the same triangle, the same shadow answer and
+    fetch the same number of entries"""
+    import gzip
+    import json
+    import struct
+    rows = json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "walk_kat.json.gz"), "rt"))[name]
+    fl = lambda words: [struct.unpack("<f", struct.pack("<I", w))[0] for w in words]
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    sc = scenes(name)
+    view = sc.view()
+    L = oracle.lib()
+    L.flx_oracle_ray_tracer.argtypes = [C.c_void_p, F3, F3, F3, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
+    L.flx_oracle_ray_tracer.restype = None
+    L.flx_oracle_shadow_test.argtypes = [C.c_void_p, F3, F3, C.c_float, C.POINTER(C.c_uint64)]
+    L.flx_oracle_shadow_test.restype = C.c_int
+    assert len(rows) >= 100 and sum(1 for r in rows if r[11] != -1) >= 60
+    for r in rows:
+        origin, d, l = F3(*fl(r[0:3])), F3(*fl(r[3:6])), fl(r[6:7])[0]
+        suv, ti, tri, visits = F3(), C.c_int(), C.c_int(), C.c_uint64(0)
+        L.flx_oracle_ray_tracer(C.byref(view), origin, d, suv, C.byref(ti), C.byref(tri), C.byref(visits))
+        assert ([bits(x) for x in suv], ti.value, tri.value, visits.value) == (r[7:10], r[10], r[11], r[12]), r
+        visits = C.c_uint64(0)
+        assert (L.flx_oracle_shadow_test(C.byref(view), origin, d, l, C.byref(visits)), visits.value) == (r[13], r[14]), r
+
+
 def test_shading_literal_known_answers(oracle):
     """tests/golden/shading_kat.json: forwardTrace (with its GGX / Smith / Schlick helpers, fragment:282-334) and reservoirSample
     (fragment:400-461, incl. its two noise() chains, the showColor / showShadow exits and renderId.w) evaluated from the shader's

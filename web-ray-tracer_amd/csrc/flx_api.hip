@@ -1444,6 +1444,31 @@ extern "C" flx_status flx_debug_intersect(flx_context *ctx, int fn, const float 
   return FLX_OK;
 }
 
+extern "C" flx_status flx_debug_walk(flx_context *ctx, int variant, const float *rays, float *out, uint32_t n) {
+  if (!ctx || !rays || !out) return FLX_ERR_INVALID;
+  if (variant < 0 || variant > 2) return fail(ctx, FLX_ERR_INVALID, "flx_debug_walk: variant 0 .. 2");
+  if (n == 0) return FLX_OK;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  flx_frame_params p;
+  memset(&p, 0, sizeof p);
+  p.width = p.height = 8; p.samples = 1; p.max_reflections = 1; p.texture_width = 1;
+  DeviceScene sc; DeviceFrame fr;
+  flx_status st = flx_make_frame(ctx, &p, sc, fr);
+  if (st != FLX_OK) return st;
+  float *d_in = nullptr, *d_out = nullptr;
+  FLX_HIP(ctx, hipMalloc(&d_in, (size_t)n * 7 * 4));
+  FLX_HIP(ctx, hipMalloc(&d_out, (size_t)n * 8 * 4));
+  FLX_HIP(ctx, hipMemcpy(d_in, rays, (size_t)n * 7 * 4, hipMemcpyHostToDevice));
+  const bool ok = launch_debug_walk(variant, sc, d_in, d_out, n, ctx->stream);
+  if (ok) {
+    FLX_HIP(ctx, hipGetLastError());
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    FLX_HIP(ctx, hipMemcpy(out, d_out, (size_t)n * 8 * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  return ok ? FLX_OK : fail(ctx, FLX_ERR_INVALID, "flx_debug_walk: this scene does not have that walk (variant 2 needs the lockstep copy: at most 128 entries in one object space)");
+}
+
 extern "C" flx_status flx_device_info(flx_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units) {
   if (!ctx) return FLX_ERR_INVALID;
   if (name && name_len) { snprintf(name, name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName); }

@@ -82,6 +82,7 @@ void launch_temporal(const TemporalRings &rings, int W, int H, int hdr, int use_
                      hipStream_t stream);
 void launch_debug_math(int fn, const float *a, const float *b, float *out, uint32_t n, hipStream_t stream);
 void launch_debug_intersect(int fn, const float *in, float *out, uint32_t n, hipStream_t stream);
+bool launch_debug_walk(int variant, const DeviceScene &sc, const float *in, float *out, uint32_t n, hipStream_t stream);      /* false: the scene does not allow that variant */
 
 }  // namespace flx
 #endif

@@ -423,6 +423,79 @@ __global__ void k_debug_intersect(int fn, const float *__restrict__ in, float *_
   } else out[i] = hit ? 1.0f : 0.0f;
 }
 
+/* ---- diagnostics: the two walks of one ray, as the kernels run them (flx_debug_walk) ---------------------------------
+ * in: 7 floats per ray (origin, direction, l); out: 8 floats per ray (s, u, v, 2 x transform, entry index of the closest hit or -1, entries the closest-hit
+ * walk fetched, shadowTest's answer for length l, entries the shadow walk fetched).
+ * variant 0: the wavefront pipeline's lane walk over the threaded copy (walkFetchP / walkBoxP / walkTriT, rays pre-transformed into every object space in LDS);
+ * variant 1: walkBounce's lane walk (k_trace_pixels / k_paths without the lockstep copy); variant 2: the wave's lockstep walk (scenes that have the copy). */
+template <int VARIANT>
+__global__ __launch_bounds__(64) void k_debug_walk(DeviceScene sc, const float *__restrict__ in, float *__restrict__ out, uint32_t n) {
+  extern __shared__ float4 ldsDebug[];
+  const uint32_t lane = threadIdx.x, i = blockIdx.x * 64u + lane;
+  const bool have = i < n;
+  const float *r = in + (size_t)(have ? i : 0u) * 7u;
+  Ray ray; ray.origin = F3(r[0], r[1], r[2]); ray.dir = F3(r[3], r[4], r[5]);
+  const float l = r[6];
+  WorkCounters cnt = {};
+  Hit hit; hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
+  bool shadowed = false;
+  if (VARIANT == 0) {
+    const uint32_t T = sc.n_transforms;
+    float4 *ldsXf = ldsDebug;
+    float2 *myRays = (float2 *)(ldsDebug + (size_t)T * 4u) + (size_t)lane * T * 5u;
+    for (uint32_t t = lane; t < T * 4u; t += 64u) {
+      const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
+      ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
+    }
+    __syncthreads();
+    for (int mode = 0; mode < 2; mode++) {                   /* the shadow walk, then the closest-hit walk: the order of a path's two walks */
+      const bool shadowMode = mode == 0;
+      WalkState w;
+      walkClearResults(w);
+      w.src = ray; w.mode = mode;
+      WalkEntry cur; cur.e0 = cur.e1 = cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
+      walkSetupRays(sc, T, ldsXf, myRays, ray, shadowMode);
+      w.tR = ray; w.cachedTI = 0; w.minLen = shadowMode ? l : POW32; w.i = (int)sc.walk_root;
+      reciprocalOfDir(sc, ray.dir, ray.origin, w.inv, w.fastDiv);
+      bool ended = !have || walkFetchP<true>(sc, nullptr, 0u, myRays, w, cur, cnt);
+      while (!ended) {
+        if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
+        if (!ended) ended = walkFetchP<true>(sc, nullptr, 0u, myRays, w, cur, cnt);
+      }
+      if (shadowMode) shadowed = w.shadowed != 0;
+      else { hit.suv = w.suv; hit.transformId = w.hitTI; hit.triangleId = w.tri; }
+    }
+  } else {
+    bool sh = false;
+    walkBounce<true, VARIANT == 2>(sc, have, false, ray, l, ray, sh, hit, cnt);      /* (two calls: each walk's own counters) */
+    shadowed = sh;
+    Hit h2; h2.suv = F3(0.0f, 0.0f, 0.0f); h2.transformId = 0; h2.triangleId = -1;
+    walkBounce<true, VARIANT == 2>(sc, false, have, ray, l, ray, sh, h2, cnt);
+    hit = h2;
+  }
+  if (!have) return;
+  float *o = out + (size_t)i * 8u;
+  o[0] = hit.triangleId != -1 ? hit.suv.x : 0.0f; o[1] = hit.triangleId != -1 ? hit.suv.y : 0.0f; o[2] = hit.triangleId != -1 ? hit.suv.z : 0.0f;
+  o[3] = (float)(hit.triangleId != -1 ? hit.transformId : 0); o[4] = (float)hit.triangleId;
+  o[5] = (float)cnt.closest_visits; o[6] = shadowed ? 1.0f : 0.0f; o[7] = (float)cnt.shadow_visits;
+}
+
+bool launch_debug_walk(int variant, const DeviceScene &sc, const float *in, float *out, uint32_t n, hipStream_t stream) {
+  const dim3 grid((n + 63u) / 64u), block(64);
+  const size_t lds = (size_t)sc.n_transforms * 4u * sizeof(float4) + 64u * (size_t)sc.n_transforms * 40u;
+  if (variant == 0) {
+    if (lds > 60u * 1024u) return false;
+    hipLaunchKernelGGL(k_debug_walk<0>, grid, block, lds, stream, sc, in, out, n);
+  } else if (variant == 1) {
+    DeviceScene s1 = sc; s1.lock_entries = 0u;
+    hipLaunchKernelGGL(k_debug_walk<1>, grid, block, 0, stream, s1, in, out, n);
+  } else {
+    if (sc.lock_entries == 0u) return false;
+    hipLaunchKernelGGL(k_debug_walk<2>, grid, block, 0, stream, sc, in, out, n);
+  }
+  return true;
+}
+
 void launch_debug_intersect(int fn, const float *in, float *out, uint32_t n, hipStream_t stream) {
   hipLaunchKernelGGL(k_debug_intersect, dim3((n + 63u) / 64u), dim3(64), 0, stream, fn, in, out, n);
 }

@@ -18,7 +18,7 @@ EXPORTS = [
     "flx_context_create", "flx_context_destroy", "flx_last_error", "flx_scene_upload", "flx_transforms_upload",
     "flx_lights_upload", "flx_atlas_upload", "flx_scene_upload_view", "flx_tile_row_count", "flx_tile_row_at",
     "flx_render", "flx_render_device", "flx_sync", "flx_set_stream", "flx_set_counters_enabled", "flx_get_counters",
-    "flx_last_frame_ms", "flx_debug_math", "flx_debug_intersect", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_set_lockstep", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
+    "flx_last_frame_ms", "flx_debug_math", "flx_debug_intersect", "flx_debug_walk", "flx_device_info", "flx_version", "flx_set_pipeline", "flx_set_lockstep", "flx_last_pipeline", "flx_get_diag", "flx_set_wavefront_groups", "flx_temporal_reset", "flx_set_walk_scheduler", "flx_render_batch", "flx_render_batch_device", "flx_render_planes_device", "flx_filter_planes_device",
     "flx_mesh_import_obj", "flx_mesh_destroy", "flx_mesh_entry_count", "flx_mesh_triangle_count", "flx_mesh_set_transform", "flx_mesh_move",
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
@@ -70,6 +70,7 @@ def _load():
         "flx_set_wavefront_groups": (C.c_int, [vp, C.c_int]),
         "flx_last_pipeline": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "flx_debug_intersect": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32]),
+        "flx_debug_walk": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32]),
         "flx_temporal_reset": (C.c_int, [vp]),
         "flx_set_walk_scheduler": (C.c_int, [vp, C.c_int, C.c_uint32]),
         "flx_render_batch": (C.c_int, [vp, C.POINTER(FrameParams), u32, fp, C.POINTER(Counters)]),
@@ -322,6 +323,13 @@ class Context:
         n = rows.shape[0]
         out = np.zeros((n, 3) if fn in (0, 3) else (n,), np.float32)
         self._check(LIB.flx_debug_intersect(self._h, int(fn), _fp(rows), _fp(out), n), "flx_debug_intersect")
+        return out
+
+    def debug_walk(self, variant, rays):
+        """flx_debug_walk: rays [n, 7] float32 (origin, direction, l) -> [n, 8] float32 (s, u, v, 2 x transform, entry, entries fetched, shadowed, entries fetched)"""
+        rays = np.ascontiguousarray(rays, np.float32)
+        out = np.zeros((rays.shape[0], 8), np.float32)
+        self._check(LIB.flx_debug_walk(self._h, int(variant), _fp(rays), _fp(out), rays.shape[0]), "flx_debug_walk")
         return out
 
     def last_pipeline(self):
