@@ -343,6 +343,47 @@ def test_walk_literal_known_answers(oracle, scenes, name):
         assert (L.flx_oracle_shadow_test(C.byref(view), origin, d, l, C.byref(visits)), visits.value) == (r[13], r[14]), r
 
 
+def _filter_kat_cases():
+    import gzip
+    import json
+    return json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "filter_kat.json.gz"), "rt"))
+
+
+def filter_kat_inputs(case):
+    """-> (FrameParams, five float planes [H, W, 4] whose RGBA8 store is the case's bytes, expected float frame [H, W, 4])"""
+    from flexlight_hip.capi import FrameParams
+    W, H = case["width"], case["height"]
+    p = FrameParams()
+    p.width, p.height, p.samples, p.max_reflections, p.use_filter, p.hdr, p.texture_width = W, H, 1, 1, 1, case["hdr"], 1
+    planes = [(np.array(pl, np.uint8).reshape(H, W, 4).astype(np.float32) / np.float32(255.0)).astype(np.float32) for pl in case["planes"]]
+    want = np.array([v for row in case["out"] for v in row], np.uint32).view(np.float32).reshape(H, W, 4)
+    return p, planes, want
+
+
+def assert_filter_kat(got, want, hdr, what):
+    if hdr == 0:
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), "%s: %d of %d floats differ, first at %s" % (what, (~same).sum(), same.size, np.argwhere(~same)[0])
+    else:                                    # pow(): include/flx_math.h's is exactly defined, not correctly rounded — within 2 ulp of the literal answer
+        ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+        assert (ulp <= 2).all() and (ulp == 0).mean() > 0.9, "%s: up to %d ulp, %.3f exact" % (what, ulp.max(), (ulp == 0).mean())
+
+
+@pytest.mark.parametrize("k", range(5))
+def test_filter_chain_literal_known_answers(oracle, k):
+    """tests/golden/filter_kat.json.gz: the three filter shaders and the host's pass schedule (pathtracerWGL2.js:462-550: which texture is bound where in which of
+    the 3 + 3 + 1 passes, which outputs land nowhere) transcribed statement by statement (tests/analysis/make_filter_kat.py: not through oracle/) on five small
+    frames of four "objects" with translucent, rough and background pixels — the oracle's chain gives the same frame bit for bit"""
+    from flexlight_hip.capi import GBuffers
+    case = _filter_kat_cases()[k]
+    p, planes, want = filter_kat_inputs(case)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    gb = GBuffers(fp(planes[0]), fp(planes[1]), fp(planes[2]), fp(planes[3]), fp(planes[4]), None)
+    got = np.zeros_like(want)
+    assert oracle.lib().flx_oracle_filter(C.byref(p), C.byref(gb), fp(got), 1) == 0
+    assert_filter_kat(got, want, case["hdr"], "oracle, case %d" % k)
+
+
 def test_shading_literal_known_answers(oracle):
     """tests/golden/shading_kat.json: forwardTrace (with its GGX / Smith / Schlick helpers, fragment:282-334) and reservoirSample
     (fragment:400-461, incl. its two noise() chains, the showColor / showShadow exits and renderId.w) evaluated from the shader's
