@@ -384,6 +384,60 @@ def test_filter_chain_literal_known_answers(oracle, k):
     assert_filter_kat(got, want, case["hdr"], "oracle, case %d" % k)
 
 
+def _pixel_kat_cases():
+    import gzip
+    import json
+    return json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pixel_kat.json.gz"), "rt"))
+
+
+def pixel_kat_expectations(case, scenes):
+    """-> (scene, params without filter, rows [n, 2] pixel (px, py_gl), literal colour [n, 4], literal G-buffers {name: [n, 4]} for use_filter = 1)"""
+    sc = scenes(case["scene"])
+    p = sc.frame_params(width=case["width"], height=case["height"], samples=case["samples"], max_reflections=case["bounces"], use_filter=0)
+    p.random_seed = case["random_seed"]
+    rows = np.array(case["rows"], np.int64)
+    f = rows[:, 10:].astype(np.uint32).view(np.float32)
+    names = ["color", "color_ip", "original_color", "id", "original_id"]
+    return sc, p, rows, f[:, 0:4], {n: f[:, 4 + 4 * k: 8 + 4 * k] for k, n in enumerate(names)}
+
+
+def assert_pixel_kat(case, rows, want_color, want_gb, frame, gbs, what):
+    H = case["height"]
+    px, py = rows[:, 0], H - 1 - rows[:, 1]
+    same = lambda a, b: ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all(axis=1)
+    ok = same(np.ascontiguousarray(frame[py, px]), np.ascontiguousarray(want_color))
+    assert ok.all(), "%s: colour of %d of %d pixels differs from the literal answer, first (px, py_gl) = %s" % (what, (~ok).sum(), ok.size, rows[~ok][0, :2])
+    for n, want in want_gb.items():
+        ok = same(np.ascontiguousarray(gbs[n][py, px]), np.ascontiguousarray(want))
+        assert ok.all(), "%s: %s of %d of %d pixels differs, first (px, py_gl) = %s" % (what, n, (~ok).sum(), ok.size, rows[~ok][0, :2])
+
+
+@pytest.mark.parametrize("k", range(3))
+def test_whole_pixels_literal_known_answers(oracle, scenes, k):
+    """tests/golden/pixel_kat.json.gz: lightTrace with all its bounces and main() (fragment:464-646) run from the shader text over the reference's arrays
+    (tests/analysis/make_pixel_kat.py: every sample, bounce and walk, the variables that live across samples, the six outputs; only the primary hit — the
+    rasteriser's part, SURVEY.md 8a P0 — is an input) on cornell.obj and on the dragon with its metals, rough surfaces and glass: the oracle's frame without
+    filter and its five G-buffers with it equal the literal pixels bit for bit"""
+    case = _pixel_kat_cases()[k]
+    sc, p, rows, want_color, want_gb = pixel_kat_expectations(case, scenes)
+    assert len(rows) >= 90
+    # the primary hits the table was made from are the oracle's own, still
+    L = oracle.lib()
+    L.flx_oracle_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, F3, C.POINTER(C.c_int), C.POINTER(C.c_int), F3]
+    L.flx_oracle_primary.restype = None
+    import struct
+    view = sc.view()
+    bits = lambda x: struct.unpack("<I", struct.pack("<f", x))[0]
+    for r in rows[:: max(1, len(rows) // 40)]:
+        suv, d, ti, tri = F3(), F3(), C.c_int(), C.c_int()
+        L.flx_oracle_primary(C.byref(view), C.byref(p), int(r[0]), int(r[1]), suv, C.byref(ti), C.byref(tri), d)
+        assert (ti.value, tri.value, [bits(x) for x in suv], [bits(x) for x in d]) == (r[2], r[3], list(r[4:7]), list(r[7:10]))
+    frame, _, _ = oracle.render(sc, p)
+    p.use_filter = 1
+    _, _, gbs = oracle.render(sc, p, gbuffers=True)
+    assert_pixel_kat(case, rows, want_color, want_gb, frame, gbs, "oracle, case %d" % k)
+
+
 def test_shading_literal_known_answers(oracle):
     """tests/golden/shading_kat.json: forwardTrace (with its GGX / Smith / Schlick helpers, fragment:282-334) and reservoirSample
     (fragment:400-461, incl. its two noise() chains, the showColor / showShadow exits and renderId.w) evaluated from the shader's
