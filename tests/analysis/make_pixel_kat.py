@@ -7,8 +7,8 @@ The pieces are the literal tables' own: forwardTrace / reservoirSample's arithme
 from make_walk_kat.py, the intersection routines from make_intersect_kat.py (one float32 operation per operation of the text; sin, cos, acos, tan, atan correctly
 rounded from 70-digit arithmetic).  ONE input per pixel does not come from the text: the primary hit (hit.suv, transform, triangle), the primary ray's direction and
 clipSpace.xy / clipSpace.z, which the shader receives from the vertex shader through the rasteriser's interpolation (implementation-defined there; pinned as a ray cast
-here: SURVEY.md 8a P0) — they are taken from the oracle's primary visibility (flx_oracle_primary) and stored with the row.  The scenes have no textures
-(fetchTexVal returns its defaults: asserted).  Uninitialised outputs start as zeros (pinned).  Writes tests/golden/pixel_kat.json.gz.   usage: make_pixel_kat.py [--check]"""
+here: SURVEY.md 8a P0) — they are taken from the oracle's primary visibility (flx_oracle_primary) and stored with the row.  fetchTexVal's arithmetic is
+the text's; what texture() does with the coordinate is the sampler set-up (REPEAT, NEAREST, RGBA8: fetch_tex_val's docstring).  Uninitialised outputs start as zeros (pinned).  Writes tests/golden/pixel_kat.json.gz.   usage: make_pixel_kat.py [--check]"""
 import ctypes as C
 import gzip, json, os, sys
 import numpy as np
@@ -79,7 +79,22 @@ def reservoir_sample(A, G, lights, randomSeed, albedo, rme, origin, unitDirectio
     return add(localColor, baseLuminance)
 
 
-def light_trace(A, attrs, lights, ambient, randomSeed, minImportancy, G, hit, dir0, camera, ndc, cosSampleN, bounces):
+def fetch_tex_val(atlas, textureWidth, uv, texNum, defaultVal):
+    """fragment:108-117.  texture() on the atlases is pinned as the reference sets its samplers up and as GL defines them where it does: REPEAT (the coordinate's
+    fract), NEAREST (the texel floor(coordinate x size), the last one where the product rounds up to size), an RGBA8 texel as byte / 255"""
+    if texNum == f32(-1.0): return list(defaultVal)
+    tex, W, H = atlas
+    tw = f32(textureWidth)
+    atlasHeightFactor = f32(f32(W) / f32(H))
+    mod_ = f32(texNum - f32(tw * f32(np.floor(f32(texNum / tw)))))
+    cx = f32(f32(uv[0] + mod_) / tw)
+    cy = f32(f32(f32(uv[1] + f32(np.floor(f32(texNum / tw)))) * atlasHeightFactor) / tw)
+    fx, fy = f32(g_fract(cx) * f32(W)), f32(g_fract(cy) * f32(H))
+    ix, iy = min(int(fx), W - 1), min(int(fy), H - 1)
+    return [f32(f32(int(c)) / f32(255)) for c in tex[iy, ix, 0:3]]
+
+
+def light_trace(A, attrs, lights, ambient, randomSeed, minImportancy, G, hit, dir0, camera, ndc, cosSampleN, bounces, atlases, textureWidth):
     """fragment:464-599; hit = (suv, transformId, triangleId)"""
     dontFilter = True
     finalColor = [ZERO, ZERO, ZERO]
@@ -105,8 +120,11 @@ def light_trace(A, attrs, lights, ambient, randomSeed, minImportancy, G, hit, di
         angles = [f_acos(abs(dot(geometryNormal, n))) for n in normals]
         angleTan = [clamp01(f_tan(a)) for a in angles]
         geometryOffset = dot(mul(diffs, angleTan), uvw)
-        assert t[15] == f32(-1.0) and t[16] == f32(-1.0) and t[17] == f32(-1.0), "a textured triangle: fetchTexVal is not part of this table"
-        albedo, rme, tpo = t[18:21], t[21:24], t[24:27]
+        # barycentric = mat3x2(t2.yzw, t3.xyz) * uvw: columns (t2.y, t2.z), (t2.w, t3.x), (t3.y, t3.z)
+        bary = [f32(f32(f32(t[9] * uvw[0]) + f32(t[11] * uvw[1])) + f32(t[13] * uvw[2])), f32(f32(f32(t[10] * uvw[0]) + f32(t[12] * uvw[1])) + f32(t[14] * uvw[2]))]
+        albedo = fetch_tex_val(atlases[0], textureWidth, bary, t[15], t[18:21])
+        rme = fetch_tex_val(atlases[1], textureWidth, bary, t[16], t[21:24])
+        tpo = fetch_tex_val(atlases[2], textureWidth, bary, t[17], t[24:27])
         unitDirection = normalize(sub(origin, lastHitPoint))
         signDir = gsign(dot(unitDirection, smoothNormal))
         smoothNormal = scale(smoothNormal, f32(-signDir))
@@ -156,13 +174,13 @@ def light_trace(A, attrs, lights, ambient, randomSeed, minImportancy, G, hit, di
     return add(finalColor, mul(importancyFactor, ambient))
 
 
-def pixel(A, attrs, lights, ambient, randomSeed, minImportancy, samples, bounces, camera, hit, dir0, ndc):
+def pixel(A, attrs, lights, ambient, randomSeed, minImportancy, samples, bounces, camera, hit, dir0, ndc, atlases, textureWidth):
     """main(), fragment:601-646: -> (colour without filter, then the five outputs with useFilter = 1)"""
     G = Globals()
     finalColor = [ZERO, ZERO, ZERO]
     for i in range(samples):
         cosSampleN = round_f32(dcos(Decimal(float(i))))
-        finalColor = add(finalColor, light_trace(A, attrs, lights, ambient, randomSeed, minImportancy, G, hit, dir0, camera, ndc, cosSampleN, bounces))
+        finalColor = add(finalColor, light_trace(A, attrs, lights, ambient, randomSeed, minImportancy, G, hit, dir0, camera, ndc, cosSampleN, bounces, atlases, textureWidth))
     invSamples = f32(ONE / f32(samples))
     finalColor = scale(finalColor, invSamples)
     plain = mul(finalColor, G.originalColor) + [ONE]
@@ -186,7 +204,7 @@ def oracle_primary(sc, params, px, py_gl):
     return [f32(x) for x in suv], ti.value, tri.value, [f32(x) for x in d]
 
 
-CASES = [("cornell_obj", 48, 27, 2, 3, 0.0), ("dragon", 24, 14, 2, 4, 1.0), ("dragon", 12, 8, 3, 6, 2.0)]
+CASES = [("cornell_obj", 48, 27, 2, 3, 0.0), ("dragon", 24, 14, 2, 4, 1.0), ("dragon", 12, 8, 3, 6, 2.0), ("theater", 32, 18, 2, 3, 3.0), ("cornell", 20, 20, 2, 2, 1.0)]
 
 
 def rows():
@@ -198,6 +216,10 @@ def rows():
         lights = [[f32(x) for x in row] for row in sc.arrays["lights"].astype(np.float32).reshape(-1, 6)]
         p = sc.frame_params(width=W, height=H, samples=spp, max_reflections=bounces, use_filter=0)
         p.random_seed = seed
+        atlases = []
+        for key, arr in (("albedo", "atlasAlbedo"), ("pbr", "atlasPbr"), ("tpo", "atlasTpo")):
+            w, h = sc.meta["atlas"][key]
+            atlases.append((sc.arrays[arr].reshape(h, w, 4), w, h))
         ambient = [f32(x) for x in p.ambient]
         camera = [f32(x) for x in p.camera]
         out = []
@@ -207,7 +229,7 @@ def rows():
                 if tri == -1: continue
                 ndc = [f32(f32(f32(f32(f32(px) + f32(0.5)) / f32(W)) * f32(2.0)) - ONE), f32(f32(f32(f32(f32(py_gl) + f32(0.5)) / f32(H)) * f32(2.0)) - ONE)]
                 try:
-                    res = pixel(A, attrs, lights, ambient, f32(p.random_seed), f32(p.min_importancy), spp, bounces, camera, (suv, tI, tri), d, ndc)
+                    res = pixel(A, attrs, lights, ambient, f32(p.random_seed), f32(p.min_importancy), spp, bounces, camera, (suv, tI, tri), d, ndc, atlases, p.texture_width)
                 except NaNInBoxTest:
                     continue
                 out.append([px, py_gl, tI, tri] + [bits(x) for x in suv] + [bits(x) for x in d] + [bits(x) for part in res for x in part])

@@ -412,7 +412,7 @@ def assert_pixel_kat(case, rows, want_color, want_gb, frame, gbs, what):
         assert ok.all(), "%s: %s of %d of %d pixels differs, first (px, py_gl) = %s" % (what, n, (~ok).sum(), ok.size, rows[~ok][0, :2])
 
 
-@pytest.mark.parametrize("k", range(3))
+@pytest.mark.parametrize("k", range(5))
 def test_whole_pixels_literal_known_answers(oracle, scenes, k):
     """tests/golden/pixel_kat.json.gz: lightTrace with all its bounces and main() (fragment:464-646) run from the shader text over the reference's arrays
     (tests/analysis/make_pixel_kat.py: every sample, bounce and walk, the variables that live across samples, the six outputs; only the primary hit — the

@@ -9,7 +9,7 @@ from test_oracle_kat import _pixel_kat_cases, assert_pixel_kat, pixel_kat_expect
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("k", range(3))
+@pytest.mark.parametrize("k", range(5))
 def test_whole_pixels_literal(hip, scenes, k):
     case = _pixel_kat_cases()[k]
     sc, p, rows, want_color, want_gb = pixel_kat_expectations(case, scenes)
