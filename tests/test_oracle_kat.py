@@ -438,6 +438,76 @@ def test_whole_pixels_literal_known_answers(oracle, scenes, k):
     assert_pixel_kat(case, rows, want_color, want_gb, frame, gbs, "oracle, case %d" % k)
 
 
+@pytest.mark.parametrize("name,w,h", [("cornell", 48, 48), ("cornell_obj", 64, 36), ("theater", 64, 36), ("dragon", 48, 27)])
+def test_primary_visibility_agrees_with_a_rasteriser(oracle, scenes, name, w, h):
+    """SURVEY.md 8a P0: the reference finds the primary hit by DRAWING the triangles (pathtracer_vertex.glsl:40-72: gl_Position = (clip.xy, -1 / (1 + exp(clip.z / 65535)), clip.z);
+    depth test, back faces culled, pathtracerWGL2.js:372,713-716) and hands the fragment shader interpolated varyings; the oracle and the kernels cast a ray instead (no text fixes
+    the rasteriser's arithmetic).  Here the draw is emulated in float64 — homogeneous coverage of the pixel centre (every triangle, clipped or not), back-face culling by the
+    sign of the clip-space determinant, nearest by z / w with the earlier instance winning ties, perspective-correct uv and position — and the ray cast has to name the same
+    triangle on every pixel whose centre is not within 1e-6 of an edge or of a second surface, with hit.suv = (distance(absolutePosition, camera), uv.y, uv.z): the distance
+    within 1e-5, the barycentrics within 1e-4"""
+    import struct
+    sc = scenes(name)
+    p = sc.frame_params(width=w, height=h, samples=1, max_reflections=1, use_filter=0)
+    a = sc.arrays
+    g = a["geometry"].astype(np.float64).reshape(-1, 12)
+    rot = a["rotation"].astype(np.float64).reshape(-1, 3, 4)[:, :, :3]                      # [matrix][column][row]
+    shift = a["shift"].astype(np.float64).reshape(-1, 4)[:, :3]
+    ids = a["ids"][: sc.meta["bufferLength"]].astype(np.int64)
+    tI = g[ids, 9].astype(np.int64) << 1
+    verts = np.stack([g[ids, 0:3], g[ids, 3:6], g[ids, 6:9]], axis=1)                      # [tri][vertex][xyz], object space
+    R = np.transpose(rot[tI], (0, 2, 1))                                                   # [tri][row][column]
+    world = np.einsum("trc,tvc->tvr", R, verts) + shift[tI][:, None, :]
+    cam = np.array(list(p.camera), np.float64)
+    V = np.array(list(p.view_matrix), np.float64).reshape(3, 3)                            # uploaded with transpose = true (pathtracerWGL2.js:333): the list's rows are the mat3's rows
+    clip = np.einsum("rc,tvc->tvr", V, world - cam)                                       # viewMatrix * (absolutePosition - cameraPosition)
+    M = np.transpose(clip, (0, 2, 1))                                                      # [tri]: columns = the vertices' (x, y, w)
+    det = np.linalg.det(M)
+    ok = np.abs(det) > 1e-300
+    Minv = np.zeros_like(M)
+    Minv[ok] = np.linalg.inv(M[ok])
+    L = oracle.lib()
+    L.flx_oracle_primary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, F3, C.POINTER(C.c_int), C.POINTER(C.c_int), F3]
+    L.flx_oracle_primary.restype = None
+    view = sc.view()
+    compared = skipped = 0
+    for py in range(h):
+        for px in range(w):
+            pix = np.array([(px + 0.5) / w * 2 - 1, (py + 0.5) / h * 2 - 1, 1.0])
+            lam = Minv @ pix                                                               # pixel = sum lam_i (x, y, w)_i
+            with np.errstate(all="ignore"):
+                wdepth = 1.0 / lam.sum(axis=1)
+                margin = lam.min(axis=1) * np.abs(wdepth)
+                beta = lam * wdepth[:, None]                                               # perspective-correct barycentrics
+                zndc = (-1.0 / (1.0 + np.exp(wdepth / 65535.0))) / wdepth
+            front = det > 0                                                                # counter-clockwise in the window (gl.frontFace's default) = a positive determinant of the (x, y, w) columns
+            cover = ok & (lam.min(axis=1) >= 0) & (wdepth > 0) & (zndc >= -1.0)
+            suv, d, ti, tri = F3(), F3(), C.c_int(), C.c_int()
+            L.flx_oracle_primary(C.byref(view), C.byref(p), px, py, suv, C.byref(ti), C.byref(tri), d)
+            c = np.flatnonzero(cover & front)                                              # gl.enable(CULL_FACE): back faces are not drawn
+            cand = (c[np.argmin(zndc[c])], c) if c.size else None
+            want_tri = -1 if cand is None else int(ids[cand[0]])
+            # pixels too close to call: the centre within 1e-6 of an edge of a covering / nearly covering triangle, or two surfaces within 1e-6 in depth
+            near_edge = ok & (np.abs(margin) < 1e-6) & (wdepth > 0) & front
+            close = False
+            if cand is not None and cand[1].size > 1:
+                z = np.sort(wdepth[cand[1]])
+                close = (z[1] - z[0]) < 1e-6 * z[0]
+            if near_edge.any() or close:
+                skipped += 1
+                continue
+            assert tri.value == want_tri, (px, py, tri.value, want_tri)
+            compared += 1
+            if want_tri != -1:
+                k = cand[0]
+                pos = (beta[k][:, None] * world[k]).sum(axis=0)
+                want = np.array([np.linalg.norm(pos - cam), beta[k][1], beta[k][2]])
+                got = np.array(list(suv), np.float64)
+                # (the distance to 1e-5; the barycentrics of a small, distant triangle to 1e-4 of the triangle: float32 Moeller-Trumbore's own conditioning)
+                assert abs(got[0] - want[0]) <= 1e-5 * want[0] and np.abs(got[1:] - want[1:]).max() <= 1e-4, (px, py, got, want)
+    assert compared > 0.97 * w * h and skipped < 0.03 * w * h, (compared, skipped)
+
+
 def test_shading_literal_known_answers(oracle):
     """tests/golden/shading_kat.json: forwardTrace (with its GGX / Smith / Schlick helpers, fragment:282-334) and reservoirSample
     (fragment:400-461, incl. its two noise() chains, the showColor / showShadow exits and renderId.w) evaluated from the shader's
