@@ -65,15 +65,19 @@ def moeller_trumbore_cull(t, origin, d, l):
     return int(s <= l and s > BIAS)
 
 
-def ray_cuboid(l, origin, d, mn, mx):
-    """-> 0 / 1, or None when a NaN reaches min / max"""
+def gmin(x, y): return y if y < x else x                # GLSL ES 3.00: min(x, y) = y if y < x, otherwise x
+def gmax(x, y): return y if x < y else x                # max(x, y) = y if x < y, otherwise x
+
+
+def ray_cuboid(l, origin, d, mn, mx, pinned_nan=False):
+    """-> 0 / 1, or None when a NaN reaches min / max (GLSL leaves that open) — unless pinned_nan: then min / max are exactly their defining comparisons, as the oracle pins them"""
     with np.errstate(all="ignore"):
         v0 = [f32(f32(mn[k] - origin[k]) / d[k]) for k in range(3)]
         v1 = [f32(f32(mx[k] - origin[k]) / d[k]) for k in range(3)]
-    if any(np.isnan(x) for x in v0 + v1): return None
-    tmin = max(max(min(v0[0], v1[0]), min(v0[1], v1[1])), min(v0[2], v1[2]))
-    tmax = min(min(max(v0[0], v1[0]), max(v0[1], v1[1])), max(v0[2], v1[2]))
-    return int(tmax >= max(tmin, BIAS) and tmin < l)
+    if not pinned_nan and any(np.isnan(x) for x in v0 + v1): return None
+    tmin = gmax(gmax(gmin(v0[0], v1[0]), gmin(v0[1], v1[1])), gmin(v0[2], v1[2]))
+    tmax = gmin(gmin(gmax(v0[0], v1[0]), gmax(v0[1], v1[1])), gmax(v0[2], v1[2]))
+    return int(tmax >= gmax(tmin, BIAS) and tmin < l)
 
 
 def rows():

@@ -50,8 +50,11 @@ class Arrays:
         self.size = len(self.entries)                                                  # geometryTexSize.y * TRIANGLES_PER_ROW
 
 
+PIN_NAN = False          # True: a NaN in a box test goes through min / max as their defining comparisons (the oracle's pin) instead of dropping the ray from the table
+
+
 def box(l, tR, t0, t1):
-    r = ray_cuboid(l, tR[0], tR[1], t0[0:3], [t0[3], t1[0], t1[1]])
+    r = ray_cuboid(l, tR[0], tR[1], t0[0:3], [t0[3], t1[0], t1[1]], pinned_nan=PIN_NAN)
     if r is None: raise NaNInBoxTest()
     return r
 

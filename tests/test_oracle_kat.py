@@ -508,6 +508,32 @@ def test_primary_visibility_agrees_with_a_rasteriser(oracle, scenes, name, w, h)
     assert compared > 0.97 * w * h and skipped < 0.03 * w * h, (compared, skipped)
 
 
+def _temporal_kat_cases():
+    import gzip
+    import json
+    return json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "temporal_kat.json.gz"), "rt"))
+
+
+def temporal_kat_expectations(case, scenes):
+    sc = scenes(case["scene"])
+    p = sc.frame_params(width=case["width"], height=case["height"], samples=case["samples"], max_reflections=case["bounces"], use_filter=0, hdr=case["hdr"])
+    p.is_temporal = 1
+    want = np.array(case["frames"], np.uint32).view(np.float32).reshape(len(case["frames"]), case["height"], case["width"], 4)
+    return sc, p, want
+
+
+@pytest.mark.parametrize("k", range(2))
+def test_temporal_sequence_literal_known_answers(oracle, scenes, k):
+    """tests/golden/temporal_kat.json.gz: runs of temporal frames — every frame traced from the shader text into the rotating history rings, averaged by the temporal shader
+    the host generates (pathtracerWGL2.js:389-402, 571-662; tests/analysis/make_temporal_kat.py) — against the oracle's flx_oracle_render_sequence: the first frames over an
+    empty history, the ring wrapping, the zero-padded mat4 groups a background pixel's id matches; bit for bit without the tone mapping, within 2 ulp with it"""
+    case = _temporal_kat_cases()[k]
+    sc, p, want = temporal_kat_expectations(case, scenes)
+    got = oracle.render_sequence(sc, p, want.shape[0])
+    for f in range(want.shape[0]):
+        assert_filter_kat(np.ascontiguousarray(got[f]), np.ascontiguousarray(want[f]), case["hdr"], "oracle, sequence %d frame %d" % (k, f))
+
+
 def test_shading_literal_known_answers(oracle):
     """tests/golden/shading_kat.json: forwardTrace (with its GGX / Smith / Schlick helpers, fragment:282-334) and reservoirSample
     (fragment:400-461, incl. its two noise() chains, the showColor / showShadow exits and renderId.w) evaluated from the shader's
