@@ -534,6 +534,34 @@ def test_temporal_sequence_literal_known_answers(oracle, scenes, k):
         assert_filter_kat(np.ascontiguousarray(got[f]), np.ascontiguousarray(want[f]), case["hdr"], "oracle, sequence %d frame %d" % (k, f))
 
 
+def _aa_kat():
+    import gzip
+    import json
+    return json.load(gzip.open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aa_kat.json.gz"), "rt"))
+
+
+def aa_kat_frame(words, W, H):
+    return np.array(words, np.uint32).view(np.float32).reshape(H, W, 4)
+
+
+def assert_aa_kat(got, want, what):
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), "%s: %d of %d floats differ, first at %s" % (what, (~same).sum(), same.size, np.argwhere(~same)[0])
+
+
+def test_fxaa_and_taa_literal_known_answers(oracle):
+    """tests/golden/aa_kat.json.gz: the FXAA and TAA shaders (modules/fxaa.js:7-137 with its macros expanded as the preprocessor does, modules/taa.js:11-59 over the nine
+    textures renderFrame keeps) transcribed one float32 operation at a time (tests/analysis/make_aa_kat.py) over frames with edges, gradients, noise, a hole of background
+    and out-of-range values; TAA with one, four, nine and eleven frames of history — the oracle's passes give the same bits"""
+    kat = _aa_kat()
+    for k, c in enumerate(kat["fxaa"]):
+        W, H = c["width"], c["height"]
+        assert_aa_kat(oracle.fxaa(aa_kat_frame(c["frame"], W, H)), aa_kat_frame(c["out"], W, H), "oracle FXAA, frame %d" % k)
+    for k, c in enumerate(kat["taa"]):
+        W, H = c["width"], c["height"]
+        assert_aa_kat(oracle.taa([aa_kat_frame(f, W, H) for f in c["frames_newest_first"]]), aa_kat_frame(c["out"], W, H), "oracle TAA, state %d" % k)
+
+
 def test_shading_literal_known_answers(oracle):
     """tests/golden/shading_kat.json: forwardTrace (with its GGX / Smith / Schlick helpers, fragment:282-334) and reservoirSample
     (fragment:400-461, incl. its two noise() chains, the showColor / showShadow exits and renderId.w) evaluated from the shader's
