@@ -1378,9 +1378,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 
 /* Can the frame kernel take this frame?  Its LDS holds the rays of its walk threads, the staged transforms, the two rings and
  * at least a little of the tree's top. */
-static bool frame_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes) {
+static bool frame_kernel_fits(const DeviceScene &sc, bool withFront, uint32_t &ldsCount, uint32_t &ldsBytes) {
   const uint32_t T = sc.n_transforms;
-  const uint32_t walkThreads = FLX_WF_WALK_THREADS - 64u * FLX_FRAME_SHADERS;
+  const uint32_t walkThreads = FLX_WF_WALK_THREADS - 64u * (withFront ? (uint32_t)FLX_FRAME_SHADERS_FRONT : (uint32_t)FLX_FRAME_SHADERS);      /* (the shade waves keep no rays) */
   const uint32_t fixed = walkThreads * T * 40u + T * 64u + FC_WORDS * 4u;
   if (!FLX_WF_PRETRANSFORM || fixed + 4096u > (uint32_t)FLX_WF_LDS_TOTAL) return false;
   ldsCount = ((uint32_t)FLX_WF_LDS_TOTAL - fixed) / 48u;
@@ -1410,7 +1410,7 @@ static bool frame_kernel_wanted(const DeviceScene &sc, const DeviceFrame &fr, ui
    * the frame inside the launch somewhere between 66 M (3.7 % ahead) and 265 M (2.7 % behind); beyond it the rounds' sixteen walk waves per CU beat
    * fourteen walk + two shade waves */
   const bool wanted = organisation == 2 || (organisation == 0 && item_count <= (withFront ? (uint32_t)FLX_FRAME_AUTO_MAX_ITEMS_FRONT : (uint32_t)FLX_FRAME_AUTO_MAX_ITEMS));
-  return wanted && walk_scheduler == 0 && suspend_max == 0u && fr.max_reflections >= 1 && frame_kernel_fits(sc, ldsCountF, ldsBytesF);
+  return wanted && walk_scheduler == 0 && suspend_max == 0u && fr.max_reflections >= 1 && frame_kernel_fits(sc, withFront, ldsCountF, ldsBytesF);
 }
 /* May the frame kernel also take the front of the frame (primary rays, bounce-0 shading: WavefrontBuffers::front)?  Then launch_primary is not needed. */
 bool wavefront_front_in_kernel(const DeviceScene &sc, const DeviceFrame &fr, uint32_t item_count, int walk_scheduler, uint32_t suspend_max, int organisation) {
