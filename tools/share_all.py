@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Every rank's share of a tile-sharded BASELINE frame on ONE GPU: what each of N GPUs renders before the gather (strips of 8 rows dealt round robin),
+one frame at a time (HIP events around the share: median of 20, min) and in the frame loop with one frame in flight on one and on two lanes (wall
+clock over 60 frames).  GPU box.
+usage: share_all.py [--workload dragon|dragon_4k|theater] [--count 8] [--indices 0,1,..] [--front MODE] [--check]
+--check: every share's frame is compared with the same rows of the whole frame (bit for bit)."""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+from flexlight_hip import capi
+from flexlight_hip.scene_io import Scene
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="dragon")
+ap.add_argument("--count", type=int, default=8)
+ap.add_argument("--indices", default="")
+ap.add_argument("--front", type=int, default=-1)
+ap.add_argument("--frames", type=int, default=60)
+ap.add_argument("--check", action="store_true")
+ap.add_argument("--no-single", action="store_true")
+a = ap.parse_args()
+work = a.workload
+sc = Scene.golden("theater" if work == "theater" else "dragon")
+size = dict(width=3840, height=2160) if work == "dragon_4k" else {}
+over = dict(samples=16, max_reflections=6) if work == "theater" else {}
+ctx = capi.Context(0)
+ctx.update_scene(sc)
+if a.front >= 0:
+    ctx.set_frame_front(a.front)
+idx = [int(x) for x in a.indices.split(",")] if a.indices else list(range(a.count))
+
+def params(i, n):
+    p = sc.frame_params(use_filter=0, **size, **over)
+    if n > 1:
+        p.tile_rows, p.tile_count, p.tile_index = 8, n, i
+    return p
+
+def single(p):
+    for _ in range(3):
+        ctx.render(p)
+    ms = []
+    for _ in range(20):
+        ctx.render(p)
+        ms.append(ctx.last_frame_ms()[0])
+    return float(np.median(ms)), min(ms)
+
+def loop(p, lanes):
+    ctx.set_frame_lanes(lanes)
+    best = 1e9
+    for rep in range(3):
+        ctx.frame_begin(p, device=True)
+        for _ in range(4):
+            ctx.frame_begin(p, device=True)
+            ctx.frame_end()
+        t0 = time.perf_counter()
+        for _ in range(a.frames):
+            ctx.frame_begin(p, device=True)
+            ctx.frame_end()
+        dt = time.perf_counter() - t0
+        ctx.frame_end()
+        best = min(best, dt * 1e3 / a.frames)
+    ctx.set_frame_lanes(1)
+    return best
+
+print("workload %s, lib %s" % (work, os.path.basename(capi.LIB_PATH)))
+whole = params(0, 1)
+wm, wmin = single(whole)
+w1, w2 = loop(whole, 1), loop(whole, 2)
+print("whole frame      single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   organisation %d pipeline %d" % (wm, wmin, w1, w2, ctx.last_organisation(), ctx.last_pipeline()))
+full = ctx.render(whole)[0] if a.check else None
+rows = []
+for i in idx:
+    p = params(i, a.count)
+    m, mn = (0.0, 0.0) if a.no_single else single(p)
+    org = ctx.last_organisation()
+    l1, l2 = loop(p, 1), loop(p, 2)
+    ok = ""
+    if a.check:
+        got = ctx.render(p)[0]
+        H = whole.height
+        sel = [y for y in range(H) if (y // 8) % a.count == i]
+        want = full[sel]
+        ok = "  equal" if got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)) else "  DIFFERS"
+    rows.append((m, l1, l2))
+    print("share %d/%d        single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   organisation %d%s" % (i, a.count, m, mn, l1, l2, org, ok), flush=True)
+r = np.array(rows)
+print("max over ranks   single %7.3f             loop 1 lane %7.3f   2 lanes %7.3f" % tuple(r.max(axis=0)))
+print("speed-up of the slowest share over the whole frame:  single %.2fx   1 lane %.2fx   2 lanes %.2fx   (2 lanes against the one-lane whole frame: %.2fx)" %
+      (wm / r[:, 0].max() if r[:, 0].max() else 0, w1 / r[:, 1].max(), w2 / r[:, 2].max(), w1 / r[:, 2].max()))

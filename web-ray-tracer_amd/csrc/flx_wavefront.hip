@@ -978,6 +978,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #ifndef FLX_FRAME_PROLOGUE_WAVES
 #define FLX_FRAME_PROLOGUE_WAVES 2          /* walk waves that make a first tile before their loop (FRONT) */
 #endif
+#ifndef FLX_FRAME_GROUPS_PER_CU
+#define FLX_FRAME_GROUPS_PER_CU 1           /* frame-kernel workgroups per CU (A/B builds with smaller workgroups) */
+#endif
 #ifndef FLX_FRAME_AUTO_MAX_ITEMS
 #define FLX_FRAME_AUTO_MAX_ITEMS (64u << 20)
 #endif
@@ -1445,7 +1448,7 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
       else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
       if (walk0_begin) (void)hipEventRecord(walk0_begin, stream);
       const uint32_t shadeWaves = wb.front ? (uint32_t)FLX_FRAME_SHADERS_FRONT : (uint32_t)FLX_FRAME_SHADERS;
-      const dim3 grid(compute_units), block(FLX_WF_WALK_THREADS);
+      const dim3 grid(compute_units * (uint32_t)FLX_FRAME_GROUPS_PER_CU), block(FLX_WF_WALK_THREADS);
       /* front inside: (tile, sample) units of 64 fresh paths a workgroup keeps ready for its walk waves before its shade waves stop making more.  What is
        * ready is bound to the workgroup, so the fewer tiles a workgroup gets the less it may hoard: FLX_FRAME_READY_UNITS from 48 tiles per workgroup on, below
        * that half a unit per tile it can expect but FLX_FRAME_READY_UNITS / 4 at the least (whole 1080p frame, 127 tiles per workgroup: 16 -> 6.61, 32 -> 6.43, 64 -> 6.49 ms; a quarter of
