@@ -101,25 +101,43 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
 #define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
 #endif
 
+/* The arguments of the shade kernels and of the frame kernel (2.7 KB: the scene's pointers, the frame with its views, the work buffers) stay in the
+ * kernarg segment and are read where they are used, through a pointer the compiler cannot see through (an empty asm; the loads stay scalar loads):
+ * as by-value parameters every field was loaded at the kernel's entry and kept — in the frame kernel 262 scalar registers spilled into vector-register
+ * lanes around the stepping loop and 92 spilled vector registers (profiles/r04_resources.txt). */
+struct FrameArgs { DeviceScene sc; DeviceFrame fr; WavefrontBuffers wb; };
+typedef const __attribute__((address_space(4))) FrameArgs *FrameArgsP;
+FLX_DEV const FrameArgs &frame_args(FrameArgsP p) { asm volatile("" : "+s"(p)); return *(const FrameArgs *)p; }
+FLX_DEV FrameArgsP kernel_frame_args() { return (FrameArgsP)__builtin_amdgcn_kernarg_segment_ptr(); }      /* the kernel's FIRST parameter is the FrameArgs: offset 0 */
+#define FLX_ARGS_OF(ab) const FrameArgs &A_ = frame_args(ab); const DeviceScene &sc = A_.sc; const DeviceFrame &fr = A_.fr; const WavefrontBuffers &wb = A_.wb; (void)sc; (void)fr; (void)wb
+
 /* Bounce 0: one lane per PIXEL.  All samples of a pixel share the primary hit (fragment:606-613), so everything the shading
  * knows before it draws a random number — triangle and attribute fetch, normals, the acos / tan of the normal deviation,
  * material (shadeSurface) — is computed once and the per-sample rest (shadeSample) runs `samples` times.  Every path gets the
  * record the per-path kernel would have written, bit for bit. */
 /* (the lane's pixel of screen tile `tile`; h = its primary hit: suv + triangle id as bits, -1 for none; returns whether the pixel's paths run) */
 template <bool COUNT>
-FLX_DEV bool shade0_tile(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t tile, uint32_t lane, float4 h, WorkCounters &cnt) {
-  const uint32_t S = (uint32_t)fr.samples;
+FLX_DEV bool shade0_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, float4 h, WorkCounters &cnt) {
+  uint32_t S, frameIdx;
+  int tri;
+  bool alive, compact;
+  f3 camera;
+  SurfaceCtx sf;
+  float ndcX = 0.0f, ndcY = 0.0f;
+  Hit hit;
+  {
+  FLX_ARGS_OF(ab);
+  S = (uint32_t)fr.samples;
   uint32_t px, k;
   tile8_pixel(fr, tile, lane, px, k);
   const bool inFrame = px < fr.width && k < fr.rows;
-  const uint32_t frameIdx = inFrame ? frame_index(fr, k) : 0u;
-  const f3 camera = frame_camera(fr, frameIdx);
-  const int tri = inFrame ? __float_as_int(h.w) : -1;
+  frameIdx = inFrame ? frame_index(fr, k) : 0u;
+  camera = frame_camera(fr, frameIdx);
+  tri = inFrame ? __float_as_int(h.w) : -1;
   /* loop guard of fragment:475 before the first bounce (importancy and originalColor are 1) */
-  const bool alive = tri != -1 && fr.max_reflections > 0 && length(F3(1.0f, 1.0f, 1.0f) * F3(1.0f, 1.0f, 1.0f)) >= fr.min_importancy * SQRT3;
-  SurfaceCtx sf;
-  float ndcX = 0.0f, ndcY = 0.0f;
-  Hit hit; hit.suv = F3(h.x, h.y, h.z); hit.triangleId = tri; hit.transformId = 0;
+  alive = tri != -1 && fr.max_reflections > 0 && length(F3(1.0f, 1.0f, 1.0f) * F3(1.0f, 1.0f, 1.0f)) >= fr.min_importancy * SQRT3;
+  hit.suv = F3(h.x, h.y, h.z); hit.triangleId = tri; hit.transformId = 0;
+  compact = wb.rec0 != nullptr;
   if (alive) {
     hit.transformId = (int)sc.geometry[3 * tri + 2].y << 1;
     const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
@@ -134,8 +152,9 @@ FLX_DEV bool shade0_tile(const DeviceScene &sc, const DeviceFrame &fr, const Wav
       cnt.atlas_texels = before.atlas_texels + (cnt.atlas_texels - before.atlas_texels) * S;
     }
   }
-  const bool compact = wb.rec0 != nullptr;
+  }
   for (uint32_t s = 0; s < S; s++) {
+    FLX_ARGS_OF(ab);                                          /* (read again per sample: nothing of the arguments stays in registers across the loop) */
     const uint32_t pathId = ((tile * S + s) << 6) | lane;
     float4 *rec = wb.rec + (size_t)pathId * 8;
     if (!alive) {
@@ -189,7 +208,9 @@ FLX_DEV bool shade0_tile(const DeviceScene &sc, const DeviceFrame &fr, const Wav
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade0(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
+__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade0(FrameArgs /* read through kernel_frame_args() */, uint32_t total_items) {
+  const FrameArgsP ab = kernel_frame_args();
+  FLX_ARGS_OF(ab);
   const uint32_t S = (uint32_t)fr.samples;
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t lane = t & 63u;
@@ -201,14 +222,16 @@ __global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade0(DeviceSce
   tile8_pixel(fr, tile, lane, px, k);
   float4 h = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
   if (px < fr.width && k < fr.rows) h = wb.hits[(size_t)k * fr.width + px];
-  (void)shade0_tile<COUNT>(sc, fr, wb, tile, lane, h, cnt);
+  (void)shade0_tile<COUNT>(ab, tile, lane, h, cnt);
   flush_counters<COUNT>(cnt, wb.counters);
 }
 
 /* The primary ray of the lane's pixel of screen tile `tile` (what k_primary does for it, flx_kernels.hip): the wave walks the forward-ordered copy
  * together.  -> suv + triangle id as bits (-1: no hit, or no pixel), also stored for k_resolve. */
 template <bool COUNT>
-FLX_DEV float4 primary_tile(const DeviceScene &sc, const DeviceFrame &fr, float4 *__restrict__ hits, uint32_t tile, uint32_t lane, WorkCounters &cnt) {
+FLX_DEV float4 primary_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, WorkCounters &cnt) {
+  FLX_ARGS_OF(ab);
+  float4 *__restrict__ hits = const_cast<float4 *>(wb.hits);
   uint32_t px, k;
   tile8_pixel(fr, tile, lane, px, k);
   const bool inImage = px < fr.width && k < fr.rows;
@@ -232,7 +255,9 @@ FLX_DEV float4 primary_tile(const DeviceScene &sc, const DeviceFrame &fr, float4
 /* k_primary and k_wf_shade0 in one launch: a wave traces the primary rays of its screen tile and shades bounce 0 for it straight away (the hits go through
  * registers; they are still stored for k_resolve), so that the slowest primary ray of the frame holds up its own tile's shading only. */
 template <bool COUNT>
-__global__ __launch_bounds__(256, FLX_WF_FRONT_WAVES) void k_wf_front(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items) {
+__global__ __launch_bounds__(256, FLX_WF_FRONT_WAVES) void k_wf_front(FrameArgs /* read through kernel_frame_args() */, uint32_t total_items) {
+  const FrameArgsP ab = kernel_frame_args();
+  FLX_ARGS_OF(ab);
   const uint32_t S = (uint32_t)fr.samples;
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t lane = t & 63u;
@@ -240,14 +265,15 @@ __global__ __launch_bounds__(256, FLX_WF_FRONT_WAVES) void k_wf_front(DeviceScen
   if (tileLocal * S * 64u >= total_items) return;
   const uint32_t tile = wb.item_base / (S * 64u) + tileLocal;
   WorkCounters cnt = {};
-  const float4 h = primary_tile<COUNT>(sc, fr, const_cast<float4 *>(wb.hits), tile, lane, cnt);
-  (void)shade0_tile<COUNT>(sc, fr, wb, tile, lane, h, cnt);
+  const float4 h = primary_tile<COUNT>(ab, tile, lane, cnt);
+  (void)shade0_tile<COUNT>(ab, tile, lane, h, cnt);
   flush_counters<COUNT>(cnt, wb.counters);
 }
 
 /* One path's shading for its next bounce (fragment:476-589): the record the last walk left -> the record the next walk reads. */
 template <bool COUNT>
-FLX_DEV void shade_path(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t pathId, WorkCounters &cnt) {
+FLX_DEV void shade_path(FrameArgsP ab, uint32_t pathId, WorkCounters &cnt) {
+  FLX_ARGS_OF(ab);
   float4 *rec = wb.rec + (size_t)pathId * 8;
   uint32_t px, k, s;
   item_pixel(fr, pathId, px, k, s);
@@ -289,14 +315,16 @@ FLX_DEV void shade_path(const DeviceScene &sc, const DeviceFrame &fr, const Wave
 
 /* Later rounds: one lane per live path. */
 template <bool COUNT>
-__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, int b) {
+__global__ __launch_bounds__(256, FLX_WF_SHADE_WAVES) void k_wf_shade(FrameArgs /* read through kernel_frame_args() */, int b) {
+  const FrameArgsP ab = kernel_frame_args();
+  FLX_ARGS_OF(ab);
   const uint32_t n = wb.counts[b];
   const uint32_t *__restrict__ listIn = wb.live[b & 1];
   WorkCounters cnt = {};
   for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < n; j += gridDim.x * 256u) {
     const uint32_t pathId = listIn[j];
     if (pathId == WF_INVALID) continue;
-    shade_path<COUNT>(sc, fr, wb, pathId, cnt);
+    shade_path<COUNT>(ab, pathId, cnt);
   }
   flush_counters<COUNT>(cnt, wb.counters);
 }
@@ -1043,29 +1071,35 @@ FLX_DEV uint32_t fq_pop(uint32_t *ring, uint32_t *ctl, unsigned long long takers
 }
 
 template <bool COUNT, bool FRONT>
-__global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_frame(DeviceScene sc, DeviceFrame fr, WavefrontBuffers wb, uint32_t total_items,
+__global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_frame(FrameArgs /* read through argBase */, uint32_t total_items,
                                                                                     uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves, uint32_t readyUnits) {
   const uint32_t n = total_items;
   if (n == 0u) return;
+  const FrameArgsP argBase = kernel_frame_args();
+#define FLX_FRAME_ARGS() FLX_ARGS_OF(argBase)
   const uint32_t WALK_WAVES = FLX_WF_WALK_THREADS / 64u - shadeWaves;
-  const bool compactRecs = wb.rec0 != nullptr;                /* bounce 0 comes with compact records (flx_kernels.h) */
+  uint32_t *frameRings; uint32_t samples; bool compactRecs;
+  { FLX_FRAME_ARGS(); frameRings = wb.frameRings; samples = (uint32_t)fr.samples; compactRecs = wb.rec0 != nullptr; }                /* compactRecs: bounce 0 comes with compact records (flx_kernels.h) */
   /* LDS: [tree top][inverse transforms][control words][per walk thread: nTransforms x 40 B of rays]; the two rings of path ids are this
    * workgroup's slice of wb.frameRings (a few lanes touch them per fold / refill, not per trip: they need no LDS) */
   extern __shared__ float4 ldsAll[];
   float4 *ldsEntries = ldsAll;
   float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u;
   uint32_t *ctl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);
-  uint32_t *shadeRing = wb.frameRings + (size_t)blockIdx.x * WF_FRAME_RINGS * FQ_SIZE, *walkRing = shadeRing + FQ_SIZE, *readyRing = walkRing + FQ_SIZE;
+  uint32_t *shadeRing = frameRings + (size_t)blockIdx.x * WF_FRAME_RINGS * FQ_SIZE, *walkRing = shadeRing + FQ_SIZE, *readyRing = walkRing + FQ_SIZE;
   /* The front of the frame inside the launch (wb.front): the shade waves also make the fresh paths — primary ray and bounce-0 shading of one 8 x 8 screen
    * tile at a time (what k_primary and k_wf_shade0 do in front of the launch otherwise) — and hand them to the walk waves as (tile, sample) units of 64
    * through a third ring; the frame's queue then counts screen tiles. */
   constexpr bool front = FRONT;                /* (a kernel of its own: the front's code costs the other one registers) */
-  const uint32_t perTile = (uint32_t)fr.samples * 64u;
+  const uint32_t perTile = samples * 64u;
   float2 *raysBase = (float2 *)(ctl + FC_WORDS);
-  for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
-  for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
-    const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
-    ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
+  {
+    FLX_FRAME_ARGS();
+    for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
+    for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
+      const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
+      ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
+    }
   }
   if (threadIdx.x < (uint32_t)FC_WORDS) ctl[threadIdx.x] = 0u;
   for (uint32_t t = threadIdx.x; t < WF_FRAME_RINGS * FQ_SIZE; t += FLX_WF_WALK_THREADS) shadeRing[t] = WF_INVALID;
@@ -1081,6 +1115,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   const uint32_t nTiles = n / perTile;
   auto makeTile = [&]() -> uint32_t {
     if (!FRONT) return 2u;
+    FLX_FRAME_ARGS();
     uint32_t take = 0, tile = 0;
     if (lane == 0 && fq_load(&ctl[FC_RQ + 2]) < readyUnits) {
       const uint32_t before = atomicAdd(&ctl[FC_ALIVE], perTile);
@@ -1095,13 +1130,13 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       return 2u;
     }
     tile += wb.item_base / perTile;
-    const float4 h = primary_tile<COUNT>(sc, fr, const_cast<float4 *>(wb.hits), tile, lane, cnt);
-    const bool runs = shade0_tile<COUNT>(sc, fr, wb, tile, lane, h, cnt);
+    const float4 h = primary_tile<COUNT>(argBase, tile, lane, cnt);
+    const bool runs = shade0_tile<COUNT>(argBase, tile, lane, h, cnt);
     if (flx_ballot(runs) == 0ull) {
       if (lane == 0) atomicSub(&ctl[FC_ALIVE], perTile);
     } else {
-      for (uint32_t s0 = 0; s0 < (uint32_t)fr.samples; s0 += 64u)
-        fq_push(readyRing, ctl + FC_RQ, s0 + lane < (uint32_t)fr.samples, tile * (uint32_t)fr.samples + s0 + lane, lane);
+      for (uint32_t s0 = 0; s0 < samples; s0 += 64u)
+        fq_push(readyRing, ctl + FC_RQ, s0 + lane < samples, tile * samples + s0 + lane, lane);
     }
     return 1u;
   };
@@ -1112,6 +1147,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     bool frontDone = !front;                                 /* this wave has found the frame's tile queue dry */
     const long long tStartShade = COUNT ? clock64() : 0;
     for (;;) {
+      FLX_FRAME_ARGS();
       const bool dry = fq_load(&ctl[FC_DRY]) != 0u;
       uint32_t id = WF_INVALID;
       const uint32_t got = fq_pop(shadeRing, ctl + FC_SQ, ~0ull, 64u, dry ? 1u : 64u, lane, id);
@@ -1142,10 +1178,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       }
       idle = 0;
       const bool mine = lane < got && id != WF_INVALID;
-      if (mine) shade_path<COUNT>(sc, fr, wb, id, cnt);
+      if (mine) shade_path<COUNT>(argBase, id, cnt);
       fq_push(walkRing, ctl + FC_WQ, mine, id, lane);
     }
-    flush_counters<COUNT>(cnt, wb.counters);
+    { FLX_FRAME_ARGS(); flush_counters<COUNT>(cnt, wb.counters); }
     return;
   }
 
@@ -1156,7 +1192,6 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   const long long tStart = COUNT ? clock64() : 0;
   if (front && wave < (uint32_t)FLX_FRAME_PROLOGUE_WAVES) while (makeTile() == 1u) {}
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
-  uint32_t *__restrict__ queue = wb.walkQueue;
   const uint32_t nWaves = gridDim.x * WALK_WAVES;
   uint32_t lastBase = 0;
   uint32_t inChunk = n / (nWaves * FLX_WF_DRAWS_PER_WAVE);
@@ -1180,7 +1215,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   bool itemsLeft = true;
   uint32_t idleSpins = 0;
 
-  auto pixPart = [&](uint32_t id) -> const float4 * {
+  auto pixPart = [&](const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id) -> const float4 * {
     uint32_t tile0, s0;
     item_tile(fr, id, tile0, s0);
     return wb.pix0 + (((size_t)tile0 << 6) | (id & 63u)) * 3;
@@ -1195,6 +1230,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
       /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475; a path that goes on is handed to the shade waves ---- */
       if (flx_ballot(st == P_DONE) != 0ull) {
+        FLX_FRAME_ARGS();
         bool toShade = false, ended = false;
         if (st == P_DONE) {
           float4 *rec = wb.rec + (size_t)pathId * 8;
@@ -1202,7 +1238,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           float4 q4, q5, q6, q7;
           const float4 *pp = nullptr;
           if (compact) {
-            pp = pixPart(pathId);
+            pp = pixPart(fr, wb, pathId);
             q4 = wb.rec0[(size_t)pathId * 3 + 2]; q7 = pp[2];
             q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
           } else {
@@ -1240,6 +1276,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       for (;;) {
         const unsigned long long idle = flx_ballot(st == P_EMPTY);
         if (idle == 0ull) break;
+        FLX_FRAME_ARGS();
+        uint32_t *__restrict__ queue = wb.walkQueue;
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         uint32_t id = WF_INVALID;
         bool fresh = false;                                    /* a bounce-0 item: compact record, may be dead */
@@ -1298,7 +1336,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           const float4 *rec = wb.rec + (size_t)id * 8;
           float4 q0, q1, q2, q3;
           if (fresh && compactRecs) {
-            const float4 *pp = pixPart(id);
+            const float4 *pp = pixPart(fr, wb, id);
             const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
             const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
             q0 = make_float4(p0.x, p0.y, p0.z, a.w);
@@ -1333,6 +1371,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         else { w.mode = 1; st = P_SETUP; }
       }
       if (flx_ballot(st == P_SETUP) != 0ull) {
+        FLX_FRAME_ARGS();
         if (st == P_SETUP) {
           const bool shadowMode = w.mode == 0;
           const Ray src = shadowMode ? shadowRay : nextRay;
@@ -1352,6 +1391,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         if (fq_load(&ctl[FC_WQ + 2]) == 0u && (front ? (fq_load(&ctl[FC_RQ + 2]) == 0u || fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT)
                                                      : !(itemsLeft && fq_load(&ctl[FC_SQ + 2]) < FQ_LIMIT && fq_load(&ctl[FC_ALIVE]) + 256u <= FQ_ALIVE_MAX))) {
           if (++idleSpins > FQ_WATCHDOG) {
+            FLX_FRAME_ARGS();
             if (COUNT && lane == 0) { for (uint32_t k = 0; k < 8u; k++) atomicMax(wb.counters + 50 + k, (unsigned long long)fq_load(&ctl[k]) + 1ull); atomicAdd(wb.counters + 58, 1ull); }
             break;
           }
@@ -1360,23 +1400,28 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         continue;
       }
     }
-    /* ---- FLX_WF_INNER entries for every walking lane ---- */
+    /* ---- FLX_WF_INNER entries for every walking lane (the few scene words the fetch needs are read before the loop) ---- */
+    {
+      FLX_FRAME_ARGS();
 #pragma unroll FLX_WF_UNROLL
-    for (int it = 0; it < FLX_WF_INNER; it++) {
-      if (st == P_WALKING) {
-        bool ended = false;
-        if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-        if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
-        if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
+      for (int it = 0; it < FLX_WF_INNER; it++) {
+        if (st == P_WALKING) {
+          bool ended = false;
+          if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
+          if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
+          if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
+        }
       }
     }
   }
+  FLX_FRAME_ARGS();
   if (COUNT && (cnt.closest_visits | cnt.shadow_visits) != 0u) atomicAdd(wb.counters + 23, (unsigned long long)cnt.closest_visits + cnt.shadow_visits);
   if (COUNT && lane == 0) {                                     /* wave lifetimes: sum / max / count (flx_get_tail_diag 24..26) */
     const unsigned long long life = (unsigned long long)(clock64() - tStart);
     atomicAdd(wb.counters + 64, life); atomicMax(wb.counters + 65, life); atomicAdd(wb.counters + 66, 1ull);
   }
   flush_counters<COUNT>(cnt, wb.counters);
+#undef FLX_FRAME_ARGS
 }
 
 /* Can the frame kernel take this frame?  Its LDS holds the rays of its walk threads, the staged transforms, the two rings and
@@ -1442,10 +1487,11 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
       const uint32_t total = wb.item_count;
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);
       const uint32_t shadeBlocks = (pixels + 255u) / 256u;
+      FrameArgs fa; fa.sc = sc; fa.fr = fr; fa.wb = wb;
       if (wb.front) { /* the frame kernel shades bounce 0 itself */ }
-      else if (fused) { if (count) hipLaunchKernelGGL(k_wf_front<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total); else hipLaunchKernelGGL(k_wf_front<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total); }
-      else if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
-      else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
+      else if (fused) { if (count) hipLaunchKernelGGL(k_wf_front<true>, dim3(shadeBlocks), dim3(256), 0, stream, fa, total); else hipLaunchKernelGGL(k_wf_front<false>, dim3(shadeBlocks), dim3(256), 0, stream, fa, total); }
+      else if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, fa, total);
+      else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, fa, total);
       if (walk0_begin) (void)hipEventRecord(walk0_begin, stream);
       const uint32_t shadeWaves = wb.front ? (uint32_t)FLX_FRAME_SHADERS_FRONT : (uint32_t)FLX_FRAME_SHADERS;
       const dim3 grid(compute_units * (uint32_t)FLX_FRAME_GROUPS_PER_CU), block(FLX_WF_WALK_THREADS);
@@ -1457,11 +1503,11 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
       uint32_t readyUnits = tilesPerGroup >= 48u ? (uint32_t)FLX_FRAME_READY_UNITS : tilesPerGroup / 2u;
       readyUnits = readyUnits < (uint32_t)FLX_FRAME_READY_UNITS / 4u ? (uint32_t)FLX_FRAME_READY_UNITS / 4u : (readyUnits > (uint32_t)FLX_FRAME_READY_UNITS ? (uint32_t)FLX_FRAME_READY_UNITS : readyUnits);
       if (wb.front) {
-        if (count) hipLaunchKernelGGL((k_wf_frame<true, true>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
-        else hipLaunchKernelGGL((k_wf_frame<false, true>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
+        if (count) hipLaunchKernelGGL((k_wf_frame<true, true>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
+        else hipLaunchKernelGGL((k_wf_frame<false, true>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
       } else {
-        if (count) hipLaunchKernelGGL((k_wf_frame<true, false>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
-        else hipLaunchKernelGGL((k_wf_frame<false, false>), grid, block, ldsBytesF, stream, sc, fr, wb, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
+        if (count) hipLaunchKernelGGL((k_wf_frame<true, false>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
+        else hipLaunchKernelGGL((k_wf_frame<false, false>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
       }
       if (walk0_end) (void)hipEventRecord(walk0_end, stream);
       return wb.front ? 3 : 2;
@@ -1500,17 +1546,18 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
   const int rounds = (suspend && !finisher) ? 2 * bounces : bounces;
   /* compact bounce-0 records: only the default walk kernel reads them (and a suspended walk re-reads its full record) */
   if (!(pre && lanes && !suspend)) { wb.rec0 = nullptr; wb.pix0 = nullptr; }
+  FrameArgs fa; fa.sc = sc; fa.fr = fr; fa.wb = wb;                /* (after the choice of the records' layout above) */
   for (int r = 0; r < rounds; r++) {
     if (r == 0) {
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);        /* 64 per screen tile */
       const uint32_t shadeBlocks = (pixels + 255u) / 256u;
-      if (fused) { if (count) hipLaunchKernelGGL(k_wf_front<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total); else hipLaunchKernelGGL(k_wf_front<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total); }
-      else if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
-      else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, total);
+      if (fused) { if (count) hipLaunchKernelGGL(k_wf_front<true>, dim3(shadeBlocks), dim3(256), 0, stream, fa, total); else hipLaunchKernelGGL(k_wf_front<false>, dim3(shadeBlocks), dim3(256), 0, stream, fa, total); }
+      else if (count) hipLaunchKernelGGL(k_wf_shade0<true>, dim3(shadeBlocks), dim3(256), 0, stream, fa, total);
+      else hipLaunchKernelGGL(k_wf_shade0<false>, dim3(shadeBlocks), dim3(256), 0, stream, fa, total);
     } else {
       const uint32_t shadeBlocks = maxBlocks * 2u;
-      if (count) hipLaunchKernelGGL(k_wf_shade<true>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r);
-      else hipLaunchKernelGGL(k_wf_shade<false>, dim3(shadeBlocks), dim3(256), 0, stream, sc, fr, wb, r);
+      if (count) hipLaunchKernelGGL(k_wf_shade<true>, dim3(shadeBlocks), dim3(256), 0, stream, fa, r);
+      else hipLaunchKernelGGL(k_wf_shade<false>, dim3(shadeBlocks), dim3(256), 0, stream, fa, r);
     }
     if (r == 0 && walk0_begin) (void)hipEventRecord(walk0_begin, stream);
     const uint32_t smax = (suspend && r < bounces) ? suspend_max : 0u;
