@@ -180,6 +180,27 @@ int flx_frames_in_flight(const flx_context *ctx);
  * every 7.3 ms instead of every 8.1 ms on the dragon workload, each frame's own time (gpu_ms) a little longer.  1: one lane, frames
  * one after the other on the context's stream.  Temporal frames always use the first lane (their history lives there). */
 flx_status flx_set_frame_lanes(flx_context *ctx, int lanes);
+/* Consecutive frames of the loop INSIDE one persistent launch (csrc/flx_chain.hip; the default, mode 1).  Where the frame kernel with the front of the frame
+ * inside it takes the frames (no filter, no temporal accumulation, no work counters, a scene of more than 128 entries, strips of a multiple of 8 rows), two
+ * lanes means: both frames in flight live in one stacked workspace of this context, the kernel of frame k completes frame k and WORKS AHEAD on frame
+ * k + 1 — whose camera flx_frame_begin of that frame posts to it while it runs — with the lanes frame k no longer fills, and hands what it holds of frame
+ * k + 1 to the next kernel when frame k is complete.  A launch then has no drain: a rank's eighth of the 1080p dragon frame completes every ~0.9 ms instead
+ * of every 1.28 ms on two separate lanes (1.65 ms one frame at a time).  The reference renders frame after frame from one context without waiting for
+ * the GPU (modules/pathtracerWGL2.js:254-303).  Frames are bit-identical to their own flx_render; they complete in order; a frame that differs in
+ * anything but camera / view matrix / ambient / seed from the one before, or follows a scene upload, starts a new chain (its kernel waits for the one
+ * before as on one lane).  mode 0: the two lanes of flx_set_frame_lanes.  A watchdog trip inside the kernel makes flx_frame_end return FLX_ERR_DEVICE. */
+flx_status flx_set_frame_chain(flx_context *ctx, int mode);
+/* The last frame begun in the loop: 0 not chained, 1 it began a chain, 2 it continued one (the kernel before it could work ahead on it). */
+flx_status flx_last_chained(flx_context *ctx, int *chained);
+/* Diagnostics of the chained kernels (tools/chain_stats.py): 64 launches (by sequence number mod 64) x 32 words — when the launch started and ended, when the
+ * next frame's view was seen, when its own frame was complete, tiles made for either frame, paths handed to the next kernel, walks abandoned. */
+flx_status flx_set_chain_stats(flx_context *ctx, int on);
+flx_status flx_get_chain_stats(flx_context *ctx, uint64_t *out /* [64 * 32] */);
+/* Experiments with the order in which a chained frame's 8 x 8 screen tiles are drawn (tools/chain_order.py): an explicit permutation of the frame's tiles
+ * (n = 0: the row-major default), and per-tile counts of the shadings its paths took after bounce 0 (n tiles per slot; 2 x n words out). */
+flx_status flx_set_chain_order(flx_context *ctx, const uint32_t *order, uint32_t n);
+flx_status flx_set_chain_cost(flx_context *ctx, uint32_t n);
+flx_status flx_get_chain_cost(flx_context *ctx, uint32_t *out);
 
 /* Filter frames on several GPUs.  The path-trace pass is per pixel and shards by row strips like a frame
  * without filter; the denoise chain reads up to ~194 rows around a pixel and runs on the whole frame.  So every rank

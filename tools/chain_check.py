@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""The chained frame loop against single renders: every frame of a loop with a moving camera must equal its own flx_render bit for bit; then the loop's
+rate with the chain on and off.  GPU box.   usage: chain_check.py [--workload dragon|dragon_4k] [--count N --index I] [--frames F] [--size WxH]"""
+import argparse, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+from flexlight_hip import capi
+from flexlight_hip.scene_io import Scene
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="dragon")
+ap.add_argument("--count", type=int, default=8)
+ap.add_argument("--index", type=int, default=0)
+ap.add_argument("--frames", type=int, default=12)
+ap.add_argument("--size", default="")
+ap.add_argument("--time-frames", type=int, default=200)
+ap.add_argument("--no-check", action="store_true")
+a = ap.parse_args()
+sc = Scene.golden("dragon")
+size = dict(width=3840, height=2160) if a.workload == "dragon_4k" else {}
+if a.size:
+    w, h = a.size.split("x"); size = dict(width=int(w), height=int(h))
+ctx = capi.Context(0)
+ctx.update_scene(sc)
+
+def params(f):
+    p = sc.frame_params(use_filter=0, **size)
+    if a.count > 1:
+        p.tile_rows, p.tile_count, p.tile_index = 8, a.count, a.index
+    p.camera[0] += 0.05 * f; p.camera[2] -= 0.03 * f          # a camera that moves from frame to frame
+    p.random_seed = float(f % 4)
+    return p
+
+if not a.no_check:
+    ps = [params(f) for f in range(a.frames)]
+    want = [ctx.render(p)[0] for p in ps]
+    for chain in (1, 0):
+        ctx.set_frame_chain(chain)
+        got, kinds = [], []
+        ctx.frame_begin(ps[0]); kinds.append(ctx.last_chained())
+        for f in range(1, a.frames):
+            ctx.frame_begin(ps[f]); kinds.append(ctx.last_chained())
+            got.append(ctx.frame_end()[0])
+        got.append(ctx.frame_end()[0])
+        bad = [f for f in range(a.frames) if not np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32))]
+        print("chain %d: %d frames, kinds %s, frames that differ from their own render: %s" % (chain, a.frames, kinds, bad or "none"), flush=True)
+        for f in bad[:3]:
+            d = (got[f].view(np.uint32) != want[f].view(np.uint32)).any(axis=2)
+            print("   frame %d: %d pixels differ, first rows %s" % (f, int(d.sum()), np.nonzero(d.any(axis=1))[0][:8]))
+
+p = params(0)
+for chain in (0, 1):
+    ctx.set_frame_chain(chain)
+    best = 1e9
+    for rep in range(3):
+        ctx.frame_begin(p, device=True)
+        for _ in range(6):
+            ctx.frame_begin(p, device=True); ctx.frame_end()
+        t0 = time.perf_counter()
+        for _ in range(a.time_frames):
+            ctx.frame_begin(p, device=True); ctx.frame_end()
+        dt = time.perf_counter() - t0
+        ctx.frame_end()
+        best = min(best, dt * 1e3 / a.time_frames)
+    print("loop, two frames in flight, chain %d: %.3f ms per frame (last frame kind %d)" % (chain, best, ctx.last_chained()), flush=True)

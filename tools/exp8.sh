@@ -1,0 +1,2 @@
+mkdir -p gpurun_out/exp8
+timeout -k 10 200 python tools/chain_stats.py --count 8 --index 0 --frames 16 > gpurun_out/exp8/stats.txt 2>&1; echo "rc=$?"; cat gpurun_out/exp8/stats.txt

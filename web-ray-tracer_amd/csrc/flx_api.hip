@@ -120,6 +120,10 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   for (hipEvent_t ev : ctx->stage_done) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
+  if (ctx->h_chain_mail) (void)hipHostFree(ctx->h_chain_mail);
+  for (void *b : { (void *)ctx->d_chain_slots, (void *)ctx->d_chain_relay, (void *)ctx->d_chain_lists, (void *)ctx->d_chain_rings, (void *)ctx->d_chain_stats, (void *)ctx->d_chain_susp, (void *)ctx->d_chain_order, (void *)ctx->d_chain_cost }) if (b) (void)hipFree(b);
+  if (ctx->h_chain_error) (void)hipHostFree(ctx->h_chain_error);
+
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }
@@ -150,6 +154,7 @@ static flx_status shared_upload_end(flx_context *ctx) {
 
 template <typename T>
 static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t bytes) {
+  ctx->scene_version++;                  /* (a chain of frames does not go on over a changed scene: flx_chain.hip) */
   size_t &cap = ctx->upload_capacity[(void **)dst];
   if (bytes == 0) {                      /* "none": the kernels test the pointer */
     if (*dst && ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
@@ -475,35 +480,12 @@ flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t
   return FLX_OK;
 }
 
-flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
-  unsigned long long *cnt = ctx->counters_enabled ? ctx->d_counters : nullptr;
-  /* The G-buffer accumulators of the filter path carry state from sample to sample (fragment:83-89),
-   * so filter frames use the sample-sequential kernel; everything else runs the wavefront pipeline. */
-  int pipeline = ctx->pipeline;
-  /* automatic: tiny scenes (a Cornell box, the theater: a few dozen entries) spend the wavefront pipeline's time on its 128-byte
-   * path records, not on walks — the persistent path kernel, which keeps a path in registers from bounce to bounce, is faster
-   * there (tools/pipeline_crossover.py: 48 entries 1.96 vs 2.41 ms, 329 entries 4.03 vs 2.85 ms) */
-  if (pipeline == 0) {
-    if (fr.use_filter || fr.is_temporal) pipeline = 1;
-    else if (ctx->walk_entries <= 128u) {
-      /* Small scenes (profiles/r02_ab_lockstep.txt, 6.): the per-pixel kernel — primary hit, surface and samples in one thread —
-       * is the fastest while a pixel's thread is short (cornell 256 x 256 1 spp 1 bounce 0.057 ms against 0.144 wavefront and 0.220
-       * persistent; cornell.obj 1080p 4 spp 3 bounces 0.65 against 1.09); the persistent path kernel, which refills the lanes of
-       * dead paths, overtakes it at 32 bounce iterations per pixel (cornell.obj 8 x 6: 1.49 against 1.66 ms), with many lights
-       * to shade per bounce from 4 on (theater 4 spp 3 bounces: 3.08 against 4.19 ms).  (A frame of fewer than 2^20 paths does
-       * not fill the persistent grid.) */
-      const uint64_t work = (uint64_t)fr.samples * (uint64_t)(fr.max_reflections > 0 ? fr.max_reflections : 1);
-      const bool persistent = path_item_count64(fr) >= (1u << 20) && (work >= 32u || (ctx->n_lights >= 4u && work >= 4u));
-      pipeline = persistent ? 2 : 1;
-    } else pipeline = 3;
-  }
-  if (pipeline == 3 && fr.max_reflections > WF_MAX_BOUNCES) pipeline = 2;
-  ctx->last_pipeline = pipeline;
-  ctx->last_organisation = 0;
-  if (pipeline != 1 && (fr.use_filter || fr.is_temporal)) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the G-buffers of filter / temporal frames");
+/* The buffers pipelines 2 and 3 need for this frame (or batch of frames): sized before anything is freed or allocated, so that a batch that is too
+ * large is refused with a message that says what to do and the context keeps the buffers it has.  -> the chains of the bounce loop (pipeline 3). */
+static flx_status ensure_workspace(flx_context *ctx, const DeviceFrame &fr, int pipeline, bool counted, int &wf_chains) {
   const size_t P = (size_t)fr.rows * fr.width;
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
-  int wf_chains = 1;
+  wf_chains = 1;
   if (pipeline != 1) {
     flx_status s;
     if (path_item_count64(fr) + 1000000ull >= 4294967296ull) return fail(ctx, FLX_ERR_INVALID, "frame (or batch of frames) too large: more than 2^32 path items");
@@ -543,7 +525,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     wf_chains = ctx->wf_groups < 1 ? 1 : (ctx->wf_groups > WF_MAX_GROUPS ? WF_MAX_GROUPS : ctx->wf_groups);
     {
       const uint32_t tiles = path_item_count(fr) / ((uint32_t)fr.samples * 64u);
-      if ((uint32_t)wf_chains > tiles || cnt) wf_chains = 1;
+      if ((uint32_t)wf_chains > tiles || counted) wf_chains = 1;
     }
     const size_t need = wavefront_live_capacity(fr, cus) * (size_t)wf_chains;
     if (ctx->live_capacity < need) {
@@ -563,6 +545,39 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       ctx->strag_capacity = needStrag;
     }
   }
+  return FLX_OK;
+}
+
+flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
+  ctx->chain_seq = 0;                    /* this frame's kernels use the workspace a chain of frames keeps its state in: the chain ends here */
+  unsigned long long *cnt = ctx->counters_enabled ? ctx->d_counters : nullptr;
+  /* The G-buffer accumulators of the filter path carry state from sample to sample (fragment:83-89),
+   * so filter frames use the sample-sequential kernel; everything else runs the wavefront pipeline. */
+  int pipeline = ctx->pipeline;
+  /* automatic: tiny scenes (a Cornell box, the theater: a few dozen entries) spend the wavefront pipeline's time on its 128-byte
+   * path records, not on walks — the persistent path kernel, which keeps a path in registers from bounce to bounce, is faster
+   * there (tools/pipeline_crossover.py: 48 entries 1.96 vs 2.41 ms, 329 entries 4.03 vs 2.85 ms) */
+  if (pipeline == 0) {
+    if (fr.use_filter || fr.is_temporal) pipeline = 1;
+    else if (ctx->walk_entries <= 128u) {
+      /* Small scenes (profiles/r02_ab_lockstep.txt, 6.): the per-pixel kernel — primary hit, surface and samples in one thread —
+       * is the fastest while a pixel's thread is short (cornell 256 x 256 1 spp 1 bounce 0.057 ms against 0.144 wavefront and 0.220
+       * persistent; cornell.obj 1080p 4 spp 3 bounces 0.65 against 1.09); the persistent path kernel, which refills the lanes of
+       * dead paths, overtakes it at 32 bounce iterations per pixel (cornell.obj 8 x 6: 1.49 against 1.66 ms), with many lights
+       * to shade per bounce from 4 on (theater 4 spp 3 bounces: 3.08 against 4.19 ms).  (A frame of fewer than 2^20 paths does
+       * not fill the persistent grid.) */
+      const uint64_t work = (uint64_t)fr.samples * (uint64_t)(fr.max_reflections > 0 ? fr.max_reflections : 1);
+      const bool persistent = path_item_count64(fr) >= (1u << 20) && (work >= 32u || (ctx->n_lights >= 4u && work >= 4u));
+      pipeline = persistent ? 2 : 1;
+    } else pipeline = 3;
+  }
+  if (pipeline == 3 && fr.max_reflections > WF_MAX_BOUNCES) pipeline = 2;
+  ctx->last_pipeline = pipeline;
+  ctx->last_organisation = 0;
+  if (pipeline != 1 && (fr.use_filter || fr.is_temporal)) return fail(ctx, FLX_ERR_INVALID, "pipelines 2 and 3 do not produce the G-buffers of filter / temporal frames");
+  const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+  int wf_chains = 1;
+  { flx_status s = ensure_workspace(ctx, fr, pipeline, cnt != nullptr, wf_chains); if (s) return s; }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
   if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, FLX_COUNTER_SLOTS * sizeof(unsigned long long), ctx->stream));
   if (pipeline == 1) {
@@ -1179,12 +1194,146 @@ static void mirror_scene(flx_context *ctx) {
   t->n_entries = ctx->n_entries; t->n_ids = ctx->n_ids; t->max_transform = ctx->max_transform; t->have_scene = ctx->have_scene;
 }
 
+
+/* ---- the chained frame loop (flx_chain.hip) -------------------------------------------------------------------------------
+ * Two frames in flight share ONE stacked workspace (the layout of a batch of two) and one stream: the kernel of frame k completes the slot of frame k and
+ * works ahead on the slot of frame k + 1 — whose view flx_frame_begin of that frame posts while the kernel runs — and hands what it holds of it to the
+ * kernel of frame k + 1 when frame k is complete.  The drain of a launch, a third of a rank's share of a 1080p frame, disappears under the next frame's bulk. */
+#ifndef FLX_CHAIN_MIN_LANES
+#define FLX_CHAIN_MIN_LANES 2
+#endif
+static bool chain_same_shape(const flx_frame_params &a, const flx_frame_params &b) {
+  return a.width == b.width && a.height == b.height && a.samples == b.samples && a.max_reflections == b.max_reflections && a.min_importancy == b.min_importancy &&
+         a.use_filter == b.use_filter && a.is_temporal == b.is_temporal && a.hdr == b.hdr && a.texture_width == b.texture_width &&
+         a.tile_rows == b.tile_rows && a.tile_index == b.tile_index && a.tile_count == b.tile_count;
+}
+/* May this frame of the loop run chained?  (The frame kernel with the front of the frame inside it must take it, uncounted; tiles must not straddle the slots.) */
+static bool chain_wanted(flx_context *ctx, const flx_frame_params *p, const DeviceScene &sc, const DeviceFrame &fr) {
+  if (!ctx->frame_chain || ctx->frame_lanes < FLX_CHAIN_MIN_LANES || ctx->is_twin) return false;
+  if (p->use_filter || p->is_temporal || ctx->counters_enabled) return false;
+  if (!(ctx->pipeline == 3 || (ctx->pipeline == 0 && ctx->walk_entries > 128u))) return false;
+  if (fr.max_reflections < 1 || fr.max_reflections > WF_MAX_BOUNCES) return false;
+  const int organisation = FLX_WF_ORGANISATION_DEFAULT ? FLX_WF_ORGANISATION_DEFAULT : ctx->wf_organisation;
+  if (organisation == 1 || ctx->walk_scheduler != 0 || ctx->walk_suspend != 0u || ctx->wf_groups > 1 || !(ctx->frame_front == 1 || ctx->frame_front == 2)) return false;
+  if (fr.frame_rows == 0u || (fr.frame_rows & 7u) != 0u) return false;
+  if (path_item_count64(fr) * 2ull >= (1ull << 31)) return false;
+  if ((uint32_t)fr.samples * 64u * 2u + (uint32_t)FLX_CHAIN_RESERVE_HOST > (uint32_t)WF_FRAME_RING - 256u) return false;
+  uint32_t a = 0, b = 0;
+  return chain_kernel_fits(sc, a, b);
+}
+
+static flx_status chain_resources(flx_context *ctx, size_t itemsPerSlot) {
+  const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+  if (!ctx->d_chain_slots) {
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_slots, 2 * sizeof(ChainSlot)));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_chain_slots, 0, 2 * sizeof(ChainSlot), ctx->stream));
+    /* the mailbox: pinned host memory the host writes with plain stores while the kernel runs and the kernel reads with system-scope loads
+     * (tools/micro/mailbox.hip).  Not a copy on a stream: a small hipMemcpyAsync is a kernel of its own, and the persistent launch leaves it no CU. */
+    FLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_chain_mail, sizeof(ChainMail), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->h_chain_mail, 0, sizeof(ChainMail));
+    FLX_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->d_chain_mail, ctx->h_chain_mail, 0));
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_relay, sizeof(ChainMail)));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_chain_relay, 0, sizeof(ChainMail), ctx->stream));
+    FLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_chain_error, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    ctx->h_chain_error[0] = 0u;
+    FLX_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->d_chain_error, ctx->h_chain_error, 0));
+    const size_t ringWords = (size_t)cus * chain_rings_per_group();
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_rings, ringWords * sizeof(uint32_t)));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_chain_rings, 0xff, ringWords * sizeof(uint32_t), ctx->stream));      /* WF_INVALID everywhere; a kernel leaves them so */
+    ctx->chain_susp_cap = (size_t)cus * 1024u;                                  /* every lane of every workgroup may hold a walk when the launch stops */
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_susp, 2 * ctx->chain_susp_cap * CH_SUSP_F4 * sizeof(float4)));
+  }
+  if (ctx->chain_list_cap < itemsPerSlot) {
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->chain_list_cap = 0; ctx->chain_seq = 0;
+    if (ctx->d_chain_lists) { FLX_HIP(ctx, hipFree(ctx->d_chain_lists)); ctx->d_chain_lists = nullptr; }
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_lists, 6 * itemsPerSlot * sizeof(uint32_t)));
+    ctx->chain_list_cap = itemsPerSlot;
+  }
+  return FLX_OK;
+}
+
+/* One frame of the loop, chained: its view posted to the kernel before it (when it continues a chain), the slot after it reset, its own kernel and the
+ * resolve of its slot — everything on the context's stream but the post. */
+static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *params, const DeviceScene &sc, const DeviceFrame &frOne, float4 *d_out) {
+  const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+  DeviceFrame fr = frOne;                                   /* the two slots stacked like a batch of two frames */
+  fr.frames = 2; fr.rows = 2u * frOne.frame_rows;
+  const size_t itemsPerSlot = (size_t)path_item_count64(frOne);
+  flx_status s;
+  if ((s = chain_resources(ctx, itemsPerSlot))) return s;
+  int chains = 1;
+  if ((s = ensure_workspace(ctx, fr, 3, false, chains))) return s;
+  const bool continuing = ctx->chain_seq != 0 && chain_same_shape(ctx->chain_params, *params) && ctx->chain_scene_version == ctx->scene_version;
+  const uint32_t seq = ++ctx->chain_counter ? ctx->chain_counter : ++ctx->chain_counter;
+  const uint32_t slotP = continuing ? 1u - ctx->chain_slot : 0u, slotS = 1u - slotP;
+  fr.view[slotP] = frOne.view[0];
+  if (slotP != 0u) memset(&fr.view[0], 0, sizeof(FrameView));
+  if (continuing) {
+    /* post: the view, then the number that says whose view it is (sequence numbers are never reused, so nothing has to be reset: a kernel takes the view of
+     * exactly the frame it was told to expect).  The kernel before this one may work ahead on this frame from now on. */
+    memcpy((void *)&ctx->h_chain_mail->view[slotP], &frOne.view[0], sizeof(FrameView));
+    __atomic_store_n(&ctx->h_chain_mail->posted[slotP], seq, __ATOMIC_RELEASE);
+  }
+  /* the other slot is free for the frame after this one: the kernel and the resolve of the frame that last used it are earlier in this stream (a frame
+   * that begins a chain resets its own slot too) */
+  launch_chain_reset(ctx->d_chain_slots, continuing ? 1u << slotS : 3u, ctx->stream);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
+  WavefrontBuffers wb = {};
+  wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
+  wb.frameRings = ctx->d_chain_rings; wb.front = 1u;
+  wb.item_base = 0u; wb.item_count = (uint32_t)(2u * itemsPerSlot);
+  wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = nullptr;
+  ChainArgs ca = {};
+  ca.slots = ctx->d_chain_slots; ca.mail = ctx->d_chain_mail; ca.relay = ctx->d_chain_relay;
+  for (int i = 0; i < 2; i++) {
+    ca.walkList[i] = ctx->d_chain_lists + (size_t)(0 + i) * ctx->chain_list_cap;
+    ca.shadeList[i] = ctx->d_chain_lists + (size_t)(2 + i) * ctx->chain_list_cap;
+    ca.readyList[i] = ctx->d_chain_lists + (size_t)(4 + i) * ctx->chain_list_cap;
+  }
+  ca.listCap = (uint32_t)ctx->chain_list_cap;
+  for (int i = 0; i < 2; i++) ca.suspList[i] = ctx->d_chain_susp + (size_t)i * ctx->chain_susp_cap * CH_SUSP_F4;
+  ca.suspCap = (uint32_t)ctx->chain_susp_cap;
+  ca.slotP = slotP;
+  ca.seqS = seq + 1u ? seq + 1u : 1u;                        /* the number the next frame of this chain will post */
+  ca.tilesPerSlot = (uint32_t)(itemsPerSlot / ((size_t)fr.samples * 64u));
+  ca.itemsPerSlot = (uint32_t)itemsPerSlot;
+  for (int i = 0; i < 2; i++) {
+    ca.order[i] = (ctx->d_chain_order && ctx->chain_order_n == ca.tilesPerSlot) ? ctx->d_chain_order : nullptr;
+    ca.cost[i] = (ctx->d_chain_cost && ctx->chain_cost_n == ca.tilesPerSlot) ? ctx->d_chain_cost + (size_t)i * ctx->chain_cost_n : nullptr;
+  }
+  ca.error = ctx->d_chain_error;
+  ca.stats = nullptr;
+  if (ctx->d_chain_stats) {
+    ca.stats = ctx->d_chain_stats + (size_t)(seq % CH_STAT_LAUNCHES) * CH_STAT_WORDS;
+    unsigned long long init[CH_STAT_WORDS] = {};
+    init[CS_START_MIN] = init[CS_SAVAIL_MIN] = init[CS_STOP_MIN] = init[CS_PDONE_MIN] = init[CS_END_MIN] = init[CS_SDRY_MIN] = ~0ull; init[CS_SEQ] = seq;
+    FLX_HIP(ctx, hipMemcpyAsync(ca.stats, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));      /* (pageable: the copy is staged before the call returns) */
+  }
+  const uint32_t cusWalk = (ctx->comm && cus > 4u * FLX_COMM_RESERVED_CUS) ? cus - FLX_COMM_RESERVED_CUS : cus;      /* (a gathering rank leaves a few CUs to the exchange of the frame before) */
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
+  if (launch_chain(sc, fr, wb, ca, cusWalk, ctx->stream) != 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the chained frame kernel does not take this scene");
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
+  const size_t P1 = (size_t)frOne.rows * frOne.width;
+  launch_resolve(frOne, ctx->d_hits + (size_t)slotP * P1, ctx->d_samples + (size_t)slotP * P1, ctx->d_last + (size_t)slotP * P1, d_out, ctx->stream, 2u * P1);
+  FLX_HIP(ctx, hipGetLastError());
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
+  ctx->timed = true;
+  ctx->last_pipeline = 3; ctx->last_organisation = 4;
+  ctx->last_chained = continuing ? 2 : 1;
+  ctx->chain_seq = seq; ctx->chain_slot = slotP; ctx->chain_params = *params; ctx->chain_scene_version = ctx->scene_version;
+  return FLX_OK;
+}
+
 constexpr int NOT_GATHERED = -2;      /* frame_begin_on's `gather`: this context's own frame; -1: gathered on every rank; >= 0: on that rank */
-static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *params, int format, int gather, int *slot) {
+static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *params, int format, int gather, int *slot, bool chained = false) {
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
   flx_status s = flx_make_frame(ctx, params, sc, fr);
   if (s) return s;
+  if (!chained) { ctx->chain_seq = 0; ctx->last_chained = 0; }      /* (a frame of another kind ends the chain: its kernels share the workspace) */
   const bool gathered = gather != NOT_GATHERED;
   const bool receiver = !gathered || gather < 0 || gather == ctx->comm_rank;
   if (gathered) { fr.rows = receiver ? params->height : 0u; }      /* the slot holds the WHOLE frame on a rank that receives it, nothing elsewhere */
@@ -1220,6 +1369,8 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
   } else if (pixels) {
     if (params->use_filter || params->is_temporal) {
       s = run_post_frame(ctx, sc, fr, params, ctx->d_slot[k]);
+    } else if (chained) {
+      s = chain_run_frame(ctx, params, sc, fr, ctx->d_slot[k]);
     } else {
       GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
       s = flx_run_frame(ctx, sc, fr, ctx->d_slot[k], gb);
@@ -1245,6 +1396,71 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
 
 extern "C" int flx_frames_in_flight(const flx_context *ctx) { return ctx ? ctx->fifo_n : 0; }
 
+extern "C" flx_status flx_set_frame_chain(flx_context *ctx, int mode) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (mode != 0 && mode != 1) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: 0 (every frame its own launches) or 1 (consecutive frames of the loop overlap inside the frame kernel where it takes them)");
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: frames are in flight");
+  ctx->frame_chain = mode; ctx->chain_seq = 0;
+  return FLX_OK;
+}
+extern "C" flx_status flx_set_chain_stats(flx_context *ctx, int on) {
+  if (!ctx) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (on && !ctx->d_chain_stats) {
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_stats, (size_t)CH_STAT_LAUNCHES * CH_STAT_WORDS * sizeof(unsigned long long)));
+    FLX_HIP(ctx, hipMemset(ctx->d_chain_stats, 0, (size_t)CH_STAT_LAUNCHES * CH_STAT_WORDS * sizeof(unsigned long long)));
+  } else if (!on && ctx->d_chain_stats) { FLX_HIP(ctx, hipFree(ctx->d_chain_stats)); ctx->d_chain_stats = nullptr; }
+  return FLX_OK;
+}
+extern "C" flx_status flx_get_chain_stats(flx_context *ctx, uint64_t *out) {
+  if (!ctx || !out) return FLX_ERR_INVALID;
+  if (!ctx->d_chain_stats) return fail(ctx, FLX_ERR_INVALID, "flx_get_chain_stats: flx_set_chain_stats(ctx, 1) first");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FLX_HIP(ctx, hipMemcpy(out, ctx->d_chain_stats, (size_t)CH_STAT_LAUNCHES * CH_STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return FLX_OK;
+}
+/* diagnostics / experiments: an explicit order of the screen tiles of a chained frame (n = tiles of the frame, or 0: none), and per-tile shading counts */
+extern "C" flx_status flx_set_chain_order(flx_context *ctx, const uint32_t *order, uint32_t n) {
+  if (!ctx) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->chain_seq = 0;
+  if (ctx->d_chain_order) { FLX_HIP(ctx, hipFree(ctx->d_chain_order)); ctx->d_chain_order = nullptr; ctx->chain_order_n = 0; }
+  if (!order || n == 0u) return FLX_OK;
+  std::vector<uint8_t> seen(n, 0);
+  for (uint32_t i = 0; i < n; i++) { if (order[i] >= n || seen[order[i]]) return fail(ctx, FLX_ERR_INVALID, "flx_set_chain_order: not a permutation"); seen[order[i]] = 1; }
+  FLX_HIP(ctx, hipMalloc(&ctx->d_chain_order, (size_t)n * sizeof(uint32_t)));
+  FLX_HIP(ctx, hipMemcpy(ctx->d_chain_order, order, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  ctx->chain_order_n = n;
+  return FLX_OK;
+}
+extern "C" flx_status flx_set_chain_cost(flx_context *ctx, uint32_t n) {
+  if (!ctx) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->chain_seq = 0;
+  if (ctx->d_chain_cost) { FLX_HIP(ctx, hipFree(ctx->d_chain_cost)); ctx->d_chain_cost = nullptr; ctx->chain_cost_n = 0; }
+  if (n == 0u) return FLX_OK;
+  FLX_HIP(ctx, hipMalloc(&ctx->d_chain_cost, 2 * (size_t)n * sizeof(uint32_t)));
+  FLX_HIP(ctx, hipMemset(ctx->d_chain_cost, 0, 2 * (size_t)n * sizeof(uint32_t)));
+  ctx->chain_cost_n = n;
+  return FLX_OK;
+}
+extern "C" flx_status flx_get_chain_cost(flx_context *ctx, uint32_t *out /* [2 * n] */) {
+  if (!ctx || !out || !ctx->d_chain_cost) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  FLX_HIP(ctx, hipMemcpy(out, ctx->d_chain_cost, 2 * ctx->chain_cost_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return FLX_OK;
+}
+extern "C" flx_status flx_last_chained(flx_context *ctx, int *chained) {
+  if (!ctx || !chained) return FLX_ERR_INVALID;
+  *chained = ctx->last_chained;
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_set_frame_lanes(flx_context *ctx, int lanes) {
   if (!ctx) return FLX_ERR_INVALID;
   if (lanes != 1 && lanes != 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_lanes: 1 (frames one after the other) or 2 (two frames overlap on the GPU)");
@@ -1263,7 +1479,15 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
     if (ctx->frame_lanes == 2 && !ctx->comm_twin) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: the second lane has no communicator (contexts of a flx_group render through flx_group_render)");
   }
   flx_context *lane = ctx;
-  if (ctx->frame_lanes == 2 && !params->is_temporal && (ctx->lane_next & 1u)) {
+  bool chained = false;
+  if (gather == NOT_GATHERED) {
+    DeviceScene scT; DeviceFrame frT;
+    if (flx_make_frame(ctx, params, scT, frT) == FLX_OK && frT.rows != 0u) chained = chain_wanted(ctx, params, scT, frT);
+  }
+  if (chained) {
+    /* both frames in flight live in the primary context: make sure nothing of the second lane is (a frame of another kind just before) */
+    if (ctx->twin && ctx->fifo_n && ctx->fifo[ctx->fifo_n - 1].lane != ctx) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
+  } else if (ctx->frame_lanes == 2 && !params->is_temporal && (ctx->lane_next & 1u)) {
     FLX_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->twin) {
       flx_status s = flx_context_create(ctx->device, &ctx->twin);
@@ -1284,7 +1508,8 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
     lane = t;
   }
   int slot = 0;
-  flx_status s = frame_begin_on(lane, params, format, gather, &slot);
+  if (!chained && lane != ctx && ctx->chain_seq) { ctx->chain_seq = 0; ctx->last_chained = 0; }
+  flx_status s = frame_begin_on(lane, params, format, gather, &slot, chained);
   if (s) { if (lane != ctx) ctx->err = lane->err; return s; }
   ctx->fifo[ctx->fifo_n].lane = lane; ctx->fifo[ctx->fifo_n].slot = slot; ctx->fifo_n++;
   if (!params->is_temporal) ctx->lane_next++;
@@ -1314,6 +1539,18 @@ extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_
   FLX_HIP(ctx, hipEventSynchronize(lane->slot_host[k] ? lane->ev_slot_done[k] : lane->ev_slot_traced[k]));
   ctx->fifo[0] = ctx->fifo[1]; ctx->fifo_n--;
   lane->frames_ended++;
+  if (ctx->h_chain_error && __atomic_load_n(&ctx->h_chain_error[0], __ATOMIC_ACQUIRE) != 0u) {
+    /* a watchdog of the chained frame kernel tripped (flx_chain.h: CH_ERR_*): this frame, and whatever the kernel had worked ahead on, is not to be trusted */
+    const uint32_t bits = ctx->h_chain_error[0];
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->h_chain_error[0] = 0u;
+    ctx->chain_seq = 0;
+    (void)hipMemsetAsync(ctx->d_chain_rings, 0xff, (size_t)ctx->prop.multiProcessorCount * chain_rings_per_group() * sizeof(uint32_t), ctx->stream);
+    char msg[200];
+    snprintf(msg, sizeof msg, "device error in the chained frame kernel (bits 0x%x:%s%s%s%s): the frame is incomplete", bits, (bits & CH_ERR_SHADE_WATCHDOG) ? " shade-wave watchdog" : "",
+             (bits & CH_ERR_WALK_WATCHDOG) ? " walk-wave watchdog" : "", (bits & CH_ERR_LIST) ? " resume list overflow" : "", (bits & CH_ERR_LEFTOVER) ? " paths left behind" : "");
+    return fail(ctx, FLX_ERR_DEVICE, msg);
+  }
   if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, lane->ev_slot_start[k], lane->ev_slot_traced[k])); *gpu_ms = ms; }
   if (pixels) *pixels = lane->slot_host[k] ? lane->h_slot[k] : (const void *)lane->d_slot[k];
   if (bytes) *bytes = lane->slot_bytes[k];

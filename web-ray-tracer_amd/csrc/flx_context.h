@@ -12,6 +12,7 @@
 
 #include "flexlight_hip.h"
 #include "flx_kernels.h"
+#include "flx_chain.h"
 
 typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept out of this header */
 
@@ -128,6 +129,31 @@ struct flx_context {
   int fifo_n = 0;
   std::vector<float> h_lights, h_rotation, h_shift;      /* host copies of what changes per frame, for the twin's own buffers */
   uint64_t dyn_version = 0, twin_dyn_version = 0;
+  /* the chained frame loop (flx_chain.hip): consecutive frames of flx_frame_begin / _end overlap inside the persistent launch */
+  int frame_chain = 1;                           /* flx_set_frame_chain: 0 never, 1 where the frame loop's second lane would be used and the frame kernel takes the frame */
+  flx::ChainSlot *d_chain_slots = nullptr;       /* [2] */
+  flx::ChainMail *h_chain_mail = nullptr;        /* pinned host memory: the next frame's view is posted (plain stores) while the kernel runs */
+  flx::ChainMail *d_chain_mail = nullptr;        /* its device address */
+  flx::ChainMail *d_chain_relay = nullptr;       /* device memory: the post as the kernel's relaying waves pass it on to the other workgroups */
+  uint32_t *d_chain_lists = nullptr;             /* 6 resume lists (walk, shade, ready) x 2 slots, chain_list_cap entries each */
+  size_t chain_list_cap = 0;
+  uint32_t *d_chain_order = nullptr;             /* flx_set_chain_order: the order of a slot's screen tiles, or nullptr */
+  size_t chain_order_n = 0;
+  uint32_t *d_chain_cost = nullptr;              /* flx_set_chain_cost: 2 x chain_cost_n per-tile counts */
+  size_t chain_cost_n = 0;
+  float4 *d_chain_susp = nullptr;                /* 2 lists of walks suspended in flight, chain_susp_cap x CH_SUSP_F4 float4 each */
+  size_t chain_susp_cap = 0;
+  uint32_t *d_chain_rings = nullptr;             /* per workgroup CH_RINGS rings; all slots WF_INVALID between launches */
+  uint32_t *h_chain_error = nullptr;             /* pinned, device-mapped: watchdog trips of the chained kernels (device error word) */
+  uint32_t *d_chain_error = nullptr;             /* its device address */
+  unsigned long long *d_chain_stats = nullptr;   /* flx_set_chain_stats: CH_STAT_LAUNCHES x CH_STAT_WORDS diagnostics, by sequence number */
+  uint64_t chain_seq = 0;                        /* sequence number of the last chained frame begun (0: no chain stands) */
+  uint32_t chain_counter = 0;                    /* sequence numbers handed out (never 0) */
+  uint32_t chain_slot = 0;                       /* the slot of that frame */
+  flx_frame_params chain_params = {};            /* its shape: a frame continues the chain only with the same one */
+  uint64_t chain_scene_version = 0;              /* ... and the same scene */
+  uint64_t scene_version = 0;                    /* bumped by every upload */
+  int last_chained = 0;                          /* flx_last_chained: 0 the last frame of the loop was not chained, 1 it began a chain, 2 it continued one */
   /* uploads: capacity of every persistent scene buffer (keyed by the address of its pointer), pinned staging ring */
   std::map<void **, size_t> upload_capacity;
   uint8_t *stage = nullptr;

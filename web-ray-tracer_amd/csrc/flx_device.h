@@ -149,8 +149,14 @@ FLX_DEV f3 shift_at(const DeviceScene &sc, int i) { float4 s = sc.shift[i]; retu
 
 /* frame of the batch packed row k belongs to */
 FLX_DEV uint32_t frame_index(const DeviceFrame &fr, uint32_t k) { return fr.frames > 1u ? k / fr.frame_rows : 0u; }
-FLX_DEV f3 frame_camera(const DeviceFrame &fr, uint32_t f) { return F3(fr.view[f].camera[0], fr.view[f].camera[1], fr.view[f].camera[2]); }
-FLX_DEV f3 frame_ambient(const DeviceFrame &fr, uint32_t f) { return F3(fr.view[f].ambient[0], fr.view[f].ambient[1], fr.view[f].ambient[2]); }
+FLX_DEV f3 view_camera(const FrameView &v) { return F3(v.camera[0], v.camera[1], v.camera[2]); }
+FLX_DEV f3 view_ambient(const FrameView &v) { return F3(v.ambient[0], v.ambient[1], v.ambient[2]); }
+FLX_DEV f3 frame_camera(const DeviceFrame &fr, uint32_t f) { return view_camera(fr.view[f]); }
+FLX_DEV f3 frame_ambient(const DeviceFrame &fr, uint32_t f) { return view_ambient(fr.view[f]); }
+/* The views of a frame's batch: the kernel's arguments (LV = false) or a copy the kernel keeps in LDS (LV = true: the chained frame kernel, whose second
+ * frame's view arrives while it runs). */
+template <bool LV>
+FLX_DEV const FrameView &view_at(const DeviceFrame &fr, const FrameView *lv, uint32_t f) { if (LV) return lv[f]; else return fr.view[f]; }
 /* image row (0 = top, within its frame) of packed row k under the tile policy */
 FLX_DEV uint32_t image_row(const DeviceFrame &fr, uint32_t k) {
   if (fr.frames > 1u) k %= fr.frame_rows;
@@ -1244,14 +1250,17 @@ FLX_DEV bool bounce(const DeviceScene &sc, const DeviceFrame &fr, PixelState &ps
 }
 
 /* Primary ray of pixel (px, py_gl) of frame f of the batch: unit direction, NDC, view depth per unit s. */
-FLX_DEV f3 primary_dir(const DeviceFrame &fr, uint32_t f, uint32_t px, uint32_t py_gl, float &nx, float &ny, float &viewDepthPerS) {
+FLX_DEV f3 primary_dir_v(const DeviceFrame &fr, const FrameView &v, uint32_t px, uint32_t py_gl, float &nx, float &ny, float &viewDepthPerS) {
   nx = ((float)px + 0.5f) / (float)fr.width * 2.0f - 1.0f;
   ny = ((float)py_gl + 0.5f) / (float)fr.height * 2.0f - 1.0f;
-  const float *iv = fr.view[f].inv_view;
+  const float *iv = v.inv_view;
   f3 d = F3((iv[0] * nx + iv[1] * ny) + iv[2], (iv[3] * nx + iv[4] * ny) + iv[5], (iv[6] * nx + iv[7] * ny) + iv[8]);
   d = normalize(d);
-  viewDepthPerS = dot(F3(fr.view[f].view_row2[0], fr.view[f].view_row2[1], fr.view[f].view_row2[2]), d);
+  viewDepthPerS = dot(F3(v.view_row2[0], v.view_row2[1], v.view_row2[2]), d);
   return d;
+}
+FLX_DEV f3 primary_dir(const DeviceFrame &fr, uint32_t f, uint32_t px, uint32_t py_gl, float &nx, float &ny, float &viewDepthPerS) {
+  return primary_dir_v(fr, fr.view[f], px, py_gl, nx, ny, viewDepthPerS);
 }
 
 }  // namespace flx

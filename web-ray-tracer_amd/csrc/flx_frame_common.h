@@ -1,0 +1,272 @@
+/* flx_frame_common.h — what the shade kernels, the frame kernel (flx_wavefront.hip) and the chained frame kernel (flx_chain.hip) share: the
+ * kernel arguments read from the kernarg segment, the front of a frame for one screen tile, one path's shading, the rings of a workgroup. */
+#pragma once
+#include "flx_kernels.h"
+#include "flx_kernel_util.h"
+#include "flx_wavefront_common.h"
+
+namespace flx {
+
+#ifndef FLX_WF_WALK_THREADS
+#define FLX_WF_WALK_THREADS 1024
+#endif
+#ifndef FLX_WF_WAVES_PER_EU
+#define FLX_WF_WAVES_PER_EU 4               /* occupancy the register allocation of the walk kernels must allow */
+#endif
+#ifndef FLX_WF_LDS_TOTAL
+#define FLX_WF_LDS_TOTAL (156 * 1024)         /* LDS a walk workgroup may use (of 160 KB per CU) */
+#endif
+#ifndef FLX_WF_INNER
+#define FLX_WF_INNER 8
+#endif
+#ifndef FLX_WF_UNROLL
+#define FLX_WF_UNROLL 1
+#endif
+#ifndef FLX_WF_BATCH
+#define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
+#endif
+#ifndef FLX_WF_DRAWS_PER_WAVE
+#define FLX_WF_DRAWS_PER_WAVE 16
+#endif
+#ifndef FLX_FRAME_SHADERS_FRONT
+#define FLX_FRAME_SHADERS_FRONT 3           /* shade waves of a frame-kernel workgroup when they also make the fresh paths (WavefrontBuffers::front) */
+#endif
+#ifndef FLX_FRAME_PROLOGUE_WAVES
+#define FLX_FRAME_PROLOGUE_WAVES 2          /* walk waves that make a first tile before their loop (FRONT) */
+#endif
+#ifndef FLX_FRAME_READY_UNITS
+#define FLX_FRAME_READY_UNITS 32            /* front in the kernel: the most (tile, sample) units of 64 fresh paths a workgroup keeps ready (launch_wavefront: readyUnits) */
+#endif
+
+/* The arguments of the shade kernels and of the frame kernel (2.7 KB: the scene's pointers, the frame with its views, the work buffers) stay in the
+ * kernarg segment and are read where they are used, through a pointer the compiler cannot see through (an empty asm; the loads stay scalar loads):
+ * as by-value parameters every field was loaded at the kernel's entry and kept — in the frame kernel 262 scalar registers spilled into vector-register
+ * lanes around the stepping loop and 92 spilled vector registers (profiles/r04_resources.txt). */
+typedef const __attribute__((address_space(4))) FrameArgs *FrameArgsP;
+FLX_DEV const FrameArgs &frame_args(FrameArgsP p) { asm volatile("" : "+s"(p)); return *(const FrameArgs *)p; }
+FLX_DEV FrameArgsP kernel_frame_args() { return (FrameArgsP)__builtin_amdgcn_kernarg_segment_ptr(); }      /* the kernel's FIRST parameter is the FrameArgs: offset 0 */
+#define FLX_ARGS_OF(ab) const FrameArgs &A_ = frame_args(ab); const DeviceScene &sc = A_.sc; const DeviceFrame &fr = A_.fr; const WavefrontBuffers &wb = A_.wb; (void)sc; (void)fr; (void)wb
+
+/* Bounce 0: one lane per PIXEL.  All samples of a pixel share the primary hit (fragment:606-613), so everything the shading
+ * knows before it draws a random number — triangle and attribute fetch, normals, the acos / tan of the normal deviation,
+ * material (shadeSurface) — is computed once and the per-sample rest (shadeSample) runs `samples` times.  Every path gets the
+ * record the per-path kernel would have written, bit for bit. */
+/* (the lane's pixel of screen tile `tile`; h = its primary hit: suv + triangle id as bits, -1 for none; returns whether the pixel's paths run) */
+template <bool COUNT, bool LV = false>
+FLX_DEV bool shade0_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, float4 h, WorkCounters &cnt, const FrameView *lv = nullptr) {
+  uint32_t S, frameIdx;
+  int tri;
+  bool alive, compact;
+  f3 camera;
+  SurfaceCtx sf;
+  float ndcX = 0.0f, ndcY = 0.0f;
+  Hit hit;
+  {
+  FLX_ARGS_OF(ab);
+  S = (uint32_t)fr.samples;
+  uint32_t px, k;
+  tile8_pixel(fr, tile, lane, px, k);
+  const bool inFrame = px < fr.width && k < fr.rows;
+  frameIdx = inFrame ? frame_index(fr, k) : 0u;
+  camera = view_camera(view_at<LV>(fr, lv, frameIdx));
+  tri = inFrame ? __float_as_int(h.w) : -1;
+  /* loop guard of fragment:475 before the first bounce (importancy and originalColor are 1) */
+  alive = tri != -1 && fr.max_reflections > 0 && length(F3(1.0f, 1.0f, 1.0f) * F3(1.0f, 1.0f, 1.0f)) >= fr.min_importancy * SQRT3;
+  hit.suv = F3(h.x, h.y, h.z); hit.triangleId = tri; hit.transformId = 0;
+  compact = wb.rec0 != nullptr;
+  if (alive) {
+    hit.transformId = (int)sc.geometry[3 * tri + 2].y << 1;
+    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+    float viewDepthPerS;
+    Ray pr;
+    pr.origin = camera;
+    pr.dir = primary_dir_v(fr, view_at<LV>(fr, lv, frameIdx), px, py_gl, ndcX, ndcY, viewDepthPerS);
+    const WorkCounters before = cnt;
+    shadeSurface<COUNT>(sc, fr, hit, pr, camera, sf, cnt);
+    if (COUNT) {                                            /* the per-path kernel counts these once per path */
+      cnt.shades = before.shades + (cnt.shades - before.shades) * S;
+      cnt.atlas_texels = before.atlas_texels + (cnt.atlas_texels - before.atlas_texels) * S;
+    }
+  }
+  }
+  for (uint32_t s = 0; s < S; s++) {
+    FLX_ARGS_OF(ab);                                          /* (read again per sample: nothing of the arguments stays in registers across the loop) */
+    const uint32_t pathId = ((tile * S + s) << 6) | lane;
+    float4 *rec = wb.rec + (size_t)pathId * 8;
+    if (!alive) {
+      if (tri != -1) finalize_path<LV>(fr, wb, pathId, F3(0.0f, 0.0f, 0.0f), F3(1.0f, 1.0f, 1.0f), F3(1.0f, 1.0f, 1.0f), lv);
+      if (compact) wb.rec0[(size_t)pathId * 3] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD));
+      else rec[0] = make_float4(0.f, 0.f, 0.f, __int_as_float(RF_DEAD));
+      continue;
+    }
+    PathState p;
+    PixelState ps;
+    ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
+    ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+    ps.renderOriginalId = ps.renderId;
+    ps.ndc_x = ndcX; ps.ndc_y = ndcY;
+    ps.seed = view_at<LV>(fr, lv, frameIdx).random_seed;
+    ps.originalColor = F3(1.0f, 1.0f, 1.0f);
+    p.hit = hit;
+    p.lastHitPoint = camera;
+    p.dontFilter = true;
+    p.importancyFactor = F3(1.0f, 1.0f, 1.0f);
+    const float cosSampleN = flx_cos((float)s);
+    ShadeOut so;
+    shadeSample(sc, fr, sf, ps, p, camera, cosSampleN, 0, so);
+    const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0) |
+                      (nextBounceRuns(fr, 0, p.importancyFactor, ps.originalColor) ? 0 : RF_NO_CLOSEST);
+    if (compact) {
+      /* the per-pixel part is the same for every sample (sf is; importancy stays (1,1,1) while dontFilter holds, as it does
+       * on entry to bounce 0): written once */
+      if (s == 0u) {
+        float4 *pp = wb.pix0 + (((size_t)tile << 6) | lane) * 3;      /* [screen tile][lane]: what a path id gives without a division */
+        pp[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, 0.0f);
+        pp[1] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, 0.0f);
+        pp[2] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, so.baseLuminance.x);
+      }
+      float4 *r0 = wb.rec0 + (size_t)pathId * 3;
+      r0[0] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, __int_as_float(flags));
+      r0[1] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, so.shadowLen);
+      r0[2] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
+      continue;
+    }
+    rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
+    rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
+    rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
+    rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, __int_as_float(0));
+    rec[4] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
+    rec[5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
+    rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
+  }
+  return alive;
+}
+
+/* The primary ray of the lane's pixel of screen tile `tile` (what k_primary does for it, flx_kernels.hip): the wave walks the forward-ordered copy
+ * together.  -> suv + triangle id as bits (-1: no hit, or no pixel), also stored for k_resolve. */
+template <bool COUNT, bool LV = false>
+FLX_DEV float4 primary_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, WorkCounters &cnt, const FrameView *lv = nullptr) {
+  FLX_ARGS_OF(ab);
+  float4 *__restrict__ hits = const_cast<float4 *>(wb.hits);
+  uint32_t px, k;
+  tile8_pixel(fr, tile, lane, px, k);
+  const bool inImage = px < fr.width && k < fr.rows;
+  float nx, ny, viewDepthPerS = 0.0f;
+  Ray pr; pr.origin = F3(0.0f, 0.0f, 0.0f); pr.dir = F3(0.0f, 0.0f, 1.0f);
+  if (inImage) {
+    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+    const uint32_t frameIdx = frame_index(fr, k);
+    const FrameView &v = view_at<LV>(fr, lv, frameIdx);
+    pr.dir = primary_dir_v(fr, v, px, py_gl, nx, ny, viewDepthPerS);
+    pr.origin = view_camera(v);
+  }
+  const Hit hp = primaryWalkF(sc, inImage, pr, viewDepthPerS, cnt.primary_visits);
+  float4 h = make_float4(hp.suv.x, hp.suv.y, hp.suv.z, __int_as_float(inImage ? hp.triangleId : -1));
+  if (inImage) {
+    if (COUNT && hp.triangleId != -1) cnt.primary_hits++;
+    hits[(size_t)k * fr.width + px] = h;
+  }
+  return h;
+}
+
+/* One path's shading for its next bounce (fragment:476-589): the record the last walk left -> the record the next walk reads. */
+template <bool COUNT, bool LV = false>
+FLX_DEV void shade_path(FrameArgsP ab, uint32_t pathId, WorkCounters &cnt, const FrameView *lv = nullptr) {
+  FLX_ARGS_OF(ab);
+  float4 *rec = wb.rec + (size_t)pathId * 8;
+  uint32_t px, k, s;
+  item_pixel(fr, pathId, px, k, s);
+  const uint32_t frameIdx = frame_index(fr, k);
+  const f3 camera = view_camera(view_at<LV>(fr, lv, frameIdx));
+  PathState p;
+  PixelState ps;
+  ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
+  ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+  ps.renderOriginalId = ps.renderId;
+  const float4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q6 = rec[6], q7 = rec[7];
+  const int pb = __float_as_int(q3.w) + 1;            /* the bounce this path is at (its record carries the last one shaded) */
+  p.ray.origin = F3(q0.x, q0.y, q0.z);
+  p.lastHitPoint = p.ray.origin;                      /* fragment:595 */
+  p.ray.dir = F3(q1.x, q1.y, q1.z);
+  p.hit.suv = F3(q2.x, q2.y, q2.z);
+  p.hit.triangleId = __float_as_int(q2.w);
+  p.hit.transformId = (int)sc.geometry[3 * p.hit.triangleId + 2].y << 1;
+  p.dontFilter = (__float_as_int(q0.w) & RF_DONT_FILTER) != 0;
+  p.importancyFactor = F3(q6.x, q6.y, q6.z);
+  ps.originalColor = F3(q7.x, q7.y, q7.z);
+  const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+  float viewDepthPerS;
+  (void)primary_dir_v(fr, view_at<LV>(fr, lv, frameIdx), px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+  ps.seed = view_at<LV>(fr, lv, frameIdx).random_seed;
+  const float cosSampleN = flx_cos((float)s);
+  ShadeOut so;
+  bounceShade<COUNT>(sc, fr, ps, p, camera, cosSampleN, pb, so, cnt);
+  const int flags = (p.dontFilter ? RF_DONT_FILTER : 0) | (so.needShadow ? RF_NEED_SHADOW : 0) | (so.shadowedNoWalk ? RF_SHADOWED_NO_WALK : 0) |
+                    (nextBounceRuns(fr, pb, p.importancyFactor, ps.originalColor) ? 0 : RF_NO_CLOSEST);
+  rec[0] = make_float4(p.ray.origin.x, p.ray.origin.y, p.ray.origin.z, __int_as_float(flags));
+  rec[1] = make_float4(p.ray.dir.x, p.ray.dir.y, p.ray.dir.z, so.shadowLen);
+  rec[2] = make_float4(so.shadowRay.origin.x, so.shadowRay.origin.y, so.shadowRay.origin.z, so.baseLuminance.x);
+  rec[3] = make_float4(so.shadowRay.dir.x, so.shadowRay.dir.y, so.shadowRay.dir.z, __int_as_float(pb));
+  rec[4] = make_float4(so.litColor.x, so.litColor.y, so.litColor.z, 0.0f);
+  rec[6] = make_float4(p.importancyFactor.x, p.importancyFactor.y, p.importancyFactor.z, 0.0f);
+  rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
+}
+
+constexpr uint32_t FQ_SIZE = WF_FRAME_RING;   /* ids per ring (the rings live in HBM-backed memory private to the workgroup, their counts in LDS) */
+#ifndef FLX_FQ_LIMIT
+#define FLX_FQ_LIMIT 4096
+#endif
+constexpr uint32_t FQ_LIMIT = FLX_FQ_LIMIT; /* paths waiting for shading beyond which the walk waves stop drawing new ones (a policy: the shade waves are behind) */
+constexpr uint32_t FQ_ALIVE_MAX = FQ_SIZE - 256u;     /* live paths of a workgroup, enforced at every draw (the rings' capacity) */
+#ifndef FLX_FQ_WATCHDOG_LOG2
+#define FLX_FQ_WATCHDOG_LOG2 24
+#endif
+constexpr uint32_t FQ_WATCHDOG = 1u << FLX_FQ_WATCHDOG_LOG2;  /* polls (~500 cycles each) after which a wave that waits gives up: a seconds-long guard against a hung GPU, never reached by a frame */
+enum { FC_ALIVE = 0, FC_DRY = 1, FC_SQ = 2 /* tail, head, avail */, FC_WQ = 5 /* tail, head, avail */, FC_RQ = 8 /* tail, head, avail */, FC_FRONT_DONE = 11, FC_WORDS = 16 };
+#ifndef FLX_FRAME_READY_UNITS
+#define FLX_FRAME_READY_UNITS 32            /* front in the kernel: the most (tile, sample) units of 64 fresh paths a workgroup keeps ready (launch_wavefront: readyUnits) */
+#endif
+
+FLX_DEV uint32_t fq_load(uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+/* the lanes of `mine` append their `id` to the ring (ctl: tail, head, avail) */
+FLX_DEV void fq_push(uint32_t *ring, uint32_t *ctl, bool mine, uint32_t id, uint32_t lane) {
+  const unsigned long long m = flx_ballot(mine);
+  if (m == 0ull) return;
+  const uint32_t c = (uint32_t)__popcll(m);
+  uint32_t pos0 = 0;
+  if (lane == 0) pos0 = atomicAdd(&ctl[0], c);
+  pos0 = __builtin_amdgcn_readfirstlane(pos0);
+  if (mine) __hip_atomic_store(&ring[(pos0 + lane_rank(m)) & (FQ_SIZE - 1u)], id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          /* the path's record (plain global stores) and the slot, before the count */
+  if (lane == 0) atomicAdd(&ctl[2], c);
+}
+/* up to `want` ids (none unless at least `atLeast` are there) for the lanes of `takers`, lowest lanes first; returns how many (uniform) */
+FLX_DEV uint32_t fq_pop(uint32_t *ring, uint32_t *ctl, unsigned long long takers, uint32_t want, uint32_t atLeast, uint32_t lane, uint32_t &id) {
+  uint32_t n = 0, pos0 = 0;
+  if (lane == 0) {
+    uint32_t a = fq_load(&ctl[2]);
+    while (a != 0u && a >= atLeast) {
+      const uint32_t take = a < want ? a : want;
+      const uint32_t seen = atomicCAS(&ctl[2], a, a - take);
+      if (seen == a) { n = take; pos0 = atomicAdd(&ctl[1], take); break; }
+      a = seen;
+    }
+  }
+  n = __builtin_amdgcn_readfirstlane(n);
+  pos0 = __builtin_amdgcn_readfirstlane(pos0);
+  if (n == 0u) return 0u;
+  const uint32_t r = lane_rank(takers);
+  if (((takers >> lane) & 1ull) != 0ull && r < n) {
+    uint32_t *slot = &ring[(pos0 + r) & (FQ_SIZE - 1u)];
+    uint32_t v, spins = 0;
+    do { v = fq_load(slot); } while (v == WF_INVALID && ++spins < FQ_WATCHDOG);      /* (pushes are counted in the order they finish, not in slot order: the slot says when it is filled) */
+    __hip_atomic_store(slot, WF_INVALID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    id = v;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  return n;
+}
+
+
+}  // namespace flx

@@ -21,8 +21,9 @@ uint64_t path_item_count64(const DeviceFrame &fr);
 void launch_primary(const DeviceScene &sc, const DeviceFrame &fr, float4 *hits, unsigned long long *counters, hipStream_t stream);
 void launch_paths(const DeviceScene &sc, const DeviceFrame &fr, const float4 *hits, float4 *sampleRadiance, float4 *lastOriginal,
                   uint32_t *queue, uint32_t blocks, unsigned long long *counters, hipStream_t stream);
+/* sampleStride: float4 between the planes of two samples (0: the frame's own pixel count; the chained frame loop resolves one slot of a stacked workspace) */
 void launch_resolve(const DeviceFrame &fr, const float4 *hits, const float4 *sampleRadiance, const float4 *lastOriginal, float4 *out,
-                    hipStream_t stream);
+                    hipStream_t stream, size_t sampleStride = 0);
 /* pipeline 3 (flx_wavefront.hip): per bounce a dense shade kernel and a persistent walk kernel; path state in HBM. */
 constexpr int WF_MAX_BOUNCES = 250;
 struct WavefrontBuffers {
@@ -49,6 +50,8 @@ struct WavefrontBuffers {
   uint32_t *frameRings;         /* the frame kernel's rings of path ids: WF_FRAME_RINGS x WF_FRAME_RING per walk workgroup (k_wf_frame), or nullptr */
   uint32_t front;               /* frame kernel: 1 = it also traces the primary rays and shades bounce 0 (hits need not be there, item_base must be 0) */
 };
+/* the arguments of the shade kernels and the frame kernels, read from the kernarg segment where they are used (flx_frame_common.h) */
+struct FrameArgs { DeviceScene sc; DeviceFrame fr; WavefrontBuffers wb; };
 constexpr uint32_t WF_FRAME_RING = 16384;
 constexpr uint32_t WF_FRAME_RINGS = 3;       /* to shade, to walk, fresh (tile, sample) units */
 constexpr size_t WF_TAIL_POOL_F4 = 1024 * 8;

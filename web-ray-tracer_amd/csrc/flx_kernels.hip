@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
 /* fragment:608-632 for one pixel: add the samples in order, average, apply originalColor of the last
  * sample (the shader's global still holds it after the loop). */
 __global__ __launch_bounds__(256) void k_resolve(DeviceFrame fr, const float4 *__restrict__ hits, const float4 *__restrict__ sampleRadiance,
-                                                 const float4 *__restrict__ lastOriginal, float4 *__restrict__ out) {
+                                                 const float4 *__restrict__ lastOriginal, float4 *__restrict__ out, size_t sampleStride) {
   const size_t P = (size_t)fr.rows * fr.width;
   const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= P) return;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void k_resolve(DeviceFrame fr, const float4 *_
   if (__float_as_int(hits[o].w) != -1) {
     f3 finalColor = F3(0.0f, 0.0f, 0.0f);
     for (int s = 0; s < fr.samples; s++) {
-      const float4 r = sampleRadiance[(size_t)s * P + o];
+      const float4 r = sampleRadiance[(size_t)s * sampleStride + o];
       finalColor = finalColor + F3(r.x, r.y, r.z);
     }
     const float invSamples = 1.0f / (float)fr.samples;
@@ -363,9 +363,9 @@ void launch_paths(const DeviceScene &sc, const DeviceFrame &fr, const float4 *hi
 }
 
 void launch_resolve(const DeviceFrame &fr, const float4 *hits, const float4 *sampleRadiance, const float4 *lastOriginal, float4 *out,
-                    hipStream_t stream) {
+                    hipStream_t stream, size_t sampleStride) {
   const size_t P = (size_t)fr.rows * fr.width;
-  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((P + 255) / 256)), dim3(256), 0, stream, fr, hits, sampleRadiance, lastOriginal, out);
+  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)((P + 255) / 256)), dim3(256), 0, stream, fr, hits, sampleRadiance, lastOriginal, out, sampleStride ? sampleStride : P);
 }
 
 /* ---- diagnostics: include/flx_math.h on the device ------------------------------------------------ */

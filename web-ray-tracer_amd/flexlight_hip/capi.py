@@ -23,7 +23,7 @@ EXPORTS = [
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
     "flx_group_create", "flx_group_destroy", "flx_group_last_error", "flx_group_size", "flx_group_uses_rccl", "flx_group_context",
-    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag",
+    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag", "flx_set_frame_chain", "flx_last_chained", "flx_set_chain_stats", "flx_get_chain_stats", "flx_set_chain_order", "flx_set_chain_cost", "flx_get_chain_cost",
     "flx_render_gathered_root_device", "flx_comm_count", "flx_frame_begin_gathered", "flx_group_set_gather", "flx_frame_host_slots", "flx_has_experiments", "flx_set_wavefront_organisation", "flx_set_frame_front", "flx_last_organisation",
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
 ]
@@ -100,6 +100,13 @@ def _load():
         "flx_frame_end": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), fp]),
         "flx_frames_in_flight": (C.c_int, [vp]),
         "flx_set_frame_lanes": (C.c_int, [vp, C.c_int]),
+        "flx_set_frame_chain": (C.c_int, [vp, C.c_int]),
+        "flx_last_chained": (C.c_int, [vp, C.POINTER(C.c_int)]),
+        "flx_set_chain_stats": (C.c_int, [vp, C.c_int]),
+        "flx_get_chain_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+        "flx_set_chain_order": (C.c_int, [vp, C.POINTER(C.c_uint32), u32]),
+        "flx_set_chain_cost": (C.c_int, [vp, u32]),
+        "flx_get_chain_cost": (C.c_int, [vp, C.POINTER(C.c_uint32)]),
         "flx_comm_unique_id": (C.c_int, [C.c_char_p]),
         "flx_comm_init_rank": (C.c_int, [vp, C.c_char_p, C.c_int, C.c_int]),
         "flx_comm_destroy": (C.c_int, [vp]),
@@ -267,6 +274,42 @@ class Context:
     def set_frame_lanes(self, lanes):
         """2 (default): the frames in flight overlap on the GPU (two streams, two workspaces); 1: one after the other"""
         self._check(LIB.flx_set_frame_lanes(self._h, int(lanes)), "flx_set_frame_lanes")
+
+    def set_frame_chain(self, mode):
+        """1 (default): consecutive frames of the loop overlap inside one persistent launch where the frame kernel takes them (flx_chain.hip); 0: two lanes"""
+        self._check(LIB.flx_set_frame_chain(self._h, int(mode)), "flx_set_frame_chain")
+
+    def set_chain_stats(self, on):
+        self._check(LIB.flx_set_chain_stats(self._h, int(bool(on))), "flx_set_chain_stats")
+
+    def chain_stats(self):
+        """-> uint64 [64 launches, 48 words] (flx_chain.h: CS_*)"""
+        out = np.zeros((64, 48), np.uint64)
+        self._check(LIB.flx_get_chain_stats(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))), "flx_get_chain_stats")
+        return out
+
+    def set_chain_order(self, order):
+        """explicit order of a chained frame's screen tiles (a permutation; None: the default)"""
+        if order is None:
+            self._check(LIB.flx_set_chain_order(self._h, None, 0), "flx_set_chain_order")
+            return
+        o = np.ascontiguousarray(order, np.uint32)
+        self._check(LIB.flx_set_chain_order(self._h, o.ctypes.data_as(C.POINTER(C.c_uint32)), o.size), "flx_set_chain_order")
+
+    def set_chain_cost(self, n):
+        self._check(LIB.flx_set_chain_cost(self._h, int(n)), "flx_set_chain_cost")
+        self._chain_cost_n = int(n)
+
+    def chain_cost(self):
+        out = np.zeros((2, self._chain_cost_n), np.uint32)
+        self._check(LIB.flx_get_chain_cost(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32))), "flx_get_chain_cost")
+        return out
+
+    def last_chained(self):
+        """0 the last frame begun in the loop was not chained, 1 it began a chain, 2 it continued one"""
+        v = C.c_int()
+        self._check(LIB.flx_last_chained(self._h, C.byref(v)), "flx_last_chained")
+        return v.value
 
     def frame_begin(self, params, rgba8=False, device=False):
         self._pending = getattr(self, "_pending", [])
