@@ -17,11 +17,15 @@ id to the ranks and provides the barrier.  The frame is cut into strips of --til
 ranks: total work is fixed as N grows -> "scaling": "strong".  The gathered frame is verified against one
 context's frame (bit for bit) and the line says how it was exchanged and over how many RCCL ranks.
 
-Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of a frame — the walk kernel of bounce 0 — by the
-limit that binds it: VALU issue (wave-instructions per second against 256 CUs x 4 SIMDs x 1/2 per cycle x 2.4 GHz), from
-SQ_INSTS_VALU of a rocprofv3 --pmc pass THIS run makes over the same frame (tools/pmc_pass.py, before the parent touches
-the GPU), with the measured HBM traffic (FETCH_SIZE / WRITE_SIZE passes) and SURVEY.md 8d's algorithmic bytes beside it.
-`cpu_baseline` is the CPU oracle timed on this box's host cores on a bounded sample.
+Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of a frame — the frame kernel (k_wf_frame: the primary
+rays, every bounce's shading and every bounce walk of the frame in one persistent launch; k_trace_pixels / k_paths for the
+small scenes; `roofline.kernel` names it) — by the limit that binds it: VALU issue (wave-instructions per second against
+256 CUs x 4 SIMDs x 1/2 per cycle x 2.4 GHz), from SQ_INSTS_VALU of a rocprofv3 --pmc pass THIS run makes over the same frame
+(tools/pmc_pass.py, before the parent touches the GPU), with the measured HBM traffic (FETCH_SIZE / WRITE_SIZE passes) and
+SURVEY.md 8d's algorithmic bytes beside it.  `cpu_baseline` is the CPU oracle timed on this box's host cores on a bounded sample.
+
+Exit status: non-zero when a rank fails, when the ranks do not finish within --rank-timeout seconds (they are killed), or when
+the gathered frame differs from the single-context frame (the line is still printed, with the field false).
 """
 import argparse
 import csv
@@ -43,6 +47,15 @@ HBM_PEAK_GBS = 8000.0                 # /opt/skills/guides/MI355X_MICROARCH.md: 
 FP32_VECTOR_PEAK_TFLOPS = 157.3       # MI355X FP32 vector peak (same guide): 256 CUs x 4 SIMDs x 32 lanes x 2 flop x 2.4 GHz
 VALU_ISSUE_PEAK = 256 * 4 * 0.5 * 2.4e9      # wave64 VALU instructions per second: one per 2 cycles per SIMD (v_fma_f32 row of the guide) = 1.2288e12
 
+DATA = {      # what the frame is rendered from (no dataset is downloaded: the fixtures travel with the repo)
+    "dragon": "the reference's own scene arrays (tests/golden/ref_dragon.flxs.gz: what its scene.js emits for objects/dragon_lp.obj + the example's scene), BASELINE camera; no weights, no dataset",
+    "dragon_4k": "the reference's own scene arrays (tests/golden/ref_dragon.flxs.gz), BASELINE camera, 3840x2160",
+    "dragon_100k": "synthetic: dragon_lp.obj with every triangle split 1 -> 4 (tools/make_dragon_100k.py)",
+    "cornell_obj": "the reference's own scene arrays (tests/golden/ref_cornell_obj.flxs.gz)",
+    "cornell": "the reference's own scene arrays (tests/golden/ref_cornell.flxs.gz)",
+    "theater": "the reference's own scene arrays (tests/golden/ref_theater.flxs.gz: examples/theater.js with its three atlases)",
+}
+
 WORKLOADS = {
     # name: (scene fixture, BASELINE.json config it is[, width, height])
     "dragon": ("dragon", "configs[2]: dragon.obj (dragon_lp.obj, 73 694 entries) 1080p, 8 spp, 4 bounces"),
@@ -53,6 +66,8 @@ WORKLOADS = {
     "dragon_4k": ("dragon", "configs[3]: dragon.obj (dragon_lp.obj) 3840x2160, 8 spp, 4 bounces", 3840, 2160),
 }
 
+PMC_WARMUP_FRAMES = 2       # frames tools/pmc_pass.py renders before the ones that count (its --warmup)
+KT_FRAMES = 12              # frames of the kernel-trace pass
 PMC_PASSES = [      # separate rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do not fit one pass: MI355X_MICROARCH.md, PMC slots)
     ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY"],
     ["FETCH_SIZE"],
@@ -146,7 +161,7 @@ def collect_pmc(args, tile=None):
             i += 1
         # the kernels' average durations as rocprofv3's kernel trace sees them (beside the HIP-event time of the timed run)
         out = os.path.join(work, "kt")
-        kt_child = [c if c != "3" else "10" for c in child]
+        kt_child = [c if c != "3" else str(KT_FRAMES) for c in child]
         cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", sys.executable, os.path.join(ROOT, "tools", "pmc_pass.py")] + kt_child
         rc, err = _run_group(cmd, "/tmp", env, 420)
         files = glob.glob(os.path.join(out, "**", "*kernel_stats.csv"), recursive=True)
@@ -155,6 +170,21 @@ def collect_pmc(args, tile=None):
             with open(files[0]) as fh:
                 for row in csv.DictReader(fh):
                     acc.setdefault(clean(row["Name"]), {})["kernel_trace_avg_ms"] = float(row["AverageNs"]) / 1e6
+            # the same pass's per-dispatch trace: the summary's average includes the first launches (cold caches, code upload); the steady state is
+            # the dispatches after the program's warm-up frames — their median and minimum are what the timed steps see
+            for tf in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+                per = {}
+                with open(tf) as fh:
+                    for row in csv.DictReader(fh):
+                        try:
+                            per.setdefault(clean(row["Kernel_Name"]), []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"])))
+                        except (KeyError, ValueError):
+                            continue
+                for name, spans in per.items():
+                    spans.sort()
+                    steady = [(b - a) / 1e6 for a, b in spans[PMC_WARMUP_FRAMES * max(1, len(spans) // (PMC_WARMUP_FRAMES + KT_FRAMES)):]] or [(b - a) / 1e6 for a, b in spans]
+                    steady.sort()
+                    acc.setdefault(name, {}).update(kernel_trace_median_ms=steady[len(steady) // 2], kernel_trace_min_ms=steady[0], kernel_trace_dispatches=len(spans))
     finally:
         shutil.rmtree(work, ignore_errors=True)
     acc["_meta"] = {"commands": commands, "collected": "by this bench.py run, before its timed region, one frame per launch" + (" (rank 0's strips: tile %s)" % (tile,) if tile else "")}
@@ -183,8 +213,35 @@ def launch_ranks(args):
             env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-        out, _ = procs[0].communicate()
-        rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+        # rank 0's line is read by a thread; this process polls EVERY rank: the first one that fails, or the wall-clock limit, ends them all
+        # (fresh child processes are killed, nothing that has touched a GPU is re-executed)
+        import threading
+        chunks = []
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        deadline = time.time() + args.rank_timeout
+        failed = None
+        while any(p.poll() is None for p in procs):
+            bad = [r for r, p in enumerate(procs) if p.poll() not in (None, 0)]
+            if bad or time.time() > deadline:
+                failed = ("rank %d exited with %s" % (bad[0], procs[bad[0]].returncode)) if bad else ("the ranks did not finish within %d s" % args.rank_timeout)
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                t_kill = time.time() + 10
+                while any(p.poll() is None for p in procs) and time.time() < t_kill:
+                    time.sleep(0.1)
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.2)
+        reader.join(timeout=10)
+        out = b"".join(c for c in chunks if c)
+        rcs = [p.wait() for p in procs]
+        if failed:
+            sys.stderr.write("bench.py: %s; the remaining ranks were stopped\n" % failed)
+            rcs = [rc if rc else 1 for rc in rcs]
     finally:
         for p in procs:
             if p.poll() is None:
@@ -290,6 +347,7 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="rehearsal of the rank logic on a one-GPU box: every rank uses GPU 0 and the strips are gathered with torch.distributed (gloo) instead of RCCL, which refuses two ranks on one device")
     ap.add_argument("--verify", action="store_true", help="rank 0 renders the whole frame on its own after the run and compares the gathered frame with it, bit for bit (the default for N > 1)")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--rank-timeout", type=int, default=900, help="N > 1 launched by bench.py itself: seconds after which ranks still running are stopped and the run fails")
     ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: root = only rank 0, which presents the frame, receives the strips (ncclSend / ncclRecv; the reference presents from its one context); all = ncclAllGather, every rank ends up with the frame")
     args = ap.parse_args()
 
@@ -531,7 +589,7 @@ def main():
         line = {
             "metric": "Mray/s at 1080p (spp x bounces x pixels / s)", "value": value, "unit": "Mray/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": DATA[args.workload],
             "config": {
                 "workload": config_name, "width": W, "height": H, "spp": spp, "bounces": bounces, "filter": bool(use_filter),
                 "scene_entries": int(scene.meta["textureLength"]),
@@ -549,6 +607,8 @@ def main():
                 "survey_8d_frac": bytes_launch / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                 "survey_8d_frac_note": "SURVEY.md 8d's figure (48 B x entries visited / kernel time / 8 TB/s): not physical when it nears or exceeds 1 — the scene is LDS / L2 resident, the visits never reach HBM (hbm_measured is what does)",
                 "traffic": traffic, "kernel_ms": k_ms, "kernel_ms_rocprofv3_kernel_trace": k.get("kernel_trace_avg_ms"),
+                "kernel_ms_rocprofv3_steady": {"median": k.get("kernel_trace_median_ms"), "min": k.get("kernel_trace_min_ms"), "dispatches": k.get("kernel_trace_dispatches"),
+                                               "note": "the kernel trace's dispatches after tools/pmc_pass.py's %d warm-up frames, output left in device memory (the summary's average above includes the first launches)" % PMC_WARMUP_FRAMES},
                 "valu_insts_per_launch": valu, "valu_lane_utilisation": lane_util,
                 "hbm_measured": {"bytes_per_launch": traffic, "GBps": traffic / (k_ms * 1e-3) / 1e9 if traffic else None, "peak_GBps": HBM_PEAK_GBS,
                                  "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
@@ -588,6 +648,9 @@ def main():
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and verified is False:
+        sys.stderr.write("bench.py: the gathered frame differs from the single-context frame\n")
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

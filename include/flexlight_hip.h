@@ -190,6 +190,13 @@ flx_status flx_set_frame_lanes(flx_context *ctx, int lanes);
  * anything but camera / view matrix / ambient / seed from the one before, or follows a scene upload, starts a new chain (its kernel waits for the one
  * before as on one lane).  mode 0: the two lanes of flx_set_frame_lanes.  A watchdog trip inside the kernel makes flx_frame_end return FLX_ERR_DEVICE. */
 flx_status flx_set_frame_chain(flx_context *ctx, int mode);
+/* Device faults reach the status code.  The frame kernels' wait loops have watchdogs (seconds); a wave that gives up — or finds a ring slot that never
+ * fills — sets a bit in the context's device error word (pinned host memory), and the next call in which the host waits for frames (flx_render,
+ * flx_render_batch, flx_frame_end, flx_sync) returns FLX_ERR_DEVICE with the bits in flx_last_error and clears the word: the frame is incomplete.  A healthy
+ * frame never gets there; this hook forces it for tests: the next frames' kernels give up after `watchdog_polls` polls (0: the built-in limit) and, with
+ * FLX_INJECT_NO_SHADING, their shade waves drop every batch they pop, so that the walk waves wait for paths that never come back. */
+#define FLX_INJECT_NO_SHADING 1u
+flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog_polls, uint32_t flags);
 /* The last frame begun in the loop: 0 not chained, 1 it began a chain, 2 it continued one (the kernel before it could work ahead on it). */
 flx_status flx_last_chained(flx_context *ctx, int *chained);
 /* Diagnostics of the chained kernels (tools/chain_stats.py): 64 launches (by sequence number mod 64) x 32 words — when the launch started and ended, when the

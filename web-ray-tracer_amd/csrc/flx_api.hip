@@ -74,6 +74,9 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if ((e = hipEventCreate(&ctx->ev_frame1)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k0)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev_k1)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipHostMalloc((void **)&ctx->h_dev_error, 64, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess) return bail("hipHostMalloc", e);
+  ctx->h_dev_error[0] = 0u;
+  if ((e = hipHostGetDevicePointer((void **)&ctx->d_dev_error, ctx->h_dev_error, 0)) != hipSuccess) return bail("hipHostGetDevicePointer", e);
   if ((e = hipMalloc(&ctx->d_counters, FLX_COUNTER_SLOTS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(ctx->d_counters, 0, FLX_COUNTER_SLOTS * sizeof(unsigned long long))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipMalloc(&ctx->d_queue, sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
@@ -122,7 +125,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->h_chain_mail) (void)hipHostFree(ctx->h_chain_mail);
   for (void *b : { (void *)ctx->d_chain_slots, (void *)ctx->d_chain_relay, (void *)ctx->d_chain_lists, (void *)ctx->d_chain_rings, (void *)ctx->d_chain_stats, (void *)ctx->d_chain_susp, (void *)ctx->d_chain_order, (void *)ctx->d_chain_cost }) if (b) (void)hipFree(b);
-  if (ctx->h_chain_error) (void)hipHostFree(ctx->h_chain_error);
+  if (ctx->h_dev_error) (void)hipHostFree(ctx->h_dev_error);
 
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
@@ -472,6 +475,30 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, DeviceSce
   return FLX_OK;
 }
 
+
+/* Did a frame kernel's watchdog trip (WavefrontBuffers::error, ChainArgs::error)?  Asked wherever the host has just waited for frames: the frame that was
+ * being rendered — and whatever a chained kernel had worked ahead on — is incomplete.  Never reached by a healthy frame; tests force it (flx_debug_inject_fault). */
+flx_status flx_check_device_error(flx_context *ctx) {
+  flx_context *owner = ctx;
+  if (!owner->h_dev_error) return FLX_OK;
+  uint32_t bits = __atomic_load_n(&owner->h_dev_error[0], __ATOMIC_ACQUIRE);
+  if (ctx->twin && ctx->twin->h_dev_error) { bits |= __atomic_load_n(&ctx->twin->h_dev_error[0], __ATOMIC_ACQUIRE); }
+  if (bits == 0u) return FLX_OK;
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->twin) { (void)hipStreamSynchronize(ctx->twin->stream); ctx->twin->h_dev_error[0] = 0u; }
+  ctx->h_dev_error[0] = 0u;
+  ctx->chain_seq = 0;
+  /* the kernels' rings may hold ids nobody popped: back to "empty" for the next launch */
+  if (ctx->d_chain_rings) (void)hipMemsetAsync(ctx->d_chain_rings, 0xff, (size_t)ctx->prop.multiProcessorCount * chain_rings_per_group() * sizeof(uint32_t), ctx->stream);
+  for (flx_context *c : { ctx, ctx->twin })
+    if (c && c->d_frame_rings) (void)hipMemsetAsync(c->d_frame_rings, 0xff, (size_t)c->frame_rings_chains * c->prop.multiProcessorCount * WF_FRAME_RINGS * WF_FRAME_RING * sizeof(uint32_t), c->stream);
+  char msg[240];
+  snprintf(msg, sizeof msg, "device error in a frame kernel (bits 0x%x:%s%s%s%s%s): the frame is incomplete", bits, (bits & WF_ERR_SHADE_WATCHDOG) ? " shade-wave watchdog" : "",
+           (bits & WF_ERR_WALK_WATCHDOG) ? " walk-wave watchdog" : "", (bits & WF_ERR_LIST) ? " resume list overflow" : "", (bits & WF_ERR_LEFTOVER) ? " paths left behind" : "",
+           (bits & WF_ERR_RING_SLOT) ? " ring slot never filled" : "");
+  return flx_fail(ctx, FLX_ERR_DEVICE, msg);
+}
+
 flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels) {
   if (*cap >= pixels && *buf) return FLX_OK;
   if (*buf) { FLX_HIP(ctx, hipFree(*buf)); *buf = nullptr; *cap = 0; }
@@ -605,7 +632,14 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_wfcounts, 0, WF_MAX_GROUPS * 4 * (WF_MAX_ROUNDS + 2) * sizeof(uint32_t), ctx->stream));
     /* scratch of the walk kernel's tail consolidation and suspension: one slice per chain and possible walk workgroup */
     if (!ctx->d_tail_pool) FLX_HIP(ctx, hipMalloc(&ctx->d_tail_pool, (size_t)WF_MAX_GROUPS * cus * 8u * WF_TAIL_POOL_F4 * sizeof(float4)));
-    if (!ctx->d_frame_rings) FLX_HIP(ctx, hipMalloc(&ctx->d_frame_rings, (size_t)WF_MAX_GROUPS * cus * WF_FRAME_RINGS * WF_FRAME_RING * sizeof(uint32_t)));
+    /* the frame kernel's rings: one slice per chain that can run (48 MB each at 256 CUs), WF_INVALID everywhere — a launch leaves them so */
+    if (ctx->frame_rings_chains < wf_chains) {
+      if (ctx->d_frame_rings) { FLX_HIP(ctx, hipStreamSynchronize(ctx->stream)); FLX_HIP(ctx, hipFree(ctx->d_frame_rings)); ctx->d_frame_rings = nullptr; ctx->frame_rings_chains = 0; }
+      const size_t words = (size_t)wf_chains * cus * WF_FRAME_RINGS * WF_FRAME_RING;
+      FLX_HIP(ctx, hipMalloc(&ctx->d_frame_rings, words * sizeof(uint32_t)));
+      FLX_HIP(ctx, hipMemsetAsync(ctx->d_frame_rings, 0xff, words * sizeof(uint32_t), ctx->stream));
+      ctx->frame_rings_chains = wf_chains;
+    }
     /* Who traces the primary rays and shades bounce 0 (flx_set_frame_front; one chain, all of the frame in it — several chains keep the two kernels):
      * the frame kernel itself from FLX_FRONT_MIN_TILES_PER_CU screen tiles per workgroup on (the fresh paths of a tile stay with the workgroup that made them,
      * and a workgroup with a dozen tiles, a rank's eighth of a 1080p frame, may have drawn the dragon or the sky: tools/front_time.py, profiles/r03_ab_front.txt);
@@ -638,6 +672,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
       wb.frameRings = ctx->d_frame_rings + (size_t)g * cus * WF_FRAME_RINGS * WF_FRAME_RING;
       wb.front = front ? 1u : (fusedFront ? 2u : 0u);
+      wb.error = ctx->d_dev_error; wb.watchdog = ctx->inject_watchdog; wb.inject = ctx->inject_flags;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
       wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
@@ -652,6 +687,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       const int ran = launch_wavefront(sc, fr, wb, cusWalk, cnt != nullptr, ctx->walk_scheduler, ctx->walk_suspend, organisationNow,
                                        g == 0 ? ctx->ev_k0 : nullptr, g == 0 ? ctx->ev_k1 : nullptr, st);
       FLX_HIP(ctx, hipGetLastError());
+      if (ran == -2) return fail(ctx, FLX_ERR_DEVICE, "the walk kernels need 156 KB of dynamic LDS and hipFuncSetAttribute refused it on this device");
       if (ran < 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the frame kernel was to trace the primary rays but does not take this frame");
       ctx->last_organisation = ran;
       if (g > 0) {
@@ -1062,7 +1098,7 @@ extern "C" flx_status flx_render_batch(flx_context *ctx, const flx_frame_params 
     memcpy(counters, host_cnt, sizeof host_cnt);
     ctx->last_counters = *counters;
   }
-  return FLX_OK;
+  return flx_check_device_error(ctx);
 }
 
 /* ---- filter frames across GPUs: the trace is per pixel and shards by row strips, the denoise chain is not ---- */
@@ -1174,7 +1210,7 @@ extern "C" flx_status flx_render(flx_context *ctx, const flx_frame_params *param
     memcpy(counters, host_cnt, sizeof host_cnt);
     ctx->last_counters = *counters;
   }
-  return FLX_OK;
+  return flx_check_device_error(ctx);
 }
 
 /* ---- the frame loop: begin / end with two frames in flight (include/flexlight_hip.h) -------------------------------------
@@ -1234,9 +1270,6 @@ static flx_status chain_resources(flx_context *ctx, size_t itemsPerSlot) {
     FLX_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->d_chain_mail, ctx->h_chain_mail, 0));
     FLX_HIP(ctx, hipMalloc(&ctx->d_chain_relay, sizeof(ChainMail)));
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_chain_relay, 0, sizeof(ChainMail), ctx->stream));
-    FLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_chain_error, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    ctx->h_chain_error[0] = 0u;
-    FLX_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->d_chain_error, ctx->h_chain_error, 0));
     const size_t ringWords = (size_t)cus * chain_rings_per_group();
     FLX_HIP(ctx, hipMalloc(&ctx->d_chain_rings, ringWords * sizeof(uint32_t)));
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_chain_rings, 0xff, ringWords * sizeof(uint32_t), ctx->stream));      /* WF_INVALID everywhere; a kernel leaves them so */
@@ -1283,6 +1316,7 @@ static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *para
   WavefrontBuffers wb = {};
   wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
   wb.frameRings = ctx->d_chain_rings; wb.front = 1u;
+  wb.error = ctx->d_dev_error; wb.watchdog = 0u; wb.inject = 0u;
   wb.item_base = 0u; wb.item_count = (uint32_t)(2u * itemsPerSlot);
   wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = nullptr;
   ChainArgs ca = {};
@@ -1303,7 +1337,7 @@ static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *para
     ca.order[i] = (ctx->d_chain_order && ctx->chain_order_n == ca.tilesPerSlot) ? ctx->d_chain_order : nullptr;
     ca.cost[i] = (ctx->d_chain_cost && ctx->chain_cost_n == ca.tilesPerSlot) ? ctx->d_chain_cost + (size_t)i * ctx->chain_cost_n : nullptr;
   }
-  ca.error = ctx->d_chain_error;
+  ca.error = ctx->d_dev_error;
   ca.stats = nullptr;
   if (ctx->d_chain_stats) {
     ca.stats = ctx->d_chain_stats + (size_t)(seq % CH_STAT_LAUNCHES) * CH_STAT_WORDS;
@@ -1396,6 +1430,13 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
 
 extern "C" int flx_frames_in_flight(const flx_context *ctx) { return ctx ? ctx->fifo_n : 0; }
 
+extern "C" flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog_polls, uint32_t flags) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (flags & ~WF_INJECT_NO_SHADING) return fail(ctx, FLX_ERR_INVALID, "flx_debug_inject_fault: unknown flag");
+  ctx->inject_watchdog = watchdog_polls; ctx->inject_flags = flags;
+  if (ctx->twin) { ctx->twin->inject_watchdog = watchdog_polls; ctx->twin->inject_flags = flags; }
+  return FLX_OK;
+}
 extern "C" flx_status flx_set_frame_chain(flx_context *ctx, int mode) {
   if (!ctx) return FLX_ERR_INVALID;
   if (mode != 0 && mode != 1) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: 0 (every frame its own launches) or 1 (consecutive frames of the loop overlap inside the frame kernel where it takes them)");
@@ -1539,18 +1580,7 @@ extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_
   FLX_HIP(ctx, hipEventSynchronize(lane->slot_host[k] ? lane->ev_slot_done[k] : lane->ev_slot_traced[k]));
   ctx->fifo[0] = ctx->fifo[1]; ctx->fifo_n--;
   lane->frames_ended++;
-  if (ctx->h_chain_error && __atomic_load_n(&ctx->h_chain_error[0], __ATOMIC_ACQUIRE) != 0u) {
-    /* a watchdog of the chained frame kernel tripped (flx_chain.h: CH_ERR_*): this frame, and whatever the kernel had worked ahead on, is not to be trusted */
-    const uint32_t bits = ctx->h_chain_error[0];
-    (void)hipStreamSynchronize(ctx->stream);
-    ctx->h_chain_error[0] = 0u;
-    ctx->chain_seq = 0;
-    (void)hipMemsetAsync(ctx->d_chain_rings, 0xff, (size_t)ctx->prop.multiProcessorCount * chain_rings_per_group() * sizeof(uint32_t), ctx->stream);
-    char msg[200];
-    snprintf(msg, sizeof msg, "device error in the chained frame kernel (bits 0x%x:%s%s%s%s): the frame is incomplete", bits, (bits & CH_ERR_SHADE_WATCHDOG) ? " shade-wave watchdog" : "",
-             (bits & CH_ERR_WALK_WATCHDOG) ? " walk-wave watchdog" : "", (bits & CH_ERR_LIST) ? " resume list overflow" : "", (bits & CH_ERR_LEFTOVER) ? " paths left behind" : "");
-    return fail(ctx, FLX_ERR_DEVICE, msg);
-  }
+  { flx_status es = flx_check_device_error(ctx); if (es) return es; }
   if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, lane->ev_slot_start[k], lane->ev_slot_traced[k])); *gpu_ms = ms; }
   if (pixels) *pixels = lane->slot_host[k] ? lane->h_slot[k] : (const void *)lane->d_slot[k];
   if (bytes) *bytes = lane->slot_bytes[k];
@@ -1575,7 +1605,7 @@ extern "C" flx_status flx_sync(flx_context *ctx) {
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
-  return FLX_OK;
+  return flx_check_device_error(ctx);
 }
 
 extern "C" flx_status flx_set_stream(flx_context *ctx, void *hip_stream) {
@@ -1663,21 +1693,25 @@ extern "C" flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, c
   return FLX_OK;
 }
 
+struct DeviceScratch {                 /* a device buffer of a debug hook */
+  void *p = nullptr;
+  ~DeviceScratch() { if (p) (void)hipFree(p); }
+};
+
 extern "C" flx_status flx_debug_intersect(flx_context *ctx, int fn, const float *in, float *out, uint32_t n) {
   if (!ctx || !in || !out) return FLX_ERR_INVALID;
   if (fn < 0 || fn > 5) return fail(ctx, FLX_ERR_INVALID, "flx_debug_intersect: fn 0 .. 5");
   if (n == 0) return FLX_OK;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   const size_t nin = (size_t)n * ((fn == 2 || fn == 5) ? 13u : 16u), nout = (size_t)n * ((fn == 0 || fn == 3) ? 3u : 1u);
-  float *d_in = nullptr, *d_out = nullptr;
-  FLX_HIP(ctx, hipMalloc(&d_in, nin * 4));
-  FLX_HIP(ctx, hipMalloc(&d_out, nout * 4));
-  FLX_HIP(ctx, hipMemcpy(d_in, in, nin * 4, hipMemcpyHostToDevice));
-  launch_debug_intersect(fn, d_in, d_out, n, ctx->stream);
+  DeviceScratch d_in, d_out;                               /* freed on every way out */
+  FLX_HIP(ctx, hipMalloc(&d_in.p, nin * 4));
+  FLX_HIP(ctx, hipMalloc(&d_out.p, nout * 4));
+  FLX_HIP(ctx, hipMemcpy(d_in.p, in, nin * 4, hipMemcpyHostToDevice));
+  launch_debug_intersect(fn, (const float *)d_in.p, (float *)d_out.p, n, ctx->stream);
   FLX_HIP(ctx, hipGetLastError());
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  FLX_HIP(ctx, hipMemcpy(out, d_out, nout * 4, hipMemcpyDeviceToHost));
-  (void)hipFree(d_in); (void)hipFree(d_out);
+  FLX_HIP(ctx, hipMemcpy(out, d_out.p, nout * 4, hipMemcpyDeviceToHost));
   return FLX_OK;
 }
 
@@ -1692,17 +1726,16 @@ extern "C" flx_status flx_debug_walk(flx_context *ctx, int variant, const float 
   DeviceScene sc; DeviceFrame fr;
   flx_status st = flx_make_frame(ctx, &p, sc, fr);
   if (st != FLX_OK) return st;
-  float *d_in = nullptr, *d_out = nullptr;
-  FLX_HIP(ctx, hipMalloc(&d_in, (size_t)n * 7 * 4));
-  FLX_HIP(ctx, hipMalloc(&d_out, (size_t)n * 8 * 4));
-  FLX_HIP(ctx, hipMemcpy(d_in, rays, (size_t)n * 7 * 4, hipMemcpyHostToDevice));
-  const bool ok = launch_debug_walk(variant, sc, d_in, d_out, n, ctx->stream);
+  DeviceScratch d_in, d_out;                               /* freed on every way out */
+  FLX_HIP(ctx, hipMalloc(&d_in.p, (size_t)n * 7 * 4));
+  FLX_HIP(ctx, hipMalloc(&d_out.p, (size_t)n * 8 * 4));
+  FLX_HIP(ctx, hipMemcpy(d_in.p, rays, (size_t)n * 7 * 4, hipMemcpyHostToDevice));
+  const bool ok = launch_debug_walk(variant, sc, (const float *)d_in.p, (float *)d_out.p, n, ctx->stream);
   if (ok) {
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    FLX_HIP(ctx, hipMemcpy(out, d_out, (size_t)n * 8 * 4, hipMemcpyDeviceToHost));
+    FLX_HIP(ctx, hipMemcpy(out, d_out.p, (size_t)n * 8 * 4, hipMemcpyDeviceToHost));
   }
-  (void)hipFree(d_in); (void)hipFree(d_out);
   return ok ? FLX_OK : fail(ctx, FLX_ERR_INVALID, "flx_debug_walk: this scene does not have that walk (variant 2 needs the lockstep copy: at most 128 entries in one object space)");
 }
 

@@ -14,8 +14,8 @@ constexpr uint32_t CH_FRESH = 0x80000000u;     /* walk resume list: the path is 
 #define FLX_CHAIN_RESERVE_HOST FLX_CHAIN_RESERVE
 constexpr uint32_t CH_SUSP_F4 = 5;             /* float4 of state a walk suspended in flight takes to the next kernel */
 constexpr uint32_t CH_RINGS = 6;               /* rings of a chained workgroup: (to shade, to walk, fresh units) x (its own frame, the next one) */
-/* device error word of a slot (ChainSlot::error; flx_frame_end returns FLX_ERR_DEVICE) */
-constexpr uint32_t CH_ERR_SHADE_WATCHDOG = 1u, CH_ERR_WALK_WATCHDOG = 2u, CH_ERR_LIST = 4u, CH_ERR_LEFTOVER = 8u;
+/* bits of the context's device error word (flx_kernels.h: WF_ERR_*) */
+constexpr uint32_t CH_ERR_SHADE_WATCHDOG = WF_ERR_SHADE_WATCHDOG, CH_ERR_WALK_WATCHDOG = WF_ERR_WALK_WATCHDOG, CH_ERR_LIST = WF_ERR_LIST, CH_ERR_LEFTOVER = WF_ERR_LEFTOVER;
 
 /* One of the two frame slots of a chain, in device memory; zeroed in stream order when the slot is recycled for a new frame. */
 struct ChainSlot {

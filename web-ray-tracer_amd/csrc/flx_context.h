@@ -20,6 +20,9 @@ typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept 
 #define FLX_WF_GROUPS 1      /* measured on MI355X: 2-4 concurrent chains are slower than one (profiles/r01_ab_stream_groups.txt) */
 #endif
 constexpr int WF_MAX_GROUPS = 4;
+#ifndef FLX_FRAME_CHAIN_DEFAULT
+#define FLX_FRAME_CHAIN_DEFAULT 0      /* flx_set_frame_chain's default */
+#endif
 constexpr int FLX_COUNTER_SLOTS = 80;          /* 8 work counters + 32 scheduler diagnostics (flx_get_diag) + 40 tail profile (flx_get_tail_diag) */
 constexpr uint32_t WF_STRAG_MAX = 512;         /* most walks a walk workgroup can suspend */
 
@@ -38,7 +41,8 @@ struct flx_context {
   uint32_t fwd_entries = 0, fwd_root = 0, lock_boxes = 0;
   int last_organisation = 0;                     /* flx_last_organisation: what launch_wavefront ran for the last frame (0: another pipeline) */
   int frame_front = 1;                           /* flx_set_frame_front: the frame kernel traces the primary rays and shades bounce 0 itself (0 two kernels in front, 1 automatic, 2 inside wherever the frame kernel runs, 3 one kernel in front) */
-  uint32_t *d_frame_rings = nullptr;             /* k_wf_frame: per chain and workgroup two rings of WF_FRAME_RING path ids */
+  uint32_t *d_frame_rings = nullptr;             /* k_wf_frame: per chain and workgroup three rings of WF_FRAME_RING path ids */
+  int frame_rings_chains = 0;                    /* chains it has slices for */
   int wf_organisation = 0;                       /* wavefront pipeline: 0 automatic, 1 rounds, 2 frame kernel (flx_set_wavefront_organisation) */
   bool lock_ok = false;                          /* the scene is small and in one object space: its bounce walks may go in lockstep */
   bool lock_use = true;                          /* flx_set_lockstep */
@@ -91,6 +95,9 @@ struct flx_context {
   int wf_groups = FLX_WF_GROUPS;                 /* wavefront pipeline: independent item groups on separate streams (tails of one overlap the other) */
   hipStream_t aux_stream[3] = { nullptr, nullptr, nullptr };
   hipEvent_t ev_fork = nullptr, ev_join[3] = { nullptr, nullptr, nullptr };
+  /* device error word: pinned, device-mapped; a frame kernel's watchdog that trips sets WF_ERR_* bits in it and the host returns FLX_ERR_DEVICE where it next waits */
+  uint32_t *h_dev_error = nullptr, *d_dev_error = nullptr;
+  uint32_t inject_watchdog = 0, inject_flags = 0; /* flx_debug_inject_fault */
   unsigned long long *d_counters = nullptr;
   bool counters_enabled = false;
   flx_counters last_counters = {};
@@ -130,7 +137,7 @@ struct flx_context {
   std::vector<float> h_lights, h_rotation, h_shift;      /* host copies of what changes per frame, for the twin's own buffers */
   uint64_t dyn_version = 0, twin_dyn_version = 0;
   /* the chained frame loop (flx_chain.hip): consecutive frames of flx_frame_begin / _end overlap inside the persistent launch */
-  int frame_chain = 1;                           /* flx_set_frame_chain: 0 never, 1 where the frame loop's second lane would be used and the frame kernel takes the frame */
+  int frame_chain = FLX_FRAME_CHAIN_DEFAULT;                           /* flx_set_frame_chain: 0 never, 1 where the frame loop's second lane would be used and the frame kernel takes the frame */
   flx::ChainSlot *d_chain_slots = nullptr;       /* [2] */
   flx::ChainMail *h_chain_mail = nullptr;        /* pinned host memory: the next frame's view is posted (plain stores) while the kernel runs */
   flx::ChainMail *d_chain_mail = nullptr;        /* its device address */
@@ -144,8 +151,7 @@ struct flx_context {
   float4 *d_chain_susp = nullptr;                /* 2 lists of walks suspended in flight, chain_susp_cap x CH_SUSP_F4 float4 each */
   size_t chain_susp_cap = 0;
   uint32_t *d_chain_rings = nullptr;             /* per workgroup CH_RINGS rings; all slots WF_INVALID between launches */
-  uint32_t *h_chain_error = nullptr;             /* pinned, device-mapped: watchdog trips of the chained kernels (device error word) */
-  uint32_t *d_chain_error = nullptr;             /* its device address */
+
   unsigned long long *d_chain_stats = nullptr;   /* flx_set_chain_stats: CH_STAT_LAUNCHES x CH_STAT_WORDS diagnostics, by sequence number */
   uint64_t chain_seq = 0;                        /* sequence number of the last chained frame begun (0: no chain stands) */
   uint32_t chain_counter = 0;                    /* sequence numbers handed out (never 0) */
@@ -183,6 +189,7 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, flx::Devi
 flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, flx::DeviceScene &sc, flx::DeviceFrame &fr);
 flx_status flx_run_frame(flx_context *ctx, const flx::DeviceScene &sc, const flx::DeviceFrame &fr, float4 *d_out, const flx::GBufferPtrs &gb);
 flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels);
+flx_status flx_check_device_error(flx_context *ctx);      /* FLX_ERR_DEVICE (and the word cleared) if a frame kernel's watchdog has tripped since the last check */
 /* flx_filter_planes_device; stamp_start = false leaves the frame's start event alone (the trace of the same frame recorded it) */
 flx_status flx_filter_planes_enqueue(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba, bool stamp_start);
 

@@ -49,10 +49,16 @@ struct WavefrontBuffers {
   float4 *rec0, *pix0;
   uint32_t *frameRings;         /* the frame kernel's rings of path ids: WF_FRAME_RINGS x WF_FRAME_RING per walk workgroup (k_wf_frame), or nullptr */
   uint32_t front;               /* frame kernel: 1 = it also traces the primary rays and shades bounce 0 (hits need not be there, item_base must be 0) */
+  uint32_t *error;              /* the context's device error word (pinned host memory, WF_ERR_* bits), or nullptr: a watchdog that trips says so here (flx_status FLX_ERR_DEVICE at the next point the host waits) */
+  uint32_t watchdog;            /* frame kernels: polls after which a wave that waits gives up (0: FQ_WATCHDOG, seconds); fault injection sets it low */
+  uint32_t inject;              /* fault injection (flx_debug_inject_fault): WF_INJECT_* */
 };
 /* the arguments of the shade kernels and the frame kernels, read from the kernarg segment where they are used (flx_frame_common.h) */
 struct FrameArgs { DeviceScene sc; DeviceFrame fr; WavefrontBuffers wb; };
 constexpr uint32_t WF_FRAME_RING = 16384;
+/* device error word: who gave up */
+constexpr uint32_t WF_ERR_SHADE_WATCHDOG = 1u, WF_ERR_WALK_WATCHDOG = 2u, WF_ERR_LIST = 4u, WF_ERR_LEFTOVER = 8u, WF_ERR_RING_SLOT = 16u;
+constexpr uint32_t WF_INJECT_NO_SHADING = 1u;      /* the shade waves of a frame kernel drop what they pop: the paths never come back and the walk waves' watchdog must trip */
 constexpr uint32_t WF_FRAME_RINGS = 3;       /* to shade, to walk, fresh (tile, sample) units */
 constexpr size_t WF_TAIL_POOL_F4 = 1024 * 8;
 constexpr uint32_t WF_STRAG_F4 = 5;
@@ -65,7 +71,8 @@ size_t wavefront_live_capacity(const DeviceFrame &fr, uint32_t compute_units);
  * hand paths to each other through LDS rings, no barrier between bounces) where the scene's transforms leave room in LDS, else
  * rounds; 1 = rounds (one k_wf_shade + k_wf_walk_pre pair per bounce); 2 = the frame kernel (rounds if it does not fit). */
 bool wavefront_front_in_kernel(const DeviceScene &sc, const DeviceFrame &fr, uint32_t item_count, int walk_scheduler, uint32_t suspend_max, int organisation);
-/* -> what ran: 1 rounds, 2 the frame kernel, 3 the frame kernel with the front of the frame inside it; -1: wb.front set but the frame kernel cannot run */
+/* -> what ran: 1 rounds, 2 the frame kernel, 3 the frame kernel with the front of the frame inside it; -1: wb.front set but the frame kernel cannot run; -2: the walk
+ * kernels' dynamic LDS limit could not be raised on this device */
 int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t compute_units, bool count,
                      int walk_scheduler, uint32_t suspend_max, int organisation, hipEvent_t walk0_begin, hipEvent_t walk0_end, hipStream_t stream);
 /* denoise chain (flx_filter.hip): 13 RGBA8 planes = the reference's RenderTexture[0..3], IpRenderTexture[0..3],

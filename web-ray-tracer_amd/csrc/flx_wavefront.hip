@@ -32,6 +32,7 @@
  * the primary rays and shade bounce 0 themselves (k_wf_frame<COUNT, true>: dragon 1080p 6.83 -> 6.40 ms).
  */
 #include <atomic>
+#include <mutex>
 #include <cstdio>
 #include "flx_kernels.h"
 #include "flx_kernel_util.h"
@@ -873,7 +874,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     }
   }
   if (threadIdx.x < (uint32_t)FC_WORDS) ctl[threadIdx.x] = 0u;
-  for (uint32_t t = threadIdx.x; t < WF_FRAME_RINGS * FQ_SIZE; t += FLX_WF_WALK_THREADS) shadeRing[t] = WF_INVALID;
+  /* (the rings are WF_INVALID everywhere when the launch begins: allocated so, and a launch clears every slot it pops — flx_api.hip re-initialises them after a device error) */
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
@@ -940,7 +941,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       }
       if (got == 0u) {
         if (dry && fq_load(&ctl[FC_ALIVE]) == 0u) break;
-        if (++idle > FQ_WATCHDOG) {                               /* never in a healthy frame; counted builds leave the control words behind (flx_get_tail_diag) */
+        if (++idle > (wb.watchdog ? wb.watchdog : FQ_WATCHDOG)) {   /* never in a healthy frame: the host is told (WavefrontBuffers::error); counted builds also leave the control words behind (flx_get_tail_diag) */
+          if (lane == 0 && wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_SHADE_WATCHDOG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           if (COUNT && lane == 0) { for (uint32_t k = 0; k < 8u; k++) atomicMax(wb.counters + 40 + k, (unsigned long long)fq_load(&ctl[k]) + 1ull); atomicAdd(wb.counters + 48, 1ull); }
           break;
         }
@@ -949,6 +951,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       }
       idle = 0;
       const bool mine = lane < got && id != WF_INVALID;
+      if (flx_ballot(lane < got && id == WF_INVALID) != 0ull && lane == 0 && wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_RING_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      /* (a slot that never filled: fq_pop gave up on it) */
+      if (wb.inject & WF_INJECT_NO_SHADING) continue;         /* fault injection: the batch is dropped */
       if (mine) shade_path<COUNT>(argBase, id, cnt);
       fq_push(walkRing, ctl + FC_WQ, mine, id, lane);
     }
@@ -1060,6 +1064,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             uint32_t unit = WF_INVALID;
             if (fq_pop(readyRing, ctl + FC_RQ, 1ull, 1u, 1u, lane, unit) == 0u) break;
             unit = __builtin_amdgcn_readfirstlane(unit);
+            if (unit == WF_INVALID) {                          /* the slot never filled (fq_pop's own watchdog): no unit, its 64 paths are written off, the host is told */
+              if (lane == 0) { atomicSub(&ctl[FC_ALIVE], 64u); if (wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_RING_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+              break;
+            }
             chunkNext = unit << 6; chunkEnd = chunkNext + 64u;
           } else if (chunkNext == chunkEnd) {
             if (!itemsLeft) break;
@@ -1161,8 +1169,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         } else if (!itemsLeft && chunkNext == chunkEnd && fq_load(&ctl[FC_ALIVE]) == 0u) break;
         if (fq_load(&ctl[FC_WQ + 2]) == 0u && (front ? (fq_load(&ctl[FC_RQ + 2]) == 0u || fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT)
                                                      : !(itemsLeft && fq_load(&ctl[FC_SQ + 2]) < FQ_LIMIT && fq_load(&ctl[FC_ALIVE]) + 256u <= FQ_ALIVE_MAX))) {
-          if (++idleSpins > FQ_WATCHDOG) {
-            FLX_FRAME_ARGS();
+          FLX_FRAME_ARGS();
+          if (++idleSpins > (wb.watchdog ? wb.watchdog : FQ_WATCHDOG)) {
+            if (lane == 0 && wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_WALK_WATCHDOG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (COUNT && lane == 0) { for (uint32_t k = 0; k < 8u; k++) atomicMax(wb.counters + 50 + k, (unsigned long long)fq_load(&ctl[k]) + 1ull); atomicAdd(wb.counters + 58, 1ull); }
             break;
           }
@@ -1210,13 +1219,18 @@ static bool frame_kernel_fits(const DeviceScene &sc, bool withFront, uint32_t &l
 
 /* A kernel's dynamic-LDS limit (hipFuncSetAttribute) belongs to the device it is set on: once per device and kernel family, whichever context launches there
  * first (a group of contexts on several GPUs lives in one process). */
-static bool first_launch_on_this_device(int family) {
-  static std::atomic<uint64_t> done[2];
+/* (A second host thread that launches on the same device — another context, a twin driven from another thread — waits until the attributes are set; a
+ * limit that cannot be raised is remembered and the launch refused, so that the caller falls back or reports it.) */
+template <typename SetAttributes>
+static bool dynamic_lds_ready(int family, SetAttributes set) {
+  static std::once_flag once[2][64];
+  static bool ok[2][64];
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-  const uint64_t bit = 1ull << dev;
-  return (done[family].fetch_or(bit) & bit) == 0ull;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::call_once(once[family][dev], [&]() { ok[family][dev] = set(); });
+  return ok[family][dev];
 }
+static bool set_lds_limit(const void *kernel) { return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; }
 
 /* Will launch_wavefront run these items as ONE frame kernel? */
 static bool frame_kernel_wanted(const DeviceScene &sc, const DeviceFrame &fr, uint32_t item_count, int walk_scheduler, uint32_t suspend_max, int organisation,
@@ -1248,13 +1262,11 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
   /* ---- one persistent launch for the whole bounce loop (k_wf_frame), where it fits ---- */
   {
     uint32_t ldsCountF = 0, ldsBytesF = 0;
-    if (wb.frameRings != nullptr && frame_kernel_wanted(sc, fr, wb.item_count, walk_scheduler, suspend_max, organisation, wb.front != 0u, ldsCountF, ldsBytesF)) {
-      if (first_launch_on_this_device(0)) {
-        (void)hipFuncSetAttribute((const void *)k_wf_frame<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_wf_frame<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_wf_frame<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)k_wf_frame<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      }
+    if (wb.frameRings != nullptr && frame_kernel_wanted(sc, fr, wb.item_count, walk_scheduler, suspend_max, organisation, wb.front != 0u, ldsCountF, ldsBytesF) &&
+        dynamic_lds_ready(0, []() {
+          return (int)set_lds_limit((const void *)k_wf_frame<true, false>) & (int)set_lds_limit((const void *)k_wf_frame<false, false>) &
+                 (int)set_lds_limit((const void *)k_wf_frame<true, true>) & (int)set_lds_limit((const void *)k_wf_frame<false, true>);
+        })) {
       const uint32_t total = wb.item_count;
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);
       const uint32_t shadeBlocks = (pixels + 255u) / 256u;
@@ -1299,14 +1311,12 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
   uint32_t perCu = (160u * 1024u) / (ldsBytes > 20480u ? ldsBytes : 20480u);
   if (perCu > 8u) perCu = 8u;
   const uint32_t walkBlocks = compute_units * perCu;
-  if (first_launch_on_this_device(1)) {
-    (void)hipFuncSetAttribute((const void *)k_wf_walk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_wf_walk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_wf_walk_pre<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  }
+  if (!dynamic_lds_ready(1, []() {
+        int ok = 1;
+        for (const void *k : { (const void *)k_wf_walk<true>, (const void *)k_wf_walk<false>, (const void *)k_wf_walk_pre<true, true>, (const void *)k_wf_walk_pre<false, true>,
+                               (const void *)k_wf_walk_pre<true, false>, (const void *)k_wf_walk_pre<false, false> }) ok &= (int)set_lds_limit(k);
+        return ok != 0;
+      })) return -2;                                    /* the walk kernels cannot have their LDS on this device */
   const int bounces = fr.max_reflections > 0 ? fr.max_reflections : 1;   /* 0 bounces: shade(0) only finalises */
   /* Suspension needs the kernel that can take a walk up again (k_wf_walk_pre), at least two bounces to gain anything, and
    * as many extra rounds as a path can be held up: one per regular round.  The extra rounds find their lists empty

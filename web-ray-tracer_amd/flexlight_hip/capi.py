@@ -23,7 +23,7 @@ EXPORTS = [
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
     "flx_group_create", "flx_group_destroy", "flx_group_last_error", "flx_group_size", "flx_group_uses_rccl", "flx_group_context",
-    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag", "flx_set_frame_chain", "flx_last_chained", "flx_set_chain_stats", "flx_get_chain_stats", "flx_set_chain_order", "flx_set_chain_cost", "flx_get_chain_cost",
+    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag", "flx_set_frame_chain", "flx_last_chained", "flx_debug_inject_fault", "flx_set_chain_stats", "flx_get_chain_stats", "flx_set_chain_order", "flx_set_chain_cost", "flx_get_chain_cost",
     "flx_render_gathered_root_device", "flx_comm_count", "flx_frame_begin_gathered", "flx_group_set_gather", "flx_frame_host_slots", "flx_has_experiments", "flx_set_wavefront_organisation", "flx_set_frame_front", "flx_last_organisation",
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
 ]
@@ -102,6 +102,7 @@ def _load():
         "flx_set_frame_lanes": (C.c_int, [vp, C.c_int]),
         "flx_set_frame_chain": (C.c_int, [vp, C.c_int]),
         "flx_last_chained": (C.c_int, [vp, C.POINTER(C.c_int)]),
+        "flx_debug_inject_fault": (C.c_int, [vp, u32, u32]),
         "flx_set_chain_stats": (C.c_int, [vp, C.c_int]),
         "flx_get_chain_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_set_chain_order": (C.c_int, [vp, C.POINTER(C.c_uint32), u32]),
@@ -279,6 +280,10 @@ class Context:
         """1 (default): consecutive frames of the loop overlap inside one persistent launch where the frame kernel takes them (flx_chain.hip); 0: two lanes"""
         self._check(LIB.flx_set_frame_chain(self._h, int(mode)), "flx_set_frame_chain")
 
+    def inject_fault(self, watchdog_polls=0, flags=0):
+        """tests: the next frames' frame kernels give up after `watchdog_polls` polls; flags 1 = their shade waves drop every batch"""
+        self._check(LIB.flx_debug_inject_fault(self._h, int(watchdog_polls), int(flags)), "flx_debug_inject_fault")
+
     def set_chain_stats(self, on):
         self._check(LIB.flx_set_chain_stats(self._h, int(bool(on))), "flx_set_chain_stats")
 
@@ -320,8 +325,10 @@ class Context:
         """-> (pixels [rows, W, 4] float32 or uint8: a COPY of the pinned buffer — or, for a frame begun with device=True, the
         device pointer of float4[rows][W] —, GPU ms of the frame)"""
         ptr, n, ms = C.c_void_p(), C.c_size_t(), C.c_float()
-        self._check(LIB.flx_frame_end(self._h, C.byref(ptr), C.byref(n), C.byref(ms)), "flx_frame_end")
-        rows, width, rgba8, device = self._pending.pop(0)
+        rc = LIB.flx_frame_end(self._h, C.byref(ptr), C.byref(n), C.byref(ms))
+        if rc != 1 or self._pending:           # (FLX_ERR_INVALID with nothing in flight took no frame)
+            rows, width, rgba8, device = self._pending.pop(0) if self._pending else (0, 0, False, False)
+        self._check(rc, "flx_frame_end")
         if device:
             return ptr.value, ms.value
         dt = np.uint8 if rgba8 else np.float32
