@@ -15,6 +15,7 @@ ap.add_argument("--frames", type=int, default=12)
 ap.add_argument("--size", default="")
 ap.add_argument("--time-frames", type=int, default=200)
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--lanes", type=int, default=2, help="frames in flight (3: only the chained loop holds three)")
 a = ap.parse_args()
 sc = Scene.golden("dragon")
 size = dict(width=3840, height=2160) if a.workload == "dragon_4k" else {}
@@ -22,6 +23,7 @@ if a.size:
     w, h = a.size.split("x"); size = dict(width=int(w), height=int(h))
 ctx = capi.Context(0)
 ctx.update_scene(sc)
+ctx.set_frame_lanes(a.lanes)
 
 def params(f):
     p = sc.frame_params(use_filter=0, **size)
@@ -37,11 +39,12 @@ if not a.no_check:
     for chain in (1, 0):
         ctx.set_frame_chain(chain)
         got, kinds = [], []
-        ctx.frame_begin(ps[0]); kinds.append(ctx.last_chained())
-        for f in range(1, a.frames):
+        for f in range(a.frames):
+            if ctx.frames_in_flight() == a.lanes:
+                got.append(ctx.frame_end()[0])
             ctx.frame_begin(ps[f]); kinds.append(ctx.last_chained())
+        while ctx.frames_in_flight():
             got.append(ctx.frame_end()[0])
-        got.append(ctx.frame_end()[0])
         bad = [f for f in range(a.frames) if not np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32))]
         print("chain %d: %d frames, kinds %s, frames that differ from their own render: %s" % (chain, a.frames, kinds, bad or "none"), flush=True)
         for f in bad[:3]:
@@ -53,13 +56,15 @@ for chain in (0, 1):
     ctx.set_frame_chain(chain)
     best = 1e9
     for rep in range(3):
-        ctx.frame_begin(p, device=True)
+        for _ in range(a.lanes - 1):
+            ctx.frame_begin(p, device=True)
         for _ in range(6):
             ctx.frame_begin(p, device=True); ctx.frame_end()
         t0 = time.perf_counter()
         for _ in range(a.time_frames):
             ctx.frame_begin(p, device=True); ctx.frame_end()
         dt = time.perf_counter() - t0
-        ctx.frame_end()
+        while ctx.frames_in_flight():
+            ctx.frame_end()
         best = min(best, dt * 1e3 / a.time_frames)
-    print("loop, two frames in flight, chain %d: %.3f ms per frame (last frame kind %d)" % (chain, best, ctx.last_chained()), flush=True)
+    print("loop, %d frames in flight, chain %d: %.3f ms per frame (last frame kind %d)" % (a.lanes, chain, best, ctx.last_chained()), flush=True)

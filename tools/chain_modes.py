@@ -20,6 +20,21 @@ def rate(frames):
     dt = time.perf_counter() - t0
     ctx.frame_end()
     return dt * 1e3 / frames
-for mode, frames in [(0, 60), (0, 400), (1, 60), (1, 400), (0, 60), (0, 400), (1, 60), (1, 60), (0, 60)]:
+LANES = 2
+def rate(frames):
+    for _ in range(LANES - 1):
+        ctx.frame_begin(p, device=True)
+    for _ in range(6):
+        ctx.frame_begin(p, device=True); ctx.frame_end()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        ctx.frame_begin(p, device=True); ctx.frame_end()
+    dt = time.perf_counter() - t0
+    while ctx.frames_in_flight():
+        ctx.frame_end()
+    return dt * 1e3 / frames
+for lanes, mode, frames in [(2, 0, 200), (2, 1, 200), (3, 1, 200), (3, 1, 400), (2, 0, 200), (3, 1, 200), (3, 0, 200)]:
+    LANES = lanes
+    ctx.set_frame_lanes(lanes)
     ctx.set_frame_chain(mode)
-    print("chain %d, %3d frames: %.3f ms per frame" % (mode, frames, rate(frames)), flush=True)
+    print("%d frames in flight, chain %d, %3d frames: %.3f ms per frame" % (lanes, mode, frames, rate(frames)), flush=True)

@@ -12,6 +12,7 @@ ap.add_argument("--workload", default="dragon")
 ap.add_argument("--count", type=int, default=8)
 ap.add_argument("--index", type=int, default=0)
 ap.add_argument("--frames", type=int, default=24)
+ap.add_argument("--lanes", type=int, default=2)
 a = ap.parse_args()
 sc = Scene.golden("dragon")
 size = dict(width=3840, height=2160) if a.workload == "dragon_4k" else {}
@@ -20,13 +21,17 @@ ctx.update_scene(sc)
 p = sc.frame_params(use_filter=0, **size)
 if a.count > 1:
     p.tile_rows, p.tile_count, p.tile_index = 8, a.count, a.index
+ctx.set_frame_lanes(a.lanes)
+ctx.set_frame_chain(1)
 ctx.set_chain_stats(1)
-ctx.frame_begin(p, device=True)
+for _ in range(a.lanes - 1):
+    ctx.frame_begin(p, device=True)
 t0 = time.perf_counter()
 for _ in range(a.frames):
     ctx.frame_begin(p, device=True); ctx.frame_end()
 dt = time.perf_counter() - t0
-ctx.frame_end()
+while ctx.frames_in_flight():
+    ctx.frame_end()
 st = ctx.chain_stats()
 rows = sorted([r for r in st if r[21] != 0], key=lambda r: int(r[21]))
 print("%d frames, %.3f ms per frame (wall clock); times in us from the launch's start" % (a.frames, dt * 1e3 / a.frames))
@@ -47,6 +52,13 @@ for r in rows:
     print("%4d  Sdry %s %s | shade tile %4.1f%% batch %4.1f%% of their time (%.0f us per wave) | walk: %.1f lanes per trip, %.0f trips per wave" %
           (r[21], us(r[25], s), us(r[26], s), 100.0 * int(r[27]) / tot, 100.0 * int(r[28]) / tot, tot / 100.0 / 768.0, int(r[30]) / max(int(r[31]), 1), int(r[31]) / (13 * 256.0)))
 
+print("the frame two ahead (depth 3): view seen at, tiles made, batches, lanes")
+for r in rows:
+    print("%4d  %s  tiles %5d  batches %6d  lanes %8d" % (r[21], us(r[47], r[0]), r[44], r[45], r[46]))
 print("workgroups through with their own frame by (us): <100 <200 <400 <600 <800 <1000 <1200 <1400 <1600 <1800 <2000 later")
 for r in rows:
     print("%4d  %s" % (r[21], " ".join("%4d" % int(v) for v in r[32:44])))
+
+print("P's own resume lists taken: walk shade ready(units) susp | folds of P's paths by bounce 0 1 2 3+ (after 500 us) | last fresh path of P began its walk at")
+for r in rows:
+    print("%4d  %7d %7d %7d %7d | %7d %7d %7d %7d  (%6d %6d %6d %6d) | %s" % (r[21], r[48], r[49], r[50], r[51], r[52], r[53], r[54], r[55], r[57], r[58], r[59], r[60], us(r[56], r[0])))

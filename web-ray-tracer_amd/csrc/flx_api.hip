@@ -114,7 +114,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   for (int i = 0; i < 3; i++) { if (ctx->aux_stream[i]) (void)hipStreamDestroy(ctx->aux_stream[i]); if (ctx->ev_join[i]) (void)hipEventDestroy(ctx->ev_join[i]); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 3; i++) {
     if (ctx->d_slot[i]) (void)hipFree(ctx->d_slot[i]);
     if (ctx->d_slot8[i]) (void)hipFree(ctx->d_slot8[i]);
     if (ctx->h_slot[i]) (void)hipHostFree(ctx->h_slot[i]);
@@ -1252,8 +1252,8 @@ static bool chain_wanted(flx_context *ctx, const flx_frame_params *p, const Devi
   const int organisation = FLX_WF_ORGANISATION_DEFAULT ? FLX_WF_ORGANISATION_DEFAULT : ctx->wf_organisation;
   if (organisation == 1 || ctx->walk_scheduler != 0 || ctx->walk_suspend != 0u || ctx->wf_groups > 1 || !(ctx->frame_front == 1 || ctx->frame_front == 2)) return false;
   if (fr.frame_rows == 0u || (fr.frame_rows & 7u) != 0u) return false;
-  if (path_item_count64(fr) * 2ull >= (1ull << 31)) return false;
-  if ((uint32_t)fr.samples * 64u * 2u + (uint32_t)FLX_CHAIN_RESERVE_HOST > (uint32_t)WF_FRAME_RING - 256u) return false;
+  if (path_item_count64(fr) * (uint64_t)(ctx->frame_lanes == 3 ? 3 : 2) >= (1ull << 31)) return false;
+  if ((uint32_t)fr.samples * 64u * 2u + 2u * (uint32_t)FLX_CHAIN_RESERVE > (uint32_t)WF_FRAME_RING - 256u) return false;
   uint32_t a = 0, b = 0;
   return chain_kernel_fits(sc, a, b);
 }
@@ -1261,8 +1261,8 @@ static bool chain_wanted(flx_context *ctx, const flx_frame_params *p, const Devi
 static flx_status chain_resources(flx_context *ctx, size_t itemsPerSlot) {
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
   if (!ctx->d_chain_slots) {
-    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_slots, 2 * sizeof(ChainSlot)));
-    FLX_HIP(ctx, hipMemsetAsync(ctx->d_chain_slots, 0, 2 * sizeof(ChainSlot), ctx->stream));
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_slots, CH_MAX_DEPTH * sizeof(ChainSlot)));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_chain_slots, 0, CH_MAX_DEPTH * sizeof(ChainSlot), ctx->stream));
     /* the mailbox: pinned host memory the host writes with plain stores while the kernel runs and the kernel reads with system-scope loads
      * (tools/micro/mailbox.hip).  Not a copy on a stream: a small hipMemcpyAsync is a kernel of its own, and the persistent launch leaves it no CU. */
     FLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_chain_mail, sizeof(ChainMail), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1274,66 +1274,68 @@ static flx_status chain_resources(flx_context *ctx, size_t itemsPerSlot) {
     FLX_HIP(ctx, hipMalloc(&ctx->d_chain_rings, ringWords * sizeof(uint32_t)));
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_chain_rings, 0xff, ringWords * sizeof(uint32_t), ctx->stream));      /* WF_INVALID everywhere; a kernel leaves them so */
     ctx->chain_susp_cap = (size_t)cus * 1024u;                                  /* every lane of every workgroup may hold a walk when the launch stops */
-    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_susp, 2 * ctx->chain_susp_cap * CH_SUSP_F4 * sizeof(float4)));
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_susp, (size_t)CH_MAX_DEPTH * 2 * ctx->chain_susp_cap * CH_SUSP_F4 * sizeof(float4)));
   }
-  if (ctx->chain_list_cap < itemsPerSlot) {
+  /* a resume list holds what the workgroups had in their rings and lanes when a launch stopped: never more than the slot's paths, nor than the rings take */
+  size_t cap = (size_t)cus * WF_FRAME_RING;
+  if (cap > itemsPerSlot) cap = itemsPerSlot;
+  if (ctx->chain_list_cap < cap) {
     FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->chain_list_cap = 0; ctx->chain_seq = 0;
     if (ctx->d_chain_lists) { FLX_HIP(ctx, hipFree(ctx->d_chain_lists)); ctx->d_chain_lists = nullptr; }
-    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_lists, 6 * itemsPerSlot * sizeof(uint32_t)));
-    ctx->chain_list_cap = itemsPerSlot;
+    FLX_HIP(ctx, hipMalloc(&ctx->d_chain_lists, (size_t)CH_MAX_DEPTH * 2 * 3 * cap * sizeof(uint32_t)));
+    ctx->chain_list_cap = cap;
   }
   return FLX_OK;
 }
 
-/* One frame of the loop, chained: its view posted to the kernel before it (when it continues a chain), the slot after it reset, its own kernel and the
- * resolve of its slot — everything on the context's stream but the post. */
+/* One frame of the loop, chained: its view posted to the kernels before it (when it continues a chain), the slot it will leave behind reset for the frame
+ * `depth` later, its own kernel and the resolve of its slot — everything on the context's stream but the post. */
 static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *params, const DeviceScene &sc, const DeviceFrame &frOne, float4 *d_out) {
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
-  DeviceFrame fr = frOne;                                   /* the two slots stacked like a batch of two frames */
-  fr.frames = 2; fr.rows = 2u * frOne.frame_rows;
+  const uint32_t depth = ctx->frame_lanes == 3 ? 3u : 2u;
+  DeviceFrame fr = frOne;                                   /* the slots stacked like a batch of frames */
+  fr.frames = depth; fr.rows = depth * frOne.frame_rows;
   const size_t itemsPerSlot = (size_t)path_item_count64(frOne);
   flx_status s;
   if ((s = chain_resources(ctx, itemsPerSlot))) return s;
   int chains = 1;
   if ((s = ensure_workspace(ctx, fr, 3, false, chains))) return s;
-  const bool continuing = ctx->chain_seq != 0 && chain_same_shape(ctx->chain_params, *params) && ctx->chain_scene_version == ctx->scene_version;
-  const uint32_t seq = ++ctx->chain_counter ? ctx->chain_counter : ++ctx->chain_counter;
-  const uint32_t slotP = continuing ? 1u - ctx->chain_slot : 0u, slotS = 1u - slotP;
+  const bool continuing = ctx->chain_seq != 0 && ctx->chain_depth == depth && chain_same_shape(ctx->chain_params, *params) && ctx->chain_scene_version == ctx->scene_version;
+  /* sequence numbers: consecutive within a chain (the kernel of frame q expects the posts q + 1, q + 2), never reused, never 0 */
+  if (!continuing) ctx->chain_counter += 8u;
+  uint32_t seq = ++ctx->chain_counter;
+  if (seq < 16u) { ctx->chain_counter = 16u; seq = 16u; }
+  const uint32_t slotP = continuing ? (ctx->chain_slot + 1u) % depth : 0u;
+  for (uint32_t i = 0; i < depth; i++) memset(&fr.view[i], 0, sizeof(FrameView));
   fr.view[slotP] = frOne.view[0];
-  if (slotP != 0u) memset(&fr.view[0], 0, sizeof(FrameView));
   if (continuing) {
-    /* post: the view, then the number that says whose view it is (sequence numbers are never reused, so nothing has to be reset: a kernel takes the view of
-     * exactly the frame it was told to expect).  The kernel before this one may work ahead on this frame from now on. */
+    /* post: the view, then the number that says whose view it is (a kernel takes the view of exactly the frame it was told to expect, so nothing has to be
+     * reset).  The kernels before this one — the one running and, at depth 3, the one queued behind it — may work ahead on this frame from now on. */
     memcpy((void *)&ctx->h_chain_mail->view[slotP], &frOne.view[0], sizeof(FrameView));
     __atomic_store_n(&ctx->h_chain_mail->posted[slotP], seq, __ATOMIC_RELEASE);
   }
-  /* the other slot is free for the frame after this one: the kernel and the resolve of the frame that last used it are earlier in this stream (a frame
-   * that begins a chain resets its own slot too) */
-  launch_chain_reset(ctx->d_chain_slots, continuing ? 1u << slotS : 3u, ctx->stream);
+  /* The slot of the frame before this one is free for the frame `depth - 1` after this one once that frame's kernel and resolve — earlier in this stream
+   * — are through: its cursors back to zero; and of every slot the list set this kernel writes (a frame that begins a chain resets everything). */
+  const uint32_t recycled = (slotP + depth - 1u) % depth;
+  launch_chain_reset(ctx->d_chain_slots, depth, continuing ? 1u << recycled : 7u, seq & 1u, ctx->stream);
   FLX_HIP(ctx, hipGetLastError());
-  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
   WavefrontBuffers wb = {};
   wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
   wb.frameRings = ctx->d_chain_rings; wb.front = 1u;
   wb.error = ctx->d_dev_error; wb.watchdog = 0u; wb.inject = 0u;
-  wb.item_base = 0u; wb.item_count = (uint32_t)(2u * itemsPerSlot);
+  wb.item_base = 0u; wb.item_count = (uint32_t)(depth * itemsPerSlot);
   wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = nullptr;
   ChainArgs ca = {};
   ca.slots = ctx->d_chain_slots; ca.mail = ctx->d_chain_mail; ca.relay = ctx->d_chain_relay;
-  for (int i = 0; i < 2; i++) {
-    ca.walkList[i] = ctx->d_chain_lists + (size_t)(0 + i) * ctx->chain_list_cap;
-    ca.shadeList[i] = ctx->d_chain_lists + (size_t)(2 + i) * ctx->chain_list_cap;
-    ca.readyList[i] = ctx->d_chain_lists + (size_t)(4 + i) * ctx->chain_list_cap;
-  }
-  ca.listCap = (uint32_t)ctx->chain_list_cap;
-  for (int i = 0; i < 2; i++) ca.suspList[i] = ctx->d_chain_susp + (size_t)i * ctx->chain_susp_cap * CH_SUSP_F4;
-  ca.suspCap = (uint32_t)ctx->chain_susp_cap;
+  ca.lists = ctx->d_chain_lists; ca.listCap = (uint32_t)ctx->chain_list_cap;
+  ca.susp = ctx->d_chain_susp; ca.suspCap = (uint32_t)ctx->chain_susp_cap;
+  ca.depth = depth; ca.ahead = depth - 1u;
   ca.slotP = slotP;
-  ca.seqS = seq + 1u ? seq + 1u : 1u;                        /* the number the next frame of this chain will post */
+  ca.seqP = seq;
   ca.tilesPerSlot = (uint32_t)(itemsPerSlot / ((size_t)fr.samples * 64u));
   ca.itemsPerSlot = (uint32_t)itemsPerSlot;
-  for (int i = 0; i < 2; i++) {
+  for (uint32_t i = 0; i < depth; i++) {
     ca.order[i] = (ctx->d_chain_order && ctx->chain_order_n == ca.tilesPerSlot) ? ctx->d_chain_order : nullptr;
     ca.cost[i] = (ctx->d_chain_cost && ctx->chain_cost_n == ca.tilesPerSlot) ? ctx->d_chain_cost + (size_t)i * ctx->chain_cost_n : nullptr;
   }
@@ -1342,22 +1344,19 @@ static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *para
   if (ctx->d_chain_stats) {
     ca.stats = ctx->d_chain_stats + (size_t)(seq % CH_STAT_LAUNCHES) * CH_STAT_WORDS;
     unsigned long long init[CH_STAT_WORDS] = {};
-    init[CS_START_MIN] = init[CS_SAVAIL_MIN] = init[CS_STOP_MIN] = init[CS_PDONE_MIN] = init[CS_END_MIN] = init[CS_SDRY_MIN] = ~0ull; init[CS_SEQ] = seq;
+    init[CS_START_MIN] = init[CS_SAVAIL_MIN] = init[CS_STOP_MIN] = init[CS_PDONE_MIN] = init[CS_END_MIN] = init[CS_SDRY_MIN] = init[CS_SAVAIL2_MIN] = ~0ull; init[CS_SEQ] = seq;
     FLX_HIP(ctx, hipMemcpyAsync(ca.stats, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));      /* (pageable: the copy is staged before the call returns) */
   }
   const uint32_t cusWalk = (ctx->comm && cus > 4u * FLX_COMM_RESERVED_CUS) ? cus - FLX_COMM_RESERVED_CUS : cus;      /* (a gathering rank leaves a few CUs to the exchange of the frame before) */
-  FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
   if (launch_chain(sc, fr, wb, ca, cusWalk, ctx->stream) != 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the chained frame kernel does not take this scene");
   FLX_HIP(ctx, hipGetLastError());
-  FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   const size_t P1 = (size_t)frOne.rows * frOne.width;
-  launch_resolve(frOne, ctx->d_hits + (size_t)slotP * P1, ctx->d_samples + (size_t)slotP * P1, ctx->d_last + (size_t)slotP * P1, d_out, ctx->stream, 2u * P1);
+  launch_resolve(frOne, ctx->d_hits + (size_t)slotP * P1, ctx->d_samples + (size_t)slotP * P1, ctx->d_last + (size_t)slotP * P1, d_out, ctx->stream, (size_t)depth * P1);
   FLX_HIP(ctx, hipGetLastError());
-  FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
-  ctx->timed = true;
+  ctx->timed = false;                                        /* (flx_last_frame_ms: the chained loop's frames are timed by flx_frame_end) */
   ctx->last_pipeline = 3; ctx->last_organisation = 4;
   ctx->last_chained = continuing ? 2 : 1;
-  ctx->chain_seq = seq; ctx->chain_slot = slotP; ctx->chain_params = *params; ctx->chain_scene_version = ctx->scene_version;
+  ctx->chain_seq = seq; ctx->chain_slot = slotP; ctx->chain_depth = depth; ctx->chain_params = *params; ctx->chain_scene_version = ctx->scene_version;
   return FLX_OK;
 }
 
@@ -1371,10 +1370,10 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
   const bool gathered = gather != NOT_GATHERED;
   const bool receiver = !gathered || gather < 0 || gather == ctx->comm_rank;
   if (gathered) { fr.rows = receiver ? params->height : 0u; }      /* the slot holds the WHOLE frame on a rank that receives it, nothing elsewhere */
-  const int k = (int)(ctx->frames_begun & 1u);
+  const int k = (int)(ctx->frames_begun % (uint64_t)(ctx->frame_lanes == 3 ? 3 : 2));      /* (the depth of the loop does not change while frames are in flight) */
   if (!ctx->copy_stream) {
     FLX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
       FLX_HIP(ctx, hipEventCreate(&ctx->ev_slot_start[i]));
       FLX_HIP(ctx, hipEventCreate(&ctx->ev_slot_traced[i]));
       FLX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slot_done[i], hipEventDisableTiming));
@@ -1504,7 +1503,7 @@ extern "C" flx_status flx_last_chained(flx_context *ctx, int *chained) {
 
 extern "C" flx_status flx_set_frame_lanes(flx_context *ctx, int lanes) {
   if (!ctx) return FLX_ERR_INVALID;
-  if (lanes != 1 && lanes != 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_lanes: 1 (frames one after the other) or 2 (two frames overlap on the GPU)");
+  if (lanes < 1 || lanes > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_lanes: 1 (frames one after the other), 2 (two frames overlap on the GPU) or 3 (three frames in flight where the loop is chained: flx_set_frame_chain; as 2 elsewhere)");
   if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_lanes: frames are in flight");
   ctx->frame_lanes = lanes;
   return FLX_OK;
@@ -1512,12 +1511,12 @@ extern "C" flx_status flx_set_frame_lanes(flx_context *ctx, int lanes) {
 
 static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, int format, int gather) {
   if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_RGBA8 && format != FLX_FRAME_DEVICE) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: format is FLX_FRAME_FLOAT, FLX_FRAME_RGBA8 or FLX_FRAME_DEVICE");
-  if (ctx->fifo_n >= 2) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: two frames are in flight already, take one with flx_frame_end first");
+  if (ctx->fifo_n >= (ctx->frame_lanes == 3 ? 3 : 2)) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: as many frames are in flight as the loop holds (flx_set_frame_lanes), take one with flx_frame_end first");
   if (!params) return fail(ctx, FLX_ERR_INVALID, "frame params are NULL");
   if (gather != NOT_GATHERED) {
     if (!ctx->comm) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: the context belongs to no communicator (flx_comm_init_rank)");
     if (params->is_temporal) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: temporal frames keep their history in one context and are not sharded");
-    if (ctx->frame_lanes == 2 && !ctx->comm_twin) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: the second lane has no communicator (contexts of a flx_group render through flx_group_render)");
+    if (ctx->frame_lanes >= 2 && !ctx->comm_twin) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: the second lane has no communicator (contexts of a flx_group render through flx_group_render)");
   }
   flx_context *lane = ctx;
   bool chained = false;
@@ -1528,7 +1527,7 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
   if (chained) {
     /* both frames in flight live in the primary context: make sure nothing of the second lane is (a frame of another kind just before) */
     if (ctx->twin && ctx->fifo_n && ctx->fifo[ctx->fifo_n - 1].lane != ctx) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
-  } else if (ctx->frame_lanes == 2 && !params->is_temporal && (ctx->lane_next & 1u)) {
+  } else if (ctx->frame_lanes >= 2 && !params->is_temporal && (ctx->lane_next & 1u)) {
     FLX_HIP(ctx, hipSetDevice(ctx->device));
     if (!ctx->twin) {
       flx_status s = flx_context_create(ctx->device, &ctx->twin);
@@ -1578,7 +1577,7 @@ extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_
   const int k = ctx->fifo[0].slot;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   FLX_HIP(ctx, hipEventSynchronize(lane->slot_host[k] ? lane->ev_slot_done[k] : lane->ev_slot_traced[k]));
-  ctx->fifo[0] = ctx->fifo[1]; ctx->fifo_n--;
+  ctx->fifo[0] = ctx->fifo[1]; ctx->fifo[1] = ctx->fifo[2]; ctx->fifo_n--;
   lane->frames_ended++;
   { flx_status es = flx_check_device_error(ctx); if (es) return es; }
   if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, lane->ev_slot_start[k], lane->ev_slot_traced[k])); *gpu_ms = ms; }

@@ -116,23 +116,24 @@ struct flx_context {
   float4 *d_gplanes = nullptr;                   /* filter frames: the five gathered render targets in image order */
   size_t gplanes_capacity = 0;
   /* the frame loop (flx_frame_begin / flx_frame_end): two slots of device output + pinned host memory, a copy stream */
-  float4 *d_slot[2] = { nullptr, nullptr };
-  size_t slot_capacity[2] = { 0, 0 };            /* pixels */
-  uint32_t *d_slot8[2] = { nullptr, nullptr };
-  size_t slot8_capacity[2] = { 0, 0 };
-  void *h_slot[2] = { nullptr, nullptr };
-  size_t h_slot_capacity[2] = { 0, 0 };          /* bytes */
-  size_t slot_bytes[2] = { 0, 0 };
+  /* (three slots where flx_set_frame_lanes(3) lets three chained frames be in flight, two otherwise) */
+  float4 *d_slot[3] = { nullptr, nullptr, nullptr };
+  size_t slot_capacity[3] = { 0, 0, 0 };         /* pixels */
+  uint32_t *d_slot8[3] = { nullptr, nullptr, nullptr };
+  size_t slot8_capacity[3] = { 0, 0, 0 };
+  void *h_slot[3] = { nullptr, nullptr, nullptr };
+  size_t h_slot_capacity[3] = { 0, 0, 0 };       /* bytes */
+  size_t slot_bytes[3] = { 0, 0, 0 };
   hipStream_t copy_stream = nullptr;
-  hipEvent_t ev_slot_start[2] = {}, ev_slot_traced[2] = {}, ev_slot_done[2] = {};
+  hipEvent_t ev_slot_start[3] = {}, ev_slot_traced[3] = {}, ev_slot_done[3] = {};
   uint64_t frames_begun = 0, frames_ended = 0;
-  bool slot_host[2] = { true, true };            /* the slot's frame is copied to pinned host memory (else it stays in d_slot) */
+  bool slot_host[3] = { true, true, true };      /* the slot's frame is copied to pinned host memory (else it stays in d_slot) */
   /* two lanes: a twin context (own stream + workspace, shared static scene arrays) takes every other frame of the loop */
   flx_context *twin = nullptr;
   bool is_twin = false;
   int frame_lanes = 2;
   uint64_t lane_next = 0;
-  struct { flx_context *lane; int slot; } fifo[2] = {};
+  struct { flx_context *lane; int slot; } fifo[3] = {};
   int fifo_n = 0;
   std::vector<float> h_lights, h_rotation, h_shift;      /* host copies of what changes per frame, for the twin's own buffers */
   uint64_t dyn_version = 0, twin_dyn_version = 0;
@@ -142,13 +143,13 @@ struct flx_context {
   flx::ChainMail *h_chain_mail = nullptr;        /* pinned host memory: the next frame's view is posted (plain stores) while the kernel runs */
   flx::ChainMail *d_chain_mail = nullptr;        /* its device address */
   flx::ChainMail *d_chain_relay = nullptr;       /* device memory: the post as the kernel's relaying waves pass it on to the other workgroups */
-  uint32_t *d_chain_lists = nullptr;             /* 6 resume lists (walk, shade, ready) x 2 slots, chain_list_cap entries each */
+  uint32_t *d_chain_lists = nullptr;             /* resume lists: [slot: 3][set: 2][walk, shade, ready] x chain_list_cap entries */
   size_t chain_list_cap = 0;
   uint32_t *d_chain_order = nullptr;             /* flx_set_chain_order: the order of a slot's screen tiles, or nullptr */
   size_t chain_order_n = 0;
   uint32_t *d_chain_cost = nullptr;              /* flx_set_chain_cost: 2 x chain_cost_n per-tile counts */
   size_t chain_cost_n = 0;
-  float4 *d_chain_susp = nullptr;                /* 2 lists of walks suspended in flight, chain_susp_cap x CH_SUSP_F4 float4 each */
+  float4 *d_chain_susp = nullptr;                /* walks suspended in flight: [slot: 3][set: 2] x chain_susp_cap x CH_SUSP_F4 float4 */
   size_t chain_susp_cap = 0;
   uint32_t *d_chain_rings = nullptr;             /* per workgroup CH_RINGS rings; all slots WF_INVALID between launches */
 
@@ -156,6 +157,7 @@ struct flx_context {
   uint64_t chain_seq = 0;                        /* sequence number of the last chained frame begun (0: no chain stands) */
   uint32_t chain_counter = 0;                    /* sequence numbers handed out (never 0) */
   uint32_t chain_slot = 0;                       /* the slot of that frame */
+  uint32_t chain_depth = 0;                      /* slots of the chain that stands (2 or 3) */
   flx_frame_params chain_params = {};            /* its shape: a frame continues the chain only with the same one */
   uint64_t chain_scene_version = 0;              /* ... and the same scene */
   uint64_t scene_version = 0;                    /* bumped by every upload */

@@ -288,8 +288,8 @@ class Context:
         self._check(LIB.flx_set_chain_stats(self._h, int(bool(on))), "flx_set_chain_stats")
 
     def chain_stats(self):
-        """-> uint64 [64 launches, 48 words] (flx_chain.h: CS_*)"""
-        out = np.zeros((64, 48), np.uint64)
+        """-> uint64 [64 launches, 64 words] (flx_chain.h: CS_*)"""
+        out = np.zeros((64, 64), np.uint64)
         self._check(LIB.flx_get_chain_stats(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))), "flx_get_chain_stats")
         return out
 
