@@ -201,6 +201,8 @@ flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog_polls, uin
 flx_status flx_last_chained(flx_context *ctx, int *chained);
 /* Diagnostics of the chained kernels (tools/chain_stats.py): 64 launches (by sequence number mod 64) x 32 words — when the launch started and ended, when the
  * next frame's view was seen, when its own frame was complete, tiles made for either frame, paths handed to the next kernel, walks abandoned. */
+/* diagnostics of the frame server's last launch (csrc/flx_server.h: SVS_*): start, end, frames completed, tiles, batches, rotations, ... */
+flx_status flx_get_server_stats(flx_context *ctx, uint64_t *out /* [16] */);
 flx_status flx_set_chain_stats(flx_context *ctx, int on);
 flx_status flx_get_chain_stats(flx_context *ctx, uint64_t *out /* [64 * 32] */);
 /* Experiments with the order in which a chained frame's 8 x 8 screen tiles are drawn (tools/chain_order.py): an explicit permutation of the frame's tiles

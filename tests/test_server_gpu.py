@@ -1,0 +1,109 @@
+"""The frame server (csrc/flx_server.hip): ONE persistent launch renders the frames of the loop as flx_frame_begin posts them — the frames in flight share the
+machine inside the launch, every workgroup resolves the screen tiles it made, the host is told through pinned memory.
+
+Per path nothing may change: every frame must equal its own flx_render bit for bit (tests/test_parity_gpu.py holds flx_render against the oracle on the same
+scenes).  Reference loop: modules/pathtracerWGL2.js:254-303 (frame after frame from one context, never waiting for the GPU inside a frame)."""
+import numpy as np
+import pytest
+
+from parity_util import bit_mismatches
+
+pytestmark = pytest.mark.gpu
+
+
+def moving(sc, f, **kw):
+    p = sc.frame_params(use_filter=0, **kw)
+    p.camera[0] += 0.05 * f
+    p.camera[2] -= 0.03 * f
+    p.random_seed = float(f % 4)
+    return p
+
+
+def loop(ctx, ps, lanes, **kw):
+    got, kinds = [], []
+    for p in ps:
+        if ctx.frames_in_flight() == lanes:
+            got.append(ctx.frame_end()[0])
+        ctx.frame_begin(p, **kw)
+        kinds.append(ctx.last_chained())
+    while ctx.frames_in_flight():
+        got.append(ctx.frame_end()[0])
+    return got, kinds
+
+
+@pytest.fixture()
+def served(hip):
+    hip.set_frame_chain(2)
+    yield hip
+    hip.set_frame_lanes(2)
+    hip.set_frame_chain(0)
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+@pytest.mark.parametrize("shape", [dict(width=640, height=360), dict(width=1920, height=1080, tile=(8, 5, 8)), dict(width=500, height=264, samples=3)])
+def test_served_frames_equal_their_own_render(served, scenes, shape, lanes):
+    """a camera that moves from frame to frame, a seed that changes; two and three frames in flight: whole frames, a rank's strips of the BASELINE frame, an
+    odd width with three samples"""
+    sc = scenes("dragon")
+    served.update_scene(sc)
+    served.set_frame_lanes(lanes)
+    ps = [moving(sc, f, **shape) for f in range(8)]
+    want = [served.render(p)[0] for p in ps]
+    got, kinds = loop(served, ps, lanes)
+    assert kinds == [3] * 8, kinds                            # every frame went to the server
+    for f in range(8):
+        assert got[f].shape == want[f].shape
+        assert bit_mismatches(got[f], want[f]) == 0, "frame %d differs from its own render" % f
+
+
+def test_the_server_ends_and_starts_again_where_the_frames_change(served, scenes):
+    """another frame shape, a scene upload, a synchronous render between frames in flight, the loop running empty: the launch ends (its frames complete
+    first) and another begins; every frame is still its own render"""
+    sc = scenes("dragon")
+    served.update_scene(sc)
+    served.set_frame_lanes(2)
+    a = [moving(sc, f, width=480, height=272) for f in range(3)]
+    b = [moving(sc, f, width=320, height=200) for f in range(3)]
+    want = [served.render(p)[0] for p in a + b]
+    got, _ = loop(served, a + b, 2)
+    for f in range(6):
+        assert bit_mismatches(got[f], want[f]) == 0, f
+    served.frame_begin(a[0])
+    served.update_primary_light_sources(sc.arrays["lights"])            # (ends the launch: frame a[0] completes first)
+    served.frame_begin(a[1])
+    g0 = served.frame_end()[0]
+    g1 = served.frame_end()[0]
+    assert bit_mismatches(g0, want[0]) == 0 and bit_mismatches(g1, want[1]) == 0
+    served.frame_begin(a[0])
+    served.frame_begin(a[1])
+    mid = served.render(b[2])[0]                                        # the workspace goes to this frame: the two in flight are resolved first
+    g0 = served.frame_end()[0]
+    g1 = served.frame_end()[0]
+    served.frame_begin(a[2])
+    g2 = served.frame_end()[0]
+    assert bit_mismatches(mid, want[5]) == 0
+    assert bit_mismatches(g0, want[0]) == 0 and bit_mismatches(g1, want[1]) == 0 and bit_mismatches(g2, want[2]) == 0
+
+
+def test_frames_the_server_does_not_take(served, scenes):
+    """a scene of fewer than 129 entries, the canvas' RGBA8 format: rendered the other ways, and right"""
+    sc = scenes("cornell_obj")
+    served.update_scene(sc)
+    served.set_frame_lanes(2)
+    ps = [moving(sc, f, width=320, height=200, samples=2, max_reflections=3) for f in range(3)]
+    want = [served.render(p)[0] for p in ps]
+    got, kinds = loop(served, ps, 2)
+    assert kinds == [0, 0, 0]
+    for f in range(3):
+        assert bit_mismatches(got[f], want[f]) == 0
+    sc = scenes("dragon")
+    served.update_scene(sc)
+    ps = [moving(sc, f, width=320, height=200) for f in range(3)]
+    want8 = []
+    for p in ps:
+        served.frame_begin(p, rgba8=True)
+        want8.append(served.frame_end()[0])
+    served.set_frame_chain(0)
+    for f, p in enumerate(ps):
+        served.frame_begin(p, rgba8=True)
+        assert np.array_equal(served.frame_end()[0], want8[f])

@@ -8,6 +8,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -93,6 +94,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
 extern "C" void flx_context_destroy(flx_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->sv_running && ctx->h_sv_mail) { __atomic_store_n(&ctx->h_sv_mail->stopAfter, ctx->sv_next_seq - 1u, __ATOMIC_RELEASE); ctx->sv_running = false; (void)hipStreamSynchronize(ctx->sv_stream); }
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->twin) { flx_context_destroy(ctx->twin); ctx->twin = nullptr; }
   if (ctx->is_twin) {                      /* the static scene arrays belong to the primary context */
@@ -124,6 +126,9 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   for (hipEvent_t ev : ctx->stage_done) if (ev) (void)hipEventDestroy(ev);
   if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->h_chain_mail) (void)hipHostFree(ctx->h_chain_mail);
+  if (ctx->h_sv_mail) (void)hipHostFree(ctx->h_sv_mail);
+  for (void *b : { (void *)ctx->d_sv_slots, (void *)ctx->d_sv_relay, (void *)ctx->d_sv_rings, (void *)ctx->d_sv_stats, (void *)ctx->d_sv_out, (void *)ctx->d_sv_tiles }) if (b) (void)hipFree(b);
+  if (ctx->sv_stream) (void)hipStreamDestroy(ctx->sv_stream);
   for (void *b : { (void *)ctx->d_chain_slots, (void *)ctx->d_chain_relay, (void *)ctx->d_chain_lists, (void *)ctx->d_chain_rings, (void *)ctx->d_chain_stats, (void *)ctx->d_chain_susp, (void *)ctx->d_chain_order, (void *)ctx->d_chain_cost }) if (b) (void)hipFree(b);
   if (ctx->h_dev_error) (void)hipHostFree(ctx->h_dev_error);
 
@@ -157,6 +162,7 @@ static flx_status shared_upload_end(flx_context *ctx) {
 
 template <typename T>
 static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t bytes) {
+  { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }      /* (a running frame server reads the scene) */
   ctx->scene_version++;                  /* (a chain of frames does not go on over a changed scene: flx_chain.hip) */
   size_t &cap = ctx->upload_capacity[(void **)dst];
   if (bytes == 0) {                      /* "none": the kernels test the pointer */
@@ -484,18 +490,26 @@ flx_status flx_check_device_error(flx_context *ctx) {
   uint32_t bits = __atomic_load_n(&owner->h_dev_error[0], __ATOMIC_ACQUIRE);
   if (ctx->twin && ctx->twin->h_dev_error) { bits |= __atomic_load_n(&ctx->twin->h_dev_error[0], __ATOMIC_ACQUIRE); }
   if (bits == 0u) return FLX_OK;
+  if (ctx->sv_stream) {                                      /* a frame server that is still up: it ends, whatever it holds */
+    if (ctx->h_sv_mail) __atomic_store_n(&ctx->h_sv_mail->stopAfter, 1u, __ATOMIC_RELEASE);
+    ctx->sv_running = false;
+    for (auto &pf : ctx->sv_pending) pf.valid = false;
+    (void)hipStreamSynchronize(ctx->sv_stream);
+  }
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->twin) { (void)hipStreamSynchronize(ctx->twin->stream); ctx->twin->h_dev_error[0] = 0u; }
   ctx->h_dev_error[0] = 0u;
   ctx->chain_seq = 0;
   /* the kernels' rings may hold ids nobody popped: back to "empty" for the next launch */
   if (ctx->d_chain_rings) (void)hipMemsetAsync(ctx->d_chain_rings, 0xff, (size_t)ctx->prop.multiProcessorCount * chain_rings_per_group() * sizeof(uint32_t), ctx->stream);
+  if (ctx->d_sv_rings) (void)hipMemsetAsync(ctx->d_sv_rings, 0xff, (size_t)ctx->prop.multiProcessorCount * server_rings_per_group() * sizeof(uint32_t), ctx->stream);
   for (flx_context *c : { ctx, ctx->twin })
     if (c && c->d_frame_rings) (void)hipMemsetAsync(c->d_frame_rings, 0xff, (size_t)c->frame_rings_chains * c->prop.multiProcessorCount * WF_FRAME_RINGS * WF_FRAME_RING * sizeof(uint32_t), c->stream);
-  char msg[240];
-  snprintf(msg, sizeof msg, "device error in a frame kernel (bits 0x%x:%s%s%s%s%s): the frame is incomplete", bits, (bits & WF_ERR_SHADE_WATCHDOG) ? " shade-wave watchdog" : "",
+  char msg[360];
+  snprintf(msg, sizeof msg, "device error in a frame kernel (bits 0x%x:%s%s%s%s%s%s%s): the frame is incomplete", bits, (bits & WF_ERR_SHADE_WATCHDOG) ? " shade-wave watchdog" : "",
            (bits & WF_ERR_WALK_WATCHDOG) ? " walk-wave watchdog" : "", (bits & WF_ERR_LIST) ? " resume list overflow" : "", (bits & WF_ERR_LEFTOVER) ? " paths left behind" : "",
-           (bits & WF_ERR_RING_SLOT) ? " ring slot never filled" : "");
+           (bits & WF_ERR_RING_SLOT) ? " ring slot never filled" : "", (bits & WF_ERR_SERVER_IDLE) ? " frame server: nothing to do for seconds" : "",
+           (bits & WF_ERR_SERVER_TIMEOUT) ? " frame server: no answer within 5 s" : "");
   return flx_fail(ctx, FLX_ERR_DEVICE, msg);
 }
 
@@ -576,6 +590,7 @@ static flx_status ensure_workspace(flx_context *ctx, const DeviceFrame &fr, int 
 }
 
 flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
+  { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }      /* (the frame server renders into the same workspace) */
   ctx->chain_seq = 0;                    /* this frame's kernels use the workspace a chain of frames keeps its state in: the chain ends here */
   unsigned long long *cnt = ctx->counters_enabled ? ctx->d_counters : nullptr;
   /* The G-buffer accumulators of the filter path carry state from sample to sample (fragment:83-89),
@@ -1292,6 +1307,7 @@ static flx_status chain_resources(flx_context *ctx, size_t itemsPerSlot) {
 /* One frame of the loop, chained: its view posted to the kernels before it (when it continues a chain), the slot it will leave behind reset for the frame
  * `depth` later, its own kernel and the resolve of its slot — everything on the context's stream but the post. */
 static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *params, const DeviceScene &sc, const DeviceFrame &frOne, float4 *d_out) {
+  { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
   const uint32_t depth = ctx->frame_lanes == 3 ? 3u : 2u;
   DeviceFrame fr = frOne;                                   /* the slots stacked like a batch of frames */
@@ -1360,8 +1376,160 @@ static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *para
   return FLX_OK;
 }
 
+
+/* ---- the frame server (flx_server.hip) -------------------------------------------------------------------------------------
+ * flx_set_frame_chain(ctx, 2): the frames of the loop are rendered by ONE persistent launch that takes them as they are posted.  flx_frame_begin posts the
+ * frame's view into pinned memory (starting the launch if none runs); flx_frame_end waits for the launch's word that the frame is complete, resolves its slot
+ * on the context's stream — a few CUs the launch leaves free — and goes on as for any frame.  The launch is told to end when the loop runs empty or anything
+ * else needs the device or the workspace (server_stop). */
+#ifndef FLX_SERVER_RESERVED_CUS
+#define FLX_SERVER_RESERVED_CUS 8u          /* CUs the server launch leaves to the resolve, the exchange and the copies of the frames it completes */
+#endif
+static flx_status server_take(flx_context *ctx, int k);
+flx_status flx_server_stop(flx_context *ctx) {
+  if (!ctx->sv_running && !(ctx->sv_pending[0].valid || ctx->sv_pending[1].valid || ctx->sv_pending[2].valid)) return FLX_OK;
+  if (ctx->sv_running) {
+    /* every frame posted is completed before the launch ends */
+    __atomic_store_n(&ctx->h_sv_mail->stopAfter, ctx->sv_next_seq - 1u, __ATOMIC_RELEASE);
+    ctx->sv_running = false;
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));
+  }
+  /* the frames still in flight are resolved into their output slots now: whoever asked for the stop may overwrite the workspace */
+  for (int i = 0; i < ctx->fifo_n; i++) {
+    if (ctx->fifo[i].lane != ctx) continue;
+    const int k = ctx->fifo[i].slot;
+    if (ctx->sv_pending[k].valid) { flx_status s = server_take(ctx, k); if (s) return s; }
+  }
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FLX_OK;
+}
+static flx_status server_stop(flx_context *ctx) { return flx_server_stop(ctx); }
+
+static flx_status server_post(flx_context *ctx, const flx_frame_params *params, const DeviceScene &sc, const DeviceFrame &frOne, uint32_t *seqOut, uint32_t *slotOut) {
+  const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+  const uint32_t depth = ctx->frame_lanes == 3 ? 3u : 2u;
+  flx_status s;
+  if (ctx->sv_running && (ctx->sv_depth != depth || !chain_same_shape(ctx->sv_params, *params) || ctx->sv_scene_version != ctx->scene_version))
+    if ((s = server_stop(ctx))) return s;
+  if (!ctx->sv_running) {
+    if (ctx->sv_stream) FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));      /* a launch that was told to end reads the mailbox until it has */
+    DeviceFrame fr = frOne;                                 /* the slots stacked like a batch of frames; the views come through the mailbox */
+    fr.frames = depth; fr.rows = depth * frOne.frame_rows;
+    for (uint32_t i = 0; i < depth; i++) memset(&fr.view[i], 0, sizeof(FrameView));
+    const size_t itemsPerSlot = (size_t)path_item_count64(frOne);
+    if (!ctx->d_sv_slots) {
+      /* The launch's stream must not share a hardware queue with the streams that work beside it (the runtime maps streams onto a few queues, and a queue
+       * is served in order: a resolve behind the persistent launch in the same queue would wait for its end).  Streams of another priority have queues of
+       * their own: the launch goes to the lowest. */
+      int prLow = 0, prHigh = 0;
+      FLX_HIP(ctx, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+      FLX_HIP(ctx, hipStreamCreateWithPriority(&ctx->sv_stream, hipStreamNonBlocking, prLow));
+      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_slots, SV_MAX_DEPTH * sizeof(ServerSlot)));
+      FLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_sv_mail, sizeof(ServerMail), hipHostMallocMapped | hipHostMallocCoherent));
+      memset(ctx->h_sv_mail, 0, sizeof(ServerMail));
+      FLX_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->d_sv_mail, ctx->h_sv_mail, 0));
+      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_relay, sizeof(ServerMail)));
+      const size_t ringWords = (size_t)cus * server_rings_per_group();
+      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_rings, ringWords * sizeof(uint32_t)));
+      FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_rings, 0xff, ringWords * sizeof(uint32_t), ctx->stream));      /* WF_INVALID everywhere; a launch leaves them so */
+      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_stats, SV_STAT_WORDS * sizeof(unsigned long long)));
+    }
+    int chains = 1;
+    if ((s = ensure_workspace(ctx, fr, 3, false, chains))) return s;
+    const size_t P1 = (size_t)frOne.rows * frOne.width;
+    if (ctx->sv_out_capacity < SV_MAX_DEPTH * P1) {
+      FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      ctx->sv_out_capacity = 0;
+      if (ctx->d_sv_out) { FLX_HIP(ctx, hipFree(ctx->d_sv_out)); ctx->d_sv_out = nullptr; }
+      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_out, SV_MAX_DEPTH * P1 * sizeof(float4)));
+      ctx->sv_out_capacity = SV_MAX_DEPTH * P1;
+    }
+    ctx->sv_out_pixels = P1;
+    /* a workgroup's list of the screen tiles it made of a frame: four times its even share, 64 at the least (its tiles come to it as it asks for them) */
+    const size_t tilesPerSlot0 = itemsPerSlot / ((size_t)fr.samples * 64u);
+    size_t tcap = 4 * (tilesPerSlot0 / (cus > 16 ? cus - 8 : cus) + 1);
+    if (tcap < 64) tcap = 64;
+    if (ctx->sv_tile_cap < tcap) {
+      ctx->sv_tile_cap = 0;
+      if (ctx->d_sv_tiles) { FLX_HIP(ctx, hipFree(ctx->d_sv_tiles)); ctx->d_sv_tiles = nullptr; }
+      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_tiles, (size_t)cus * SV_MAX_DEPTH * tcap * sizeof(uint32_t)));
+      ctx->sv_tile_cap = tcap;
+    }
+    ctx->chain_seq = 0;                                      /* (the workspace a chain of launches keeps its state in is the server's now) */
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));         /* whatever used the workspace before, and the allocations above */
+    ctx->sv_counter += 16u;                                  /* sequence numbers: consecutive within a launch, never reused across launches, never 0 */
+    if (ctx->sv_counter < 16u) ctx->sv_counter = 16u;
+    const uint32_t seq0 = ctx->sv_counter;
+    memset((void *)ctx->h_sv_mail, 0, sizeof(ServerMail));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_slots, 0, SV_MAX_DEPTH * sizeof(ServerSlot), ctx->sv_stream));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_relay, 0, sizeof(ServerMail), ctx->sv_stream));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_stats, 0, SV_STAT_WORDS * sizeof(unsigned long long), ctx->sv_stream));
+    WavefrontBuffers wb = {};
+    wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
+    wb.frameRings = ctx->d_sv_rings; wb.front = 1u;
+    wb.error = ctx->d_dev_error; wb.watchdog = 0u; wb.inject = 0u;
+    wb.item_base = 0u; wb.item_count = (uint32_t)(depth * itemsPerSlot);
+    wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = nullptr;
+    ServerArgs sa = {};
+    sa.slots = ctx->d_sv_slots; sa.mail = ctx->d_sv_mail; sa.relay = ctx->d_sv_relay;
+    sa.depth = depth; sa.slot0 = 0u; sa.seq0 = seq0;
+    sa.tilesPerSlot = (uint32_t)(itemsPerSlot / ((size_t)fr.samples * 64u));
+    sa.itemsPerSlot = (uint32_t)itemsPerSlot;
+    for (uint32_t i = 0; i < depth; i++) sa.out[i] = ctx->d_sv_out + (size_t)i * P1;
+    sa.tileLists = ctx->d_sv_tiles; sa.tileListCap = (uint32_t)ctx->sv_tile_cap;
+    sa.idleExit = 200000000u;                                /* 2 s at 100 MHz: a safety net, the host always says when to stop */
+    sa.error = ctx->d_dev_error;
+    sa.stats = ctx->d_sv_stats;
+    const uint32_t cusWalk = cus > 4u * FLX_SERVER_RESERVED_CUS ? cus - FLX_SERVER_RESERVED_CUS : cus;
+    if (launch_server(sc, fr, wb, sa, cusWalk, ctx->sv_stream) != 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the frame server does not take this scene");
+    FLX_HIP(ctx, hipGetLastError());
+    ctx->sv_running = true; ctx->sv_depth = depth; ctx->sv_next_seq = seq0; ctx->sv_next_slot = 0u;
+    ctx->sv_params = *params; ctx->sv_scene_version = ctx->scene_version;
+  }
+  const uint32_t seq = ctx->sv_next_seq++, slot = ctx->sv_next_slot;
+  ctx->sv_next_slot = (slot + 1u) % depth;
+  /* post: the view, then the number that says whose view it is.  (The frame that was in this slot was taken by flx_frame_end `depth` frames ago.) */
+  memcpy((void *)&ctx->h_sv_mail->view[slot], &frOne.view[0], sizeof(FrameView));
+  __atomic_store_n(&ctx->h_sv_mail->posted[slot], seq, __ATOMIC_RELEASE);
+  *seqOut = seq; *slotOut = slot;
+  ctx->last_pipeline = 3; ctx->last_organisation = 5; ctx->last_chained = 3;
+  return FLX_OK;
+}
+
+/* flx_frame_end of a server frame: wait for the launch's word, resolve the frame's slot into the output slot */
+static flx_status server_take(flx_context *ctx, int k) {
+  auto &pf = ctx->sv_pending[k];
+  pf.valid = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  uint32_t spins = 0;
+  while (__atomic_load_n(&ctx->h_sv_mail->done[pf.slot], __ATOMIC_ACQUIRE) != pf.seq) {
+    if (__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u) break;
+    if ((++spins & 1023u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+      __atomic_fetch_or(&ctx->h_dev_error[0], WF_ERR_SERVER_TIMEOUT, __ATOMIC_RELEASE);
+      break;
+    }
+  }
+  if (__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u) {
+    /* the launch gave up (or never answered): tell it to end, then report */
+    __atomic_store_n(&ctx->h_sv_mail->stopAfter, 1u, __ATOMIC_RELEASE);
+    ctx->sv_running = false;
+    return FLX_OK;                                           /* (flx_frame_end's own check reports the error word) */
+  }
+  if (getenv("FLX_SERVER_DEBUG")) fprintf(stderr, "server_take: slot %u seq %u done after %.3f ms (%u spins)\n", pf.slot, pf.seq, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), spins);
+  /* the frame is in the launch's output buffer of its slot (every workgroup resolved the screen tiles it made): nothing to launch beside the server */
+  const float4 *src = ctx->d_sv_out + (size_t)pf.slot * ctx->sv_out_pixels;
+  ctx->slot_dev_ptr[k] = src;
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_start[k], ctx->copy_stream));
+  FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_traced[k], ctx->copy_stream));
+  if (pf.format != FLX_FRAME_DEVICE) {
+    if (ctx->slot_bytes[k]) FLX_HIP(ctx, hipMemcpyAsync(ctx->h_slot[k], src, ctx->slot_bytes[k], hipMemcpyDeviceToHost, ctx->copy_stream));
+    FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_done[k], ctx->copy_stream));
+  }
+  return FLX_OK;
+}
+
 constexpr int NOT_GATHERED = -2;      /* frame_begin_on's `gather`: this context's own frame; -1: gathered on every rank; >= 0: on that rank */
-static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *params, int format, int gather, int *slot, bool chained = false) {
+static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *params, int format, int gather, int *slot, int chained = 0 /* 1: a chain of launches, 2: the frame server */) {
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
   flx_status s = flx_make_frame(ctx, params, sc, fr);
@@ -1394,6 +1562,18 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
     FLX_HIP(ctx, hipHostMalloc(&ctx->h_slot[k], bytes ? bytes : 16, hipHostMallocDefault));
     ctx->h_slot_capacity[k] = bytes;
   }
+  if (chained == 2 && !gathered && pixels) {
+    /* the frame server: the frame is posted to the running launch; flx_frame_end takes it (server_take) */
+    uint32_t seq = 0, sslot = 0;
+    if ((s = server_post(ctx, params, sc, fr, &seq, &sslot))) return s;
+    ctx->sv_pending[k].valid = true; ctx->sv_pending[k].seq = seq; ctx->sv_pending[k].slot = sslot; ctx->sv_pending[k].format = format; ctx->sv_pending[k].fr = fr;
+    ctx->slot_host[k] = format != FLX_FRAME_DEVICE;
+    ctx->slot_bytes[k] = bytes;
+    ctx->frames_begun++;
+    *slot = k;
+    return FLX_OK;
+  }
+  ctx->slot_dev_ptr[k] = nullptr;
   FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_start[k], ctx->stream));
   if (gathered) {
     /* this rank's strips, the exchange over the lane's communicator and the reassembly, all on the lane's stream */
@@ -1402,7 +1582,7 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
   } else if (pixels) {
     if (params->use_filter || params->is_temporal) {
       s = run_post_frame(ctx, sc, fr, params, ctx->d_slot[k]);
-    } else if (chained) {
+    } else if (chained == 1) {
       s = chain_run_frame(ctx, params, sc, fr, ctx->d_slot[k]);
     } else {
       GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -1438,7 +1618,7 @@ extern "C" flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog
 }
 extern "C" flx_status flx_set_frame_chain(flx_context *ctx, int mode) {
   if (!ctx) return FLX_ERR_INVALID;
-  if (mode != 0 && mode != 1) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: 0 (every frame its own launches) or 1 (consecutive frames of the loop overlap inside the frame kernel where it takes them)");
+  if (mode < 0 || mode > 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: 0 (every frame its own launches), 1 (a chain of launches that work ahead on each other's frames) or 2 (the frame server: one persistent launch takes the loop's frames as they are posted)");
   if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: frames are in flight");
   ctx->frame_chain = mode; ctx->chain_seq = 0;
   return FLX_OK;
@@ -1495,6 +1675,14 @@ extern "C" flx_status flx_get_chain_cost(flx_context *ctx, uint32_t *out /* [2 *
   FLX_HIP(ctx, hipMemcpy(out, ctx->d_chain_cost, 2 * ctx->chain_cost_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return FLX_OK;
 }
+extern "C" flx_status flx_get_server_stats(flx_context *ctx, uint64_t *out /* [16] */) {
+  if (!ctx || !out) return FLX_ERR_INVALID;
+  if (!ctx->d_sv_stats) return fail(ctx, FLX_ERR_INVALID, "flx_get_server_stats: no frame server has run");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipMemcpy(out, ctx->d_sv_stats, SV_STAT_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (ctx->h_sv_mail) { out[13] = ((uint64_t)ctx->h_sv_mail->done[0] << 32) | ctx->h_sv_mail->done[1]; out[14] = ((uint64_t)ctx->h_sv_mail->posted[0] << 32) | ctx->h_sv_mail->posted[1]; out[15] = ((uint64_t)ctx->sv_next_seq << 32) | ctx->h_sv_mail->stopAfter; }
+  return FLX_OK;
+}
 extern "C" flx_status flx_last_chained(flx_context *ctx, int *chained) {
   if (!ctx || !chained) return FLX_ERR_INVALID;
   *chained = ctx->last_chained;
@@ -1519,11 +1707,13 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
     if (ctx->frame_lanes >= 2 && !ctx->comm_twin) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: the second lane has no communicator (contexts of a flx_group render through flx_group_render)");
   }
   flx_context *lane = ctx;
-  bool chained = false;
+  int chained = 0;
   if (gather == NOT_GATHERED) {
     DeviceScene scT; DeviceFrame frT;
-    if (flx_make_frame(ctx, params, scT, frT) == FLX_OK && frT.rows != 0u) chained = chain_wanted(ctx, params, scT, frT);
+    if (flx_make_frame(ctx, params, scT, frT) == FLX_OK && frT.rows != 0u && chain_wanted(ctx, params, scT, frT)) chained = ctx->frame_chain;
   }
+  if (chained == 2 && format == FLX_FRAME_RGBA8) chained = 0;      /* (the 8-bit store is a kernel of its own: not beside the server's launch) */
+  if (chained != 2) { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }      /* (a frame of another kind: the server's launch ends, its frames are resolved) */
   if (chained) {
     /* both frames in flight live in the primary context: make sure nothing of the second lane is (a frame of another kind just before) */
     if (ctx->twin && ctx->fifo_n && ctx->fifo[ctx->fifo_n - 1].lane != ctx) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
@@ -1576,12 +1766,21 @@ extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_
   flx_context *lane = ctx->fifo[0].lane;
   const int k = ctx->fifo[0].slot;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
-  FLX_HIP(ctx, hipEventSynchronize(lane->slot_host[k] ? lane->ev_slot_done[k] : lane->ev_slot_traced[k]));
+  if (lane == ctx && ctx->sv_pending[k].valid) { flx_status ss = server_take(ctx, k); if (ss) return ss; }
+  if (ctx->fifo_n == 1 && ctx->sv_running) {                  /* the loop runs empty: the launch is told to end (the next flx_frame_begin starts another) */
+    __atomic_store_n(&ctx->h_sv_mail->stopAfter, ctx->sv_next_seq - 1u, __ATOMIC_RELEASE);
+    ctx->sv_running = false;
+  }
+  if (!(__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u && lane == ctx)) {
+    const auto te = std::chrono::steady_clock::now();
+    FLX_HIP(ctx, hipEventSynchronize(lane->slot_host[k] ? lane->ev_slot_done[k] : lane->ev_slot_traced[k]));
+    if (getenv("FLX_SERVER_DEBUG")) fprintf(stderr, "frame_end: event after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te).count());
+  }
   ctx->fifo[0] = ctx->fifo[1]; ctx->fifo[1] = ctx->fifo[2]; ctx->fifo_n--;
   lane->frames_ended++;
   { flx_status es = flx_check_device_error(ctx); if (es) return es; }
   if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, lane->ev_slot_start[k], lane->ev_slot_traced[k])); *gpu_ms = ms; }
-  if (pixels) *pixels = lane->slot_host[k] ? lane->h_slot[k] : (const void *)lane->d_slot[k];
+  if (pixels) *pixels = lane->slot_host[k] ? lane->h_slot[k] : (lane->slot_dev_ptr[k] ? lane->slot_dev_ptr[k] : (const void *)lane->d_slot[k]);
   if (bytes) *bytes = lane->slot_bytes[k];
   return FLX_OK;
 }
@@ -1602,6 +1801,7 @@ extern "C" flx_status flx_frame_host_slots(flx_context *ctx, const void *slots[4
 extern "C" flx_status flx_sync(flx_context *ctx) {
   if (!ctx) return FLX_ERR_INVALID;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
+  { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->twin) FLX_HIP(ctx, hipStreamSynchronize(ctx->twin->stream));
   return flx_check_device_error(ctx);

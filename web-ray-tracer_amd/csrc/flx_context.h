@@ -13,6 +13,7 @@
 #include "flexlight_hip.h"
 #include "flx_kernels.h"
 #include "flx_chain.h"
+#include "flx_server.h"
 
 typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept out of this header */
 
@@ -162,6 +163,22 @@ struct flx_context {
   uint64_t chain_scene_version = 0;              /* ... and the same scene */
   uint64_t scene_version = 0;                    /* bumped by every upload */
   int last_chained = 0;                          /* flx_last_chained: 0 the last frame of the loop was not chained, 1 it began a chain, 2 it continued one */
+  /* the frame server (flx_server.hip): one persistent launch renders the loop's frames as they are posted (flx_set_frame_chain mode 2) */
+  flx::ServerSlot *d_sv_slots = nullptr;
+  flx::ServerMail *h_sv_mail = nullptr, *d_sv_mail = nullptr, *d_sv_relay = nullptr;      /* pinned host memory (and its device address); device memory */
+  uint32_t *d_sv_rings = nullptr;
+  float4 *d_sv_out = nullptr;                    /* the launch's resolved frames: [slot] x sv_out_pixels */
+  size_t sv_out_capacity = 0, sv_out_pixels = 0;
+  uint32_t *d_sv_tiles = nullptr;                /* [workgroup][slot] x sv_tile_cap: the screen tiles a workgroup made of a frame */
+  size_t sv_tile_cap = 0;
+  const void *slot_dev_ptr[3] = { nullptr, nullptr, nullptr };      /* where the frame of an output slot really is in device memory when that is not d_slot[k] (server frames) */
+  unsigned long long *d_sv_stats = nullptr;
+  hipStream_t sv_stream = nullptr;
+  bool sv_running = false;
+  uint32_t sv_depth = 0, sv_next_seq = 0, sv_next_slot = 0, sv_counter = 0;
+  flx_frame_params sv_params = {};               /* the shape of the frames the running launch takes */
+  uint64_t sv_scene_version = 0;
+  struct { bool valid; uint32_t seq, slot; int format; flx::DeviceFrame fr; } sv_pending[3] = {};      /* per output slot: the server frame that will land there */
   /* uploads: capacity of every persistent scene buffer (keyed by the address of its pointer), pinned staging ring */
   std::map<void **, size_t> upload_capacity;
   uint8_t *stage = nullptr;
@@ -191,6 +208,7 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, flx::Devi
 flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, flx::DeviceScene &sc, flx::DeviceFrame &fr);
 flx_status flx_run_frame(flx_context *ctx, const flx::DeviceScene &sc, const flx::DeviceFrame &fr, float4 *d_out, const flx::GBufferPtrs &gb);
 flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels);
+flx_status flx_server_stop(flx_context *ctx);      /* the frame server's launch ends (after the frames posted to it), the frames in flight are resolved into their output slots */
 flx_status flx_check_device_error(flx_context *ctx);      /* FLX_ERR_DEVICE (and the word cleared) if a frame kernel's watchdog has tripped since the last check */
 /* flx_filter_planes_device; stamp_start = false leaves the frame's start event alone (the trace of the same frame recorded it) */
 flx_status flx_filter_planes_enqueue(flx_context *ctx, const flx_frame_params *params, const void *d_planes, void *d_out_rgba, bool stamp_start);

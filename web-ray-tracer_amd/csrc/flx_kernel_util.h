@@ -41,6 +41,27 @@ __device__ __forceinline__ bool item_pixel(const DeviceFrame &fr, uint32_t item,
   return px < fr.width && k < fr.rows;
 }
 
+/* fragment:608-632 for one pixel: the samples added in order, averaged, times originalColor of the last sample (the shader's global still holds it after
+ * the loop).  o: the pixel in the (stacked) planes, sampleStride: float4 between two samples' planes. */
+__device__ __forceinline__ float4 resolve_pixel(const DeviceFrame &fr, const float4 *__restrict__ hits, const float4 *__restrict__ sampleRadiance, const float4 *__restrict__ lastOriginal,
+                                                size_t o, size_t sampleStride) {
+  float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (__float_as_int(hits[o].w) != -1) {
+    f3 finalColor = F3(0.0f, 0.0f, 0.0f);
+    for (int s = 0; s < fr.samples; s++) {
+      const float4 r = sampleRadiance[(size_t)s * sampleStride + o];
+      finalColor = finalColor + F3(r.x, r.y, r.z);
+    }
+    const float invSamples = 1.0f / (float)fr.samples;
+    finalColor = finalColor * invSamples;
+    const float4 oc = lastOriginal[o];
+    finalColor = finalColor * F3(oc.x, oc.y, oc.z);
+    if (fr.is_temporal == 1) color = make_float4(flx_fract(finalColor.x), flx_fract(finalColor.y), flx_fract(finalColor.z), 1.0f);
+    else color = make_float4(finalColor.x, finalColor.y, finalColor.z, 1.0f);
+  }
+  return color;
+}
+
 /* rank of this lane among the set bits of `mask` below it */
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long mask) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));

@@ -57,7 +57,7 @@ struct WavefrontBuffers {
 struct FrameArgs { DeviceScene sc; DeviceFrame fr; WavefrontBuffers wb; };
 constexpr uint32_t WF_FRAME_RING = 16384;
 /* device error word: who gave up */
-constexpr uint32_t WF_ERR_SHADE_WATCHDOG = 1u, WF_ERR_WALK_WATCHDOG = 2u, WF_ERR_LIST = 4u, WF_ERR_LEFTOVER = 8u, WF_ERR_RING_SLOT = 16u;
+constexpr uint32_t WF_ERR_SHADE_WATCHDOG = 1u, WF_ERR_WALK_WATCHDOG = 2u, WF_ERR_LIST = 4u, WF_ERR_LEFTOVER = 8u, WF_ERR_RING_SLOT = 16u, WF_ERR_SERVER_IDLE = 32u, WF_ERR_SERVER_TIMEOUT = 64u;
 constexpr uint32_t WF_INJECT_NO_SHADING = 1u;      /* the shade waves of a frame kernel drop what they pop: the paths never come back and the walk waves' watchdog must trip */
 constexpr uint32_t WF_FRAME_RINGS = 3;       /* to shade, to walk, fresh (tile, sample) units */
 constexpr size_t WF_TAIL_POOL_F4 = 1024 * 8;

@@ -313,27 +313,13 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
   flush_counters<COUNT>(cnt, counters);
 }
 
-/* fragment:608-632 for one pixel: add the samples in order, average, apply originalColor of the last
- * sample (the shader's global still holds it after the loop). */
+/* fragment:608-632, one thread per pixel (flx_kernel_util.h: resolve_pixel) */
 __global__ __launch_bounds__(256) void k_resolve(DeviceFrame fr, const float4 *__restrict__ hits, const float4 *__restrict__ sampleRadiance,
                                                  const float4 *__restrict__ lastOriginal, float4 *__restrict__ out, size_t sampleStride) {
   const size_t P = (size_t)fr.rows * fr.width;
   const size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (o >= P) return;
-  float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (__float_as_int(hits[o].w) != -1) {
-    f3 finalColor = F3(0.0f, 0.0f, 0.0f);
-    for (int s = 0; s < fr.samples; s++) {
-      const float4 r = sampleRadiance[(size_t)s * sampleStride + o];
-      finalColor = finalColor + F3(r.x, r.y, r.z);
-    }
-    const float invSamples = 1.0f / (float)fr.samples;
-    finalColor = finalColor * invSamples;
-    const float4 oc = lastOriginal[o];
-    finalColor = finalColor * F3(oc.x, oc.y, oc.z);
-    if (fr.is_temporal == 1) color = make_float4(flx_fract(finalColor.x), flx_fract(finalColor.y), flx_fract(finalColor.z), 1.0f);
-    else color = make_float4(finalColor.x, finalColor.y, finalColor.z, 1.0f);
-  }
+  const float4 color = resolve_pixel(fr, hits, sampleRadiance, lastOriginal, o, sampleStride);
   out[o] = color;
 }
 

@@ -1,0 +1,55 @@
+/* flx_server.h — the frame server: ONE persistent launch that renders the frames of the loop as they are posted (flx_server.hip), and the words it
+ * shares with the frame loop (flx_api.hip). */
+#ifndef FLX_SERVER_H
+#define FLX_SERVER_H
+
+#include "flx_kernels.h"
+
+namespace flx {
+
+constexpr uint32_t SV_MAX_DEPTH = 3;           /* most frame slots = most frames in flight */
+#ifndef FLX_SERVER_RESERVE
+#define FLX_SERVER_RESERVE 2048           /* places of a workgroup's rings that only paths of an older frame may take: the r-th oldest frame draws up to FQ_ALIVE_MAX - r x this */
+#endif
+constexpr uint32_t SV_RINGS = 3 * SV_MAX_DEPTH;   /* rings of a workgroup: (to shade, to walk, fresh units) x slot */
+
+/* Device memory: what the workgroups of the launch share about a slot. */
+struct ServerSlot {
+  uint32_t tileNext;                           /* cursor of the queue of screen tiles of the frame in the slot */
+  uint32_t groupsDone;                         /* workgroups that are through with that frame */
+  uint32_t pad[14];
+};
+/* Pinned host memory.  Host -> device: the frames' views and sequence numbers (plain stores, the view before the number), and the number after which the
+ * launch ends.  Device -> host: the frame in a slot is complete. */
+struct ServerMail {
+  uint32_t posted[4];                          /* [slot] sequence number of the frame whose view is in view[slot] */
+  uint32_t stopAfter;                          /* the launch ends when every workgroup is through with this frame (0: go on) */
+  uint32_t pad[3];
+  uint32_t done[4];                            /* [slot] device -> host: sequence number of the last frame completed in the slot */
+  FrameView view[SV_MAX_DEPTH];
+};
+struct ServerArgs {
+  ServerSlot *slots;                           /* [depth], zeroed before the launch */
+  ServerMail *mail;                            /* pinned host memory */
+  ServerMail *relay;                           /* device memory: posts and the stop word as the relaying waves pass them on */
+  uint32_t depth;                              /* slots (2 or 3) */
+  uint32_t slot0, seq0;                        /* the first frame: the slot it is in, its sequence number; frame seq0 + i is in slot (slot0 + i) % depth */
+  uint32_t tilesPerSlot, itemsPerSlot;
+  float4 *out[SV_MAX_DEPTH];                   /* per slot: the resolved frame (float4[frame_rows][width]); a workgroup resolves the screen tiles it made when it is through with the frame */
+  uint32_t *tileLists;                         /* [workgroup][slot] x tileListCap: the screen tiles the workgroup made of the frame in the slot */
+  uint32_t tileListCap;
+  uint32_t idleExit;                           /* 100 MHz ticks without anything to do after which a workgroup gives up (an error: the host always says when to stop) */
+  uint32_t *error;                             /* the context's device error word (pinned host memory) */
+  unsigned long long *stats;                   /* or nullptr: SV_STAT_WORDS diagnostics of the launch */
+};
+enum { SVS_START = 0, SVS_END, SVS_FRAMES, SVS_TILES, SVS_BATCHES, SVS_BATCH_LANES, SVS_ROTATIONS, SVS_WALK_LANE_TRIPS, SVS_WALK_TRIPS, SVS_SHADE_TILE_T, SVS_SHADE_BATCH_T, SVS_SHADE_TOTAL_T,
+       SVS_POST_WAIT_T, SV_STAT_WORDS = 16 };
+struct ServerKernelArgs { FrameArgs fa; ServerArgs sa; };
+
+bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes);
+size_t server_rings_per_group();
+/* fr: the slots stacked (frames = depth); its views are NOT used (they come through the mailbox).  0, or -1 if the kernel does not fit */
+int launch_server(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, const ServerArgs &sa, uint32_t compute_units, hipStream_t stream);
+
+}  // namespace flx
+#endif
