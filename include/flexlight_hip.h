@@ -203,6 +203,8 @@ flx_status flx_last_chained(flx_context *ctx, int *chained);
  * next frame's view was seen, when its own frame was complete, tiles made for either frame, paths handed to the next kernel, walks abandoned. */
 /* diagnostics of the frame server's last launch (csrc/flx_server.h: SVS_*): start, end, frames completed, tiles, batches, rotations, ... */
 flx_status flx_get_server_stats(flx_context *ctx, uint64_t *out /* [16] */);
+/* the control words of up to four workgroups of the frame server that gave up (72 words each: workgroup, wave, its 64 LDS control words, the relayed posts, the slots' tile cursors) */
+flx_status flx_get_server_dump(flx_context *ctx, uint64_t *out /* [4 * 72] */);
 flx_status flx_set_chain_stats(flx_context *ctx, int on);
 flx_status flx_get_chain_stats(flx_context *ctx, uint64_t *out /* [64 * 32] */);
 /* Experiments with the order in which a chained frame's 8 x 8 screen tiles are drawn (tools/chain_order.py): an explicit permutation of the frame's tiles

@@ -37,7 +37,7 @@ def chained(hip):
     hip.set_frame_lanes(2)
     hip.set_frame_chain(1)
     yield hip
-    hip.set_frame_chain(0)
+    hip.set_frame_chain(2)
 
 
 @pytest.mark.parametrize("shape", [dict(width=640, height=360), dict(width=1920, height=1080, tile=(8, 3, 8)), dict(width=500, height=264, samples=3)])
@@ -128,5 +128,6 @@ def test_a_tripped_watchdog_reaches_the_status_code(hip, scenes):
         assert "device error" in str(e.value)
     finally:
         hip.inject_fault(0, 0)
+        hip.set_frame_chain(2)
     got = hip.render(p)[0]                                     # the word was cleared, the rings re-initialised
     assert bit_mismatches(got, want) == 0

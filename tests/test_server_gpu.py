@@ -33,10 +33,10 @@ def loop(ctx, ps, lanes, **kw):
 
 @pytest.fixture()
 def served(hip):
-    hip.set_frame_chain(2)
+    hip.set_frame_chain(3)                                    # (every frame the server can take, whatever its size)
     yield hip
     hip.set_frame_lanes(2)
-    hip.set_frame_chain(0)
+    hip.set_frame_chain(2)
 
 
 @pytest.mark.parametrize("lanes", [2, 3])

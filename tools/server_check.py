@@ -18,6 +18,7 @@ ap.add_argument("--time-frames", type=int, default=200)
 ap.add_argument("--lanes", type=int, default=3)
 ap.add_argument("--no-check", action="store_true")
 ap.add_argument("--modes", default="2,0")
+ap.add_argument("--stats", action="store_true")
 a = ap.parse_args()
 sc = Scene.golden("dragon")
 size = dict(width=3840, height=2160) if a.workload == "dragon_4k" else {}
@@ -49,7 +50,7 @@ if not a.no_check:
     want = [ctx.render(p)[0] for p in ps]
     for lanes in sorted(set([2, a.lanes])):
         ctx.set_frame_lanes(lanes)
-        ctx.set_frame_chain(2)
+        ctx.set_frame_chain(3)
         got, kinds = run(ps, lanes)
         bad = [f for f in range(a.frames) if not np.array_equal(got[f].view(np.uint32), want[f].view(np.uint32))]
         print("server, %d frames in flight: %d frames, kinds %s, frames that differ from their own render: %s" % (lanes, a.frames, kinds, bad or "none"), flush=True)
@@ -61,7 +62,7 @@ p = params(0)
 for mode in [int(m) for m in a.modes.split(",")]:
     for lanes in ([2, 3] if mode else [2]):
         ctx.set_frame_lanes(lanes)
-        ctx.set_frame_chain(mode)
+        ctx.set_frame_chain(3 if mode == 2 else mode)
         best = 1e9
         for rep in range(3):
             for _ in range(lanes - 1):
@@ -76,3 +77,10 @@ for mode in [int(m) for m in a.modes.split(",")]:
                 ctx.frame_end()
             best = min(best, dt * 1e3 / a.time_frames)
         print("loop, mode %d (%s), %d frames in flight: %.3f ms per frame" % (mode, {0: "two lanes", 1: "chain of launches", 2: "frame server"}[mode], lanes, best), flush=True)
+        if a.stats and mode == 2:
+            st = ctx.server_stats()
+            dur = (st["end"] - st["start"]) / 100.0
+            tot = max(st["shade_total_t"], 1)
+            print("   last launch: %.0f us, %d frames (%.1f us per frame), %d tiles, %d batches of %.1f lanes; shade waves: tiles %.0f%% batches %.0f%% of their time; walk waves: %.1f lanes per trip" %
+                  (dur, st["frames"], dur / max(st["frames"], 1), st["tiles"], st["batches"], st["batch_lanes"] / max(st["batches"], 1), 100.0 * st["shade_tile_t"] / tot, 100.0 * st["shade_batch_t"] / tot,
+                   st["walk_lane_trips"] / max(st["walk_trips"], 1)))

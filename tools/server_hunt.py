@@ -1,0 +1,42 @@
+"""repeat the failing server case until it fails; print the control words of the workgroups that gave up"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+from flexlight_hip import capi
+from flexlight_hip.scene_io import Scene
+sc = Scene.golden("dragon")
+ctx = capi.Context(0)
+ctx.update_scene(sc)
+ctx.set_frame_chain(3)
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+ctx.set_frame_lanes(lanes)
+def moving(f):
+    p = sc.frame_params(use_filter=0, width=1920, height=1080, tile=(8, 5, 8))
+    p.camera[0] += 0.05 * f; p.camera[2] -= 0.03 * f; p.random_seed = float(f % 4)
+    return p
+ps = [moving(f) for f in range(8)]
+names = {0: "alive0", 1: "alive1", 2: "alive2", 30: "tiledry0", 31: "tiledry1", 32: "tiledry2", 33: "savail0", 34: "savail1", 35: "savail2", 36: "seq0", 37: "seq1", 38: "seq2", 39: "slotP", 40: "rotlock", 41: "exit", 42: "stopped", 43: "stopafter", 44: "lastwork", 45: "ntiles0", 46: "ntiles1", 47: "ntiles2"}
+for rep in range(40):
+    try:
+        lanes = 2 + (rep & 1)
+        ctx.update_scene(sc)
+        ctx.set_frame_lanes(lanes)
+        if rep % 4 < 2:
+            want = [ctx.render(p)[0] for p in ps[:3]]
+        for p in ps:
+            if ctx.frames_in_flight() == lanes:
+                ctx.frame_end()
+            ctx.frame_begin(p)
+        while ctx.frames_in_flight():
+            ctx.frame_end()
+    except Exception as e:
+        print("rep", rep, "FAILED:", e)
+        print(ctx.server_stats())
+        for d in ctx.server_dump():
+            if d[1] == 0 and d[0] == 0 and d[2:66].sum() == 0:
+                continue
+            print("workgroup %d wave %d:" % (d[0], d[1]), {names.get(i, "ring%d" % (i - 3)): int(d[2 + i]) for i in range(48) if d[2 + i] != 0 or i in (36, 37, 38, 39)}, "relay posted", d[66:69].tolist(), "tileNext", d[69:72].tolist())
+        break
+else:
+    print("40 repetitions without a failure")

@@ -510,7 +510,17 @@ flx_status flx_check_device_error(flx_context *ctx) {
            (bits & WF_ERR_WALK_WATCHDOG) ? " walk-wave watchdog" : "", (bits & WF_ERR_LIST) ? " resume list overflow" : "", (bits & WF_ERR_LEFTOVER) ? " paths left behind" : "",
            (bits & WF_ERR_RING_SLOT) ? " ring slot never filled" : "", (bits & WF_ERR_SERVER_IDLE) ? " frame server: nothing to do for seconds" : "",
            (bits & WF_ERR_SERVER_TIMEOUT) ? " frame server: no answer within 5 s" : "");
-  return flx_fail(ctx, FLX_ERR_DEVICE, msg);
+  std::string full = msg;
+  if (ctx->h_sv_mail && (bits & (WF_ERR_SERVER_IDLE | WF_ERR_SERVER_TIMEOUT))) {
+    char more[240];
+    unsigned long long st[SV_STAT_WORDS] = {};
+    if (ctx->d_sv_stats) (void)hipMemcpy(st, ctx->d_sv_stats, sizeof st, hipMemcpyDeviceToHost);
+    snprintf(more, sizeof more, " [frame server: posted %u %u %u, done %u %u %u, stop after %u, next %u; launch completed %llu frames, %llu rotations, %llu tiles]", ctx->h_sv_mail->posted[0],
+             ctx->h_sv_mail->posted[1], ctx->h_sv_mail->posted[2], ctx->h_sv_mail->done[0], ctx->h_sv_mail->done[1], ctx->h_sv_mail->done[2], ctx->h_sv_mail->stopAfter, ctx->sv_next_seq,
+             st[SVS_FRAMES], st[SVS_ROTATIONS], st[SVS_TILES]);
+    full += more;
+  }
+  return flx_fail(ctx, FLX_ERR_DEVICE, full.c_str());
 }
 
 flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels) {
@@ -1250,6 +1260,9 @@ static void mirror_scene(flx_context *ctx) {
  * Two frames in flight share ONE stacked workspace (the layout of a batch of two) and one stream: the kernel of frame k completes the slot of frame k and
  * works ahead on the slot of frame k + 1 — whose view flx_frame_begin of that frame posts while the kernel runs — and hands what it holds of it to the
  * kernel of frame k + 1 when frame k is complete.  The drain of a launch, a third of a rank's share of a 1080p frame, disappears under the next frame's bulk. */
+#ifndef FLX_SERVER_MAX_TILES_PER_CU
+#define FLX_SERVER_MAX_TILES_PER_CU 64
+#endif
 #ifndef FLX_CHAIN_MIN_LANES
 #define FLX_CHAIN_MIN_LANES 2
 #endif
@@ -1383,7 +1396,8 @@ static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *para
  * on the context's stream — a few CUs the launch leaves free — and goes on as for any frame.  The launch is told to end when the loop runs empty or anything
  * else needs the device or the workspace (server_stop). */
 #ifndef FLX_SERVER_RESERVED_CUS
-#define FLX_SERVER_RESERVED_CUS 8u          /* CUs the server launch leaves to the resolve, the exchange and the copies of the frames it completes */
+#define FLX_SERVER_RESERVED_CUS 0u          /* CUs the server launch leaves free (nothing needs them: the frames are resolved inside the launch and copied out by the DMA engines;
+                                             * a kernel beside the launch would not get them anyway — its workgroups are dealt to shader engines that may have no free CU) */
 #endif
 static flx_status server_take(flx_context *ctx, int k);
 flx_status flx_server_stop(flx_context *ctx) {
@@ -1432,7 +1446,7 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
       const size_t ringWords = (size_t)cus * server_rings_per_group();
       FLX_HIP(ctx, hipMalloc(&ctx->d_sv_rings, ringWords * sizeof(uint32_t)));
       FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_rings, 0xff, ringWords * sizeof(uint32_t), ctx->stream));      /* WF_INVALID everywhere; a launch leaves them so */
-      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_stats, SV_STAT_WORDS * sizeof(unsigned long long)));
+      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_stats, SV_STAT_TOTAL * sizeof(unsigned long long)));
     }
     int chains = 1;
     if ((s = ensure_workspace(ctx, fr, 3, false, chains))) return s;
@@ -1463,7 +1477,7 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
     memset((void *)ctx->h_sv_mail, 0, sizeof(ServerMail));
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_slots, 0, SV_MAX_DEPTH * sizeof(ServerSlot), ctx->sv_stream));
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_relay, 0, sizeof(ServerMail), ctx->sv_stream));
-    FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_stats, 0, SV_STAT_WORDS * sizeof(unsigned long long), ctx->sv_stream));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_stats, 0, SV_STAT_TOTAL * sizeof(unsigned long long), ctx->sv_stream));
     WavefrontBuffers wb = {};
     wb.rec = ctx->d_rec; wb.rec0 = ctx->d_rec0; wb.pix0 = ctx->d_pix0;
     wb.frameRings = ctx->d_sv_rings; wb.front = 1u;
@@ -1549,6 +1563,10 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
   }
   const size_t pixels = (size_t)fr.rows * fr.width;
   const size_t bytes = pixels * (format == FLX_FRAME_RGBA8 ? sizeof(uint32_t) : sizeof(float4));
+  /* (hipMalloc / hipFree / hipHostMalloc wait for the device: with the frame server's launch running they would wait for its end — which waits for this
+   * frame.  A slot that has to grow ends the launch first; the next frame starts another.) */
+  if (ctx->sv_running && (ctx->slot_capacity[k] < (pixels ? pixels : 1) || !ctx->d_slot[k] || (format != FLX_FRAME_DEVICE && (ctx->h_slot_capacity[k] < bytes || !ctx->h_slot[k]))))
+    if ((s = flx_server_stop(ctx))) return s;
   if ((s = flx_ensure_pixels(ctx, &ctx->d_slot[k], &ctx->slot_capacity[k], pixels ? pixels : 1))) return s;
   if (format == FLX_FRAME_RGBA8 && ctx->slot8_capacity[k] < pixels) {
     ctx->slot8_capacity[k] = 0;
@@ -1618,7 +1636,7 @@ extern "C" flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog
 }
 extern "C" flx_status flx_set_frame_chain(flx_context *ctx, int mode) {
   if (!ctx) return FLX_ERR_INVALID;
-  if (mode < 0 || mode > 2) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: 0 (every frame its own launches), 1 (a chain of launches that work ahead on each other's frames) or 2 (the frame server: one persistent launch takes the loop's frames as they are posted)");
+  if (mode < 0 || mode > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: 0 (every frame its own launches), 1 (a chain of launches that work ahead on each other's frames), 2 (the frame server — one persistent launch takes the loop's frames as they are posted — for frames of fewer than 64 screen tiles per CU) or 3 (the frame server for every frame it can take)");
   if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: frames are in flight");
   ctx->frame_chain = mode; ctx->chain_seq = 0;
   return FLX_OK;
@@ -1675,6 +1693,12 @@ extern "C" flx_status flx_get_chain_cost(flx_context *ctx, uint32_t *out /* [2 *
   FLX_HIP(ctx, hipMemcpy(out, ctx->d_chain_cost, 2 * ctx->chain_cost_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return FLX_OK;
 }
+extern "C" flx_status flx_get_server_dump(flx_context *ctx, uint64_t *out /* [4 * 72] */) {
+  if (!ctx || !out || !ctx->d_sv_stats) return FLX_ERR_INVALID;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipMemcpy(out, ctx->d_sv_stats + SV_STAT_WORDS, (size_t)SV_DUMP_MAX * SV_DUMP_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return FLX_OK;
+}
 extern "C" flx_status flx_get_server_stats(flx_context *ctx, uint64_t *out /* [16] */) {
   if (!ctx || !out) return FLX_ERR_INVALID;
   if (!ctx->d_sv_stats) return fail(ctx, FLX_ERR_INVALID, "flx_get_server_stats: no frame server has run");
@@ -1699,7 +1723,7 @@ extern "C" flx_status flx_set_frame_lanes(flx_context *ctx, int lanes) {
 
 static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, int format, int gather) {
   if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_RGBA8 && format != FLX_FRAME_DEVICE) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: format is FLX_FRAME_FLOAT, FLX_FRAME_RGBA8 or FLX_FRAME_DEVICE");
-  if (ctx->fifo_n >= (ctx->frame_lanes == 3 ? 3 : 2)) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: as many frames are in flight as the loop holds (flx_set_frame_lanes), take one with flx_frame_end first");
+  if (ctx->fifo_n >= (ctx->frame_lanes == 3 ? 3 : 2)) return fail(ctx, FLX_ERR_INVALID, ctx->frame_lanes == 3 ? "flx_frame_begin: three frames are in flight already (flx_set_frame_lanes), take one with flx_frame_end first" : "flx_frame_begin: two frames are in flight already, take one with flx_frame_end first");
   if (!params) return fail(ctx, FLX_ERR_INVALID, "frame params are NULL");
   if (gather != NOT_GATHERED) {
     if (!ctx->comm) return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_gathered: the context belongs to no communicator (flx_comm_init_rank)");
@@ -1710,9 +1734,17 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
   int chained = 0;
   if (gather == NOT_GATHERED) {
     DeviceScene scT; DeviceFrame frT;
-    if (flx_make_frame(ctx, params, scT, frT) == FLX_OK && frT.rows != 0u && chain_wanted(ctx, params, scT, frT)) chained = ctx->frame_chain;
+    if (flx_make_frame(ctx, params, scT, frT) == FLX_OK && frT.rows != 0u && chain_wanted(ctx, params, scT, frT)) {
+      chained = ctx->frame_chain;
+      /* The frame server pays where a frame is short against its own chains — a rank's share of a frame: below FLX_SERVER_MAX_TILES_PER_CU screen tiles per
+       * workgroup (a rank's eighth of a 1080p frame has 16, a whole 1080p frame 127: 6.46 ms per frame through the server against 6.32 on two lanes,
+       * profiles/r04_server.txt); mode 3 takes every frame it can. */
+      if (chained == 2 && path_item_count64(frT) / ((uint64_t)frT.samples * 64u) >= (uint64_t)FLX_SERVER_MAX_TILES_PER_CU * (uint64_t)ctx->prop.multiProcessorCount) chained = 0;
+      if (chained == 3) chained = 2;
+    }
   }
   if (chained == 2 && format == FLX_FRAME_RGBA8) chained = 0;      /* (the 8-bit store is a kernel of its own: not beside the server's launch) */
+  if (chained == 0) ctx->last_chained = 0;
   if (chained != 2) { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }      /* (a frame of another kind: the server's launch ends, its frames are resolved) */
   if (chained) {
     /* both frames in flight live in the primary context: make sure nothing of the second lane is (a frame of another kind just before) */

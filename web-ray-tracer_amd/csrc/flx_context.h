@@ -22,7 +22,7 @@ typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept 
 #endif
 constexpr int WF_MAX_GROUPS = 4;
 #ifndef FLX_FRAME_CHAIN_DEFAULT
-#define FLX_FRAME_CHAIN_DEFAULT 0      /* flx_set_frame_chain's default */
+#define FLX_FRAME_CHAIN_DEFAULT 2      /* flx_set_frame_chain's default: the frame server where a frame is a rank's thin share */
 #endif
 constexpr int FLX_COUNTER_SLOTS = 80;          /* 8 work counters + 32 scheduler diagnostics (flx_get_diag) + 40 tail profile (flx_get_tail_diag) */
 constexpr uint32_t WF_STRAG_MAX = 512;         /* most walks a walk workgroup can suspend */

@@ -43,7 +43,8 @@ struct ServerArgs {
   unsigned long long *stats;                   /* or nullptr: SV_STAT_WORDS diagnostics of the launch */
 };
 enum { SVS_START = 0, SVS_END, SVS_FRAMES, SVS_TILES, SVS_BATCHES, SVS_BATCH_LANES, SVS_ROTATIONS, SVS_WALK_LANE_TRIPS, SVS_WALK_TRIPS, SVS_SHADE_TILE_T, SVS_SHADE_BATCH_T, SVS_SHADE_TOTAL_T,
-       SVS_POST_WAIT_T, SV_STAT_WORDS = 16 };
+       SVS_POST_WAIT_T, SVS_DUMPS = 15 /* workgroups that gave up and left their control words behind */, SV_STAT_WORDS = 16,
+       SV_DUMP_MAX = 4, SV_DUMP_WORDS = 72 /* blockIdx, wave, 64 control words, ... */, SV_STAT_TOTAL = SV_STAT_WORDS + SV_DUMP_MAX * SV_DUMP_WORDS };
 struct ServerKernelArgs { FrameArgs fa; ServerArgs sa; };
 
 bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes);

@@ -33,6 +33,9 @@ namespace flx {
 #ifndef FLX_SERVER_RELAY_GROUPS
 #define FLX_SERVER_RELAY_GROUPS 16           /* workgroups whose shade waves read the host's mailbox and pass it on in device memory */
 #endif
+#ifndef FLX_SERVER_SHADERS
+#define FLX_SERVER_SHADERS FLX_FRAME_SHADERS_FRONT      /* shade waves of a server workgroup (they also make the fresh paths) */
+#endif
 #ifndef FLX_SERVER_PRIO
 #define FLX_SERVER_PRIO 1                    /* waves that hold paths of the oldest frame run at a raised priority once its tile queue is dry */
 #endif
@@ -100,6 +103,19 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   auto worked = [&]() { if (lane == 0) __hip_atomic_store(&ctl[SC_LASTWORK], (uint32_t)wall_clock64(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
   auto giveUp = [&](uint32_t code) {
     FLX_SERVER_ARGS();
+    if (sa.stats && fq_load(&ctl[SC_EXIT]) == 0u) {                     /* the first workgroups that give up leave their control words behind (flx_get_server_stats) */
+      unsigned long long at = SV_DUMP_MAX;
+      if (lane == 0) at = atomicAdd(sa.stats + SVS_DUMPS, 1ull);
+      at = __shfl(at, 0, 64);
+      if (at < (unsigned long long)SV_DUMP_MAX) {
+        unsigned long long *d = sa.stats + SV_STAT_WORDS + at * SV_DUMP_WORDS;
+        d[2 + lane] = ctl[lane];
+        if (lane == 0) { d[0] = blockIdx.x | ((unsigned long long)__hip_atomic_load(&sa.mail->posted[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) << 32);
+                         d[1] = wave | ((unsigned long long)__hip_atomic_load(&sa.mail->posted[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) << 32); d[66] = __hip_atomic_load(&sa.relay->posted[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d[67] = __hip_atomic_load(&sa.relay->posted[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                         d[68] = __hip_atomic_load(&sa.relay->posted[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d[69] = __hip_atomic_load(&sa.slots[0].tileNext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                         d[70] = __hip_atomic_load(&sa.slots[1].tileNext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d[71] = __hip_atomic_load(&sa.slots[2].tileNext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+      }
+    }
     if (lane == 0) { __hip_atomic_fetch_or(sa.error, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(&ctl[SC_EXIT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
   };
   if (wave == 0u && blockIdx.x == 0u) { FLX_SERVER_ARGS(); if (sa.stats && lane == 0) sa.stats[SVS_START] = (unsigned long long)wall_clock64(); }
@@ -233,10 +249,16 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   /* Through with the last frame the host will post, or nothing to do for milliseconds?  Then the workgroup ends. */
   auto checkExit = [&]() {
     const uint32_t stop = fq_load(&ctl[SC_STOPAFTER]);
-    const uint32_t P = fq_load(&ctl[SC_SLOTP]);
-    if (stop != 0u && (int32_t)(fq_load(&ctl[SC_SEQ + P]) - stop) > 0 && aliveAll() == 0u) {
-      if (lane == 0) __hip_atomic_store(&ctl[SC_EXIT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      return;
+    if (stop != 0u && aliveAll() == 0u) {
+      /* (under the rotation's lock: the slot of the oldest frame and that slot's sequence number are two words, and a rotation changes both) */
+      uint32_t out = 0;
+      if (lane == 0 && atomicCAS(&ctl[SC_ROTLOCK], 0u, 1u) == 0u) {
+        const uint32_t P = fq_load(&ctl[SC_SLOTP]);
+        out = ((int32_t)(fq_load(&ctl[SC_SEQ + P]) - stop) > 0 && aliveAll() == 0u) ? 1u : 0u;
+        if (out) __hip_atomic_store(&ctl[SC_EXIT], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(&ctl[SC_ROTLOCK], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      if (__builtin_amdgcn_readfirstlane(out) != 0u) return;
     }
     FLX_SERVER_ARGS();
     const uint32_t last = fq_load(&ctl[SC_LASTWORK]);
@@ -264,26 +286,39 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       tryRotate();
       const uint32_t P = fq_load(&ctl[SC_SLOTP]);
       bool did = false;
+      /* ---- a batch of paths to shade, from every frame's ring, the oldest frame's first: when 64 wait in all, or one of the oldest frame once its fresh
+       * paths are all out (its last chains set its end), or anything at all once this wave has found nothing else to do.  (Batches are not per frame: a
+       * workgroup seldom has 64 paths of ONE frame waiting, and a batch costs its wave the same time whatever its size.) ---- */
+      uint32_t nAvail = 0, waiting = 0;
       for (uint32_t r = 0; r < depth; r++) {
         const uint32_t slot = slotAt(P, r);
         if (!sAvail(slot, (idle & 7u) == 0u)) break;      /* (a frame that is not posted yet: nor are the ones after it) */
-        const bool dry = fq_load(&ctl[SC_TILEDRY + slot]) != 0u;
-        uint32_t id = WF_INVALID;
-        const uint32_t got = fq_pop(ring(RK_SHADE, slot), rctl(RK_SHADE, slot), ~0ull, 64u, dry ? 1u : 64u, lane, id);
+        nAvail = r + 1u;
+        waiting += fq_load(&rctl(RK_SHADE, slot)[2]);
+      }
+      if (nAvail != 0u && waiting != 0u &&
+          (waiting >= 64u || idle != 0u || (fq_load(&ctl[SC_TILEDRY + P]) != 0u && fq_load(&rctl(RK_SHADE, P)[2]) != 0u))) {
+        uint32_t id = WF_INVALID, got = 0;
+        for (uint32_t r = 0; r < nAvail && got < 64u; r++) {
+          const uint32_t slot = slotAt(P, r);
+          const unsigned long long takers = got == 0u ? ~0ull : (~0ull << got);
+          got += fq_pop(ring(RK_SHADE, slot), rctl(RK_SHADE, slot), takers, 64u - got, 1u, lane, id);
+        }
         if (got != 0u) {
           const long long tb0 = wall_clock64();
           const bool mine = lane < got && id != WF_INVALID;
           statAdd(SVS_BATCHES, 1ull); statAdd(SVS_BATCH_LANES, got);
-          if (FLX_SERVER_PRIO && r == 0u) __builtin_amdgcn_s_setprio(3);
           if (mine) shade_path<false, true>(ab, id, cnt, lv);
-          if (FLX_SERVER_PRIO && r == 0u) __builtin_amdgcn_s_setprio(0);
-          fq_push(ring(RK_WALK, slot), rctl(RK_WALK, slot), mine, id, lane);
+          const uint32_t slotMine = slotOf(id);
+          for (uint32_t sl = 0; sl < depth; sl++) fq_push(ring(RK_WALK, sl), rctl(RK_WALK, sl), mine && slotMine == sl, id, lane);
           tBatch += wall_clock64() - tb0;
           did = true;
-          break;
         }
+      }
+      /* ---- else the front of a frame for one screen tile, the oldest frame that still has tiles first ---- */
+      for (uint32_t r = 0; r < nAvail && !did; r++) {
         const long long tt0 = wall_clock64();
-        if (makeTile(slot, r) == 1u) { tTile += wall_clock64() - tt0; did = true; break; }
+        if (makeTile(slotAt(P, r), r) == 1u) { tTile += wall_clock64() - tt0; did = true; }
       }
       if (did) { idle = 0; worked(); continue; }
       checkExit();
@@ -495,7 +530,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 
 bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes) {
   const uint32_t T = sc.n_transforms;
-  const uint32_t walkThreads = FLX_WF_WALK_THREADS - 64u * (uint32_t)FLX_FRAME_SHADERS_FRONT;
+  const uint32_t walkThreads = FLX_WF_WALK_THREADS - 64u * (uint32_t)FLX_SERVER_SHADERS;
   const uint32_t fixed = walkThreads * T * 40u + T * 64u + (SC_WORDS + SC_VIEW_WORDS) * 4u;
   if (fixed + 4096u > (uint32_t)FLX_WF_LDS_TOTAL) return false;
   ldsCount = ((uint32_t)FLX_WF_LDS_TOTAL - fixed) / 48u;
@@ -521,7 +556,7 @@ int launch_server(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontB
   const uint32_t tilesPerGroup = sa.tilesPerSlot / compute_units;
   uint32_t readyUnits = tilesPerGroup >= 48u ? (uint32_t)FLX_FRAME_READY_UNITS : tilesPerGroup / 2u;
   readyUnits = readyUnits < (uint32_t)FLX_FRAME_READY_UNITS / 4u ? (uint32_t)FLX_FRAME_READY_UNITS / 4u : (readyUnits > (uint32_t)FLX_FRAME_READY_UNITS ? (uint32_t)FLX_FRAME_READY_UNITS : readyUnits);
-  hipLaunchKernelGGL(k_wf_server, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, (uint32_t)FLX_FRAME_SHADERS_FRONT, readyUnits);
+  hipLaunchKernelGGL(k_wf_server, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, (uint32_t)FLX_SERVER_SHADERS, readyUnits);
   return 0;
 }
 

@@ -23,7 +23,7 @@ EXPORTS = [
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
     "flx_group_create", "flx_group_destroy", "flx_group_last_error", "flx_group_size", "flx_group_uses_rccl", "flx_group_context",
-    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag", "flx_set_frame_chain", "flx_last_chained", "flx_debug_inject_fault", "flx_set_chain_stats", "flx_get_chain_stats", "flx_get_server_stats", "flx_set_chain_order", "flx_set_chain_cost", "flx_get_chain_cost",
+    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag", "flx_set_frame_chain", "flx_last_chained", "flx_debug_inject_fault", "flx_set_chain_stats", "flx_get_chain_stats", "flx_get_server_stats", "flx_get_server_dump", "flx_set_chain_order", "flx_set_chain_cost", "flx_get_chain_cost",
     "flx_render_gathered_root_device", "flx_comm_count", "flx_frame_begin_gathered", "flx_group_set_gather", "flx_frame_host_slots", "flx_has_experiments", "flx_set_wavefront_organisation", "flx_set_frame_front", "flx_last_organisation",
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
 ]
@@ -105,6 +105,7 @@ def _load():
         "flx_debug_inject_fault": (C.c_int, [vp, u32, u32]),
         "flx_set_chain_stats": (C.c_int, [vp, C.c_int]),
         "flx_get_server_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
+        "flx_get_server_dump": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_get_chain_stats": (C.c_int, [vp, C.POINTER(C.c_uint64)]),
         "flx_set_chain_order": (C.c_int, [vp, C.POINTER(C.c_uint32), u32]),
         "flx_set_chain_cost": (C.c_int, [vp, u32]),
@@ -284,6 +285,11 @@ class Context:
     def inject_fault(self, watchdog_polls=0, flags=0):
         """tests: the next frames' frame kernels give up after `watchdog_polls` polls; flags 1 = their shade waves drop every batch"""
         self._check(LIB.flx_debug_inject_fault(self._h, int(watchdog_polls), int(flags)), "flx_debug_inject_fault")
+
+    def server_dump(self):
+        out = np.zeros((4, 72), np.uint64)
+        self._check(LIB.flx_get_server_dump(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64))), "flx_get_server_dump")
+        return out
 
     def server_stats(self):
         """-> dict of the frame server's last launch (flx_server.h: SVS_*)"""
