@@ -44,11 +44,14 @@ def single(p):
         ms.append(ctx.last_frame_ms()[0])
     return float(np.median(ms)), min(ms)
 
-def loop(p, lanes):
+def loop(p, lanes, server=False):
+    """ms per frame of the frame loop with `lanes` frames in flight (wall clock over a.frames frames, best of 3); server: through the frame server where it takes the frame"""
     ctx.set_frame_lanes(lanes)
+    ctx.set_frame_chain(3 if server else 0)
     best = 1e9
     for rep in range(3):
-        ctx.frame_begin(p, device=True)
+        for _ in range(max(lanes, 2) - 1):
+            ctx.frame_begin(p, device=True)
         for _ in range(4):
             ctx.frame_begin(p, device=True)
             ctx.frame_end()
@@ -57,16 +60,22 @@ def loop(p, lanes):
             ctx.frame_begin(p, device=True)
             ctx.frame_end()
         dt = time.perf_counter() - t0
-        ctx.frame_end()
+        while ctx.frames_in_flight():
+            ctx.frame_end()
         best = min(best, dt * 1e3 / a.frames)
+    served = ctx.last_chained() == 3
     ctx.set_frame_lanes(1)
-    return best
+    ctx.set_frame_chain(2)
+    return best if (served or not server) else float("nan")
 
 print("workload %s, lib %s" % (work, os.path.basename(capi.LIB_PATH)))
 whole = params(0, 1)
 wm, wmin = single(whole)
 w1, w2 = loop(whole, 1), loop(whole, 2)
-print("whole frame      single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   organisation %d pipeline %d" % (wm, wmin, w1, w2, ctx.last_organisation(), ctx.last_pipeline()))
+org, pipe = ctx.last_organisation(), ctx.last_pipeline()
+ws2, ws3 = loop(whole, 2, True), loop(whole, 3, True)
+print("columns: one frame at a time (HIP events: median of 20, min) | frame loop, wall clock per frame: 1 lane, 2 lanes, frame server with 2 and with 3 frames in flight (nan: the server does not take the frame)")
+print("whole frame      single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   server 2: %7.3f  3: %7.3f   organisation %d pipeline %d" % (wm, wmin, w1, w2, ws2, ws3, org, pipe))
 full = ctx.render(whole)[0] if a.check else None
 rows = []
 for i in idx:
@@ -74,6 +83,7 @@ for i in idx:
     m, mn = (0.0, 0.0) if a.no_single else single(p)
     org = ctx.last_organisation()
     l1, l2 = loop(p, 1), loop(p, 2)
+    s2, s3 = loop(p, 2, True), loop(p, 3, True)
     ok = ""
     if a.check:
         got = ctx.render(p)[0]
@@ -81,9 +91,12 @@ for i in idx:
         sel = [y for y in range(H) if (y // 8) % a.count == i]
         want = full[sel]
         ok = "  equal" if got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)) else "  DIFFERS"
-    rows.append((m, l1, l2))
-    print("share %d/%d        single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   organisation %d%s" % (i, a.count, m, mn, l1, l2, org, ok), flush=True)
+    rows.append((m, l1, l2, s2, s3))
+    print("share %d/%d        single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   server 2: %7.3f  3: %7.3f   organisation %d%s" % (i, a.count, m, mn, l1, l2, s2, s3, org, ok), flush=True)
 r = np.array(rows)
-print("max over ranks   single %7.3f             loop 1 lane %7.3f   2 lanes %7.3f" % tuple(r.max(axis=0)))
-print("speed-up of the slowest share over the whole frame:  single %.2fx   1 lane %.2fx   2 lanes %.2fx   (2 lanes against the one-lane whole frame: %.2fx)" %
-      (wm / r[:, 0].max() if r[:, 0].max() else 0, w1 / r[:, 1].max(), w2 / r[:, 2].max(), w1 / r[:, 2].max()))
+mx = np.nanmax(r, axis=0) if not np.isnan(r[:, 3]).all() else np.concatenate([r[:, :3].max(axis=0), [float("nan")] * 2])
+print("max over ranks   single %7.3f             loop 1 lane %7.3f   2 lanes %7.3f   server 2: %7.3f  3: %7.3f" % tuple(mx))
+best_whole = min(w1, w2)
+print("speed-up of the slowest share over the whole frame, frame after frame (%.3f ms):  single %.2fx   1 lane %.2fx   2 lanes %.2fx   server, 2 in flight %.2fx   server, 3 in flight %.2fx" %
+      (w1, w1 / mx[0] if mx[0] else 0, w1 / mx[1], w1 / mx[2], w1 / mx[3], w1 / mx[4]))
+print("... and over the whole frame at its best on one GPU (%.3f ms, two lanes):  2 lanes %.2fx   server, 3 in flight %.2fx" % (best_whole, best_whole / mx[2], best_whole / mx[4]))
