@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Soak of the frame server: thousands of frames with random numbers of frames in flight, random pauses of the host, shape changes, scene uploads and synchronous
+renders in between; every Nth frame compared with its own flx_render.  GPU box.  usage: server_soak.py [frames] [seed]"""
+import os, random, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+from flexlight_hip import capi
+from flexlight_hip.scene_io import Scene
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+rnd = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+sc = Scene.golden("dragon")
+ctx = capi.Context(0)
+ctx.update_scene(sc)
+ctx.set_frame_chain(3)
+shapes = [dict(width=480, height=272), dict(width=1920, height=1080, tile=(8, 2, 8)), dict(width=640, height=360, samples=4), dict(width=320, height=200, max_reflections=2)]
+def frame(f, shape):
+    p = sc.frame_params(use_filter=0, **shape)
+    p.camera[0] += 0.01 * (f % 97); p.camera[2] -= 0.007 * (f % 89); p.random_seed = float(f % 4)
+    return p
+lanes, shape = 3, shapes[0]
+ctx.set_frame_lanes(lanes)
+inflight, checked, bad, served, t0 = [], 0, 0, 0, time.time()
+f = 0
+while f < N or inflight:
+    r = rnd.random()
+    if f < N and len(inflight) < lanes and (r < 0.6 or not inflight):
+        p = frame(f, shape)
+        ctx.frame_begin(p)
+        served += ctx.last_chained() == 3
+        inflight.append((f, p))
+        f += 1
+    elif inflight:
+        g, p = inflight.pop(0)
+        got = ctx.frame_end()[0]
+        if g % 37 == 0 and not inflight:                     # (the comparison render would end the launch anyway: only when nothing is in flight)
+            want = ctx.render(p)[0]
+            checked += 1
+            bad += not np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    if rnd.random() < 0.01:
+        time.sleep(rnd.random() * 0.01)                      # the host pauses: the launch waits for posts
+    if rnd.random() < 0.004 and not inflight:
+        lanes = rnd.choice([2, 3]); ctx.set_frame_lanes(lanes)
+    if rnd.random() < 0.006:
+        shape = rnd.choice(shapes)                           # frames of another shape: the launch ends, another begins
+    if rnd.random() < 0.003:
+        ctx.update_primary_light_sources(sc.arrays["lights"])
+    if rnd.random() < 0.002:
+        ctx.render(frame(f, shapes[3]))                      # a synchronous render while frames are in flight
+print("%d frames (%d through the server) in %.1f s, %d compared with their own render, %d differ" % (N, served, time.time() - t0, checked, bad))
+sys.exit(1 if bad else 0)
