@@ -160,8 +160,8 @@ flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_ker
  * JavaScript thread never waits for the GPU.  flx_frame_begin is that half: it enqueues one frame — trace, temporal pass,
  * denoise chain as flx_render would run them, then optionally the 8-bit store of the canvas (flx_present) — and the copy of
  * the result into a pinned host buffer the context owns (on a copy stream: the next frame's kernels start meanwhile), and
- * returns.  flx_frame_end waits for the OLDEST frame begun and hands out its pixels and its GPU time.  At most two frames are
- * in flight (two sets of buffers): the host prepares and begins frame N + 1 while frame N is traced and copied.  The pixels
+ * returns.  flx_frame_end waits for the OLDEST frame begun and hands out its pixels and its GPU time.  At most two frames (three with
+ * flx_set_frame_lanes(ctx, 3)) are in flight (a set of buffers each): the host prepares and begins frame N + 1 while frame N is traced and copied.  The pixels
  * stay valid until the second flx_frame_begin after the one that made them (or the context's end); rows as flx_render. */
 #define FLX_FRAME_FLOAT 0      /* float32 RGBA, what flx_render returns */
 #define FLX_FRAME_RGBA8 1      /* bytes R G B A as the canvas' drawing buffer holds them (flx_present): a quarter of the bytes over PCIe */
@@ -173,23 +173,43 @@ flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_t *bytes, f
  * frame begun last will be copied into, -1 if that frame stays in device memory or none was begun.  For bindings that hand the
  * buffers out as zero-copy views and must retire a view when its memory is re-used or re-allocated (napi/flexlight_napi.cc). */
 flx_status flx_frame_host_slots(flx_context *ctx, const void *slots[4], int *last_begun);
-/* frames begun and not yet ended (0 .. 2) */
+/* frames begun and not yet ended (0 .. 3) */
 int flx_frames_in_flight(const flx_context *ctx);
 /* 2 (default): the two frames in flight run on two lanes — two streams with a workspace each (+2 GB at 1080p x 8 spp), the static
- * scene arrays shared — so that frame k + 1's kernels fill the CUs the tails of frame k's kernels leave idle: a frame completes
- * every 7.3 ms instead of every 8.1 ms on the dragon workload, each frame's own time (gpu_ms) a little longer.  1: one lane, frames
- * one after the other on the context's stream.  Temporal frames always use the first lane (their history lives there). */
+ * scene arrays shared — so that frame k + 1's kernels fill the CUs the tails of frame k's kernels leave idle: a whole 1080p dragon frame
+ * completes every 6.3 ms instead of every 6.5 ms, each frame's own time (gpu_ms) a little longer.  1: one lane, frames one after the other
+ * on the context's stream.  3: three frames in flight where the frame server takes the frames (flx_set_frame_chain), as 2 elsewhere.
+ * Temporal frames always use the first lane (their history lives there). */
 flx_status flx_set_frame_lanes(flx_context *ctx, int lanes);
-/* Consecutive frames of the loop INSIDE one persistent launch (csrc/flx_chain.hip; the default, mode 1).  Where the frame kernel with the front of the frame
- * inside it takes the frames (no filter, no temporal accumulation, no work counters, a scene of more than 128 entries, strips of a multiple of 8 rows), two
- * lanes means: both frames in flight live in one stacked workspace of this context, the kernel of frame k completes frame k and WORKS AHEAD on frame
- * k + 1 — whose camera flx_frame_begin of that frame posts to it while it runs — with the lanes frame k no longer fills, and hands what it holds of frame
- * k + 1 to the next kernel when frame k is complete.  A launch then has no drain: a rank's eighth of the 1080p dragon frame completes every ~0.9 ms instead
- * of every 1.28 ms on two separate lanes (1.65 ms one frame at a time).  The reference renders frame after frame from one context without waiting for
- * the GPU (modules/pathtracerWGL2.js:254-303).  Frames are bit-identical to their own flx_render; they complete in order; a frame that differs in
- * anything but camera / view matrix / ambient / seed from the one before, or follows a scene upload, starts a new chain (its kernel waits for the one
- * before as on one lane).  mode 0: the two lanes of flx_set_frame_lanes.  A watchdog trip inside the kernel makes flx_frame_end return FLX_ERR_DEVICE. */
+/* How consecutive frames of the loop overlap on the GPU.  The reference renders frame after frame from one context without waiting for the GPU
+ * (modules/pathtracerWGL2.js:254-303); a frame's own launches, though, end in a drain — the last paths of the frame keep a few waves busy while the
+ * other CUs idle — and for a short frame (a rank's eighth of a 1080p frame: 0.8 ms of work, 1.65 ms from launch to end) the drain is half of the time.
+ *   0  every frame has its own launches, on the lanes of flx_set_frame_lanes;
+ *   1  a chain of launches (csrc/flx_chain.hip): the frame kernel of frame k works ahead on frame k + 1, whose camera flx_frame_begin posts to it while it
+ *      runs, and hands what it holds of that frame to the next launch.  Correct and kept for comparison; the relaunch per frame costs what the overlap gains;
+ *   2  (default) the frame server (csrc/flx_server.hip) for frames of fewer than 64 8 x 8 screen tiles per CU — a rank's share of a frame — and mode 0 for the
+ *      others: ONE persistent launch renders the loop's frames as flx_frame_begin posts them (the view goes through pinned memory; nothing is launched per
+ *      frame), every workgroup works on the oldest frame first and fills its idle lanes with the next ones, resolves the screen tiles it made and the last
+ *      one through with a frame tells the host.  With three frames in flight a rank's eighth of the 1080p dragon frame completes every 0.93 - 0.98 ms (all
+ *      eight ranks; two lanes: 1.29, one frame at a time: 1.65; profiles/r04_share_scaling.txt).  The launch ends when the loop runs empty, or when a frame
+ *      of another shape, a scene upload, a synchronous render or flx_sync needs the device;
+ *   3  the frame server for every frame it can take, whatever its size (a whole 1080p frame: 6.46 ms against 6.32 on two lanes).
+ * The chained modes take frames without filter and temporal accumulation, scenes of more than 128 entries, strips of a multiple of 8 rows, float or
+ * device output, work counters off; any other frame runs as in mode 0.  Frames are bit-identical to their own flx_render and complete in order.  A
+ * watchdog that trips inside a launch makes flx_frame_end return FLX_ERR_DEVICE. */
 flx_status flx_set_frame_chain(flx_context *ctx, int mode);
+/* The last frame begun in the loop: 0 its own launches, 1 it began a chain of launches, 2 it continued one, 3 it went to the frame server. */
+flx_status flx_last_chained(flx_context *ctx, int *chained);
+/* Would flx_frame_begin hand this frame to the frame server (under flx_set_frame_chain(ctx, 3): whatever its size)?  1 / 0. */
+int flx_frame_server_takes(flx_context *ctx, const flx_frame_params *params);
+/* The frame server resolves the loop's frames straight into images the CALLER owns: d_images[i] (n_images = 2 or 3 = the loop's frames in flight;
+ * float4[height][width]; addresses this context's GPU can write — its own memory, a peer GPU's through the peer mapping, pinned host memory) takes the frames
+ * begun i-th, (i + n)-th, ...  With params.tile_count > 1 the context writes its row strips where the image has them, so the contexts of a device group
+ * complete ONE image between them with no exchange, no reassembly kernel and no copy (flx_group_frame_begin does exactly this).  While a target is set, frames
+ * must be ones the server takes and FLX_FRAME_DEVICE; flx_frame_end hands out the image's address.  n_images = 0: the launch's own buffers again.  Frames in
+ * flight are completed where they were begun. */
+flx_status flx_frame_target_set(flx_context *ctx, void *const *d_images, uint32_t n_images);
+int flx_frame_target_index(const flx_context *ctx);      /* which of the images the frame begun last goes to (-1: none) */
 /* Device faults reach the status code.  The frame kernels' wait loops have watchdogs (seconds); a wave that gives up — or finds a ring slot that never
  * fills — sets a bit in the context's device error word (pinned host memory), and the next call in which the host waits for frames (flx_render,
  * flx_render_batch, flx_frame_end, flx_sync) returns FLX_ERR_DEVICE with the bits in flx_last_error and clears the word: the frame is incomplete.  A healthy
@@ -197,16 +217,17 @@ flx_status flx_set_frame_chain(flx_context *ctx, int mode);
  * FLX_INJECT_NO_SHADING, their shade waves drop every batch they pop, so that the walk waves wait for paths that never come back. */
 #define FLX_INJECT_NO_SHADING 1u
 flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog_polls, uint32_t flags);
-/* The last frame begun in the loop: 0 not chained, 1 it began a chain, 2 it continued one (the kernel before it could work ahead on it). */
-flx_status flx_last_chained(flx_context *ctx, int *chained);
-/* Diagnostics of the chained kernels (tools/chain_stats.py): 64 launches (by sequence number mod 64) x 32 words — when the launch started and ended, when the
- * next frame's view was seen, when its own frame was complete, tiles made for either frame, paths handed to the next kernel, walks abandoned. */
+/* Rehearsal of a device group on ONE GPU: the frame server's launch takes `groups` CUs only (0: all), so that the launches of several contexts run beside
+ * each other. */
+flx_status flx_debug_set_server_groups(flx_context *ctx, uint32_t groups);
 /* diagnostics of the frame server's last launch (csrc/flx_server.h: SVS_*): start, end, frames completed, tiles, batches, rotations, ... */
 flx_status flx_get_server_stats(flx_context *ctx, uint64_t *out /* [16] */);
 /* the control words of up to four workgroups of the frame server that gave up (72 words each: workgroup, wave, its 64 LDS control words, the relayed posts, the slots' tile cursors) */
 flx_status flx_get_server_dump(flx_context *ctx, uint64_t *out /* [4 * 72] */);
+/* Diagnostics of the chained launches of mode 1 (tools/chain_stats.py): 64 launches (by sequence number mod 64) x 64 words — when the launch started and ended,
+ * when the next frame's view was seen, when its own frame was complete, tiles made for either frame, paths handed to the next kernel, walks abandoned. */
 flx_status flx_set_chain_stats(flx_context *ctx, int on);
-flx_status flx_get_chain_stats(flx_context *ctx, uint64_t *out /* [64 * 32] */);
+flx_status flx_get_chain_stats(flx_context *ctx, uint64_t *out /* [64 * 64] */);
 /* Experiments with the order in which a chained frame's 8 x 8 screen tiles are drawn (tools/chain_order.py): an explicit permutation of the frame's tiles
  * (n = 0: the row-major default), and per-tile counts of the shadings its paths took after bounce 0 (n tiles per slot; 2 x n words out). */
 flx_status flx_set_chain_order(flx_context *ctx, const uint32_t *order, uint32_t n);
@@ -284,6 +305,19 @@ flx_status flx_group_scene_upload_view(flx_group *group, const flx_scene_view *s
  * flx_render / flx_render_batch of one context bit for bit.  counters (may be NULL): summed over the contexts. */
 flx_status flx_group_render(flx_group *group, const flx_frame_params *params, uint32_t n_frames, uint32_t tile_rows, float *out_rgba,
                             flx_counters *counters);
+/* The group's frame loop — what the reference's render loop is to its one context (pathtracerWGL2.js:254-303: a frame per animation callback, the host
+ * never waits for the GPU).  flx_group_frame_begin posts the frame to every context's frame server (flx_set_frame_chain) and returns; every server renders
+ * its context's strips and resolves them straight into ONE image the group owns — pinned host memory that every GPU writes over its own PCIe link
+ * (FLX_FRAME_FLOAT), or context 0's device memory through the peer mapping (FLX_FRAME_DEVICE) — so a frame needs no exchange, no reassembly and no copy.
+ * flx_group_frame_end waits for the oldest frame's completion words (no stream is synchronised) and hands the image out: float4[height][width], valid until
+ * `lanes` more frames have been begun; ms: the slowest context's time from the post to its word, on the host's clock.  Up to `lanes` frames (2 or 3,
+ * default 3) are in flight; frames complete in order and equal flx_render's bit for bit.  Frames the server does not take (filter and temporal frames,
+ * scenes of <= 128 entries, strips that are no multiple of 8 rows) are rendered by flx_group_render inside flx_group_frame_begin and handed out by the
+ * matching flx_group_frame_end. */
+flx_status flx_group_frame_begin(flx_group *group, const flx_frame_params *params, uint32_t tile_rows, int format);
+flx_status flx_group_frame_end(flx_group *group, const void **pixels, size_t *bytes, float *ms);
+int flx_group_frames_in_flight(const flx_group *group);
+flx_status flx_group_set_frame_lanes(flx_group *group, int lanes);
 
 /* Anti-aliasing post passes: config.antialiasing = 'fxaa' | 'taa' of the reference (modules/fxaa.js:7-137,
  * modules/taa.js:11-59).  Both read the RGBA8 texture the renderer drew into — the frame is stored as the reference stores it,

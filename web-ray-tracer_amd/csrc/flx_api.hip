@@ -1399,6 +1399,10 @@ static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *para
 #define FLX_SERVER_RESERVED_CUS 0u          /* CUs the server launch leaves free (nothing needs them: the frames are resolved inside the launch and copied out by the DMA engines;
                                              * a kernel beside the launch would not get them anyway — its workgroups are dealt to shader engines that may have no free CU) */
 #endif
+#ifndef FLX_SERVER_TILE_LIST_FACTOR
+#define FLX_SERVER_TILE_LIST_FACTOR 4       /* a workgroup's list of tiles to resolve: this many times its even share .. */
+#define FLX_SERVER_TILE_LIST_MIN 64         /* .. this many at the least; a workgroup whose list is full leaves the rest of the frame's tiles to the others */
+#endif
 static flx_status server_take(flx_context *ctx, int k);
 flx_status flx_server_stop(flx_context *ctx) {
   if (!ctx->sv_running && !(ctx->sv_pending[0].valid || ctx->sv_pending[1].valid || ctx->sv_pending[2].valid)) return FLX_OK;
@@ -1419,11 +1423,86 @@ flx_status flx_server_stop(flx_context *ctx) {
 }
 static flx_status server_stop(flx_context *ctx) { return flx_server_stop(ctx); }
 
+/* everything a launch for frames of this shape needs in memory (hipMalloc / hipFree wait for the device: never while a launch is running there) */
+static flx_status server_allocate(flx_context *ctx, const DeviceFrame &frOne, uint32_t depth) {
+  const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
+  flx_status s;
+  DeviceFrame fr = frOne;
+  fr.frames = depth; fr.rows = depth * frOne.frame_rows;
+  const size_t itemsPerSlot = (size_t)path_item_count64(frOne);
+  if (!ctx->d_sv_slots) {
+    /* The launch's stream must not share a hardware queue with the streams that work beside it (the runtime maps streams onto a few queues, and a queue
+     * is served in order: a copy behind the persistent launch in the same queue would wait for its end).  Streams of another priority have queues of
+     * their own: the launch goes to the lowest. */
+    int prLow = 0, prHigh = 0;
+    FLX_HIP(ctx, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+    FLX_HIP(ctx, hipStreamCreateWithPriority(&ctx->sv_stream, hipStreamNonBlocking, prLow));
+    FLX_HIP(ctx, hipMalloc(&ctx->d_sv_slots, SV_MAX_DEPTH * sizeof(ServerSlot)));
+    FLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_sv_mail, sizeof(ServerMail), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(ctx->h_sv_mail, 0, sizeof(ServerMail));
+    FLX_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->d_sv_mail, ctx->h_sv_mail, 0));
+    FLX_HIP(ctx, hipMalloc(&ctx->d_sv_relay, sizeof(ServerMail)));
+    const size_t ringWords = (size_t)cus * server_rings_per_group();
+    FLX_HIP(ctx, hipMalloc(&ctx->d_sv_rings, ringWords * sizeof(uint32_t)));
+    FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_rings, 0xff, ringWords * sizeof(uint32_t), ctx->stream));      /* WF_INVALID everywhere; a launch leaves them so */
+    FLX_HIP(ctx, hipMalloc(&ctx->d_sv_stats, SV_STAT_TOTAL * sizeof(unsigned long long)));
+  }
+  int chains = 1;
+  if ((s = ensure_workspace(ctx, fr, 3, false, chains))) return s;
+  const size_t P1 = (size_t)frOne.rows * frOne.width;
+  if (!ctx->sv_target_slots && ctx->sv_out_capacity < SV_MAX_DEPTH * P1) {      /* (with a frame target the launch resolves into the caller's images) */
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sv_out_capacity = 0;
+    if (ctx->d_sv_out) { FLX_HIP(ctx, hipFree(ctx->d_sv_out)); ctx->d_sv_out = nullptr; }
+    FLX_HIP(ctx, hipMalloc(&ctx->d_sv_out, SV_MAX_DEPTH * P1 * sizeof(float4)));
+    ctx->sv_out_capacity = SV_MAX_DEPTH * P1;
+  }
+  /* a workgroup's list of the screen tiles it made of a frame: a few times its even share (its tiles come to it as it asks for them) */
+  const size_t tilesPerSlot0 = itemsPerSlot / ((size_t)fr.samples * 64u);
+  const size_t groupsMin = ctx->sv_groups && ctx->sv_groups < cus ? ctx->sv_groups : (cus > 16 ? cus - 8 : cus);
+  size_t tcap = FLX_SERVER_TILE_LIST_FACTOR * (tilesPerSlot0 / groupsMin + 1);
+  if (tcap < FLX_SERVER_TILE_LIST_MIN) tcap = FLX_SERVER_TILE_LIST_MIN;
+  if (ctx->sv_tile_cap < tcap) {
+    ctx->sv_tile_cap = 0;
+    if (ctx->d_sv_tiles) { FLX_HIP(ctx, hipFree(ctx->d_sv_tiles)); ctx->d_sv_tiles = nullptr; }
+    FLX_HIP(ctx, hipMalloc(&ctx->d_sv_tiles, (size_t)cus * SV_MAX_DEPTH * tcap * sizeof(uint32_t)));
+    ctx->sv_tile_cap = tcap;
+  }
+  if (!ctx->copy_stream) {
+    FLX_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 3; i++) {
+      FLX_HIP(ctx, hipEventCreate(&ctx->ev_slot_start[i]));
+      FLX_HIP(ctx, hipEventCreate(&ctx->ev_slot_traced[i]));
+      FLX_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_slot_done[i], hipEventDisableTiming));
+    }
+  }
+  return FLX_OK;
+}
+
+static bool server_continues(flx_context *ctx, const flx_frame_params *params) {      /* the running launch takes this frame as it is */
+  const uint32_t depth = ctx->frame_lanes == 3 ? 3u : 2u;
+  return ctx->sv_running && ctx->sv_depth == depth && chain_same_shape(ctx->sv_params, *params) && ctx->sv_scene_version == ctx->scene_version;
+}
+/* For a device group (flx_group_frame_begin): would flx_frame_begin of this frame have to end or start a launch?  And the memory a launch needs, made while
+ * NO launch of the group runs — where contexts share a device, an allocation in one waits for the launch of the other. */
+int flx_server_continues(flx_context *ctx, const flx_frame_params *params) { return server_continues(ctx, params) ? 1 : 0; }
+flx_status flx_server_prepare(flx_context *ctx, const flx_frame_params *params) {
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  DeviceScene sc; DeviceFrame fr;
+  flx_status s = flx_make_frame(ctx, params, sc, fr);
+  if (s) return s;
+  if ((s = flx_server_stop(ctx))) return s;
+  if (ctx->sv_stream) FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));
+  if ((s = server_allocate(ctx, fr, ctx->frame_lanes == 3 ? 3u : 2u))) return s;
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return FLX_OK;
+}
+
 static flx_status server_post(flx_context *ctx, const flx_frame_params *params, const DeviceScene &sc, const DeviceFrame &frOne, uint32_t *seqOut, uint32_t *slotOut) {
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
   const uint32_t depth = ctx->frame_lanes == 3 ? 3u : 2u;
   flx_status s;
-  if (ctx->sv_running && (ctx->sv_depth != depth || !chain_same_shape(ctx->sv_params, *params) || ctx->sv_scene_version != ctx->scene_version))
+  if (ctx->sv_running && !server_continues(ctx, params))
     if ((s = server_stop(ctx))) return s;
   if (!ctx->sv_running) {
     if (ctx->sv_stream) FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));      /* a launch that was told to end reads the mailbox until it has */
@@ -1431,44 +1510,9 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
     fr.frames = depth; fr.rows = depth * frOne.frame_rows;
     for (uint32_t i = 0; i < depth; i++) memset(&fr.view[i], 0, sizeof(FrameView));
     const size_t itemsPerSlot = (size_t)path_item_count64(frOne);
-    if (!ctx->d_sv_slots) {
-      /* The launch's stream must not share a hardware queue with the streams that work beside it (the runtime maps streams onto a few queues, and a queue
-       * is served in order: a resolve behind the persistent launch in the same queue would wait for its end).  Streams of another priority have queues of
-       * their own: the launch goes to the lowest. */
-      int prLow = 0, prHigh = 0;
-      FLX_HIP(ctx, hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
-      FLX_HIP(ctx, hipStreamCreateWithPriority(&ctx->sv_stream, hipStreamNonBlocking, prLow));
-      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_slots, SV_MAX_DEPTH * sizeof(ServerSlot)));
-      FLX_HIP(ctx, hipHostMalloc((void **)&ctx->h_sv_mail, sizeof(ServerMail), hipHostMallocMapped | hipHostMallocCoherent));
-      memset(ctx->h_sv_mail, 0, sizeof(ServerMail));
-      FLX_HIP(ctx, hipHostGetDevicePointer((void **)&ctx->d_sv_mail, ctx->h_sv_mail, 0));
-      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_relay, sizeof(ServerMail)));
-      const size_t ringWords = (size_t)cus * server_rings_per_group();
-      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_rings, ringWords * sizeof(uint32_t)));
-      FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_rings, 0xff, ringWords * sizeof(uint32_t), ctx->stream));      /* WF_INVALID everywhere; a launch leaves them so */
-      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_stats, SV_STAT_TOTAL * sizeof(unsigned long long)));
-    }
-    int chains = 1;
-    if ((s = ensure_workspace(ctx, fr, 3, false, chains))) return s;
+    if ((s = server_allocate(ctx, frOne, depth))) return s;
     const size_t P1 = (size_t)frOne.rows * frOne.width;
-    if (ctx->sv_out_capacity < SV_MAX_DEPTH * P1) {
-      FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      ctx->sv_out_capacity = 0;
-      if (ctx->d_sv_out) { FLX_HIP(ctx, hipFree(ctx->d_sv_out)); ctx->d_sv_out = nullptr; }
-      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_out, SV_MAX_DEPTH * P1 * sizeof(float4)));
-      ctx->sv_out_capacity = SV_MAX_DEPTH * P1;
-    }
     ctx->sv_out_pixels = P1;
-    /* a workgroup's list of the screen tiles it made of a frame: four times its even share, 64 at the least (its tiles come to it as it asks for them) */
-    const size_t tilesPerSlot0 = itemsPerSlot / ((size_t)fr.samples * 64u);
-    size_t tcap = 4 * (tilesPerSlot0 / (cus > 16 ? cus - 8 : cus) + 1);
-    if (tcap < 64) tcap = 64;
-    if (ctx->sv_tile_cap < tcap) {
-      ctx->sv_tile_cap = 0;
-      if (ctx->d_sv_tiles) { FLX_HIP(ctx, hipFree(ctx->d_sv_tiles)); ctx->d_sv_tiles = nullptr; }
-      FLX_HIP(ctx, hipMalloc(&ctx->d_sv_tiles, (size_t)cus * SV_MAX_DEPTH * tcap * sizeof(uint32_t)));
-      ctx->sv_tile_cap = tcap;
-    }
     ctx->chain_seq = 0;                                      /* (the workspace a chain of launches keeps its state in is the server's now) */
     FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));         /* whatever used the workspace before, and the allocations above */
     ctx->sv_counter += 16u;                                  /* sequence numbers: consecutive within a launch, never reused across launches, never 0 */
@@ -1486,18 +1530,26 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
     wb.hits = ctx->d_hits; wb.sampleRadiance = ctx->d_samples; wb.lastOriginal = ctx->d_last; wb.counters = nullptr;
     ServerArgs sa = {};
     sa.slots = ctx->d_sv_slots; sa.mail = ctx->d_sv_mail; sa.relay = ctx->d_sv_relay;
-    sa.depth = depth; sa.slot0 = 0u; sa.seq0 = seq0;
+    /* frames of the launch before may still be in its images (taken, not yet handed out): this launch goes on with the slot after them */
+    const uint32_t slot0 = (ctx->fifo_n && ctx->sv_depth == depth) ? ctx->sv_next_slot % depth : 0u;
+    sa.depth = depth; sa.slot0 = slot0; sa.seq0 = seq0;
     sa.tilesPerSlot = (uint32_t)(itemsPerSlot / ((size_t)fr.samples * 64u));
     sa.itemsPerSlot = (uint32_t)itemsPerSlot;
     for (uint32_t i = 0; i < depth; i++) sa.out[i] = ctx->d_sv_out + (size_t)i * P1;
+    if (ctx->sv_target_slots) {
+      /* the frames are this context's row strips of images somebody else owns: resolved straight into them, each row where the image has it */
+      for (uint32_t i = 0; i < depth; i++) sa.out[i] = ctx->sv_target[i] + (size_t)params->tile_index * params->tile_rows * params->width;
+      sa.outStripRows = params->tile_rows; sa.outStripStep = params->tile_rows * params->tile_count; sa.outSystem = 1u;
+    }
     sa.tileLists = ctx->d_sv_tiles; sa.tileListCap = (uint32_t)ctx->sv_tile_cap;
     sa.idleExit = 200000000u;                                /* 2 s at 100 MHz: a safety net, the host always says when to stop */
     sa.error = ctx->d_dev_error;
     sa.stats = ctx->d_sv_stats;
-    const uint32_t cusWalk = cus > 4u * FLX_SERVER_RESERVED_CUS ? cus - FLX_SERVER_RESERVED_CUS : cus;
+    uint32_t cusWalk = cus > 4u * FLX_SERVER_RESERVED_CUS ? cus - FLX_SERVER_RESERVED_CUS : cus;
+    if (ctx->sv_groups && ctx->sv_groups < cusWalk) cusWalk = ctx->sv_groups;
     if (launch_server(sc, fr, wb, sa, cusWalk, ctx->sv_stream) != 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the frame server does not take this scene");
     FLX_HIP(ctx, hipGetLastError());
-    ctx->sv_running = true; ctx->sv_depth = depth; ctx->sv_next_seq = seq0; ctx->sv_next_slot = 0u;
+    ctx->sv_running = true; ctx->sv_depth = depth; ctx->sv_next_seq = seq0; ctx->sv_next_slot = slot0;
     ctx->sv_params = *params; ctx->sv_scene_version = ctx->scene_version;
   }
   const uint32_t seq = ctx->sv_next_seq++, slot = ctx->sv_next_slot;
@@ -1514,6 +1566,7 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
 static flx_status server_take(flx_context *ctx, int k) {
   auto &pf = ctx->sv_pending[k];
   pf.valid = false;
+  ctx->slot_latency_ms[k] = -1.f;
   const auto t0 = std::chrono::steady_clock::now();
   uint32_t spins = 0;
   while (__atomic_load_n(&ctx->h_sv_mail->done[pf.slot], __ATOMIC_ACQUIRE) != pf.seq) {
@@ -1529,9 +1582,9 @@ static flx_status server_take(flx_context *ctx, int k) {
     ctx->sv_running = false;
     return FLX_OK;                                           /* (flx_frame_end's own check reports the error word) */
   }
-  if (getenv("FLX_SERVER_DEBUG")) fprintf(stderr, "server_take: slot %u seq %u done after %.3f ms (%u spins)\n", pf.slot, pf.seq, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), spins);
   /* the frame is in the launch's output buffer of its slot (every workgroup resolved the screen tiles it made): nothing to launch beside the server */
-  const float4 *src = ctx->d_sv_out + (size_t)pf.slot * ctx->sv_out_pixels;
+  ctx->slot_latency_ms[k] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - pf.posted).count();      /* post .. the launch's word, on the host's clock */
+  const float4 *src = ctx->sv_target_slots ? ctx->sv_target[pf.slot] : ctx->d_sv_out + (size_t)pf.slot * ctx->sv_out_pixels;
   ctx->slot_dev_ptr[k] = src;
   FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_start[k], ctx->copy_stream));
   FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_traced[k], ctx->copy_stream));
@@ -1565,9 +1618,10 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
   const size_t bytes = pixels * (format == FLX_FRAME_RGBA8 ? sizeof(uint32_t) : sizeof(float4));
   /* (hipMalloc / hipFree / hipHostMalloc wait for the device: with the frame server's launch running they would wait for its end — which waits for this
    * frame.  A slot that has to grow ends the launch first; the next frame starts another.) */
-  if (ctx->sv_running && (ctx->slot_capacity[k] < (pixels ? pixels : 1) || !ctx->d_slot[k] || (format != FLX_FRAME_DEVICE && (ctx->h_slot_capacity[k] < bytes || !ctx->h_slot[k]))))
+  const bool served = chained == 2 && !gathered && pixels;      /* (a frame of the server is handed out from the launch's own images, or the caller's: it needs no device slot) */
+  if (ctx->sv_running && ((!served && (ctx->slot_capacity[k] < (pixels ? pixels : 1) || !ctx->d_slot[k])) || (format != FLX_FRAME_DEVICE && (ctx->h_slot_capacity[k] < bytes || !ctx->h_slot[k]))))
     if ((s = flx_server_stop(ctx))) return s;
-  if ((s = flx_ensure_pixels(ctx, &ctx->d_slot[k], &ctx->slot_capacity[k], pixels ? pixels : 1))) return s;
+  if (!served && (s = flx_ensure_pixels(ctx, &ctx->d_slot[k], &ctx->slot_capacity[k], pixels ? pixels : 1))) return s;
   if (format == FLX_FRAME_RGBA8 && ctx->slot8_capacity[k] < pixels) {
     ctx->slot8_capacity[k] = 0;
     if (ctx->d_slot8[k]) { FLX_HIP(ctx, hipFree(ctx->d_slot8[k])); ctx->d_slot8[k] = nullptr; }
@@ -1580,18 +1634,19 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
     FLX_HIP(ctx, hipHostMalloc(&ctx->h_slot[k], bytes ? bytes : 16, hipHostMallocDefault));
     ctx->h_slot_capacity[k] = bytes;
   }
-  if (chained == 2 && !gathered && pixels) {
+  if (served) {
     /* the frame server: the frame is posted to the running launch; flx_frame_end takes it (server_take) */
     uint32_t seq = 0, sslot = 0;
     if ((s = server_post(ctx, params, sc, fr, &seq, &sslot))) return s;
     ctx->sv_pending[k].valid = true; ctx->sv_pending[k].seq = seq; ctx->sv_pending[k].slot = sslot; ctx->sv_pending[k].format = format; ctx->sv_pending[k].fr = fr;
+    ctx->sv_pending[k].posted = std::chrono::steady_clock::now();
     ctx->slot_host[k] = format != FLX_FRAME_DEVICE;
     ctx->slot_bytes[k] = bytes;
     ctx->frames_begun++;
     *slot = k;
     return FLX_OK;
   }
-  ctx->slot_dev_ptr[k] = nullptr;
+  ctx->slot_dev_ptr[k] = nullptr; ctx->slot_latency_ms[k] = -1.f;
   FLX_HIP(ctx, hipEventRecord(ctx->ev_slot_start[k], ctx->stream));
   if (gathered) {
     /* this rank's strips, the exchange over the lane's communicator and the reassembly, all on the lane's stream */
@@ -1713,6 +1768,45 @@ extern "C" flx_status flx_last_chained(flx_context *ctx, int *chained) {
   return FLX_OK;
 }
 
+/* Would flx_frame_begin hand this frame to the frame server (with flx_set_frame_chain(ctx, 3): whatever its size)? */
+extern "C" int flx_frame_server_takes(flx_context *ctx, const flx_frame_params *params) {
+  if (!ctx || !params) return 0;
+  DeviceScene scT; DeviceFrame frT;
+  if (flx_make_frame(ctx, params, scT, frT) != FLX_OK || frT.rows == 0u) return 0;
+  return chain_wanted(ctx, params, scT, frT) && ctx->frame_chain >= 2 ? 1 : 0;
+}
+
+/* The frames of the loop are resolved by the server's launch straight into images the caller owns: d_images[i] (i < n_images = the loop's frames in flight;
+ * float4[height][width], addresses this context's GPU can write: a peer's memory, pinned host memory, its own) takes the frames begun i-th, (i + n)-th, ..
+ * With params.tile_count > 1 the context writes its row strips where the image has them, so the contexts of a device group complete ONE image between them
+ * without any exchange.  n_images = 0: the launch's own buffers again. */
+extern "C" flx_status flx_frame_target_set(flx_context *ctx, void *const *d_images, uint32_t n_images) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (n_images > 3u || n_images == 1u || (n_images && !d_images)) return fail(ctx, FLX_ERR_INVALID, "flx_frame_target_set: 0, 2 or 3 images");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  flx_status s = flx_server_stop(ctx);      /* (frames in flight are completed where they were begun: flx_frame_end still hands them out from there) */
+  if (s) return s;
+  if (ctx->sv_stream) FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));
+  for (uint32_t i = 0; i < 3u; i++) ctx->sv_target[i] = i < n_images ? (float4 *)d_images[i] : nullptr;
+  for (uint32_t i = 0; i < n_images; i++) if (!ctx->sv_target[i]) { ctx->sv_target_slots = 0; return fail(ctx, FLX_ERR_INVALID, "flx_frame_target_set: an image is NULL"); }
+  ctx->sv_target_slots = n_images;
+  return FLX_OK;
+}
+/* the image (index into flx_frame_target_set's) the frame begun last will be in */
+extern "C" int flx_frame_target_index(const flx_context *ctx) {
+  if (!ctx || !ctx->sv_target_slots || !ctx->sv_running) return -1;
+  return (int)((ctx->sv_next_slot + ctx->sv_depth - 1u) % ctx->sv_depth);
+}
+/* rehearsal of a device group on ONE GPU: the server's launch takes only `groups` CUs, so that the launches of several contexts run beside each other */
+extern "C" flx_status flx_debug_set_server_groups(flx_context *ctx, uint32_t groups) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_server_groups: frames are in flight");
+  flx_status s = flx_server_stop(ctx);
+  if (s) return s;
+  ctx->sv_groups = groups;
+  return FLX_OK;
+}
+
 extern "C" flx_status flx_set_frame_lanes(flx_context *ctx, int lanes) {
   if (!ctx) return FLX_ERR_INVALID;
   if (lanes < 1 || lanes > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_lanes: 1 (frames one after the other), 2 (two frames overlap on the GPU) or 3 (three frames in flight where the loop is chained: flx_set_frame_chain; as 2 elsewhere)");
@@ -1739,11 +1833,13 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
       /* The frame server pays where a frame is short against its own chains — a rank's share of a frame: below FLX_SERVER_MAX_TILES_PER_CU screen tiles per
        * workgroup (a rank's eighth of a 1080p frame has 16, a whole 1080p frame 127: 6.46 ms per frame through the server against 6.32 on two lanes,
        * profiles/r04_server.txt); mode 3 takes every frame it can. */
-      if (chained == 2 && path_item_count64(frT) / ((uint64_t)frT.samples * 64u) >= (uint64_t)FLX_SERVER_MAX_TILES_PER_CU * (uint64_t)ctx->prop.multiProcessorCount) chained = 0;
+      if (chained == 2 && !ctx->sv_target_slots && path_item_count64(frT) / ((uint64_t)frT.samples * 64u) >= (uint64_t)FLX_SERVER_MAX_TILES_PER_CU * (uint64_t)ctx->prop.multiProcessorCount) chained = 0;
       if (chained == 3) chained = 2;
     }
   }
   if (chained == 2 && format == FLX_FRAME_RGBA8) chained = 0;      /* (the 8-bit store is a kernel of its own: not beside the server's launch) */
+  if (ctx->sv_target_slots && (chained != 2 || format != FLX_FRAME_DEVICE || ctx->sv_target_slots != (ctx->frame_lanes == 3 ? 3u : 2u)))
+    return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: a frame target is set (flx_frame_target_set) — the frame must be one the frame server takes (flx_frame_server_takes), FLX_FRAME_DEVICE, and the target must have as many images as the loop has frames in flight");
   if (chained == 0) ctx->last_chained = 0;
   if (chained != 2) { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }      /* (a frame of another kind: the server's launch ends, its frames are resolved) */
   if (chained) {
@@ -1804,14 +1900,16 @@ extern "C" flx_status flx_frame_end(flx_context *ctx, const void **pixels, size_
     ctx->sv_running = false;
   }
   if (!(__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u && lane == ctx)) {
-    const auto te = std::chrono::steady_clock::now();
     FLX_HIP(ctx, hipEventSynchronize(lane->slot_host[k] ? lane->ev_slot_done[k] : lane->ev_slot_traced[k]));
-    if (getenv("FLX_SERVER_DEBUG")) fprintf(stderr, "frame_end: event after %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - te).count());
   }
   ctx->fifo[0] = ctx->fifo[1]; ctx->fifo[1] = ctx->fifo[2]; ctx->fifo_n--;
   lane->frames_ended++;
   { flx_status es = flx_check_device_error(ctx); if (es) return es; }
-  if (gpu_ms) { float ms = 0.f; FLX_HIP(ctx, hipEventElapsedTime(&ms, lane->ev_slot_start[k], lane->ev_slot_traced[k])); *gpu_ms = ms; }
+  if (gpu_ms) {
+    float ms = lane->slot_latency_ms[k];                      /* a frame of the frame server: there are no events inside its launch — the time from its post to the launch's word */
+    if (ms < 0.f) FLX_HIP(ctx, hipEventElapsedTime(&ms, lane->ev_slot_start[k], lane->ev_slot_traced[k]));
+    *gpu_ms = ms;
+  }
   if (pixels) *pixels = lane->slot_host[k] ? lane->h_slot[k] : (lane->slot_dev_ptr[k] ? lane->slot_dev_ptr[k] : (const void *)lane->d_slot[k]);
   if (bytes) *bytes = lane->slot_bytes[k];
   return FLX_OK;

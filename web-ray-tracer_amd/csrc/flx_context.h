@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdint>
 #include <map>
 #include <string>
@@ -171,6 +172,7 @@ struct flx_context {
   size_t sv_out_capacity = 0, sv_out_pixels = 0;
   uint32_t *d_sv_tiles = nullptr;                /* [workgroup][slot] x sv_tile_cap: the screen tiles a workgroup made of a frame */
   size_t sv_tile_cap = 0;
+  float slot_latency_ms[3] = { -1.f, -1.f, -1.f }; /* server frames: post .. complete on the host's clock (flx_frame_end's gpu_ms); < 0: timed by events */
   const void *slot_dev_ptr[3] = { nullptr, nullptr, nullptr };      /* where the frame of an output slot really is in device memory when that is not d_slot[k] (server frames) */
   unsigned long long *d_sv_stats = nullptr;
   hipStream_t sv_stream = nullptr;
@@ -178,7 +180,10 @@ struct flx_context {
   uint32_t sv_depth = 0, sv_next_seq = 0, sv_next_slot = 0, sv_counter = 0;
   flx_frame_params sv_params = {};               /* the shape of the frames the running launch takes */
   uint64_t sv_scene_version = 0;
-  struct { bool valid; uint32_t seq, slot; int format; flx::DeviceFrame fr; } sv_pending[3] = {};      /* per output slot: the server frame that will land there */
+  float4 *sv_target[3] = { nullptr, nullptr, nullptr };      /* flx_frame_target_set: whole images the launch resolves this context's strips into (a peer GPU's memory, pinned host memory, ..) */
+  uint32_t sv_target_slots = 0;                  /* 0: none — the launch's own d_sv_out */
+  uint32_t sv_groups = 0;                        /* flx_debug_set_server_groups: workgroups of the launch (0: one per CU) — two launches beside each other on one GPU, to rehearse a device group */
+  struct { bool valid; uint32_t seq, slot; int format; flx::DeviceFrame fr; std::chrono::steady_clock::time_point posted; } sv_pending[3] = {};      /* per output slot: the server frame that will land there */
   /* uploads: capacity of every persistent scene buffer (keyed by the address of its pointer), pinned staging ring */
   std::map<void **, size_t> upload_capacity;
   uint8_t *stage = nullptr;
@@ -208,6 +213,8 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, flx::Devi
 flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, flx::DeviceScene &sc, flx::DeviceFrame &fr);
 flx_status flx_run_frame(flx_context *ctx, const flx::DeviceScene &sc, const flx::DeviceFrame &fr, float4 *d_out, const flx::GBufferPtrs &gb);
 flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels);
+int flx_server_continues(flx_context *ctx, const flx_frame_params *params);      /* the running launch of the frame server takes this frame as it is */
+flx_status flx_server_prepare(flx_context *ctx, const flx_frame_params *params); /* the launch ends; everything a launch for frames like this needs is allocated */
 flx_status flx_server_stop(flx_context *ctx);      /* the frame server's launch ends (after the frames posted to it), the frames in flight are resolved into their output slots */
 flx_status flx_check_device_error(flx_context *ctx);      /* FLX_ERR_DEVICE (and the word cleared) if a frame kernel's watchdog has tripped since the last check */
 /* flx_filter_planes_device; stamp_start = false leaves the frame's start event alone (the trace of the same frame recorded it) */

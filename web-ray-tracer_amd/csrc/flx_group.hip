@@ -14,6 +14,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "flx_context.h"
@@ -233,14 +234,42 @@ struct flx_group {
   std::vector<hipEvent_t> traced;       /* per context: its strips are in d_send */
   std::vector<hipEvent_t> gathered;     /* per context: every copy INTO its d_recv has been enqueued and this marks their end */
   std::string err;
+  /* the frame loop (flx_group_frame_begin / _end): every context's frame server resolves its strips straight into ONE image — in context 0's memory
+   * (FLX_FRAME_DEVICE) or in pinned host memory (FLX_FRAME_FLOAT) — so a frame needs no exchange, no reassembly and no copy */
+  int lanes = 3;
+  bool peer_ok = true;                  /* every context's GPU can write context 0's memory */
+  struct Target { void *base = nullptr; bool host = false; size_t pixels = 0; uint32_t n = 0; };
+  Target target;                        /* target.n images of target.pixels float4 */
+  std::vector<Target> retired;          /* targets of an earlier frame shape that frames in flight still live in */
+  flx_frame_params shape = {};          /* what the target was made for */
+  int shape_format = -1;
+  struct InFlight { int kind; /* 1: through the servers, 0: rendered synchronously (frames the server does not take) */ const void *pixels; size_t bytes; float ms; };
+  InFlight fifo[3] = {};
+  int fifo_n = 0;
+  float4 *h_sync[3] = { nullptr, nullptr, nullptr };      /* pinned: frames rendered synchronously (as many as may be in flight) */
+  size_t h_sync_pixels[3] = { 0, 0, 0 };
+  uint32_t h_sync_next = 0;
 };
 
 static thread_local std::string g_group_error;
 
 extern "C" const char *flx_group_last_error(const flx_group *g) { return g ? g->err.c_str() : g_group_error.c_str(); }
 
+static void group_free_target(flx_group *g, flx_group::Target &t) {
+  if (!t.base) return;
+  if (t.host) (void)hipHostFree(t.base);
+  else { (void)hipSetDevice(g->ctx[0]->device); (void)hipFree(t.base); }
+  t = flx_group::Target();
+}
+
 extern "C" void flx_group_destroy(flx_group *g) {
   if (!g) return;
+  for (flx_context *c : g->ctx) if (c) { (void)hipSetDevice(c->device); (void)flx_frame_target_set(c, nullptr, 0); }      /* (ends the servers' launches) */
+  if (!g->ctx.empty() && g->ctx[0]) {
+    group_free_target(g, g->target);
+    for (auto &t : g->retired) group_free_target(g, t);
+    for (float4 *h : g->h_sync) if (h) (void)hipHostFree(h);
+  }
   for (size_t r = 0; r < g->ctx.size(); r++) {
     if (!g->ctx[r]) continue;
     (void)hipSetDevice(g->ctx[r]->device);
@@ -281,6 +310,17 @@ extern "C" flx_status flx_group_create(int n, const int *devices, flx_group **ou
       g->comms.clear(); flx_group_destroy(g); return FLX_ERR_DEVICE;
     }
     for (int r = 0; r < n; r++) g->ctx[r]->comm = (flx_nccl_comm)g->comms[r];
+    /* the frame loop's contexts write their strips into context 0's memory: a peer mapping where the devices have one (else that loop hands out host frames only) */
+    for (int r = 1; r < n; r++) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[r], devices[0]) == hipSuccess && can) {
+        (void)hipSetDevice(devices[r]);
+        const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+        (void)hipGetLastError();
+      }
+      if (!can) g->peer_ok = false;
+    }
   }
   *out = g;
   return FLX_OK;
@@ -385,5 +425,152 @@ extern "C" flx_status flx_group_render(flx_group *g, const flx_frame_params *par
       for (size_t k = 0; k < sizeof one / sizeof(uint64_t); k++) acc[k] += v[k];
     }
   }
+  return FLX_OK;
+}
+
+
+/* ---- the group's frame loop ------------------------------------------------------------------------------------------------
+ * The reference's loop never waits for the GPU (pathtracerWGL2.js:254-303: requestAnimationFrame, a frame per callback).  Here: flx_group_frame_begin posts
+ * the frame to every context's frame server (flx_server.hip) and returns; each server renders its context's row strips and resolves them straight into the
+ * ONE image the group owns — pinned host memory every GPU writes over its own PCIe link (FLX_FRAME_FLOAT), or context 0's device memory through the peer
+ * mapping (FLX_FRAME_DEVICE).  flx_group_frame_end waits for every server's word and hands the image out: no exchange, no reassembly kernel, no copy, and no
+ * host synchronisation with any stream.  Frames the server does not take (filter / temporal frames, scenes of <= 128 entries, strips that are no multiple of
+ * 8 rows) are rendered synchronously by flx_group_render at flx_group_frame_begin and handed out by the matching _end. */
+extern "C" flx_status flx_group_set_frame_lanes(flx_group *g, int lanes) {
+  if (!g) return FLX_ERR_INVALID;
+  if (lanes < 2 || lanes > 3) { g->err = "flx_group_set_frame_lanes: 2 or 3 frames in flight"; return FLX_ERR_INVALID; }
+  if (g->fifo_n) { g->err = "flx_group_set_frame_lanes: frames are in flight"; return FLX_ERR_INVALID; }
+  g->lanes = lanes;
+  g->shape_format = -1;                 /* (the target is made again, with as many images) */
+  return FLX_OK;
+}
+extern "C" int flx_group_frames_in_flight(const flx_group *g) { return g ? g->fifo_n : 0; }
+
+static bool group_same_shape(const flx_frame_params &a, const flx_frame_params &b) {
+  return a.width == b.width && a.height == b.height && a.samples == b.samples && a.tile_rows == b.tile_rows;
+}
+
+/* the target for frames of this shape and format exists and every context resolves into it */
+static flx_status group_target(flx_group *g, const flx_frame_params *p, uint32_t tile_rows, int format) {
+  const bool host = format == FLX_FRAME_FLOAT;
+  const size_t pixels = (size_t)p->width * p->height;
+  flx_frame_params want = *p; want.tile_rows = tile_rows;
+  if (g->target.base && g->shape_format == format && group_same_shape(g->shape, want) && g->target.n == (uint32_t)g->lanes) return FLX_OK;
+  const int n = (int)g->ctx.size();
+  flx_status s;
+  /* the servers end (frames in flight are completed in the old target, which lives until they are taken) */
+  for (int r = 0; r < n; r++) if ((s = flx_frame_target_set(g->ctx[r], nullptr, 0))) { g->err = flx_last_error(g->ctx[r]); return s; }
+  if (g->target.base) { if (g->fifo_n) g->retired.push_back(g->target); else group_free_target(g, g->target); g->target = flx_group::Target(); }
+  flx_group::Target t;
+  t.host = host; t.pixels = pixels; t.n = (uint32_t)g->lanes;
+  (void)hipSetDevice(g->ctx[0]->device);
+  const size_t bytes = (size_t)t.n * pixels * sizeof(float4);
+  const hipError_t e = host ? hipHostMalloc(&t.base, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) : hipMalloc(&t.base, bytes);
+  if (e != hipSuccess) { g->err = std::string("flx_group_frame_begin: the frames' images: ") + hipGetErrorString(e); return FLX_ERR_DEVICE; }
+  g->target = t; g->shape = want; g->shape_format = format;
+  for (int r = 0; r < n; r++) {
+    void *img[3] = { nullptr, nullptr, nullptr };
+    for (uint32_t i = 0; i < t.n; i++) {
+      void *at = (char *)t.base + (size_t)i * pixels * sizeof(float4);
+      if (host) {
+        (void)hipSetDevice(g->ctx[r]->device);
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, at, 0) != hipSuccess) { g->err = "flx_group_frame_begin: the pinned frame has no address on a device of the group"; return FLX_ERR_DEVICE; }
+        at = dp;
+      }
+      img[i] = at;
+    }
+    if ((s = flx_frame_target_set(g->ctx[r], img, t.n))) { g->err = flx_last_error(g->ctx[r]); return s; }
+  }
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params *params, uint32_t tile_rows, int format) {
+  if (!g) return FLX_ERR_INVALID;
+  if (!params || tile_rows == 0u) { g->err = "flx_group_frame_begin: params and tile_rows"; return FLX_ERR_INVALID; }
+  if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_DEVICE) { g->err = "flx_group_frame_begin: format is FLX_FRAME_FLOAT (the frame in pinned host memory) or FLX_FRAME_DEVICE (in context 0's device memory)"; return FLX_ERR_INVALID; }
+  if (g->fifo_n >= g->lanes) { g->err = "flx_group_frame_begin: as many frames are in flight as the loop has lanes (flx_group_set_frame_lanes), take one with flx_group_frame_end first"; return FLX_ERR_INVALID; }
+  const int n = (int)g->ctx.size();
+  if (g->fifo_n == 0) for (auto &t : g->retired) group_free_target(g, t);
+  if (g->fifo_n == 0) g->retired.clear();
+  std::vector<flx_frame_params> p((size_t)n, *params);
+  bool server = format == FLX_FRAME_FLOAT || g->peer_ok;
+  flx_status s;
+  for (int r = 0; r < n; r++) {
+    p[r].tile_rows = tile_rows; p[r].tile_index = (uint32_t)r; p[r].tile_count = (uint32_t)n;
+    flx_context *c = g->ctx[r];
+    if (c->frame_lanes != g->lanes || c->frame_chain != 3) {
+      if (c->fifo_n == 0) { c->frame_lanes = g->lanes; c->frame_chain = 3; }      /* (every frame the server can take, whatever its size: the target says where it goes) */
+    }
+    if (!flx_frame_server_takes(c, &p[r])) server = false;
+  }
+  auto &slot = g->fifo[g->fifo_n];
+  if (!server && format == FLX_FRAME_DEVICE) { g->err = "flx_group_frame_begin: FLX_FRAME_DEVICE takes only frames the frame server takes (flx_frame_server_takes) on GPUs that can write context 0's memory; FLX_FRAME_FLOAT takes every frame"; return FLX_ERR_INVALID; }
+  if (!server) {
+    /* a frame of another kind: the frames in flight stay where they are, this one is rendered now */
+    const size_t pixels = (size_t)params->width * params->height;
+    for (int r = 0; r < n; r++) if ((s = flx_frame_target_set(g->ctx[r], nullptr, 0))) { g->err = flx_last_error(g->ctx[r]); return s; }      /* (the servers end; their frames are complete) */
+    if (g->target.base) { if (g->fifo_n) g->retired.push_back(g->target); else group_free_target(g, g->target); g->target = flx_group::Target(); g->shape_format = -1; }
+    const uint32_t b = g->h_sync_next; g->h_sync_next = (b + 1u) % 3u;
+    if (g->h_sync_pixels[b] < pixels) {
+      if (g->h_sync[b]) (void)hipHostFree(g->h_sync[b]);
+      g->h_sync[b] = nullptr; g->h_sync_pixels[b] = 0;
+      if (hipHostMalloc((void **)&g->h_sync[b], pixels * sizeof(float4), hipHostMallocDefault) != hipSuccess) { g->err = "flx_group_frame_begin: pinned memory for the frame"; return FLX_ERR_DEVICE; }
+      g->h_sync_pixels[b] = pixels;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((s = flx_group_render(g, params, 1, tile_rows, (float *)g->h_sync[b], nullptr))) return s;
+    slot.kind = 0; slot.bytes = pixels * sizeof(float4);
+    slot.pixels = (const void *)g->h_sync[b];
+    slot.ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    g->fifo_n++;
+    return FLX_OK;
+  }
+  if ((s = group_target(g, params, tile_rows, format))) return s;
+  /* A launch that has to end or start allocates (and hipMalloc / hipFree wait for the device): where contexts share a device that must not happen while
+   * another context's launch runs — it would wait for a launch that waits for the host.  So if ANY context cannot simply post, all launches end first (their
+   * frames complete), every context gets its memory, and then the frame is posted everywhere. */
+  bool simply = true;
+  for (int r = 0; r < n; r++) if (!flx_server_continues(g->ctx[r], &p[r])) simply = false;
+  if (!simply) {
+    for (int r = 0; r < n; r++) if ((s = flx_server_stop(g->ctx[r]))) { g->err = flx_last_error(g->ctx[r]); return s; }
+    for (int r = 0; r < n; r++) if ((s = flx_server_prepare(g->ctx[r], &p[r]))) { g->err = flx_last_error(g->ctx[r]); return s; }
+  }
+  int image = -1;
+  for (int r = 0; r < n; r++) {
+    flx_context *c = g->ctx[r];
+    if ((s = flx_frame_begin(c, &p[r], FLX_FRAME_DEVICE))) { g->err = flx_last_error(c); return s; }
+    const int at = flx_frame_target_index(c);
+    if (r == 0) image = at;
+    else if (at != image) { g->err = "flx_group_frame_begin: internal: the contexts' servers disagree about the frame's image"; return FLX_ERR_DEVICE; }
+  }
+  if (image < 0) { g->err = "flx_group_frame_begin: internal: no image"; return FLX_ERR_DEVICE; }
+  slot.kind = 1; slot.bytes = g->target.pixels * sizeof(float4);
+  slot.pixels = (const char *)g->target.base + (size_t)image * slot.bytes;
+  slot.ms = 0.f;
+  g->fifo_n++;
+  return FLX_OK;
+}
+
+extern "C" flx_status flx_group_frame_end(flx_group *g, const void **pixels, size_t *bytes, float *ms) {
+  if (!g) return FLX_ERR_INVALID;
+  if (g->fifo_n == 0) { g->err = "flx_group_frame_end: no frame in flight"; return FLX_ERR_INVALID; }
+  flx_group::InFlight f = g->fifo[0];
+  g->fifo[0] = g->fifo[1]; g->fifo[1] = g->fifo[2]; g->fifo_n--;
+  flx_status first = FLX_OK;
+  if (f.kind == 1) {
+    float worst = 0.f;
+    for (flx_context *c : g->ctx) {     /* every context's part of the image is complete (and written back to where the image lives) when its server says so */
+      float one = 0.f;
+      const flx_status s = flx_frame_end(c, nullptr, nullptr, &one);
+      if (s && !first) { first = s; g->err = flx_last_error(c); }
+      if (one > worst) worst = one;
+    }
+    f.ms = worst;
+  }
+  if (first) return first;
+  if (pixels) *pixels = f.pixels;
+  if (bytes) *bytes = f.bytes;
+  if (ms) *ms = f.ms;
   return FLX_OK;
 }

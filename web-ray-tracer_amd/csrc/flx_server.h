@@ -36,6 +36,9 @@ struct ServerArgs {
   uint32_t slot0, seq0;                        /* the first frame: the slot it is in, its sequence number; frame seq0 + i is in slot (slot0 + i) % depth */
   uint32_t tilesPerSlot, itemsPerSlot;
   float4 *out[SV_MAX_DEPTH];                   /* per slot: the resolved frame (float4[frame_rows][width]); a workgroup resolves the screen tiles it made when it is through with the frame */
+  uint32_t outStripRows, outStripStep;         /* 0, or: the frame is a rank's row strips and out[] the WHOLE image from the rank's first strip on — row r of the frame is row
+                                                * (r / outStripRows) x outStripStep + r % outStripRows there (strips of outStripRows rows, the rank's next one outStripStep rows on) */
+  uint32_t outSystem;                          /* out[] is not this GPU's memory (a peer's, or the host's): a workgroup's part is released at system scope */
   uint32_t *tileLists;                         /* [workgroup][slot] x tileListCap: the screen tiles the workgroup made of the frame in the slot */
   uint32_t tileListCap;
   uint32_t idleExit;                           /* 100 MHz ticks without anything to do after which a workgroup gives up (an error: the host always says when to stop) */

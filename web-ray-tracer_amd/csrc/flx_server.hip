@@ -159,6 +159,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     if (fq_load(&ctl[SC_TILEDRY + slot]) != 0u) return 2u;
     FLX_SERVER_ARGS();
     uint32_t take = 0, tile = 0;
+    if (lane == 0 && fq_load(&ctl[SC_NTILES + slot]) >= sa.tileListCap) {
+      /* the list of the tiles this workgroup has to resolve is full (a frame of mostly empty tiles, and this workgroup found them): the others make the rest;
+       * all it still needs of the queue is to see it dry */
+      if (fq_load(&ctl[SC_SAVAIL + slot]) == 1u && __hip_atomic_load(&sa.slots[slot].tileNext, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tilesPerSlot)
+        __hip_atomic_store(&ctl[SC_TILEDRY + slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else
     if (lane == 0 && fq_load(&rctl(RK_READY, slot)[2]) < readyUnits) {
       const uint32_t mySeq = fq_load(&ctl[SC_SEQ + slot]);
       atomicAdd(&ctl[SC_ALIVE + slot], perTile);
@@ -216,10 +222,13 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         if (px < fr.width && k < fr.rows) {
           const size_t o = (size_t)k * fr.width + px;
           const float4 c = resolve_pixel(fr, wb.hits, wb.sampleRadiance, wb.lastOriginal, o, stride);
-          sa.out[P][(size_t)(k - P * fr.frame_rows) * fr.width + px] = c;
+          uint32_t row = k - P * fr.frame_rows;
+          if (sa.outStripRows) { const uint32_t strip = row / sa.outStripRows; row = strip * sa.outStripStep + (row - strip * sa.outStripRows); }
+          sa.out[P][(size_t)row * fr.width + px] = c;
         }
       }
-      /* this workgroup's part of the frame is in its XCD's L2 at the latest: written back, then counted */
+      /* this workgroup's part of the frame is in its XCD's L2 at the latest: written back (to the memory of whoever owns the frame), then counted */
+      if (sa.outSystem) __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); else
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) {

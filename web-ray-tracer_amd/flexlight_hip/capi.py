@@ -26,6 +26,8 @@ EXPORTS = [
     "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag", "flx_set_frame_chain", "flx_last_chained", "flx_debug_inject_fault", "flx_set_chain_stats", "flx_get_chain_stats", "flx_get_server_stats", "flx_get_server_dump", "flx_set_chain_order", "flx_set_chain_cost", "flx_get_chain_cost",
     "flx_render_gathered_root_device", "flx_comm_count", "flx_frame_begin_gathered", "flx_group_set_gather", "flx_frame_host_slots", "flx_has_experiments", "flx_set_wavefront_organisation", "flx_set_frame_front", "flx_last_organisation",
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
+    "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
+    "flx_frame_server_takes", "flx_frame_target_set", "flx_frame_target_index", "flx_debug_set_server_groups",
 ]
 
 
@@ -135,6 +137,14 @@ def _load():
         "flx_group_atlas_upload": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint8), u32, u32]),
         "flx_group_scene_upload_view": (C.c_int, [vp, C.POINTER(SceneView)]),
         "flx_group_render": (C.c_int, [vp, C.POINTER(FrameParams), u32, u32, fp, C.POINTER(Counters)]),
+        "flx_group_frame_begin": (C.c_int, [vp, C.POINTER(FrameParams), u32, C.c_int]),
+        "flx_group_frame_end": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
+        "flx_group_frames_in_flight": (C.c_int, [vp]),
+        "flx_group_set_frame_lanes": (C.c_int, [vp, C.c_int]),
+        "flx_frame_server_takes": (C.c_int, [vp, C.POINTER(FrameParams)]),
+        "flx_frame_target_set": (C.c_int, [vp, C.POINTER(vp), u32]),
+        "flx_frame_target_index": (C.c_int, [vp]),
+        "flx_debug_set_server_groups": (C.c_int, [vp, u32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -279,8 +289,23 @@ class Context:
         self._check(LIB.flx_set_frame_lanes(self._h, int(lanes)), "flx_set_frame_lanes")
 
     def set_frame_chain(self, mode):
-        """1 (default): consecutive frames of the loop overlap inside one persistent launch where the frame kernel takes them (flx_chain.hip); 0: two lanes"""
+        """0 every frame its own launches; 1 a chain of launches (flx_chain.hip); 2 (default) the frame server (flx_server.hip) for thin frames; 3 the server for every frame it takes"""
         self._check(LIB.flx_set_frame_chain(self._h, int(mode)), "flx_set_frame_chain")
+
+    def frame_server_takes(self, params):
+        return bool(LIB.flx_frame_server_takes(self._h, C.byref(params)))
+
+    def frame_target_set(self, images):
+        """images: device-visible addresses of float4[H][W] images (2 or 3; [] clears): the frame server resolves this context's strips straight into them"""
+        arr = (C.c_void_p * max(1, len(images)))(*[C.c_void_p(int(p)) for p in images])
+        self._check(LIB.flx_frame_target_set(self._h, arr if images else None, len(images)), "flx_frame_target_set")
+
+    def frame_target_index(self):
+        return int(LIB.flx_frame_target_index(self._h))
+
+    def set_server_groups(self, groups):
+        """rehearsal: the frame server's launch takes only `groups` CUs (0: all)"""
+        self._check(LIB.flx_debug_set_server_groups(self._h, int(groups)), "flx_debug_set_server_groups")
 
     def inject_fault(self, watchdog_polls=0, flags=0):
         """tests: the next frames' frame kernels give up after `watchdog_polls` polls; flags 1 = their shade waves drop every batch"""
@@ -584,6 +609,30 @@ class Group:
         cnt = Counters() if counters else None
         self._check(LIB.flx_group_render(self._h, arr, n, tile_rows, _fp(out), C.byref(cnt) if cnt else None), "flx_group_render")
         return out, (cnt.as_dict() if cnt else None)
+
+    # -- the group's frame loop (flx_group_frame_begin / _end): every context's frame server resolves its strips into ONE image ----
+    def set_frame_lanes(self, lanes):
+        self._check(LIB.flx_group_set_frame_lanes(self._h, int(lanes)), "flx_group_set_frame_lanes")
+
+    def frames_in_flight(self):
+        return int(LIB.flx_group_frames_in_flight(self._h))
+
+    def frame_begin(self, params, tile_rows=8, device=False):
+        self._pending = getattr(self, "_pending", [])
+        self._check(LIB.flx_group_frame_begin(self._h, C.byref(params), tile_rows, 2 if device else 0), "flx_group_frame_begin")
+        self._pending.append((params.height, params.width, device))
+
+    def frame_end(self):
+        """-> (pixels [H, W, 4] float32: a COPY of the pinned image — or, for a frame begun with device=True, its address in context 0's memory —, ms)"""
+        ptr, n, ms = C.c_void_p(), C.c_size_t(), C.c_float()
+        rc = LIB.flx_group_frame_end(self._h, C.byref(ptr), C.byref(n), C.byref(ms))
+        if rc != 1 or self._pending:
+            h, w, device = self._pending.pop(0)
+        self._check(rc, "flx_group_frame_end")
+        if device:
+            return ptr.value, ms.value
+        buf = (C.c_float * (h * w * 4)).from_address(ptr.value)
+        return np.frombuffer(buf, np.float32).reshape(h, w, 4).copy(), ms.value
 
 
 class Mesh:
