@@ -280,6 +280,22 @@ int flx_comm_count(const flx_context *ctx);
  * (0 bytes elsewhere).  Frames complete in order; at most two in flight. */
 flx_status flx_frame_begin_gathered(flx_context *ctx, const flx_frame_params *params, int format, int root);
 
+/* One process per GPU WITHOUT a collective: the ranks' frame servers (flx_set_frame_chain) complete ONE image in the root rank's device memory.  The root
+ * allocates n_images (2 or 3 = frames in flight) images and exports them (flx_share_create: a hipIpcMemHandle and the name of a page of POSIX shared memory
+ * in `handle`, which the caller hands to the other ranks — bench.py broadcasts it over torch.distributed); the others map them (flx_share_join: their stores
+ * go over xGMI); every rank's launch resolves its row strips where the image has them.  The loop is the frame loop's: flx_frame_begin_shared (params.tile_count
+ * = the ranks, .tile_index = this rank; a frame the frame server takes) / flx_frame_end_shared, up to n_images frames in flight on every rank; on the root
+ * flx_frame_end_shared waits until every rank has completed its strips of the frame and hands out the image (device memory; valid until the root's next
+ * flx_frame_begin_shared — no rank overwrites an image before that), elsewhere it returns NULL / 0 bytes.  Frames equal flx_render of one context bit for bit.
+ * A rank that fails or does not answer within 5 s makes every rank's next call return FLX_ERR_DEVICE instead of waiting.  The root is the context that
+ * presents, as the reference's one context does (pathtracerWGL2.js:552-553). */
+#define FLX_SHARE_HANDLE_BYTES 128
+flx_status flx_share_create(flx_context *ctx, uint32_t width, uint32_t height, uint32_t n_images, int n_ranks, int rank, uint8_t *handle /* [FLX_SHARE_HANDLE_BYTES] out */);
+flx_status flx_share_join(flx_context *ctx, const uint8_t *handle, int rank);
+flx_status flx_share_leave(flx_context *ctx);      /* (also done by flx_context_destroy) */
+flx_status flx_frame_begin_shared(flx_context *ctx, const flx_frame_params *params);
+flx_status flx_frame_end_shared(flx_context *ctx, const void **image, size_t *bytes, float *ms);
+
 /* One process, n GPUs (the JavaScript host: Node is one process): n contexts, one RCCL communicator each (ncclCommInitAll).
  * `devices` may name one GPU more than once — a rehearsal on a one-GPU box, where RCCL refuses two ranks on a device: the
  * strips are then exchanged with device-to-device copies, everything else is unchanged (flx_group_uses_rccl says which). */

@@ -1,0 +1,106 @@
+"""One process per GPU without a collective (csrc/flx_share.hip): the ranks' frame servers complete ONE image in the root rank's device memory, which the
+other ranks map through hipIpc; the ranks tell each other about frames through a page of POSIX shared memory.
+
+Rehearsed here with two PROCESSES on the one GPU of the box, each server's launch taking half of the CUs (flx_debug_set_server_groups) so that both run at
+once as they do on two GPUs; the stores of the second process go through its IPC mapping of the first one's allocation.  Every frame the root hands out must
+equal flx_render of one context bit for bit (tests/test_parity_gpu.py holds that against the oracle)."""
+import ctypes
+import multiprocessing as mp
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H, FRAMES, LANES, RANKS = 640, 368, 7, 3, 2
+
+
+def _moving(sc, f, **kw):
+    p = sc.frame_params(use_filter=0, width=W, height=H, **kw)
+    p.camera[0] += 0.05 * f
+    p.camera[2] -= 0.03 * f
+    p.random_seed = float(f % 4)
+    return p
+
+
+def _rank_main(rank, conn, tile_rows):
+    """one rank: rank 0 creates the share and sends the handle up; the others receive it from the parent"""
+    try:
+        from flexlight_hip import capi
+        from flexlight_hip.scene_io import Scene
+        sc = Scene.golden("dragon")
+        ctx = capi.Context(0)
+        ctx.update_scene(sc)
+        ctx.set_server_groups(ctx.device_info()[1] // RANKS)
+        want = None
+        if rank == 0:
+            want = [ctx.render(_moving(sc, f))[0] for f in range(FRAMES)]      # (before any launch of the other rank holds CUs)
+            conn.send(ctx.share_create(W, H, LANES, RANKS, 0))
+            assert conn.recv() == "go"
+        else:
+            ctx.share_join(conn.recv(), rank)
+            conn.send("joined")
+            assert conn.recv() == "go"
+        try:
+            hiprt = ctypes.CDLL("libamdhip64.so")
+        except OSError:
+            hiprt = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+        bad, inflight = [], []
+
+        def take():
+            ptr, _ = ctx.frame_end_shared()
+            f = inflight.pop(0)
+            if rank == 0:
+                out = np.empty((H, W, 4), np.float32)
+                assert hiprt.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(H * W * 16), 2) == 0
+                if not np.array_equal(out.view(np.uint32), want[f].view(np.uint32)):
+                    bad.append(f)
+            else:
+                assert ptr is None
+        for f in range(FRAMES):
+            if len(inflight) == LANES:
+                take()
+            ctx.frame_begin_shared(_moving(sc, f, tile=(tile_rows, rank, RANKS)))
+            assert ctx.last_chained() == 3
+            inflight.append(f)
+        while inflight:
+            take()
+        # a frame of another size is refused, a second share too
+        with pytest.raises(capi.FlexLightHipError):
+            ctx.frame_begin_shared(sc.frame_params(use_filter=0, width=W, height=H - 8, tile=(tile_rows, rank, RANKS)))
+        ctx.share_leave()
+        ctx.close()
+        conn.send(("ok", bad))
+    except BaseException as e:      # noqa: BLE001 — reported to the parent, which fails the test
+        import traceback
+        conn.send(("error", traceback.format_exc() + repr(e)))
+
+
+@pytest.mark.parametrize("tile_rows", [8, 16])
+def test_two_processes_complete_one_image(tile_rows):
+    mpc = mp.get_context("spawn")
+    pipes = [mpc.Pipe() for _ in range(RANKS)]
+    procs = [mpc.Process(target=_rank_main, args=(r, pipes[r][1], tile_rows)) for r in range(RANKS)]
+    for p in procs:
+        p.start()
+    try:
+        assert pipes[0][0].poll(120), "rank 0 did not create the share"
+        handle = pipes[0][0].recv()
+        assert isinstance(handle, bytes), handle
+        for r in range(1, RANKS):
+            pipes[r][0].send(handle)
+            assert pipes[r][0].poll(120), "rank %d did not join" % r
+            got = pipes[r][0].recv()
+            assert got == "joined", got
+        for r in range(RANKS):
+            pipes[r][0].send("go")
+        for r in range(RANKS):
+            assert pipes[r][0].poll(120), "rank %d did not finish" % r
+            status, detail = pipes[r][0].recv()
+            assert status == "ok", detail
+            assert detail == [], "frames %s differ from one context's render" % detail
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.kill()

@@ -6,6 +6,8 @@ usage: share_all.py [--workload dragon|dragon_4k|theater] [--count 8] [--indices
 --check: every share's frame is compared with the same rows of the whole frame (bit for bit)."""
 import argparse, os, sys, time
 import numpy as np
+if "--target" in sys.argv:
+    import torch                           # (before the library: both must end up on ONE HIP runtime — the first libamdhip64 loaded)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
 from flexlight_hip import capi
@@ -18,6 +20,7 @@ ap.add_argument("--front", type=int, default=-1)
 ap.add_argument("--frames", type=int, default=60)
 ap.add_argument("--check", action="store_true")
 ap.add_argument("--no-single", action="store_true")
+ap.add_argument("--target", action="store_true", help="also: the share resolved straight into whole images in pinned host memory / device memory (flx_frame_target_set)")
 a = ap.parse_args()
 work = a.workload
 sc = Scene.golden("theater" if work == "theater" else "dragon")
@@ -68,6 +71,39 @@ def loop(p, lanes, server=False):
     ctx.set_frame_chain(2)
     return best if (served or not server) else float("nan")
 
+_images = {}
+def loop_target(p, where):
+    """the same loop through the frame server with three frames in flight, the share resolved straight into WHOLE images of the caller's (flx_frame_target_set):
+    pinned host memory (what flx_group_frame_begin's FLX_FRAME_FLOAT does on every GPU of a group) or device memory"""
+    import torch
+    if where not in _images:
+        _images[where] = torch.zeros((3, p.height, p.width, 4), dtype=torch.float32, device="cuda") if where == "device" else torch.zeros((3, p.height, p.width, 4), dtype=torch.float32).pin_memory()
+    img = _images[where]
+    ctx.set_frame_lanes(3)
+    ctx.set_frame_chain(3)
+    ctx.frame_target_set([img[i].data_ptr() for i in range(3)])
+    best = 1e9
+    try:
+        for rep in range(3):
+            for _ in range(2):
+                ctx.frame_begin(p, device=True)
+            for _ in range(4):
+                ctx.frame_begin(p, device=True)
+                ctx.frame_end()
+            t0 = time.perf_counter()
+            for _ in range(a.frames):
+                ctx.frame_begin(p, device=True)
+                ctx.frame_end()
+            dt = time.perf_counter() - t0
+            while ctx.frames_in_flight():
+                ctx.frame_end()
+            best = min(best, dt * 1e3 / a.frames)
+    finally:
+        ctx.frame_target_set([])
+        ctx.set_frame_lanes(1)
+        ctx.set_frame_chain(2)
+    return best
+
 print("workload %s, lib %s" % (work, os.path.basename(capi.LIB_PATH)))
 whole = params(0, 1)
 wm, wmin = single(whole)
@@ -78,6 +114,7 @@ print("columns: one frame at a time (HIP events: median of 20, min) | frame loop
 print("whole frame      single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   server 2: %7.3f  3: %7.3f   organisation %d pipeline %d" % (wm, wmin, w1, w2, ws2, ws3, org, pipe))
 full = ctx.render(whole)[0] if a.check else None
 rows = []
+targets = []
 for i in idx:
     p = params(i, a.count)
     m, mn = (0.0, 0.0) if a.no_single else single(p)
@@ -92,7 +129,15 @@ for i in idx:
         want = full[sel]
         ok = "  equal" if got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32)) else "  DIFFERS"
     rows.append((m, l1, l2, s2, s3))
-    print("share %d/%d        single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   server 2: %7.3f  3: %7.3f   organisation %d%s" % (i, a.count, m, mn, l1, l2, s2, s3, org, ok), flush=True)
+    tgt = ""
+    if a.target:
+        th, td = loop_target(p, "host"), loop_target(p, "device")
+        targets.append((th, td))
+        tgt = "   into a whole image, 3 in flight: pinned host %7.3f  device %7.3f" % (th, td)
+        if a.check:
+            sel = [y for y in range(whole.height) if (y // 8) % a.count == i]
+            ok += "  host image " + ("equal" if np.array_equal(_images["host"][0].numpy()[sel].view(np.uint32), full[sel].view(np.uint32)) else "DIFFERS")
+    print("share %d/%d        single %7.3f (%7.3f)   loop 1 lane %7.3f   2 lanes %7.3f   server 2: %7.3f  3: %7.3f   organisation %d%s%s" % (i, a.count, m, mn, l1, l2, s2, s3, org, tgt, ok), flush=True)
 r = np.array(rows)
 mx = np.nanmax(r, axis=0) if not np.isnan(r[:, 3]).all() else np.concatenate([r[:, :3].max(axis=0), [float("nan")] * 2])
 print("max over ranks   single %7.3f             loop 1 lane %7.3f   2 lanes %7.3f   server 2: %7.3f  3: %7.3f" % tuple(mx))
@@ -100,3 +145,6 @@ best_whole = min(w1, w2)
 print("speed-up of the slowest share over the whole frame, frame after frame (%.3f ms):  single %.2fx   1 lane %.2fx   2 lanes %.2fx   server, 2 in flight %.2fx   server, 3 in flight %.2fx" %
       (w1, w1 / mx[0] if mx[0] else 0, w1 / mx[1], w1 / mx[2], w1 / mx[3], w1 / mx[4]))
 print("... and over the whole frame at its best on one GPU (%.3f ms, two lanes):  2 lanes %.2fx   server, 3 in flight %.2fx" % (best_whole, best_whole / mx[2], best_whole / mx[4]))
+if targets:
+    t = np.array(targets)
+    print("max over ranks, share resolved into a whole image with 3 frames in flight:  pinned host memory %.3f ms (%.2fx the whole frame on two lanes)   device memory %.3f ms (%.2fx)" % (t[:, 0].max(), best_whole / t[:, 0].max(), t[:, 1].max(), best_whole / t[:, 1].max()))

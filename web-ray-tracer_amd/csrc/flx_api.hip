@@ -94,6 +94,7 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
 extern "C" void flx_context_destroy(flx_context *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->share) (void)flx_share_leave(ctx);
   if (ctx->sv_running && ctx->h_sv_mail) { __atomic_store_n(&ctx->h_sv_mail->stopAfter, ctx->sv_next_seq - 1u, __ATOMIC_RELEASE); ctx->sv_running = false; (void)hipStreamSynchronize(ctx->sv_stream); }
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->twin) { flx_context_destroy(ctx->twin); ctx->twin = nullptr; }

@@ -16,6 +16,7 @@
 #include "flx_chain.h"
 #include "flx_server.h"
 
+struct flx_share;                                 /* flx_share.hip: this context's part in the ranks' shared frames */
 typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept out of this header */
 
 #ifndef FLX_WF_GROUPS
@@ -182,6 +183,7 @@ struct flx_context {
   uint64_t sv_scene_version = 0;
   float4 *sv_target[3] = { nullptr, nullptr, nullptr };      /* flx_frame_target_set: whole images the launch resolves this context's strips into (a peer GPU's memory, pinned host memory, ..) */
   uint32_t sv_target_slots = 0;                  /* 0: none — the launch's own d_sv_out */
+  flx_share *share = nullptr;
   uint32_t sv_groups = 0;                        /* flx_debug_set_server_groups: workgroups of the launch (0: one per CU) — two launches beside each other on one GPU, to rehearse a device group */
   struct { bool valid; uint32_t seq, slot; int format; flx::DeviceFrame fr; std::chrono::steady_clock::time_point posted; } sv_pending[3] = {};      /* per output slot: the server frame that will land there */
   /* uploads: capacity of every persistent scene buffer (keyed by the address of its pointer), pinned staging ring */

@@ -28,9 +28,11 @@ EXPORTS = [
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
     "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
     "flx_frame_server_takes", "flx_frame_target_set", "flx_frame_target_index", "flx_debug_set_server_groups",
+    "flx_share_create", "flx_share_join", "flx_share_leave", "flx_frame_begin_shared", "flx_frame_end_shared",
 ]
 
 
+SHARE_HANDLE_BYTES = 128      # FLX_SHARE_HANDLE_BYTES
 MAX_BATCH_FRAMES = 32          # FLX_MAX_BATCH_FRAMES of include/flexlight_hip.h
 
 
@@ -145,6 +147,11 @@ def _load():
         "flx_frame_target_set": (C.c_int, [vp, C.POINTER(vp), u32]),
         "flx_frame_target_index": (C.c_int, [vp]),
         "flx_debug_set_server_groups": (C.c_int, [vp, u32]),
+        "flx_share_create": (C.c_int, [vp, u32, u32, u32, C.c_int, C.c_int, C.c_char_p]),
+        "flx_share_join": (C.c_int, [vp, C.c_char_p, C.c_int]),
+        "flx_share_leave": (C.c_int, [vp]),
+        "flx_frame_begin_shared": (C.c_int, [vp, C.POINTER(FrameParams)]),
+        "flx_frame_end_shared": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -302,6 +309,28 @@ class Context:
 
     def frame_target_index(self):
         return int(LIB.flx_frame_target_index(self._h))
+
+    # -- one process per GPU, no collective: the ranks' servers complete one image in the root's memory (flx_share_*) ----
+    def share_create(self, width, height, n_images, n_ranks, rank):
+        """root: -> the FLX_SHARE_HANDLE_BYTES handle the other ranks join with"""
+        buf = C.create_string_buffer(SHARE_HANDLE_BYTES)
+        self._check(LIB.flx_share_create(self._h, width, height, n_images, n_ranks, rank, buf), "flx_share_create")
+        return buf.raw
+
+    def share_join(self, handle, rank):
+        self._check(LIB.flx_share_join(self._h, bytes(handle), rank), "flx_share_join")
+
+    def share_leave(self):
+        self._check(LIB.flx_share_leave(self._h), "flx_share_leave")
+
+    def frame_begin_shared(self, params):
+        self._check(LIB.flx_frame_begin_shared(self._h, C.byref(params)), "flx_frame_begin_shared")
+
+    def frame_end_shared(self):
+        """-> (address of the whole image in the root's device memory (None on the other ranks), ms)"""
+        ptr, n, ms = C.c_void_p(), C.c_size_t(), C.c_float()
+        self._check(LIB.flx_frame_end_shared(self._h, C.byref(ptr), C.byref(n), C.byref(ms)), "flx_frame_end_shared")
+        return ptr.value, ms.value
 
     def set_server_groups(self, groups):
         """rehearsal: the frame server's launch takes only `groups` CUs (0: all)"""
