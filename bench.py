@@ -24,6 +24,10 @@ small scenes; `roofline.kernel` names it) — by the limit that binds it: VALU i
 (tools/pmc_pass.py, before the parent touches the GPU), with the measured HBM traffic (FETCH_SIZE / WRITE_SIZE passes) and
 SURVEY.md 8d's algorithmic bytes beside it.  `cpu_baseline` is the CPU oracle timed on this box's host cores on a bounded sample.
 
+N > 1 also reports `pipelined` (the frame loop over the communicator, two lanes) and `shared`: the same loop WITHOUT a collective — every rank's frame
+server (one persistent launch, three frames in flight) resolves its strips straight into one image in rank 0's device memory (flx_share_*: hipIpc mapping,
+stores over xGMI), verified against one context's frame.
+
 Exit status: non-zero when a rank fails, when the ranks do not finish within --rank-timeout seconds (they are killed), or when
 the gathered frame differs from the single-context frame (the line is still printed, with the field false).
 """
@@ -332,6 +336,116 @@ def moved(scene, p, i):
     return q
 
 
+def shared_loop(args, dist, capi, scene, params, full, rank, world, local_rank, frames, lanes=3):
+    """The frame loop of N ranks without a collective (include/flexlight_hip.h: flx_share_*): -> the `shared` entry of the line (rank 0; None elsewhere).
+    Library calls sit in try blocks and every torch.distributed call outside them is reached by every rank whatever failed, so a rank that fails (the
+    others then fail within flx_share's 5 s instead of waiting) cannot wedge the run."""
+    import ctypes
+    import numpy as np
+    import torch
+    W, H = full.width, full.height
+    err, ctx_s, handle, last_ptr, lat = None, None, None, None, []
+
+    def agree(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def run(n):
+        nonlocal last_ptr
+        inflight = 0
+        for _ in range(n):
+            if inflight == lanes:
+                last_ptr, ms = ctx_s.frame_end_shared()
+                lat.append(ms)
+                inflight -= 1
+            ctx_s.frame_begin_shared(params)
+            inflight += 1
+        while inflight:
+            last_ptr, ms = ctx_s.frame_end_shared()
+            lat.append(ms)
+            inflight -= 1
+
+    try:
+        ctx_s = capi.Context(local_rank)
+        ctx_s.update_scene(scene)
+        if args.one_device:                      # rehearsal on one GPU: every rank's server launch takes its part of the CUs, so that they run at once
+            ctx_s.set_server_groups(max(1, ctx_s.device_info()[1] // world))
+        if not ctx_s.frame_server_takes(params):
+            raise RuntimeError("not a frame the frame server takes (flx_frame_server_takes)")
+        if rank == 0:
+            handle = ctx_s.share_create(W, H, lanes, world, 0)
+    except Exception as e:                       # noqa: BLE001 — reported in the line
+        err = "%s: %s" % (type(e).__name__, e)
+    box = [handle]
+    dist.broadcast_object_list(box, src=0)
+    try:
+        if err is None and rank != 0:
+            if box[0] is None:
+                raise RuntimeError("rank 0 could not create the share")
+            ctx_s.share_join(box[0], rank)
+    except Exception as e:                       # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    ok = agree(err is None and box[0] is not None)
+    dt, equal = None, None
+    if ok:
+        try:
+            run(2 * lanes)                       # warm-up: the workspaces of the frames in flight, the server's first launch
+        except Exception as e:                   # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        torch.cuda.synchronize()
+        dist.barrier()
+        lat.clear()
+        t1 = time.perf_counter()
+        try:
+            if err is None:
+                run(frames)
+        except Exception as e:                   # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t1
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        ok = agree(err is None)
+        if ok and rank == 0 and last_ptr:
+            try:                                 # the image the loop's last frame left in rank 0's memory against one context's render of the whole frame
+                try:
+                    hiprt = ctypes.CDLL("libamdhip64.so")
+                except OSError:
+                    hiprt = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+                got = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+                whole = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+                torch.cuda.synchronize()
+                if hiprt.hipMemcpy(ctypes.c_void_p(got.data_ptr()), ctypes.c_void_p(last_ptr), ctypes.c_size_t(H * W * 16), 3) != 0:
+                    raise RuntimeError("hipMemcpy of the shared image")
+                ctx_v = capi.Context(local_rank)
+                ctx_v.update_scene(scene)
+                ctx_v.render_device(full, whole.data_ptr())
+                ctx_v.sync()
+                ctx_v.close()
+                equal = bool(torch.equal(whole.view(torch.int32), got.view(torch.int32)))
+            except Exception as e:               # noqa: BLE001
+                err = "verification: %s: %s" % (type(e).__name__, e)
+    try:
+        if ctx_s is not None:
+            ctx_s.close()                        # (leaves the share)
+    except Exception:                            # noqa: BLE001
+        pass
+    errs = [None] * world
+    dist.all_gather_object(errs, err)            # (also the barrier behind the loop: every rank has left the share)
+    if rank != 0:
+        return None
+    if not ok or dt is None:
+        return {"error": "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e) or "a rank failed", "frames_in_flight": lanes}
+    return {"frames_in_flight": lanes, "ms_per_frame": dt / frames * 1e3, "frames": frames, "frame_gpu_ms_median": float(np.median(lat[-frames:])) if lat else None,
+            "image_equals_single_context_frame": equal, "error": err,
+            "note": "flx_frame_begin_shared / flx_frame_end_shared on every rank: each rank's frame server (one persistent launch, %d frames in flight) resolves its strips straight "
+                    "into one image in rank 0's device memory (hipIpc mapping, stores over xGMI) — no collective, no reassembly kernel, no copy; rank 0 hands a frame out when every "
+                    "rank's strips of it are complete%s" % (lanes, "; REHEARSAL on one device: every rank's launch takes 1/%d of the CUs" % world if args.one_device else "")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,6 +462,7 @@ def main():
     ap.add_argument("--verify", action="store_true", help="rank 0 renders the whole frame on its own after the run and compares the gathered frame with it, bit for bit (the default for N > 1)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--rank-timeout", type=int, default=900, help="N > 1 launched by bench.py itself: seconds after which ranks still running are stopped and the run fails")
+    ap.add_argument("--no-shared", action="store_true", help="N > 1: skip the frame loop without a collective (flx_share_*: the `shared` entry of the line)")
     ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: root = only rank 0, which presents the frame, receives the strips (ncclSend / ncclRecv; the reference presents from its one context); all = ncclAllGather, every rank ends up with the frame")
     args = ap.parse_args()
 
@@ -515,6 +630,14 @@ def main():
         pipelined = {"frames_in_flight": 2, "ms_per_frame": dtp / n * 1e3, "frames": n, "frame_gpu_ms_median": float(np.median(lat[-n:])),
                      "note": ("flx_frame_begin_gathered / flx_frame_end on every rank, each of the two lanes gathering over its own communicator" if rccl else "flx_frame_begin / flx_frame_end") +
                              ", pixels left in device memory: one frame per pass, frames complete in order; a frame completes every ms_per_frame, its own GPU time (first kernel .. last, overlapped with its neighbours) is frame_gpu_ms_median"}
+    # N > 1, the same loop WITHOUT a collective (flx_share_*): every rank's frame server — one persistent launch that takes the loop's frames as they
+    # are posted, three in flight — resolves its strips straight into ONE image in rank 0's device memory (mapped through hipIpc: the other ranks'
+    # stores go over xGMI); a page of shared memory carries done / released.  A context of its own, after the timed region; a failure here is
+    # reported in the line and never touches `value`.
+    shared = None
+    if multi and not use_filter and not args.no_shared:
+        shared = shared_loop(args, dist, capi, scene, params, full, rank, world, local_rank, max(args.steps, 20))
+
     batched = None
     if F > 1:
         passes = max(2, (args.steps + F - 1) // F)
@@ -629,6 +752,11 @@ def main():
             pipelined["value"] = rays / (pipelined["ms_per_frame"] * 1e-3) / 1e6
             pipelined["unit"] = "Mray/s"
             line["pipelined"] = pipelined
+        if shared:
+            if shared.get("ms_per_frame"):
+                shared["value"] = rays / (shared["ms_per_frame"] * 1e-3) / 1e6
+                shared["unit"] = "Mray/s"
+            line["shared"] = shared
         if batched:
             batched["value"] = rays / (batched["ms_per_frame"] * 1e-3) / 1e6
             batched["unit"] = "Mray/s"
@@ -650,6 +778,9 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and verified is False:
         sys.stderr.write("bench.py: the gathered frame differs from the single-context frame\n")
+        raise SystemExit(3)
+    if rank == 0 and shared and shared.get("image_equals_single_context_frame") is False:
+        sys.stderr.write("bench.py: the image the ranks completed without a collective differs from the single-context frame\n")
         raise SystemExit(3)
 
 

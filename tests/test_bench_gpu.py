@@ -47,6 +47,23 @@ def test_bench_two_ranks_gather_the_frame():
     assert "row-strip tiles x2" in d["config"]["parallelism"]
 
 
+def test_bench_two_ranks_complete_one_image_without_a_collective():
+    """the `shared` entry of the N > 1 line: the two ranks' frame servers (half of the CUs each on this one GPU) resolve their strips into ONE image in rank 0's
+    memory (flx_share_*: hipIpc mapping + a page of shared memory), three frames in flight; the image equals one context's render of the whole frame"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    args = [a if a != "270" else "272" for a in SMALL]          # strips of whole 8-row tiles: a frame the frame server takes
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--batch", "0", "--no-pmc"] + args, timeout=1200, env=env, stderr=subprocess.DEVNULL)
+    d = _last_json(out)
+    sh = d["shared"]
+    assert sh.get("error") is None, sh
+    assert sh["frames_in_flight"] == 3 and sh["ms_per_frame"] > 0 and sh["value"] > 0
+    assert sh["image_equals_single_context_frame"] is True
+    assert d["gathered_frame_equals_single_context_frame"] is True
+    # a frame the server does not take (a last strip of 6 rows) is reported, not fatal
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--batch", "0", "--no-pmc"] + SMALL, timeout=1200, env=env, stderr=subprocess.DEVNULL)
+    assert "frame server" in _last_json(out)["shared"]["error"]
+
+
 def test_bench_rccl_path_with_one_rank():
     """the code path `bench.py --gpus N` takes for N > 1 — gloo bootstrap, communicator id, ncclCommInitRank, frames through
     flx_render_gathered_device (trace, ncclAllGather, reassembly in the library) in the timed loop — with a communicator of one rank"""

@@ -371,6 +371,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   /* ================================ walk wave ================================ */
   if (wave < (uint32_t)FLX_FRAME_PROLOGUE_WAVES) while (makeTile(0u) == 1u) {}
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
+  const float4 *walkG; { FLX_ARGS_OF(ab); walkG = pinnedWalkCopy(sc); }      /* the global copy of the tree, for the entries beyond the LDS top: in registers for the stepping loop */
   int st = P_EMPTY;
   uint32_t pathId = 0;
   int flags = 0;
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
             reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);
             st = P_WALKING;
-            if (walkFetchP<false>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
+            if (walkFetchG<false>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
           } else {
             /* a suspended walk: its registers came back from the list, the rays in LDS are recomputed (the same arithmetic on the same record), the entry it
              * was about to test is fetched again */
@@ -613,13 +614,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     }
     /* ---- FLX_WF_INNER entries for every walking lane (the few scene words the fetch needs are read before the loop) ---- */
     {
-      FLX_ARGS_OF(ab);
 #pragma unroll FLX_WF_UNROLL
       for (int it = 0; it < FLX_WF_INNER; it++) {
         if (st == P_WALKING) {
           bool ended = false;
           if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-          if (!ended) ended = walkFetchP<false>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
+          if (!ended) ended = walkFetchG<false>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt);
           if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
         }
       }

@@ -971,19 +971,21 @@ FLX_DEV void walkLoadRay(const float2 *raysGeneric, int t, WalkState &w) {
   w.inv = F3(d.x, d.y, e.x);
   w.fastDiv = e.y != 0.0f;
 }
+/* (walkG = sc.walk: the kernels whose arguments stay in the kernarg segment hand it over in registers — pinnedWalkCopy() — so that the stepping loop does
+ * not read it again, with a wait that also covers the LDS reads in flight, every time a lane's entry lies outside the tree top) */
 template <bool COUNT>
-FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float2 *rays, WalkState &w, WalkEntry &cur,
+FLX_DEV bool walkFetchG(const float4 *walkG, const float4 *lds, uint32_t ldsCount, const float2 *rays, WalkState &w, WalkEntry &cur,
                         WorkCounters &cnt) {
   if (((uint32_t)w.i == WALK_END)) return true;
   const uint32_t i = linkIndex((uint32_t)w.i);
 #if FLX_WF_FLAT_FETCH
   {   /* one instruction stream for both homes of an entry: a generic pointer into LDS or into the global copy (flat_load) */
-    const float4 *src = (i < ldsCount) ? lds + 3u * i : sc.walk + 3 * (size_t)i;
+    const float4 *src = (i < ldsCount) ? lds + 3u * i : walkG + 3 * (size_t)i;
     cur.e0 = src[0]; cur.e1 = src[1]; cur.e2 = src[2];
   }
 #else
   if (i < ldsCount) { const lds_cf4 *L = (const lds_cf4 *)lds + __umul24(i, 3u); cur.e0 = ldsLoad4(L); cur.e1 = ldsLoad4(L + 1); cur.e2 = ldsLoad4(L + 2); }      /* (i < ldsCount <= 3 328) */
-  else { cur.e0 = sc.walk[3 * (size_t)i]; cur.e1 = sc.walk[3 * (size_t)i + 1]; cur.e2 = sc.walk[3 * (size_t)i + 2]; }
+  else { cur.e0 = walkG[3 * (size_t)i]; cur.e1 = walkG[3 * (size_t)i + 1]; cur.e2 = walkG[3 * (size_t)i + 2]; }
 #endif
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
   const int meta = __float_as_int(cur.e2.z);
@@ -993,6 +995,17 @@ FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
     walkLoadRay(rays, tI >> 1, w);
   }
   return (meta & 3) == 0;
+}
+template <bool COUNT>
+FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float2 *rays, WalkState &w, WalkEntry &cur,
+                        WorkCounters &cnt) {
+  return walkFetchG<COUNT>(sc.walk, lds, ldsCount, rays, w, cur, cnt);
+}
+/* sc.walk held in scalar registers from here on: the compiler may move the registers about, not read the argument again */
+FLX_DEV const float4 *pinnedWalkCopy(const DeviceScene &sc) {
+  const float4 *p = sc.walk;
+  asm volatile("" : "+s"(p));
+  return p;
 }
 /* Entry fetch split from its use, so the loads of BOTH possible successors can be issued before the
  * current entry is tested and complete while the test's ~100 VALU instructions run. */

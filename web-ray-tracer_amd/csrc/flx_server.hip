@@ -36,6 +36,9 @@ namespace flx {
 #ifndef FLX_SERVER_SHADERS
 #define FLX_SERVER_SHADERS FLX_FRAME_SHADERS_FRONT      /* shade waves of a server workgroup (they also make the fresh paths) */
 #endif
+#ifndef FLX_SERVER_SHADE_PRIO
+#define FLX_SERVER_SHADE_PRIO 0              /* issue priority of the shade waves (s_setprio 0 .. 3) */
+#endif
 #ifndef FLX_SERVER_PRIO
 #define FLX_SERVER_PRIO 1                    /* waves that hold paths of the oldest frame run at a raised priority once its tile queue is dry */
 #endif
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   if (wave >= WALK_WAVES) {
     /* ================================ shade wave ================================ */
     uint32_t idle = 0;
+    if (FLX_SERVER_SHADE_PRIO) __builtin_amdgcn_s_setprio(FLX_SERVER_SHADE_PRIO);
     const long long tShade0 = wall_clock64();
     long long tTile = 0, tBatch = 0;
     for (;;) {
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 
   /* ================================ walk wave ================================ */
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
+  const float4 *walkG; { FLX_ARGS_OF(ab); walkG = pinnedWalkCopy(sc); }      /* the global copy of the tree, for the entries beyond the LDS top: in registers for the stepping loop */
   int st = P_EMPTY;
   uint32_t pathId = 0;
   int flags = 0;
@@ -507,7 +512,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
           reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);
           st = P_WALKING;
-          if (walkFetchP<false>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
+          if (walkFetchG<false>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
         }
       }
       if (flx_ballot(st == P_WALKING) == 0ull) {
@@ -521,13 +526,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     }
     /* ---- FLX_WF_INNER entries for every walking lane (the few scene words the fetch needs are read before the loop) ---- */
     {
-      FLX_ARGS_OF(ab);
 #pragma unroll FLX_WF_UNROLL
       for (int it = 0; it < FLX_WF_INNER; it++) {
         if (st == P_WALKING) {
           bool ended = false;
           if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-          if (!ended) ended = walkFetchP<false>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
+          if (!ended) ended = walkFetchG<false>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt);
           if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
         }
       }

@@ -824,6 +824,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
  * tiles; k_primary and k_wf_shade0 are not launched.  The fresh paths of a tile stay with the workgroup that made them, so a frame needs
  * enough tiles per workgroup to balance (flx_api.hip: automatic from 32 on); FRONT = false is the kernel described above, register for
  * register. */
+#ifndef FLX_FRAME_WALK_PRIO
+#define FLX_FRAME_WALK_PRIO 0               /* ... and of the walk waves (shade waves above the walk waves: dragon 1080p 6.37 -> 6.82 ms; profiles/r04_ab_priority.txt) */
+#endif
+#ifndef FLX_FRAME_SHADE_PRIO
+#define FLX_FRAME_SHADE_PRIO 0              /* issue priority of the shade waves (s_setprio 0 .. 3; the walk waves run at 0) */
+#endif
 #ifndef FLX_FRAME_SHADERS
 #define FLX_FRAME_SHADERS 2                 /* shade waves of a frame-kernel workgroup (dragon 1080p: 1 -> 7.27, 2 -> 6.87, 3 -> 7.16 ms per frame) */
 #endif
@@ -917,6 +923,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     /* ================================ shade wave ================================ */
     uint32_t idle = 0;
     bool frontDone = !front;                                 /* this wave has found the frame's tile queue dry */
+    uint32_t inject; { FLX_FRAME_ARGS(); inject = wb.inject; } asm volatile("" : "+s"(inject));      /* (read once: a scalar load per batch — and its wait — measures 0.3 % of the frame) */
+    if (FLX_FRAME_SHADE_PRIO) __builtin_amdgcn_s_setprio(FLX_FRAME_SHADE_PRIO);
     const long long tStartShade = COUNT ? clock64() : 0;
     for (;;) {
       FLX_FRAME_ARGS();
@@ -952,7 +960,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       idle = 0;
       const bool mine = lane < got && id != WF_INVALID;
       if (flx_ballot(lane < got && id == WF_INVALID) != 0ull && lane == 0 && wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_RING_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      /* (a slot that never filled: fq_pop gave up on it) */
-      if (wb.inject & WF_INJECT_NO_SHADING) continue;         /* fault injection: the batch is dropped */
+      if (inject & WF_INJECT_NO_SHADING) continue;            /* fault injection: the batch is dropped */
       if (mine) shade_path<COUNT>(argBase, id, cnt);
       fq_push(walkRing, ctl + FC_WQ, mine, id, lane);
     }
@@ -966,7 +974,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
    * the more tiles are bound to the workgroup at once, the worse the frame's balance) */
   const long long tStart = COUNT ? clock64() : 0;
   if (front && wave < (uint32_t)FLX_FRAME_PROLOGUE_WAVES) while (makeTile() == 1u) {}
+  if (FLX_FRAME_WALK_PRIO) __builtin_amdgcn_s_setprio(FLX_FRAME_WALK_PRIO);
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
+  const float4 *walkG; { FLX_FRAME_ARGS(); walkG = pinnedWalkCopy(sc); }      /* the global copy of the tree, for the entries beyond the LDS top */
   const uint32_t nWaves = gridDim.x * WALK_WAVES;
   uint32_t lastBase = 0;
   uint32_t inChunk = n / (nWaves * FLX_WF_DRAWS_PER_WAVE);
@@ -1158,7 +1168,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
           reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);
           st = P_WALKING;
-          if (walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
+          if (walkFetchG<COUNT>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
         }
       }
       if (flx_ballot(st == P_WALKING) == 0ull) {
@@ -1180,15 +1190,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         continue;
       }
     }
-    /* ---- FLX_WF_INNER entries for every walking lane (the few scene words the fetch needs are read before the loop) ---- */
+    /* ---- FLX_WF_INNER entries for every walking lane (the one scene word the fetch needs — the global copy's address — is in registers: walkG) ---- */
     {
-      FLX_FRAME_ARGS();
 #pragma unroll FLX_WF_UNROLL
       for (int it = 0; it < FLX_WF_INNER; it++) {
         if (st == P_WALKING) {
           bool ended = false;
           if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-          if (!ended) ended = walkFetchP<COUNT>(sc, ldsEntries, ldsCount, myRays, w, cur, cnt);
+          if (!ended) ended = walkFetchG<COUNT>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt);
           if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
         }
       }

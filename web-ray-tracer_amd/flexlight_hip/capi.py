@@ -154,7 +154,12 @@ def _load():
         "flx_frame_end_shared": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(lib, name)
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            if os.environ.get("FLX_LIB"):      # an A/B variant (an earlier round's library): what it lacks fails when it is called
+                continue
+            raise
         fn.restype, fn.argtypes = res, args
     return lib
 
