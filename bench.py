@@ -446,6 +446,52 @@ def shared_loop(args, dist, capi, scene, params, full, rank, world, local_rank, 
                     "rank's strips of it are complete%s" % (lanes, "; REHEARSAL on one device: every rank's launch takes 1/%d of the CUs" % world if args.one_device else "")}
 
 
+class SecondaryGuard:
+    """A wall-clock limit over the secondary measurements (main(): "measured LAST"): when it runs out, rank 0 prints the line it has — with `secondary_incomplete`
+    naming the phase that did not come back — and every rank's process ends (os._exit: the main thread may be stuck inside a library call)."""
+
+    def __init__(self, rank, line, seconds):
+        import threading
+        self.rank, self.line, self.seconds = rank, line, seconds
+        self.lock = threading.Lock()
+        self.current, self.timer, self.finished = None, None, False
+
+    def start(self):
+        import threading
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+
+    def phase(self, name):
+        with self.lock:
+            self.current = name
+        if os.environ.get("FLX_BENCH_TEST_HANG") == name:      # tests: this phase never comes back
+            time.sleep(1e6)
+
+    def put(self, key, value):
+        with self.lock:
+            if self.line is not None:
+                self.line[key] = value
+
+    def done(self):
+        with self.lock:
+            self.finished = True
+        if self.timer:
+            self.timer.cancel()
+
+    def _fire(self):
+        with self.lock:
+            if self.finished:
+                return
+            sys.stderr.write("bench.py: rank %d: the secondary measurement `%s` did not finish within %d s; ending the run with the line as it stands\n" % (self.rank, self.current, self.seconds))
+            if self.rank == 0 and self.line is not None:
+                self.line["secondary_incomplete"] = {"phase": self.current, "limit_s": self.seconds}
+                print(json.dumps(self.line), flush=True)
+            sys.stderr.flush()
+            os._exit(0 if self.rank == 0 else 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -462,6 +508,7 @@ def main():
     ap.add_argument("--verify", action="store_true", help="rank 0 renders the whole frame on its own after the run and compares the gathered frame with it, bit for bit (the default for N > 1)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--rank-timeout", type=int, default=900, help="N > 1 launched by bench.py itself: seconds after which ranks still running are stopped and the run fails")
+    ap.add_argument("--secondary-timeout", type=int, default=300, help="seconds the measurements after the timed region (`pipelined`, `shared`, `batched`) may take in all before the run ends with the line as it stands; 0 = no limit")
     ap.add_argument("--no-shared", action="store_true", help="N > 1: skip the frame loop without a collective (flx_share_*: the `shared` entry of the line)")
     ap.add_argument("--gather", choices=["root", "all"], default="root", help="N > 1: root = only rank 0, which presents the frame, receives the strips (ncclSend / ncclRecv; the reference presents from its one context); all = ncclAllGather, every rank ends up with the frame")
     args = ap.parse_args()
@@ -603,57 +650,6 @@ def main():
         a, b = ctx.last_frame_ms()
         gpu_ms.append(a)
         kernel_ms.append(b)
-    # two frames in flight (flx_frame_begin / flx_frame_end with two lanes: what the JavaScript frame loop runs): still one frame per
-    # pass and frames complete in order, but frame k + 1's kernels fill the CUs the tails of frame k's kernels leave idle
-    pipelined = None
-    if not multi or rccl:
-        lat = []
-        for phase in range(2):               # 0 = warm-up (the second lane sizes its workspace), 1 = timed
-            n = 6 if phase == 0 else max(args.steps, 20)
-            fence()
-            t1 = time.perf_counter()
-            for i in range(n):
-                if rccl:                     # the same loop over the communicator: every lane gathers over its own (flx_frame_begin_gathered)
-                    ctx.frame_begin_gathered(params, root=0 if to_root else -1)
-                else:
-                    ctx.frame_begin(params, device=True)
-                if ctx.frames_in_flight() == 2:
-                    lat.append(ctx.frame_end()[1])
-            while ctx.frames_in_flight():
-                lat.append(ctx.frame_end()[1])
-            fence()
-            dtp = time.perf_counter() - t1
-            if multi:
-                t = torch.tensor([dtp], dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dtp = float(t.item())
-        pipelined = {"frames_in_flight": 2, "ms_per_frame": dtp / n * 1e3, "frames": n, "frame_gpu_ms_median": float(np.median(lat[-n:])),
-                     "note": ("flx_frame_begin_gathered / flx_frame_end on every rank, each of the two lanes gathering over its own communicator" if rccl else "flx_frame_begin / flx_frame_end") +
-                             ", pixels left in device memory: one frame per pass, frames complete in order; a frame completes every ms_per_frame, its own GPU time (first kernel .. last, overlapped with its neighbours) is frame_gpu_ms_median"}
-    # N > 1, the same loop WITHOUT a collective (flx_share_*): every rank's frame server — one persistent launch that takes the loop's frames as they
-    # are posted, three in flight — resolves its strips straight into ONE image in rank 0's device memory (mapped through hipIpc: the other ranks'
-    # stores go over xGMI); a page of shared memory carries done / released.  A context of its own, after the timed region; a failure here is
-    # reported in the line and never touches `value`.
-    shared = None
-    if multi and not use_filter and not args.no_shared:
-        shared = shared_loop(args, dist, capi, scene, params, full, rank, world, local_rank, max(args.steps, 20))
-
-    batched = None
-    if F > 1:
-        passes = max(2, (args.steps + F - 1) // F)
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(passes):
-            render(batch_params)
-        fence()
-        dtb = time.perf_counter() - t1
-        if multi:
-            t = torch.tensor([dtb], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dtb = float(t.item())
-        batched = {"frames_per_pass": F, "ms_per_frame": dtb / (passes * F) * 1e3, "passes": passes,
-                   "cameras": "a different camera position and view direction for every frame of a batch",
-                   "note": "throughput mode (flx_render_batch): every frame complete and bit-identical to its own render, latency %d frames" % F}
     # work counters of ONE frame (this rank's share), a counted launch
     ctx.set_counters_enabled(True)
     if rccl:
@@ -669,6 +665,7 @@ def main():
     ctx.set_counters_enabled(False)
     torch.cuda.synchronize()
 
+    line, rays = None, 0
     if rank == 0:
         spp, bounces = full.samples, full.max_reflections
         rays = spp * bounces * W * H
@@ -748,19 +745,6 @@ def main():
                        "Gsegments_per_s": segments / (ms_per_step * 1e-3) / 1e9, "scope": "this rank's share of the frame" if multi else "the frame",
                        "note": "`value` counts nominal rays (spp x bounces x pixels); these are the rays the frame really traces (its own work counters: closest-hit walks + shadow walks + primary rays that hit), paths that left the scene or fell below minImportancy trace none"},
         }
-        if pipelined:
-            pipelined["value"] = rays / (pipelined["ms_per_frame"] * 1e-3) / 1e6
-            pipelined["unit"] = "Mray/s"
-            line["pipelined"] = pipelined
-        if shared:
-            if shared.get("ms_per_frame"):
-                shared["value"] = rays / (shared["ms_per_frame"] * 1e-3) / 1e6
-                shared["unit"] = "Mray/s"
-            line["shared"] = shared
-        if batched:
-            batched["value"] = rays / (batched["ms_per_frame"] * 1e-3) / 1e6
-            batched["unit"] = "Mray/s"
-            line["batched"] = batched
         if multi:
             line["gather"] = {"exchange": ("root" if to_root else "all_gather") if rccl else "gloo rehearsal", "uses_rccl": bool(rccl), "rccl_ranks": ctx.comm_count() if rccl else 0,
                               "launched_by": "bench.py itself (child processes)" if os.environ.get("FLX_BENCH_SELF_LAUNCHED") else "torch.distributed.run"}
@@ -768,6 +752,84 @@ def main():
             line["gathered_frame_equals_single_context_frame"] = verified
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, full)
+
+    # ---- the batched mode and the frame loops: measured LAST, under a wall-clock limit -------------------------------------------
+    # Everything the line must carry is in it now.  What follows runs code paths that no hardware with N > 1 GPUs has executed yet (the frame loop over a split
+    # communicator, the shared image over hipIpc): if one of them does not come back within --secondary-timeout seconds, every rank's guard ends its process —
+    # rank 0 after printing the line with what it has and the name of the phase that hung — instead of the run hanging until somebody's limit kills it without a line.
+    guard = SecondaryGuard(rank, line, args.secondary_timeout)
+    if multi:
+        dist.barrier()                       # (rank 0 has been timing the CPU oracle: the guards start together)
+    guard.start()
+    guard.phase("batched")
+    batched = None
+    if F > 1:
+        passes = max(2, (args.steps + F - 1) // F)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(passes):
+            render(batch_params)
+        fence()
+        dtb = time.perf_counter() - t1
+        if multi:
+            t = torch.tensor([dtb], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtb = float(t.item())
+        batched = {"frames_per_pass": F, "ms_per_frame": dtb / (passes * F) * 1e3, "passes": passes,
+                   "cameras": "a different camera position and view direction for every frame of a batch",
+                   "note": "throughput mode (flx_render_batch): every frame complete and bit-identical to its own render, latency %d frames" % F}
+    if rank == 0 and batched:
+        batched["value"] = rays / (batched["ms_per_frame"] * 1e-3) / 1e6
+        batched["unit"] = "Mray/s"
+        guard.put("batched", batched)
+    guard.phase("pipelined")
+    # two frames in flight (flx_frame_begin / flx_frame_end with two lanes: what the JavaScript frame loop runs): still one frame per
+    # pass and frames complete in order, but frame k + 1's kernels fill the CUs the tails of frame k's kernels leave idle
+    pipelined = None
+    if not multi or rccl:
+        lat = []
+        for phase in range(2):               # 0 = warm-up (the second lane sizes its workspace), 1 = timed
+            n = 6 if phase == 0 else max(args.steps, 20)
+            fence()
+            t1 = time.perf_counter()
+            for i in range(n):
+                if rccl:                     # the same loop over the communicator: every lane gathers over its own (flx_frame_begin_gathered)
+                    ctx.frame_begin_gathered(params, root=0 if to_root else -1)
+                else:
+                    ctx.frame_begin(params, device=True)
+                if ctx.frames_in_flight() == 2:
+                    lat.append(ctx.frame_end()[1])
+            while ctx.frames_in_flight():
+                lat.append(ctx.frame_end()[1])
+            fence()
+            dtp = time.perf_counter() - t1
+            if multi:
+                t = torch.tensor([dtp], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dtp = float(t.item())
+        pipelined = {"frames_in_flight": 2, "ms_per_frame": dtp / n * 1e3, "frames": n, "frame_gpu_ms_median": float(np.median(lat[-n:])),
+                     "note": ("flx_frame_begin_gathered / flx_frame_end on every rank, each of the two lanes gathering over its own communicator" if rccl else "flx_frame_begin / flx_frame_end") +
+                             ", pixels left in device memory: one frame per pass, frames complete in order; a frame completes every ms_per_frame, its own GPU time (first kernel .. last, overlapped with its neighbours) is frame_gpu_ms_median"}
+    if rank == 0 and pipelined:
+        pipelined["value"] = rays / (pipelined["ms_per_frame"] * 1e-3) / 1e6
+        pipelined["unit"] = "Mray/s"
+        guard.put("pipelined", pipelined)
+    guard.phase("shared")
+    # N > 1, the same loop WITHOUT a collective (flx_share_*): every rank's frame server — one persistent launch that takes the loop's frames as they
+    # are posted, three in flight — resolves its strips straight into ONE image in rank 0's device memory (mapped through hipIpc: the other ranks'
+    # stores go over xGMI); a page of shared memory carries done / released.  A context of its own, after the timed region; a failure here is
+    # reported in the line and never touches `value`.
+    shared = None
+    if multi and not use_filter and not args.no_shared:
+        shared = shared_loop(args, dist, capi, scene, params, full, rank, world, local_rank, max(args.steps, 20))
+
+    if rank == 0 and shared:
+        if shared.get("ms_per_frame"):
+            shared["value"] = rays / (shared["ms_per_frame"] * 1e-3) / 1e6
+            shared["unit"] = "Mray/s"
+        guard.put("shared", shared)
+    guard.done()
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if rccl:
         ctx.sync()

@@ -64,6 +64,16 @@ def test_bench_two_ranks_complete_one_image_without_a_collective():
     assert "frame server" in _last_json(out)["shared"]["error"]
 
 
+def test_bench_line_survives_a_secondary_measurement_that_hangs():
+    """the measurements after the timed region run under a wall-clock limit: when one does not come back the line is printed as it stands, names the phase, and the run ends"""
+    env = dict(os.environ, FLX_BENCH_TEST_HANG="pipelined")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "4", "--no-pmc", "--secondary-timeout", "5"] + SMALL, timeout=600, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    assert p.returncode == 0
+    d = _last_json(p.stdout)
+    assert d["secondary_incomplete"] == {"phase": "pipelined", "limit_s": 5}
+    assert d["value"] > 0 and d["batched"]["frames_per_pass"] == 4 and "pipelined" not in d and d["roofline"]["kernel_ms"] > 0
+
+
 def test_bench_rccl_path_with_one_rank():
     """the code path `bench.py --gpus N` takes for N > 1 — gloo bootstrap, communicator id, ncclCommInitRank, frames through
     flx_render_gathered_device (trace, ncclAllGather, reassembly in the library) in the timed loop — with a communicator of one rank"""
