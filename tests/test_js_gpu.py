@@ -148,3 +148,38 @@ def test_group_of_two_contexts_through_node(hip, scenes, tmp_path):
         info = json.loads(subprocess.check_output(base + ["--out", str(two), "--filter", filt, "--devices", "0,0"], timeout=300).decode().splitlines()[-1])
         assert info["gpus"] == {"size": 2, "rccl": False}
         assert np.array_equal(np.fromfile(one, np.uint32), np.fromfile(two, np.uint32))
+
+
+@pytest.mark.parametrize("move_scene", [False, True])
+def test_group_frame_loop_through_node(hip, oracle, scenes, tmp_path, move_scene):
+    """new FlexLight(canvas, { devices: [0, 0] }).renderer.render(): the renderer's frame loop over a GROUP of contexts — flx_group_frame_begin / _end, every
+    context's frame server resolving its strips straight into one pinned image, three frames in flight, nothing waits for a GPU inside a frame (round-3 review,
+    item 5; pathtracerWGL2.js:191, 254-303).  Frames of a moving camera equal the oracle's frames for their ticks, with the scene's transforms static (the
+    servers' launches live on across the frames: an upload of unchanged lights / transforms is nothing) and with the monkey turning every tick (the launches
+    end and start again at every change of the scene)."""
+    import copy
+    node = shutil.which("node")
+    w, h, spp, bounces = 320, 176, 2, 3            # (176 rows: strips of whole 8 x 8 tiles for both contexts — frames the server takes)
+    prefix = str(tmp_path / "gloop")
+    cmd = [node, os.path.join(ROOT, "tools", "js_loop.js"), os.path.join(ROOT, "tests", "golden", "ref_dragon.flxs.gz"), "--frames", "6", "--move", "1" if move_scene else "2",
+           "--width", str(w), "--height", str(h), "--spp", str(spp), "--bounces", str(bounces), "--dump", prefix, "--dump-frames", "5", "--devices", "0,0"]
+    info = json.loads(subprocess.check_output(cmd, timeout=300).decode().splitlines()[-1])
+    assert info["frames"] == 6 and info["devices"] == [0, 0] and info["lanes"] == 3 and info["gpuMsMedian"] > 0
+    log = json.load(open(prefix + "log.json"))
+    assert len(log) == 5
+    sc = scenes("dragon")
+    frames = []
+    for k, tick in enumerate(log):
+        sck = copy.copy(sc)
+        sck.arrays = dict(sc.arrays, rotation=np.asarray(tick["rotation"], np.float32), shift=np.asarray(tick["shift"], np.float32))
+        p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+        p.camera[:] = tick["camera"]
+        p.view_matrix[:] = tick["viewMatrix"]
+        want, _, _ = oracle.render(sck, p)
+        got = np.fromfile(prefix + "%d.f32" % k, np.float32).reshape(h, w, 4)
+        _, mism = assert_parity(got, want, "group loop frame %d" % k)
+        assert mism == 0, "frame %d" % k
+        frames.append(got)
+    assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[3], frames[4])
+    if not move_scene:
+        assert log[0]["rotation"] == log[4]["rotation"]

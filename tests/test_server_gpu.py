@@ -85,6 +85,44 @@ def test_the_server_ends_and_starts_again_where_the_frames_change(served, scenes
     assert bit_mismatches(g0, want[0]) == 0 and bit_mismatches(g1, want[1]) == 0 and bit_mismatches(g2, want[2]) == 0
 
 
+def test_an_upload_of_unchanged_lights_and_transforms_is_nothing(served, scenes):
+    """the reference refills its transform buffer and its light texture every frame (pathtracerWGL2.js:258-262, 361-365) and so does the JavaScript host here:
+    the same arrays again must not end the server's launch (an upload stops it: it reads the scene) — ONE launch serves the whole loop; arrays that did change
+    end it, and the frames after show the change"""
+    sc = scenes("dragon")
+    served.update_scene(sc)
+    served.set_frame_lanes(3)
+    served.set_chain_stats(True)
+    try:
+        ps = [moving(sc, f, width=480, height=272) for f in range(8)]
+        want = [served.render(p)[0] for p in ps]
+        got = []
+        for p in ps:
+            if served.frames_in_flight() == 3:
+                got.append(served.frame_end()[0])
+            served.update_primary_light_sources(sc.arrays["lights"])
+            served.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+            served.frame_begin(p)
+            assert served.last_chained() == 3
+        while served.frames_in_flight():
+            got.append(served.frame_end()[0])
+        for f in range(8):
+            assert bit_mismatches(got[f], want[f]) == 0, f
+        assert served.server_stats()["frames"] == 8                     # one launch rendered all eight
+        dim = np.array(sc.arrays["lights"], np.float32).copy()
+        dim.reshape(-1, 6)[:, 3] *= 0.5
+        served.update_primary_light_sources(dim)
+        served.frame_begin(ps[0])
+        darker = served.frame_end()[0]
+        assert bit_mismatches(darker, want[0]) != 0 and darker[..., :3].sum() < want[0][..., :3].sum()
+        served.update_primary_light_sources(sc.arrays["lights"])
+        served.frame_begin(ps[0])
+        assert bit_mismatches(served.frame_end()[0], want[0]) == 0
+    finally:
+        served.set_chain_stats(False)
+        served.update_primary_light_sources(sc.arrays["lights"])
+
+
 def test_frames_the_server_does_not_take(served, scenes):
     """a scene of fewer than 129 entries, the canvas' RGBA8 format: rendered the other ways, and right"""
     sc = scenes("cornell_obj")

@@ -4,6 +4,7 @@
  * box without the OBJ assets (the GPU box): the flattened scene comes from a .flxs fixture, the Transform objects are re-created
  * here so that the animation of examples/dragon.js:97-110 (the monkey turns to face the camera, every tick) can run.
  *   node tools/js_loop.js tests/golden/ref_dragon.flxs.gz [--frames N] [--move 1] [--present8 1] [--width W --height H --spp S --bounces B]
+ *                         [--devices 0,1,..  (a group of GPUs in this process; a number may repeat: rehearsal on one GPU)  --lanes 2|3]
  *                         [--dump PREFIX --dump-frames K]    (the first K frames as PREFIX<k>.f32 + the camera / transforms used, for the parity test)
  * Prints one JSON line: frames, seconds, fps (wall clock over the loop), the renderer's own fps counter, median GPU ms per frame.
  */
@@ -19,11 +20,13 @@ const replay = sceneFile.sceneFromFlxs(path.resolve(args[0]));
 const meta = replay.meta;
 const canvas = { width: Number(opt('--width', meta.frame.width)), height: Number(opt('--height', meta.frame.height)) };
 const frames = Number(opt('--frames', 120));
-const move = Number(opt('--move', 0)) === 1;
+const moveMode = Number(opt('--move', 0));
+const move = moveMode !== 0;                              // 1: the camera moves and the monkey turns to face it; 2: only the camera moves (the scene's arrays stay as they are)
 const dumpPrefix = opt('--dump', null), dumpFrames = Number(opt('--dump-frames', 3));
 
 Transform.reset();
-const engine = new FlexLight(canvas, {});
+const devices = opt('--devices', null);
+const engine = new FlexLight(canvas, devices ? { devices: devices.split(',').map(Number) } : {});
 engine.scene = replay;
 Object.assign(engine.camera, meta.camera);
 engine.config.samplesPerRay = Number(opt('--spp', meta.frame.samplesPerRay));
@@ -48,6 +51,7 @@ if (meta.name === 'dragon') {                              // the two transforms
 engine.renderer = 'pathtracer';
 engine.renderer.scene = replay;
 engine.renderer.present8 = Number(opt('--present8', 0)) === 1;
+if (devices) engine.renderer.groupLanes = Number(opt('--lanes', 3));
 
 const gpuMs = [];
 const log = [];
@@ -56,7 +60,7 @@ const tick = () => {                                        // the application's
   if (move) {
     engine.camera.x += 0.05; engine.camera.y += 0.02; engine.camera.z -= 0.03;
     engine.camera.fx += 0.004; engine.camera.fy -= 0.002;
-    faceCamera();
+    if (moveMode === 1) faceCamera();
   }
   if (dumpPrefix && begun < dumpFrames) {
     const tr = Transform.buildWGL2Arrays();
@@ -80,7 +84,7 @@ canvas.onFrame = f => {
     gpuMs.sort((a, b) => a - b);
     if (dumpPrefix) fs.writeFileSync(dumpPrefix + 'log.json', JSON.stringify(log));
     console.log(JSON.stringify({ scene: meta.name, width: canvas.width, height: canvas.height, spp: engine.config.samplesPerRay, bounces: engine.config.maxReflections,
-      frames, seconds, fps: frames / seconds, rendererFps: Number(rendererFps), gpuMsMedian: gpuMs[gpuMs.length >> 1], present8: engine.renderer.present8, moving: move }));
+      frames, seconds, fps: frames / seconds, rendererFps: Number(rendererFps), gpuMsMedian: gpuMs[gpuMs.length >> 1], present8: engine.renderer.present8, moving: move, devices: devices ? devices.split(',').map(Number) : null, lanes: devices ? engine.renderer.groupLanes : 2 }));
   }
 };
 engine.renderer.render().catch(e => { console.error(e); process.exit(1); });

@@ -368,8 +368,15 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
 extern "C" flx_status flx_transforms_upload(flx_context *ctx, const float *rotation, const float *shift, uint32_t n_transforms) {
   if (!ctx) return FLX_ERR_INVALID;
   if (!rotation || !shift || n_transforms == 0) return fail(ctx, FLX_ERR_INVALID, "flx_transforms_upload: need at least the identity transform");
+  /* The reference refills its transform UBO and its light texture every frame (pathtracerWGL2.js:258-262, 361-365), changed or not.  An upload of what the
+   * device holds already is nothing: no copy — and above all no end of a running frame server (upload() stops it: it reads the scene), whose frames in
+   * flight would otherwise be completed one by one under a host that re-sends a static scene's arrays per frame. */
+  if (!ctx->is_twin && ctx->have_transforms && ctx->n_transforms == n_transforms && ctx->d_rotation && ctx->d_shift &&
+      ctx->h_rotation.size() == (size_t)n_transforms * 24 && ctx->h_shift.size() == (size_t)n_transforms * 8 &&
+      memcmp(ctx->h_rotation.data(), rotation, (size_t)n_transforms * 96) == 0 && memcmp(ctx->h_shift.data(), shift, (size_t)n_transforms * 32) == 0) return FLX_OK;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   flx_status s;
+  ctx->have_transforms = false;             /* (until both arrays are in: a failed upload must not pass for the arrays it replaced) */
   if ((s = upload(ctx, &ctx->d_rotation, rotation, (size_t)n_transforms * 96))) return s;
   if ((s = upload(ctx, &ctx->d_shift, shift, (size_t)n_transforms * 32))) return s;
   ctx->n_transforms = n_transforms;
@@ -385,11 +392,14 @@ extern "C" flx_status flx_transforms_upload(flx_context *ctx, const float *rotat
 extern "C" flx_status flx_lights_upload(flx_context *ctx, const float *lights, uint32_t n_lights) {
   if (!ctx) return FLX_ERR_INVALID;
   if (n_lights && !lights) return fail(ctx, FLX_ERR_INVALID, "flx_lights_upload: lights is NULL");
+  if (!ctx->is_twin && ctx->have_lights && ctx->n_lights == n_lights && ctx->h_lights.size() == (size_t)n_lights * 6 &&
+      (n_lights == 0 || memcmp(ctx->h_lights.data(), lights, (size_t)n_lights * 24) == 0)) return FLX_OK;      /* (as flx_transforms_upload: the same lights again) */
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   flx_status s;
+  ctx->have_lights = false;
   if ((s = upload(ctx, &ctx->d_lights, lights, (size_t)n_lights * 24))) return s;
   ctx->n_lights = n_lights;
-  if (!ctx->is_twin) { ctx->h_lights.assign(lights, lights + (size_t)n_lights * 6); ctx->dyn_version++; }
+  if (!ctx->is_twin) { ctx->h_lights.assign(lights, lights + (size_t)n_lights * 6); ctx->dyn_version++; ctx->have_lights = true; }
   return FLX_OK;
 }
 

@@ -57,7 +57,7 @@ struct flx_context {
   uint32_t atlas_w[3] = { 0, 0, 0 }, atlas_h[3] = { 0, 0, 0 };
   uint32_t n_entries = 0, n_ids = 0, n_transforms = 0, n_lights = 0;
   uint32_t max_transform = 0;                   /* largest transform number an entry names */
-  bool have_scene = false, have_transforms = false;
+  bool have_scene = false, have_transforms = false, have_lights = false;
   /* frame workspace */
   float4 *d_out = nullptr;
   size_t out_capacity = 0;                       /* pixels */

@@ -322,6 +322,17 @@ extern "C" flx_status flx_group_create(int n, const int *devices, flx_group **ou
       if (!can) g->peer_ok = false;
     }
   }
+  /* A device named more than once (the rehearsal of a group on a one-GPU box): the frame loop's servers are persistent launches, and two of them want the
+   * whole GPU each — the second would not start before the first ends, which it never does while the host waits for both.  Their launches take an equal
+   * part of the CUs each (what flx_debug_set_server_groups sets by hand), so that they run beside each other as they do on two GPUs. */
+  if (!distinct) {
+    for (int r = 0; r < n; r++) {
+      uint32_t sharing = 0;
+      for (int q = 0; q < n; q++) if (devices[q] == devices[r]) sharing++;
+      const uint32_t cus = (uint32_t)g->ctx[r]->prop.multiProcessorCount;
+      if (sharing > 1u) g->ctx[r]->sv_groups = cus / sharing ? cus / sharing : 1u;
+    }
+  }
   *out = g;
   return FLX_OK;
 }

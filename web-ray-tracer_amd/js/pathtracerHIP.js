@@ -46,6 +46,7 @@ class PathTracerHIP {
     this._devices = Array.isArray(dv) ? dv.slice() : (dv > 1 ? Array.from({ length: dv }, (_, i) => i) : null);
     this._tileRows = (options && options.tileRows) || 8;
     this.present8 = !!(options && options.present8);     // the frame loop hands out the canvas' RGBA8 instead of float radiance
+    this.groupLanes = 3;                                  // frames in flight of a group's frame loop (2 or 3)
     this._group = null;
     this._ctx = null;
     this._halt = true;
@@ -103,6 +104,7 @@ class PathTracerHIP {
     this._haveScene = false;
     this._atlasLists = [null, null, null];
     this._inFlight = 0;
+    this._lanesSet = undefined;
   }
 
   async updateScene () {                                  // pathtracerWGL2.js:167-189
@@ -253,8 +255,9 @@ class PathTracerHIP {
   /* The frame loop (pathtracerWGL2.js:191-831).  Like the reference's, it does not wait for the GPU inside a frame: frame
    * k + 1 is prepared and enqueued (flx_frame_begin) while frame k is traced and copied to pinned host memory, then frame k is
    * taken (flx_frame_end) and handed to canvas.onFrame — `pixels` is a view of that pinned memory (Float32Array, or the canvas'
-   * RGBA8 as a Uint8ClampedArray with this.present8), valid until the frame after the next is begun.  Anti-aliasing passes,
-   * tiles and GPU groups take the synchronous renderFrame() per cycle instead.  `fps` as in pathtracerWGL2.js:293-298;
+   * RGBA8 as a Uint8ClampedArray with this.present8), valid until the frame after the next is begun.  A group of GPUs (`devices`) runs the
+   * same loop through flx_group_frame_begin / _end with up to this.groupLanes (3) frames in flight, `pixels` valid until the next frame is begun.
+   * Anti-aliasing passes, tiles and a group with present8 take the synchronous renderFrame() per cycle instead.  `fps` as in pathtracerWGL2.js:293-298;
    * `gpuMs` = GPU time of the last frame taken. */
   async render () {
     if (!this._halt) return;                              // already running (the WebGPU renderer guards the same way)
@@ -275,7 +278,7 @@ class PathTracerHIP {
     };
     const take = () => {
       const q = pending.shift();
-      const r = native().frameEnd(this._ctx, q.rgba8);
+      const r = q.group ? native().groupFrameEnd(this._group) : native().frameEnd(this._ctx, q.rgba8);
       this._inFlight--;
       this.gpuMs = r.gpuMs;
       deliver({ width: q.width, height: q.height, rows: q.rows, radiance: q.rgba8 ? undefined : r.pixels, rgba8: q.rgba8 ? r.pixels : undefined, pixels: r.pixels, frameMs: r.gpuMs });
@@ -283,8 +286,26 @@ class PathTracerHIP {
     const cycle = () => {
       if (this._halt) return;
       try {
-        const pipelined = !this._devices && !this._tile && !this._antialiasing();
-        if (pipelined) {
+        const aa = this._antialiasing();
+        /* a group of GPUs (flx_group_frame_begin / _end): every GPU's frame server resolves its strips straight into one image in pinned host memory, up to
+         * three frames in flight, nothing waits for a GPU inside a frame; `pixels` is a view of that image, the frame's until the next frame is begun */
+        const grouped = !!this._devices && !this._tile && !aa && !this.present8;
+        const pipelined = !this._devices && !this._tile && !aa;
+        if (grouped) {
+          this._uploadFrameState();
+          const p = this.frameParams();
+          if (this._lanesSet !== this.groupLanes) {         // (the library's default is 3)
+            while (this._inFlight > 0) take();
+            native().groupSetFrameLanes(this._group, this.groupLanes);
+            this._lanesSet = this.groupLanes;
+          }
+          if (this._inFlight === this.groupLanes) take();
+          if (this._halt) return;                           // (the application halted the renderer from its onFrame)
+          native().groupFrameBegin(this._group, p, this._tileRows);
+          this._inFlight++;
+          pending.push({ width: p.width, height: p.height, rows: p.height, rgba8: false, group: true });
+          this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);
+        } else if (pipelined) {
           this._uploadFrameState();
           const p = this.frameParams();
           native().frameBegin(this._context(), p, this.present8);

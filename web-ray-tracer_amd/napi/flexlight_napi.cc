@@ -598,17 +598,32 @@ static napi_value FramesInFlight(napi_env env, napi_callback_info info) {
 }
 
 /* ---- several GPUs in this process (flx_group_*): the same calls with a group handle -------------------------------------- */
-static void finalize_group(napi_env, void *data, void *) {
-  flx_group **slot = static_cast<flx_group **>(data);
-  if (*slot) flx_group_destroy(*slot);
-  delete slot;
+/* What a group handle points to: the group and the ArrayBuffers handed out over its frame images (groupFrameEnd), detached when their memory stops being
+ * that frame's (CtxBox above does the same for one context). */
+struct GroupBox {
+  flx_group *g = nullptr;                  /* first member: a handle also reads as flx_group ** */
+  std::vector<CtxBox::View> views;
+};
+static void detach_group_views(napi_env env, GroupBox *box) {
+  for (auto &v : box->views) detach_view(env, v);
+  box->views.clear();
 }
-static flx_group *get_group(napi_env env, napi_value v) {
+static void finalize_group(napi_env env, void *data, void *) {
+  GroupBox *box = static_cast<GroupBox *>(data);
+  for (auto &v : box->views) napi_delete_reference(env, v.ref);
+  if (box->g) flx_group_destroy(box->g);
+  delete box;
+}
+static GroupBox *get_group_box(napi_env env, napi_value v) {
   void *p = nullptr;
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a group handle"); return nullptr; }
-  flx_group *g = *static_cast<flx_group **>(p);
-  if (!g) napi_throw_error(env, nullptr, "group was halted");
-  return g;
+  GroupBox *box = static_cast<GroupBox *>(p);
+  if (!box->g) { napi_throw_error(env, nullptr, "group was halted"); return nullptr; }
+  return box;
+}
+static flx_group *get_group(napi_env env, napi_value v) {
+  GroupBox *box = get_group_box(env, v);
+  return box ? box->g : nullptr;
 }
 static napi_value gfail(napi_env env, flx_group *g, const char *what, flx_status rc) {
   std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + flx_group_last_error(g);
@@ -629,7 +644,9 @@ static napi_value CreateGroup(napi_env env, napi_callback_info info) {
   flx_status rc = flx_group_create((int)n, devices, &g);
   if (rc != FLX_OK) return gfail(env, nullptr, "flx_group_create", rc);
   napi_value ext;
-  NAPI_OK(env, napi_create_external(env, new flx_group *(g), finalize_group, nullptr, &ext));
+  GroupBox *box = new GroupBox();
+  box->g = g;
+  NAPI_OK(env, napi_create_external(env, box, finalize_group, nullptr, &ext));
   return ext;
 }
 static napi_value DestroyGroup(napi_env env, napi_callback_info info) {
@@ -637,8 +654,9 @@ static napi_value DestroyGroup(napi_env env, napi_callback_info info) {
   if (!get_args(env, info, 1, argv)) return nullptr;
   void *p = nullptr;
   if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
-    flx_group **slot = static_cast<flx_group **>(p);
-    if (*slot) { flx_group_destroy(*slot); *slot = nullptr; }
+    GroupBox *box = static_cast<GroupBox *>(p);
+    detach_group_views(env, box);          /* the images are freed with the group: whoever still holds a frame reads an empty array */
+    if (box->g) { flx_group_destroy(box->g); box->g = nullptr; }
   }
   return nullptr;
 }
@@ -752,6 +770,67 @@ static napi_value GroupRender(napi_env env, napi_callback_info info) {
   return res;
 }
 
+/* ---- the group's frame loop: groupFrameBegin(handle, params, tileRows) / groupFrameEnd(handle) -> { pixels, gpuMs } --------------------
+ * flx_group_frame_begin / _end: every GPU's frame server resolves its strips straight into ONE image in pinned host memory; `pixels` is a Float32Array
+ * over that image (no copy), the frame's until the NEXT groupFrameBegin — which may be the frame that re-uses the image — detaches it (and
+ * groupSetFrameLanes, destroyGroup). */
+static napi_value GroupFrameBegin(napi_env env, napi_callback_info info) {
+  napi_value argv[3];
+  if (!get_args(env, info, 3, argv)) return nullptr;
+  GroupBox *box = get_group_box(env, argv[0]);
+  if (!box) return nullptr;
+  flx_frame_params p;
+  if (!read_params(env, argv[1], &p)) return nullptr;
+  uint32_t tileRows = 8;
+  NAPI_OK(env, napi_get_value_uint32(env, argv[2], &tileRows));
+  detach_group_views(env, box);
+  flx_status rc = flx_group_frame_begin(box->g, &p, tileRows, FLX_FRAME_FLOAT);
+  if (rc != FLX_OK) return gfail(env, box->g, "flx_group_frame_begin", rc);
+  return nullptr;
+}
+static napi_value GroupFrameEnd(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  GroupBox *box = get_group_box(env, argv[0]);
+  if (!box) return nullptr;
+  const void *pixels = nullptr; size_t bytes = 0; float ms = 0.f;
+  flx_status rc = flx_group_frame_end(box->g, &pixels, &bytes, &ms);
+  if (rc != FLX_OK) return gfail(env, box->g, "flx_group_frame_end", rc);
+  napi_value res, buf, arr, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  NAPI_OK(env, napi_create_external_arraybuffer(env, const_cast<void *>(pixels), bytes, no_free, nullptr, &buf));
+  {
+    CtxBox::View view = { pixels, nullptr };
+    NAPI_OK(env, napi_create_reference(env, buf, 0, &view.ref));
+    box->views.push_back(view);
+  }
+  NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, bytes / 4, buf, 0, &arr));
+  napi_set_named_property(env, res, "pixels", arr);
+  napi_create_double(env, ms, &v); napi_set_named_property(env, res, "gpuMs", v);
+  return res;
+}
+static napi_value GroupFramesInFlight(napi_env env, napi_callback_info info) {
+  napi_value argv[1];
+  if (!get_args(env, info, 1, argv)) return nullptr;
+  flx_group *g = get_group(env, argv[0]);
+  if (!g) return nullptr;
+  napi_value v;
+  napi_create_int32(env, flx_group_frames_in_flight(g), &v);
+  return v;
+}
+static napi_value GroupSetFrameLanes(napi_env env, napi_callback_info info) {
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
+  GroupBox *box = get_group_box(env, argv[0]);
+  if (!box) return nullptr;
+  int32_t lanes = 3;
+  NAPI_OK(env, napi_get_value_int32(env, argv[1], &lanes));
+  flx_status rc = flx_group_set_frame_lanes(box->g, lanes);
+  if (rc != FLX_OK) return gfail(env, box->g, "flx_group_set_frame_lanes", rc);
+  detach_group_views(env, box);            /* (the images are made again for the new depth) */
+  return nullptr;
+}
+
 static napi_value Version(napi_env env, napi_callback_info) {
   napi_value v;
   napi_create_string_utf8(env, flx_version(), NAPI_AUTO_LENGTH, &v);
@@ -769,7 +848,8 @@ static napi_value Init(napi_env env, napi_value exports) {
     { "frameBegin", FrameBegin }, { "frameEnd", FrameEnd }, { "framesInFlight", FramesInFlight },
     { "createGroup", CreateGroup }, { "destroyGroup", DestroyGroup }, { "groupInfo", GroupInfo }, { "groupUploadScene", GroupUploadScene },
     { "groupUploadTransforms", GroupUploadTransforms }, { "groupUploadLights", GroupUploadLights }, { "groupUploadAtlas", GroupUploadAtlas },
-    { "groupRender", GroupRender },
+    { "groupRender", GroupRender }, { "groupFrameBegin", GroupFrameBegin }, { "groupFrameEnd", GroupFrameEnd }, { "groupFramesInFlight", GroupFramesInFlight },
+    { "groupSetFrameLanes", GroupSetFrameLanes },
   };
   for (const auto &f : fns) {
     napi_value fn;
