@@ -271,6 +271,11 @@ flx_status flx_render_gathered_device(flx_context *ctx, const flx_frame_params *
  * reassembles (and runs the denoise chain of a filter frame), the others are done when their strips are sent.  d_frames is read
  * on `root` only (may be NULL elsewhere).  The reference presents from its one context (pathtracerWGL2.js:60-68, 552-553). */
 flx_status flx_render_gathered_root_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames);
+/* The gathered frames as the canvas' RGBA8 — the bytes flx_present stores, floor(clamp(x) * 255 + 0.5) per channel (what the reference's canvas holds after
+ * pathtracerWGL2.js:552-553 has drawn into it): every rank quantises its strips where it traced them and a QUARTER of the bytes is exchanged (8.3 MB of a
+ * 1080p frame in all instead of 33 MB; 33 instead of 133 MB at 4K).  d_frames_rgba8 = uint8[n_frames][height][width][4] in device memory.  root < 0: all-gather,
+ * every rank gets the frames; root >= 0: that rank alone (NULL elsewhere).  Frames without the filter (a filter frame's exchange is its five render targets). */
+flx_status flx_render_gathered_rgba8_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames_rgba8);
 /* ranks of the context's communicator as RCCL reports them (ncclCommCount); 0: the context belongs to none */
 int flx_comm_count(const flx_context *ctx);
 /* The frame loop (flx_frame_begin / flx_frame_end) over the communicator: every rank begins the same frame with its own
@@ -321,6 +326,9 @@ flx_status flx_group_scene_upload_view(flx_group *group, const flx_scene_view *s
  * flx_render / flx_render_batch of one context bit for bit.  counters (may be NULL): summed over the contexts. */
 flx_status flx_group_render(flx_group *group, const flx_frame_params *params, uint32_t n_frames, uint32_t tile_rows, float *out_rgba,
                             flx_counters *counters);
+/* ... as the canvas' RGBA8 (flx_render_gathered_rgba8_device): out_rgba8 = uint8[n_frames][height][width][4] on the host, equal to flx_present of flx_group_render's frames */
+flx_status flx_group_render_rgba8(flx_group *group, const flx_frame_params *params, uint32_t n_frames, uint32_t tile_rows, uint8_t *out_rgba8,
+                                  flx_counters *counters);
 /* The group's frame loop — what the reference's render loop is to its one context (pathtracerWGL2.js:254-303: a frame per animation callback, the host
  * never waits for the GPU).  flx_group_frame_begin posts the frame to every context's frame server (flx_set_frame_chain) and returns; every server renders
  * its context's strips and resolves them straight into ONE image the group owns — pinned host memory that every GPU writes over its own PCIe link

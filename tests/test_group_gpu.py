@@ -158,6 +158,51 @@ def test_gather_to_root_on_repeated_devices_and_with_one_rank(hip, scenes):
         ctx.close()
 
 
+def test_frames_gathered_as_the_canvas_rgba8(hip, oracle, scenes):
+    """the presenter wants RGBA8 (round-3 review, item 8): every rank quantises its strips where it traced them and a quarter of the bytes is exchanged —
+    flx_group_render_rgba8 on repeated devices (ragged strips, more ranks than some frames have strips, both gathers, a batch of moved cameras) and
+    flx_render_gathered_rgba8_device with a communicator of one rank (all-gather and to the root); the bytes are flx_present's (= the oracle's) of the
+    float frame one context renders"""
+    import torch
+    from flexlight_hip import capi
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=224, height=126, samples=2, max_reflections=3, use_filter=0)
+    frames = [_moved(sc, p, i) for i in range(3)]
+    want = [oracle.present(hip_render(hip, sc, q)) for q in frames]
+    assert np.array_equal(want[0], hip.present(hip_render(hip, sc, frames[0])))
+    for ranks, tile_rows in ((3, 8), (5, 16), (8, 8)):
+        with capi.Group([0] * ranks) as g:
+            g.update_scene(sc)
+            got = g.render_rgba8(frames, tile_rows=tile_rows)
+            for i in range(3):
+                assert np.array_equal(got[i], want[i]), (ranks, tile_rows, i)
+            g.set_gather(False)
+            assert np.array_equal(g.render_rgba8(frames[1], tile_rows=tile_rows)[0], want[1])
+            assert np.array_equal(g.render(frames[1], tile_rows=tile_rows)[0][0], hip_render(hip, sc, frames[1]), equal_nan=True)      # (the float path after it: its buffers are its own)
+            with pytest.raises(capi.FlexLightHipError, match="filter"):
+                g.render_rgba8(sc.frame_params(width=224, height=126, samples=1, max_reflections=2, use_filter=1), tile_rows=tile_rows)
+    ctx = capi.Context(0)
+    try:
+        ctx.update_scene(sc)
+        ctx.comm_init_rank(capi.comm_unique_id(), 1, 0)
+        out = torch.zeros((3, 126, 224, 4), dtype=torch.uint8, device="cuda")
+        tiled = []
+        for q in frames:
+            t = type(q).from_buffer_copy(q)
+            t.tile_rows, t.tile_index, t.tile_count = 8, 0, 1
+            tiled.append(t)
+        for root in (-1, 0):
+            out.zero_()
+            ctx.render_gathered_rgba8_device(tiled, root, out.data_ptr())
+            ctx.sync()
+            got = out.cpu().numpy()
+            for i in range(3):
+                assert np.array_equal(got[i], want[i]), (root, i)
+    finally:
+        ctx.close()
+
+
 def test_frame_loop_over_a_communicator(hip, scenes):
     """flx_frame_begin_gathered: the frames of a camera move alternate between the two lanes, each lane gathering over its own
     communicator (the second is an ncclCommSplit of the first); every frame taken equals its own render — with a communicator of

@@ -183,3 +183,24 @@ def test_group_frame_loop_through_node(hip, oracle, scenes, tmp_path, move_scene
     assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[3], frames[4])
     if not move_scene:
         assert log[0]["rotation"] == log[4]["rotation"]
+
+
+def test_group_presents_rgba8_through_node(hip, oracle, scenes, tmp_path):
+    """a group whose renderer presents the canvas' RGBA8 (renderer.present8 with devices): flx_group_render_rgba8 — the strips quantised on their GPUs, a quarter
+    of the bytes gathered — hands the loop the bytes flx_present / the oracle store for the float frame of the same tick"""
+    node = shutil.which("node")
+    w, h, spp, bounces = 320, 180, 2, 3
+    prefix = str(tmp_path / "g8")
+    cmd = [node, os.path.join(ROOT, "tools", "js_loop.js"), os.path.join(ROOT, "tests", "golden", "ref_dragon.flxs.gz"), "--frames", "3", "--move", "2", "--present8", "1",
+           "--width", str(w), "--height", str(h), "--spp", str(spp), "--bounces", str(bounces), "--dump", prefix, "--dump-frames", "2", "--devices", "0,0,0"]
+    info = json.loads(subprocess.check_output(cmd, timeout=300).decode().splitlines()[-1])
+    assert info["present8"] is True and info["devices"] == [0, 0, 0]
+    log = json.load(open(prefix + "log.json"))
+    sc = scenes("dragon")
+    for k, tick in enumerate(log):
+        p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+        p.camera[:] = tick["camera"]
+        p.view_matrix[:] = tick["viewMatrix"]
+        want = oracle.present(oracle.render(sc, p)[0])
+        got = np.fromfile(prefix + "%d.f32" % k, np.uint8).reshape(h, w, 4)
+        assert np.array_equal(got, want), "frame %d" % k

@@ -114,6 +114,8 @@ struct flx_context {
   bool comm_owned = false;                       /* made by flx_comm_init_rank (else by a group's ncclCommInitAll) */
   float4 *d_send = nullptr, *d_recv = nullptr;   /* this rank's packed strips; every rank's */
   size_t send_capacity = 0, recv_capacity = 0;   /* float4 units */
+  float4 *d_send8 = nullptr;                     /* this rank's strips as RGBA8 texels (flx_render_gathered_rgba8_device) */
+  size_t send8_capacity = 0;
   float4 *d_frames = nullptr;                    /* group mode: the gathered frames in image order */
   size_t frames_capacity = 0;
   float4 *d_gplanes = nullptr;                   /* filter frames: the five gathered render targets in image order */
@@ -208,7 +210,7 @@ flx_status flx_fail(flx_context *ctx, flx_status code, const char *msg);
 
 /* flx_group.hip: this context's strips traced, exchanged over its communicator (root < 0: all-gather; else only `root` receives) and
  * put in image order, all enqueued on its stream */
-flx_status flx_gather_enqueue(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames);
+flx_status flx_gather_enqueue(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames, bool rgba8 = false);
 
 /* flx_api.hip */
 flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, flx::DeviceScene &sc, flx::DeviceFrame &fr);

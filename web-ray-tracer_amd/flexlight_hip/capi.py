@@ -29,6 +29,7 @@ EXPORTS = [
     "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
     "flx_frame_server_takes", "flx_frame_target_set", "flx_frame_target_index", "flx_debug_set_server_groups",
     "flx_share_create", "flx_share_join", "flx_share_leave", "flx_frame_begin_shared", "flx_frame_end_shared",
+    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8",
 ]
 
 
@@ -139,6 +140,8 @@ def _load():
         "flx_group_atlas_upload": (C.c_int, [vp, C.c_int, C.POINTER(C.c_uint8), u32, u32]),
         "flx_group_scene_upload_view": (C.c_int, [vp, C.POINTER(SceneView)]),
         "flx_group_render": (C.c_int, [vp, C.POINTER(FrameParams), u32, u32, fp, C.POINTER(Counters)]),
+        "flx_group_render_rgba8": (C.c_int, [vp, C.POINTER(FrameParams), u32, u32, C.POINTER(C.c_uint8), C.POINTER(Counters)]),
+        "flx_render_gathered_rgba8_device": (C.c_int, [vp, C.POINTER(FrameParams), u32, C.c_int, vp]),
         "flx_group_frame_begin": (C.c_int, [vp, C.POINTER(FrameParams), u32, C.c_int]),
         "flx_group_frame_end": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
         "flx_group_frames_in_flight": (C.c_int, [vp]),
@@ -284,6 +287,12 @@ class Context:
         n = len(params_list)
         arr = (FrameParams * n)(*params_list)
         self._check(LIB.flx_render_gathered_root_device(self._h, arr, n, int(root), C.c_void_p(device_ptr or 0)), "flx_render_gathered_root_device")
+
+    def render_gathered_rgba8_device(self, params_list, root, device_ptr):
+        """the gathered frames as the canvas' RGBA8 (a quarter of the bytes exchanged): uint8[n][H][W][4] at device_ptr; root < 0: all-gather"""
+        n = len(params_list)
+        arr = (FrameParams * n)(*params_list)
+        self._check(LIB.flx_render_gathered_rgba8_device(self._h, arr, n, int(root), C.c_void_p(device_ptr or 0)), "flx_render_gathered_rgba8_device")
 
     def comm_count(self):
         """ranks of this context's RCCL communicator (ncclCommCount); 0 without one"""
@@ -643,6 +652,16 @@ class Group:
         cnt = Counters() if counters else None
         self._check(LIB.flx_group_render(self._h, arr, n, tile_rows, _fp(out), C.byref(cnt) if cnt else None), "flx_group_render")
         return out, (cnt.as_dict() if cnt else None)
+
+    def render_rgba8(self, params_list, tile_rows=8):
+        """the frames as the canvas' RGBA8, quantised before the exchange -> uint8 [n, H, W, 4]"""
+        if isinstance(params_list, FrameParams):
+            params_list = [params_list]
+        n = len(params_list)
+        arr = (FrameParams * n)(*params_list)
+        out = np.zeros((n, params_list[0].height, params_list[0].width, 4), np.uint8)
+        self._check(LIB.flx_group_render_rgba8(self._h, arr, n, tile_rows, out.ctypes.data_as(C.POINTER(C.c_uint8)), None), "flx_group_render_rgba8")
+        return out
 
     # -- the group's frame loop (flx_group_frame_begin / _end): every context's frame server resolves its strips into ONE image ----
     def set_frame_lanes(self, lanes):

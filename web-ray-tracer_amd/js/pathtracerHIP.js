@@ -313,6 +313,14 @@ class PathTracerHIP {
           pending.push({ width: p.width, height: p.height, rows: p.height, rgba8: this.present8 });
           this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);
           if (this._inFlight === 2) take();
+        } else if (this._devices && this.present8 && !this._tile && !aa && !this.config.filter && !this.config.temporal) {
+          /* a group that presents the canvas' RGBA8: every GPU quantises its strips and a quarter of the bytes is gathered (flx_group_render_rgba8) */
+          while (this._inFlight > 0) take();
+          this._uploadFrameState();
+          const p = this.frameParams();
+          if (!this._out8 || this._out8.length !== p.width * p.height * 4) this._out8 = new Uint8ClampedArray(p.width * p.height * 4);
+          const info = native().groupRenderRgba8(this._group, p, this._tileRows, this._out8);
+          deliver({ width: p.width, height: p.height, rows: p.height, rgba8: this._out8, pixels: this._out8, frameMs: info.frameMs });
         } else {
           while (this._inFlight > 0) take();
           deliver(this.renderFrame({ reuse: true }));

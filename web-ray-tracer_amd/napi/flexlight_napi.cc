@@ -770,6 +770,30 @@ static napi_value GroupRender(napi_env env, napi_callback_info info) {
   return res;
 }
 
+/* groupRenderRgba8(handle, params, tileRows, out Uint8ClampedArray(height*width*4)) -> { frameMs }: one frame as the canvas' RGBA8, the strips quantised on
+ * their GPUs before the exchange (flx_group_render_rgba8: a quarter of the bytes gathered and copied out) */
+static napi_value GroupRenderRgba8(napi_env env, napi_callback_info info) {
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
+  flx_group *grp = get_group(env, argv[0]);
+  if (!grp) return nullptr;
+  flx_frame_params p;
+  if (!read_params(env, argv[1], &p)) return nullptr;
+  uint32_t tileRows = 8;
+  NAPI_OK(env, napi_get_value_uint32(env, argv[2], &tileRows));
+  void *out; size_t n;
+  if (!typed(env, argv[3], napi_uint8_array, &out, &n)) return nullptr;
+  if (!out || n != (size_t)p.height * p.width * 4) { napi_throw_range_error(env, nullptr, "out needs height*width*4 bytes"); return nullptr; }
+  flx_status rc = flx_group_render_rgba8(grp, &p, 1, tileRows, (uint8_t *)out, nullptr);
+  if (rc != FLX_OK) return gfail(env, grp, "flx_group_render_rgba8", rc);
+  float frame_ms = 0.f, trace_ms = 0.f;
+  flx_last_frame_ms(flx_group_context(grp, 0), &frame_ms, &trace_ms);
+  napi_value res, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  napi_create_double(env, frame_ms, &v); napi_set_named_property(env, res, "frameMs", v);
+  return res;
+}
+
 /* ---- the group's frame loop: groupFrameBegin(handle, params, tileRows) / groupFrameEnd(handle) -> { pixels, gpuMs } --------------------
  * flx_group_frame_begin / _end: every GPU's frame server resolves its strips straight into ONE image in pinned host memory; `pixels` is a Float32Array
  * over that image (no copy), the frame's until the NEXT groupFrameBegin — which may be the frame that re-uses the image — detaches it (and
@@ -848,7 +872,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     { "frameBegin", FrameBegin }, { "frameEnd", FrameEnd }, { "framesInFlight", FramesInFlight },
     { "createGroup", CreateGroup }, { "destroyGroup", DestroyGroup }, { "groupInfo", GroupInfo }, { "groupUploadScene", GroupUploadScene },
     { "groupUploadTransforms", GroupUploadTransforms }, { "groupUploadLights", GroupUploadLights }, { "groupUploadAtlas", GroupUploadAtlas },
-    { "groupRender", GroupRender }, { "groupFrameBegin", GroupFrameBegin }, { "groupFrameEnd", GroupFrameEnd }, { "groupFramesInFlight", GroupFramesInFlight },
+    { "groupRender", GroupRender }, { "groupRenderRgba8", GroupRenderRgba8 }, { "groupFrameBegin", GroupFrameBegin }, { "groupFrameEnd", GroupFrameEnd }, { "groupFramesInFlight", GroupFramesInFlight },
     { "groupSetFrameLanes", GroupSetFrameLanes },
   };
   for (const auto &f : fns) {
