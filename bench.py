@@ -782,6 +782,38 @@ def main():
         batched["value"] = rays / (batched["ms_per_frame"] * 1e-3) / 1e6
         batched["unit"] = "Mray/s"
         guard.put("batched", batched)
+    guard.phase("gathered_rgba8")
+    # N > 1 over RCCL: the same frame-after-frame loop with the frames travelling as the canvas' RGBA8 (every rank quantises its strips before the exchange:
+    # a quarter of the bytes; flx_render_gathered_rgba8_device) — what a presenter that shows the frame needs
+    rgba8 = None
+    if rccl and not use_filter:
+        out8 = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+        n8 = max(args.steps, 20)
+        for phase in range(2):
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(3 if phase == 0 else n8):
+                ctx.render_gathered_rgba8_device([params], 0 if to_root else -1, out8.data_ptr())
+            fence()
+            dt8 = time.perf_counter() - t1
+        if multi:
+            t = torch.tensor([dt8], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt8 = float(t.item())
+        rgba8 = {"ms_per_frame": dt8 / n8 * 1e3, "frames": n8, "bytes_exchanged_per_frame": tiles.padded_rows(H, args.tile_rows, world) * W * 4 * world,
+                 "bytes_exchanged_per_frame_float": tiles.padded_rows(H, args.tile_rows, world) * W * 16 * world,
+                 "note": "flx_render_gathered_rgba8_device, frame after frame: trace, quantise the strips (flx_present's bytes), %s of the RGBA8 strips, reassembly" % ("ncclSend / ncclRecv to rank 0" if to_root else "ncclAllGather")}
+        if rank == 0 and verified is not None:
+            whole8 = torch.zeros((H, W, 4), dtype=torch.uint8, device="cuda")
+            wholef = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+            ctx.render_device(full, wholef.data_ptr())
+            ctx.present_device(W, H, wholef.data_ptr(), whole8.data_ptr())
+            ctx.sync()
+            rgba8["equals_present_of_single_context_frame"] = bool(torch.equal(whole8, out8))
+    if rank == 0 and rgba8:
+        rgba8["value"] = rays / (rgba8["ms_per_frame"] * 1e-3) / 1e6
+        rgba8["unit"] = "Mray/s"
+        guard.put("gathered_rgba8", rgba8)
     guard.phase("pipelined")
     # two frames in flight (flx_frame_begin / flx_frame_end with two lanes: what the JavaScript frame loop runs): still one frame per
     # pass and frames complete in order, but frame k + 1's kernels fill the CUs the tails of frame k's kernels leave idle

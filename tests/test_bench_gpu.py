@@ -84,6 +84,9 @@ def test_bench_rccl_path_with_one_rank():
     assert d["batched"]["frames_per_pass"] == 4
     assert d["gather"] == {"exchange": "root", "uses_rccl": True, "rccl_ranks": 1, "launched_by": "torch.distributed.run"} or d["gather"]["rccl_ranks"] == 1
     assert d["pipelined"]["frames_in_flight"] == 2 and "communicator" in d["pipelined"]["note"]      # the frame loop over the communicator
+    g8 = d["gathered_rgba8"]                                                                        # the frames travelling as the canvas' RGBA8
+    assert g8["ms_per_frame"] > 0 and g8["equals_present_of_single_context_frame"] is True and g8["bytes_exchanged_per_frame"] * 4 == g8["bytes_exchanged_per_frame_float"]
+    assert "frame server" in d["shared"]["error"]                                                    # (270 rows: a last strip of 6 the frame server does not take — reported, not fatal)
     e = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "0", "--gather", "all", "--no-pmc"] + SMALL, timeout=900, env=env, stderr=subprocess.DEVNULL))
     assert "ncclAllGather" in e["config"]["parallelism"] and e["gathered_frame_equals_single_context_frame"] is True and e["gather"]["exchange"] == "all_gather"
 

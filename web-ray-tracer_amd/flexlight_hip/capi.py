@@ -496,6 +496,10 @@ class Context:
         self._check(LIB.flx_present(self._h, a.shape[1], a.shape[0], a.ctypes.data, out.ctypes.data), "flx_present")
         return out
 
+    def present_device(self, width, height, d_in_rgba, d_out_rgba8):
+        """device pointers: float4[H][W] -> the canvas' uint8[H][W][4], enqueued on the context's stream"""
+        self._check(LIB.flx_present_device(self._h, width, height, C.c_void_p(d_in_rgba), C.c_void_p(d_out_rgba8)), "flx_present_device")
+
     def taa(self, frame):
         """the TAA pass: the context keeps the last nine frames"""
         a = np.ascontiguousarray(frame, np.float32)
