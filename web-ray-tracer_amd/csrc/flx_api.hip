@@ -208,6 +208,9 @@ static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t byte
  * entry makes the storage order free, so the shallow levels — which every ray crosses — go to the
  * front where the walk kernel keeps them in LDS.  Entry contents, the sequence of entries a given
  * ray visits and therefore every result are unchanged. */
+#ifndef FLX_AB_HOT_ORDER
+#define FLX_AB_HOT_ORDER 0
+#endif
 static void build_threaded(const float *geometry, uint32_t n, std::vector<float> &out, uint32_t &n_out, uint32_t &n_hot, uint32_t &root) {
   const uint32_t HOT_MAX = 4096;                 /* upper bound of entries worth ordering by depth */
   /* live entries: everything a walk can reach = all entries before the first terminator that is reached;
@@ -228,6 +231,16 @@ static void build_threaded(const float *geometry, uint32_t n, std::vector<float>
   /* shallowest HOT_MAX entries first (stable: by depth, then original index), the rest in original order */
   std::vector<uint32_t> byDepth(order);
   std::stable_sort(byDepth.begin(), byDepth.end(), [&](uint32_t a, uint32_t b) { return depth[a] < depth[b]; });
+#if FLX_AB_HOT_ORDER      /* A/B builds only: the hot-first order from a file of original indices (tools: the oracle's visit histogram), to bound what a better choice of the LDS top can bring */
+  if (const char *f = getenv("FLX_HOT_ORDER")) {
+    if (FILE *fh = fopen(f, "rb")) {
+      std::vector<uint32_t> given(byDepth.size());
+      const size_t got = fread(given.data(), 4, given.size(), fh);
+      fclose(fh);
+      if (got == given.size()) byDepth = given;
+    }
+  }
+#endif
   const uint32_t hot = (uint32_t)std::min<size_t>(HOT_MAX, byDepth.size());
   std::vector<char> isHot(n, 0);
   for (uint32_t k = 0; k < hot; k++) isHot[byDepth[k]] = 1;

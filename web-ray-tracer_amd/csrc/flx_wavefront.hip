@@ -825,7 +825,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
  * enough tiles per workgroup to balance (flx_api.hip: automatic from 32 on); FRONT = false is the kernel described above, register for
  * register. */
 #ifndef FLX_FRAME_WALK_PRIO
-#define FLX_FRAME_WALK_PRIO 0               /* ... and of the walk waves (shade waves above the walk waves: dragon 1080p 6.37 -> 6.82 ms; profiles/r04_ab_priority.txt) */
+#define FLX_FRAME_WALK_PRIO 0               /* ... and of the walk waves (shade waves above the walk waves: dragon 1080p 6.37 -> 6.82 ms; profiles/r04_ab_frame_kernel.txt) */
 #endif
 #ifndef FLX_FRAME_SHADE_PRIO
 #define FLX_FRAME_SHADE_PRIO 0              /* issue priority of the shade waves (s_setprio 0 .. 3; the walk waves run at 0) */
