@@ -6,6 +6,7 @@ once as they do on two GPUs; the stores of the second process go through its IPC
 equal flx_render of one context bit for bit (tests/test_parity_gpu.py holds that against the oracle)."""
 import ctypes
 import multiprocessing as mp
+import os
 
 import numpy as np
 import pytest
@@ -99,6 +100,75 @@ def test_two_processes_complete_one_image(tile_rows):
             status, detail = pipes[r][0].recv()
             assert status == "ok", detail
             assert detail == [], "frames %s differ from one context's render" % detail
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.kill()
+
+
+def _quitter_main(rank, conn):
+    """rank 0 creates the share and renders; rank 1 joins and then goes away without rendering a frame (its process ends: flx_share_leave is never called)"""
+    try:
+        from flexlight_hip import capi
+        from flexlight_hip.scene_io import Scene
+        sc = Scene.golden("dragon")
+        ctx = capi.Context(0)
+        ctx.update_scene(sc)
+        ctx.set_server_groups(ctx.device_info()[1] // RANKS)
+        if rank == 0:
+            conn.send(ctx.share_create(W, H, LANES, RANKS, 0))
+            assert conn.recv() == "go"
+            import time
+            t0 = time.time()
+            ctx.frame_begin_shared(_moving(sc, 0, tile=(8, 0, RANKS)))
+            try:
+                ctx.frame_end_shared()
+                conn.send(("error", "the root handed out a frame the other rank never rendered"))
+                return
+            except capi.FlexLightHipError as e:
+                waited = time.time() - t0
+                msg = str(e)
+            # ... and the share stays failed: the next frame is refused at once instead of waiting again
+            t1 = time.time()
+            try:
+                ctx.frame_begin_shared(_moving(sc, 1, tile=(8, 0, RANKS)))
+                again = "accepted"
+            except capi.FlexLightHipError:
+                again = "refused"
+            conn.send(("ok", (waited, msg, again, time.time() - t1)))
+            ctx.close()
+        else:
+            ctx.share_join(conn.recv(), rank)
+            conn.send("joined")
+            os._exit(0)                                   # gone: no flx_share_leave, no error word
+    except BaseException as e:      # noqa: BLE001
+        import traceback
+        conn.send(("error", traceback.format_exc() + repr(e)))
+
+
+def test_a_rank_that_goes_away_does_not_wedge_the_root():
+    """the root waits for every rank's strips of a frame — for at most 5 s: then its call fails with FLX_ERR_DEVICE, and the share stays failed"""
+    mpc = mp.get_context("spawn")
+    pipes = [mpc.Pipe() for _ in range(RANKS)]
+    procs = [mpc.Process(target=_quitter_main, args=(r, pipes[r][1])) for r in range(RANKS)]
+    for p in procs:
+        p.start()
+    try:
+        assert pipes[0][0].poll(120)
+        handle = pipes[0][0].recv()
+        assert isinstance(handle, bytes), handle
+        pipes[1][0].send(handle)
+        assert pipes[1][0].poll(120) and pipes[1][0].recv() == "joined"
+        procs[1].join(30)
+        pipes[0][0].send("go")
+        assert pipes[0][0].poll(60), "the root is still waiting"
+        status, detail = pipes[0][0].recv()
+        assert status == "ok", detail
+        waited, msg, again, t_again = detail
+        assert 4.0 <= waited <= 12.0, waited
+        assert "did not complete" in msg or "failed" in msg, msg
+        assert again == "refused" and t_again < 1.0
     finally:
         for p in procs:
             p.join(20)
