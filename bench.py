@@ -27,6 +27,8 @@ SURVEY.md 8d's algorithmic bytes beside it.  `cpu_baseline` is the CPU oracle ti
 N > 1 also reports `pipelined` (the frame loop over the communicator, two lanes) and `shared`: the same loop WITHOUT a collective — every rank's frame
 server (one persistent launch, three frames in flight) resolves its strips straight into one image in rank 0's device memory (flx_share_*: hipIpc mapping,
 stores over xGMI), verified against one context's frame.
+`gathered_rgba8` is the frame-after-frame loop with the frames travelling as the canvas' RGBA8 (a quarter of the bytes).  These and `batched` are measured
+AFTER the line is complete, under --secondary-timeout: a phase that does not come back ends the run with the line as it stands (`secondary_incomplete`).
 
 Exit status: non-zero when a rank fails, when the ranks do not finish within --rank-timeout seconds (they are killed), or when
 the gathered frame differs from the single-context frame (the line is still printed, with the field false).
@@ -489,7 +491,8 @@ class SecondaryGuard:
                 self.line["secondary_incomplete"] = {"phase": self.current, "limit_s": self.seconds}
                 print(json.dumps(self.line), flush=True)
             sys.stderr.flush()
-            os._exit(0 if self.rank == 0 else 0)
+            bad = self.rank == 0 and self.line is not None and self.line.get("gathered_frame_equals_single_context_frame") is False
+            os._exit(3 if bad else 0)                  # (the line is valid without the phase that hung; a failed verification still fails the run)
 
 
 def main():
