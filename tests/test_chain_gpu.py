@@ -65,14 +65,25 @@ def test_a_chain_ends_where_the_frames_change(chained, scenes):
     assert kinds == [1, 2, 2, 1, 2, 2], kinds
     for f in range(6):
         assert bit_mismatches(got[f], want[f]) == 0, f
-    # the lights uploaded again between two frames: the kernel before must not have worked ahead with the old ones
+    # other lights between two frames: the kernel before must not have worked ahead with the old ones (the SAME lights again are nothing: the chain goes on)
+    dim = np.array(sc.arrays["lights"], np.float32).copy()
+    dim.reshape(-1, 6)[:, 3] *= 0.5
+    chained.update_primary_light_sources(dim)
+    want_dim = chained.render(a[1])[0]
+    chained.update_primary_light_sources(sc.arrays["lights"])
     chained.frame_begin(a[0])
     chained.update_primary_light_sources(sc.arrays["lights"])
+    chained.frame_begin(a[1])
+    assert chained.last_chained() == 2
+    assert bit_mismatches(chained.frame_end()[0], want[0]) == 0 and bit_mismatches(chained.frame_end()[0], want[1]) == 0
+    chained.frame_begin(a[0])
+    chained.update_primary_light_sources(dim)
     chained.frame_begin(a[1])
     assert chained.last_chained() == 1
     g0 = chained.frame_end()[0]
     g1 = chained.frame_end()[0]
-    assert bit_mismatches(g0, want[0]) == 0 and bit_mismatches(g1, want[1]) == 0
+    chained.update_primary_light_sources(sc.arrays["lights"])
+    assert bit_mismatches(g0, want[0]) == 0 and bit_mismatches(g1, want_dim) == 0 and bit_mismatches(want_dim, want[1]) != 0
     # a synchronous render between chained frames uses the same workspace: the chain must not resume state it overwrote
     chained.frame_begin(a[0])
     chained.frame_begin(a[1])
