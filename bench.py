@@ -78,7 +78,36 @@ PMC_PASSES = [      # separate rocprofv3 passes (FETCH_SIZE and WRITE_SIZE do no
     ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY"],
     ["FETCH_SIZE"],
     ["WRITE_SIZE"],
+    # the vector instructions by class (profiles/r04_valu_rates.txt: which instruction which counter counts, and what a class costs to issue)
+    ["SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT"],
+    ["SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"],
 ]
+
+# SIMD cycles a wave64 vector instruction of a class takes to issue with four waves per SIMD (tools/micro/valu_rates.hip on this part, profiles/r04_valu_rates.txt):
+# full rate 2 (f32 add / sub / mul / fma, moves, logic, selects, add_u32), half rate 4 (min / max / compares / shifts / mbcnt / conversions, f64 arithmetic), quarter rate 8 (f32
+# transcendentals; f64 ones 16).  "int32" mixes full and half rate (3).  What no class counter counts ("other": compares, min / max, selects, moves, logic, shifts) lies between 2 and 4;
+# the frame kernel's stepping loop holds 70 % half-rate ones among them (tools/asm_mix.py): 3.4.
+ISSUE_CYCLES = {"f32": 2.0, "trans_f32": 8.0, "int32": 3.0, "int64": 4.0, "cvt": 4.0, "f64": 4.0, "trans_f64": 16.0}
+ISSUE_CYCLES_OTHER = (2.0, 3.4, 4.0)
+
+
+def issue_cycles(k, kernel_ms):
+    """the dominant kernel's vector instructions priced per class -> share of the launch in which the SIMDs' vector pipes issue, as (low, estimate, high) with the classes' counts"""
+    need = ["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT"]
+    if any(k.get(n) is None for n in need) or not kernel_ms:
+        return None
+    n = {"f32": k["SQ_INSTS_VALU_ADD_F32"] + k["SQ_INSTS_VALU_MUL_F32"] + k["SQ_INSTS_VALU_FMA_F32"], "trans_f32": k["SQ_INSTS_VALU_TRANS_F32"], "int32": k["SQ_INSTS_VALU_INT32"],
+         "int64": k["SQ_INSTS_VALU_INT64"], "cvt": k["SQ_INSTS_VALU_CVT"],
+         "f64": (k.get("SQ_INSTS_VALU_ADD_F64") or 0) + (k.get("SQ_INSTS_VALU_MUL_F64") or 0) + (k.get("SQ_INSTS_VALU_FMA_F64") or 0), "trans_f64": k.get("SQ_INSTS_VALU_TRANS_F64") or 0}
+    other = max(0.0, k["SQ_INSTS_VALU"] - sum(n.values()))
+    counted = sum(ISSUE_CYCLES[c] * v for c, v in n.items())
+    available = 256 * 4 * kernel_ms * 1e-3 * 2.4e9
+    lo, est, hi = [(counted + c * other) / available for c in ISSUE_CYCLES_OTHER]
+    return {"frac_low": lo, "frac": est, "frac_high": hi, "instructions_by_class": dict(n, other=other), "cycles_per_class": dict(ISSUE_CYCLES, other=list(ISSUE_CYCLES_OTHER)),
+            "simd_cycles_available": available,
+            "note": "the kernel's vector instructions priced by what their class costs to issue on gfx950 (measured: profiles/r04_valu_rates.txt) over the SIMD cycles of the launch: the share of the launch in "
+                    "which the vector pipes are issuing; `frac` above prices every instruction as an FMA (1 per 2 cycles).  `other` = SQ_INSTS_VALU minus the class counters (compares, min / max, selects, "
+                    "moves, logic, shifts): 2 .. 4 cycles, 3.4 for the estimate"}
 
 
 def algorithmic_bytes(cnt, n_lights, pixels, use_filter):
@@ -137,6 +166,7 @@ def collect_pmc(args, tile=None):
 
     def clean(name):
         return name.split("(")[0].replace("void ", "").replace("flx::", "").strip()
+    class_error = None
     try:
         passes = [list(c) for c in PMC_PASSES]
         i = 0
@@ -153,6 +183,9 @@ def collect_pmc(args, tile=None):
                     passes[0] = [c for c in counters if c != "SQ_THREAD_CYCLES_VALU"]
                     continue
                 commands.append(line)
+                if i >= 3:                                                  # the per-class passes are an extra: without them the line carries no `issue_cycles`, everything else stands
+                    class_error = "pmc pass %d failed (rc %s): %s" % (i, rc, err)
+                    break
                 return {"_meta": {"error": "pmc pass %d failed (rc %s): %s" % (i, rc, err), "commands": commands}}
             commands.append(line)
             per = {}
@@ -194,6 +227,8 @@ def collect_pmc(args, tile=None):
     finally:
         shutil.rmtree(work, ignore_errors=True)
     acc["_meta"] = {"commands": commands, "collected": "by this bench.py run, before its timed region, one frame per launch" + (" (rank 0's strips: tile %s)" % (tile,) if tile else "")}
+    if class_error:
+        acc["_meta"]["class_passes"] = class_error
     return acc
 
 
@@ -733,6 +768,7 @@ def main():
                 "kernel_ms_rocprofv3_steady": {"median": k.get("kernel_trace_median_ms"), "min": k.get("kernel_trace_min_ms"), "dispatches": k.get("kernel_trace_dispatches"),
                                                "note": "the kernel trace's dispatches after tools/pmc_pass.py's %d warm-up frames, output left in device memory (the summary's average above includes the first launches)" % PMC_WARMUP_FRAMES},
                 "valu_insts_per_launch": valu, "valu_lane_utilisation": lane_util,
+                "issue_cycles": issue_cycles(k, k_ms),
                 "hbm_measured": {"bytes_per_launch": traffic, "GBps": traffic / (k_ms * 1e-3) / 1e9 if traffic else None, "peak_GBps": HBM_PEAK_GBS,
                                  "frac": traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None,
                                  "note": "2 x FETCH_SIZE + WRITE_SIZE (KB, separate rocprofv3 passes of this run): on gfx950 FETCH_SIZE counts 64 B per 128-byte fabric read request (guide's HBM section; TCC_EA0_RDREQ_128B of this kernel in profiles/r03_pmc_cache.txt); Infinity-Cache hits are included, so HBM proper is at most this"},

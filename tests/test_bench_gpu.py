@@ -33,6 +33,10 @@ def test_bench_line_single_gpu():
     else:
         assert r["achieved"] > 0 and 0 < r["frac"] <= 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
         assert r["traffic"] > 0 and 0 < r["hbm_measured"]["frac"] <= 1
+        ic = r["issue_cycles"]                  # the same instructions priced by what their class costs to issue (profiles/r04_valu_rates.txt): never below the all-FMA price
+        if ic is not None:
+            assert r["frac"] <= ic["frac_low"] * 1.001 and ic["frac_low"] <= ic["frac"] <= ic["frac_high"] <= 1.05
+            assert abs(sum(ic["instructions_by_class"].values()) - r["valu_insts_per_launch"]) <= 1e-6 * r["valu_insts_per_launch"]
     assert d["pipelined"]["frames_in_flight"] == 2 and d["pipelined"]["ms_per_frame"] > 0
     assert d["counters"]["primary_hits"] > 0
 
