@@ -37,9 +37,14 @@
 #define OP_FMAABS(x) asm volatile("v_fma_f32 %0, -|%0|, %1, %0" : "+v"(x) : "v"(a));
 #define OP_MBCNT(x) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, %0" : "+v"(x));
 #define OP_SUBREV(x) asm volatile("v_subrev_f32 %0, %1, %0" : "+v"(x) : "v"(b));
-#define OP_PKFMA(x) { typedef float v2f __attribute__((ext_vector_type(2))); }
+#define OP_BFI(x) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x) : "v"(a), "v"(b));
+#define OP_CNDS(x) asm volatile("v_cndmask_b32 %0, %0, %1, s[22:23]" : "+v"(x) : "v"(a));
+#define OP_ASHR(x) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(x));
+#define OP_MAX3(x) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
+#define OP_XOR(x) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(x) : "v"(a));
 
 K(k_fma, OP_FMA) K(k_mul, OP_MUL) K(k_add, OP_ADD) K(k_sub, OP_SUB) K(k_max, OP_MAX) K(k_min, OP_MIN) K(k_mov, OP_MOV) K(k_and, OP_AND) K(k_addu, OP_ADDU)
+K(k_bfi, OP_BFI) K(k_cnds, OP_CNDS) K(k_ashr, OP_ASHR) K(k_max3, OP_MAX3) K(k_xor, OP_XOR)
 K(k_lshl, OP_LSHL) K(k_cmp, OP_CMP) K(k_cnd, OP_CND) K(k_cmpcnd, OP_CMPCND) K(k_cmps, OP_CMPS) K(k_rcp, OP_RCP) K(k_med3, OP_MED3) K(k_fmaabs, OP_FMAABS) K(k_mbcnt, OP_MBCNT)
 
 struct Case { const char *name; void (*fn)(float *, int, float, float); int per_op; };
@@ -49,7 +54,7 @@ int main() {
   const int iters = 2048;
   const Case cases[] = { { "v_fma_f32", k_fma, 1 }, { "v_mul_f32", k_mul, 1 }, { "v_add_f32", k_add, 1 }, { "v_sub_f32", k_sub, 1 }, { "v_max_f32", k_max, 1 }, { "v_min_f32", k_min, 1 },
                          { "v_med3_f32", k_med3, 1 }, { "v_fma_f32 with -|x|", k_fmaabs, 1 }, { "v_mov_b32", k_mov, 1 }, { "v_and_b32", k_and, 1 }, { "v_add_u32", k_addu, 1 }, { "v_lshlrev_b32", k_lshl, 1 },
-                         { "v_mbcnt_lo_u32_b32", k_mbcnt, 1 }, { "v_cmp_lt_f32 -> vcc", k_cmp, 1 }, { "v_cmp_lt_f32 -> sgpr pair", k_cmps, 1 }, { "v_cndmask_b32 (vcc)", k_cnd, 1 },
+                         { "v_mbcnt_lo_u32_b32", k_mbcnt, 1 }, { "v_bfi_b32", k_bfi, 1 }, { "v_xor_b32", k_xor, 1 }, { "v_ashrrev_i32", k_ashr, 1 }, { "v_max3_f32", k_max3, 1 }, { "v_cndmask_b32 (sgpr mask)", k_cnds, 1 }, { "v_cmp_lt_f32 -> vcc", k_cmp, 1 }, { "v_cmp_lt_f32 -> sgpr pair", k_cmps, 1 }, { "v_cndmask_b32 (vcc)", k_cnd, 1 },
                          { "v_cmp_lt_f32 + v_cndmask_b32", k_cmpcnd, 2 }, { "v_rcp_f32", k_rcp, 1 } };
   int cus = 256; hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, 0) == hipSuccess) cus = prop.multiProcessorCount;
   printf("%-32s %10s %22s %28s\n", "instruction (wave64)", "ms", "G wave-instructions/s", "cycles per instr and SIMD @2.4GHz");
