@@ -217,6 +217,9 @@ int flx_frame_target_index(const flx_context *ctx);      /* which of the images 
  * FLX_INJECT_NO_SHADING, their shade waves drop every batch they pop, so that the walk waves wait for paths that never come back. */
 #define FLX_INJECT_NO_SHADING 1u
 flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog_polls, uint32_t flags);
+/* The shading keeps a per-triangle table of what fragment:500-512 derives from a triangle and its transform alone (three acos and three tan per shade otherwise),
+ * made again at scene / transform uploads.  0: every shade computes the values itself — the same floats; for A/B runs. */
+flx_status flx_debug_set_angle_table(flx_context *ctx, int on);
 /* Rehearsal of a device group on ONE GPU: the frame server's launch takes `groups` CUs only (0: all), so that the launches of several contexts run beside
  * each other. */
 flx_status flx_debug_set_server_groups(flx_context *ctx, uint32_t groups);

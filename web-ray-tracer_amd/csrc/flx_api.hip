@@ -106,7 +106,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_send, ctx->d_send8, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings, ctx->d_qbatch,
+                   ctx->d_send, ctx->d_send8, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_angle_tan, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings, ctx->d_qbatch,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -346,6 +346,7 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
   flx_status s;
   if ((s = shared_upload_begin(ctx))) return s;
   ctx->have_scene = false;
+  ctx->geometry_version++;
   if ((s = upload(ctx, &ctx->d_geometry, geometry, (size_t)n_entries_padded * 48))) return s;
   if ((s = upload(ctx, &ctx->d_attributes, attributes, (size_t)n_entries_padded * 112))) return s;
   if ((s = upload(ctx, &ctx->d_ids, ids, (size_t)n_ids * 4))) return s;
@@ -390,6 +391,7 @@ extern "C" flx_status flx_transforms_upload(flx_context *ctx, const float *rotat
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   flx_status s;
   ctx->have_transforms = false;             /* (until both arrays are in: a failed upload must not pass for the arrays it replaced) */
+  ctx->transforms_version++;
   if ((s = upload(ctx, &ctx->d_rotation, rotation, (size_t)n_transforms * 96))) return s;
   if ((s = upload(ctx, &ctx->d_shift, shift, (size_t)n_transforms * 32))) return s;
   ctx->n_transforms = n_transforms;
@@ -486,6 +488,22 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, DeviceSce
   sc.walk = ctx->d_walk; sc.walk_entries = ctx->walk_entries; sc.walk_hot = ctx->walk_hot; sc.walk_root = ctx->walk_root; sc.walk_fast_boxes = ctx->walk_fast_boxes;
   sc.fwd = ctx->d_fwd; sc.fwd_entries = ctx->fwd_entries; sc.fwd_root = ctx->fwd_root;
   sc.lock = ctx->d_fwd; sc.lock_entries = (ctx->lock_ok && ctx->lock_use) ? ctx->fwd_entries : 0u; sc.lock_root = ctx->fwd_root;
+  /* the per-triangle table of the shading (DeviceScene::angle_tan): made again, on this context's stream and so in front of whatever this frame launches
+   * there (the frame server synchronises with the stream before its launch), when the geometry, the attributes or this context's transforms were uploaded
+   * since it was made */
+  sc.angle_tan = nullptr;
+  if (ctx->angle_table && ctx->n_entries != 0u) {
+    const uint64_t key = ((uint64_t)ctx->geometry_version << 32) | ctx->transforms_version;
+    if (key != ctx->angle_key || !ctx->d_angle_tan) {
+      FLX_HIP(ctx, hipSetDevice(ctx->device));
+      flx_status es = flx_ensure_pixels(ctx, &ctx->d_angle_tan, &ctx->angle_capacity, ctx->n_entries);
+      if (es) return es;
+      launch_angle_tan(sc, ctx->d_angle_tan, ctx->stream);
+      FLX_HIP(ctx, hipGetLastError());
+      ctx->angle_key = key;
+    }
+    sc.angle_tan = ctx->d_angle_tan;
+  }
   uint32_t tr, ti, tc;
   tile_normalise(p, tr, ti, tc);
   fr.width = p->width; fr.height = p->height;
@@ -1277,6 +1295,7 @@ static void mirror_scene(flx_context *ctx) {
   t->walk_entries = ctx->walk_entries; t->walk_hot = ctx->walk_hot; t->walk_root = ctx->walk_root; t->walk_fast_boxes = ctx->walk_fast_boxes;
   for (int i = 0; i < 3; i++) { t->d_atlas[i] = ctx->d_atlas[i]; t->atlas_w[i] = ctx->atlas_w[i]; t->atlas_h[i] = ctx->atlas_h[i]; }
   t->n_entries = ctx->n_entries; t->n_ids = ctx->n_ids; t->max_transform = ctx->max_transform; t->have_scene = ctx->have_scene;
+  t->geometry_version = ctx->geometry_version; t->angle_table = ctx->angle_table;      /* (the lane's own angle table follows: flx_make_frame) */
 }
 
 
@@ -1821,6 +1840,17 @@ extern "C" int flx_frame_target_index(const flx_context *ctx) {
   if (!ctx || !ctx->sv_target_slots || !ctx->sv_running) return -1;
   return (int)((ctx->sv_next_slot + ctx->sv_depth - 1u) % ctx->sv_depth);
 }
+/* the shading's per-triangle table (DeviceScene::angle_tan) off: every shade computes the values itself, as before round 4 — for A/B runs and the test that both agree */
+extern "C" flx_status flx_debug_set_angle_table(flx_context *ctx, int on) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_angle_table: frames are in flight");
+  flx_status s = flx_server_stop(ctx);
+  if (s) return s;
+  ctx->angle_table = on ? 1 : 0;
+  ctx->scene_version++;                    /* (a chain of frames does not go on over it) */
+  return FLX_OK;
+}
+
 /* rehearsal of a device group on ONE GPU: the server's launch takes only `groups` CUs, so that the launches of several contexts run beside each other */
 extern "C" flx_status flx_debug_set_server_groups(flx_context *ctx, uint32_t groups) {
   if (!ctx) return FLX_ERR_INVALID;

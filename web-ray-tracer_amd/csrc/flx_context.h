@@ -58,6 +58,14 @@ struct flx_context {
   uint32_t n_entries = 0, n_ids = 0, n_transforms = 0, n_lights = 0;
   uint32_t max_transform = 0;                   /* largest transform number an entry names */
   bool have_scene = false, have_transforms = false, have_lights = false;
+  /* DeviceScene::angle_tan: per triangle, from the geometry / attribute arrays and this context's transforms; made again (on this context's stream, in front of
+   * the frame that needs it) when any of them changed: angle_key = the versions it was made from */
+  float4 *d_angle_tan = nullptr;
+  size_t angle_capacity = 0;
+  uint64_t angle_key = ~0ull;
+  uint32_t geometry_version = 0;                 /* counts uploads of the geometry / attribute arrays (the second lane copies the primary's: mirror_scene) */
+  uint32_t transforms_version = 0;               /* counts uploads of this context's transforms */
+  int angle_table = 1;                           /* flx_debug: 0 = the shading computes the values itself */
   /* frame workspace */
   float4 *d_out = nullptr;
   size_t out_capacity = 0;                       /* pixels */

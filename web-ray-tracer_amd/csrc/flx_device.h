@@ -94,6 +94,11 @@ struct DeviceScene {
    * screen tile visit nearly the same entries, so the wave steps through them together.  (lock == fwd for the small scenes.) */
   const float4 *fwd;
   uint32_t fwd_entries, fwd_root;
+  /* Per triangle: clamp(tan(acos(|geometryNormal . n_i|)), 0, 1) for its three vertex normals (fragment:500-512: what the geometry offset of a hit is weighted
+   * with).  It depends on the triangle and on its transform only — not on the ray — so it is computed once per scene / transform upload by the same device
+   * function (triangleAngleTan, k_angle_tan) instead of by every shade: three acos and three tan in double, a cross product and a normalize per shade.
+   * float4 per entry (xyz; boxes: unused); nullptr: shadeSurface computes it itself. */
+  const float4 *angle_tan;
 };
 #ifndef FLX_LOCKSTEP
 #define FLX_LOCKSTEP 1
@@ -451,6 +456,24 @@ struct SurfaceCtx {
   Material material;
 };
 
+/* fragment:500-512 from the triangle's transformed vertices and vertex normals: independent of the ray (DeviceScene::angle_tan) */
+FLX_DEV f3 triangleAngleTan(f3 t0v, f3 t1v, f3 t2v, f3 n0, f3 n1, f3 n2) {
+  f3 geometryNormal = normalize(cross(t0v - t1v, t0v - t2v));
+  f3 angles = F3(flx_acos(flx_abs(dot(geometryNormal, n0))), flx_acos(flx_abs(dot(geometryNormal, n1))),
+                 flx_acos(flx_abs(dot(geometryNormal, n2))));
+  return F3(flx_clamp(flx_tan(angles.x), 0.0f, 1.0f), flx_clamp(flx_tan(angles.y), 0.0f, 1.0f),
+            flx_clamp(flx_tan(angles.z), 0.0f, 1.0f));
+}
+/* ... for entry `tri` of the scene, as shadeSurface forms its operands (the entry's own transform: fragment:478-499) */
+FLX_DEV f3 triangleAngleTanOf(const DeviceScene &sc, int tri) {
+  const float4 g0 = sc.geometry[3 * tri], g1 = sc.geometry[3 * tri + 1], g2 = sc.geometry[3 * tri + 2];
+  const M3 rTI = rotation_at(sc, (int)g2.y << 1);
+  const float4 *at = sc.attributes + 7 * (size_t)tri;
+  const float4 a0 = at[0], a1 = at[1], a2 = at[2];
+  return triangleAngleTan(mul(rTI, F3(g0.x, g0.y, g0.z)), mul(rTI, F3(g0.w, g1.x, g1.y)), mul(rTI, F3(g1.z, g1.w, g2.x)),
+                          mul(rTI, F3(a0.x, a0.y, a0.z)), mul(rTI, F3(a0.w, a1.x, a1.y)), mul(rTI, F3(a1.z, a1.w, a2.x)));
+}
+
 template <bool COUNT>
 FLX_DEV void shadeSurface(const DeviceScene &sc, const DeviceFrame &fr, const Hit &hit, const Ray &ray, f3 lastHitPoint, SurfaceCtx &sf,
                           WorkCounters &cnt) {
@@ -464,7 +487,6 @@ FLX_DEV void shadeSurface(const DeviceScene &sc, const DeviceFrame &fr, const Hi
   f3 t1v = mul(rTI, F3(g0.w, g1.x, g1.y));
   f3 t2v = mul(rTI, F3(g1.z, g1.w, g2.x));
   f3 offsetRayTarget = sf.origin - sTI;
-  f3 geometryNormal = normalize(cross(t0v - t1v, t0v - t2v));
   f3 diffs = F3(distance(offsetRayTarget, t0v), distance(offsetRayTarget, t1v), distance(offsetRayTarget, t2v));
   const float4 *at = sc.attributes + 7 * (size_t)hit.triangleId;
   float4 a0 = at[0], a1 = at[1], a2 = at[2], a3 = at[3], a4 = at[4], a5 = at[5], a6 = at[6];
@@ -474,10 +496,9 @@ FLX_DEV void shadeSurface(const DeviceScene &sc, const DeviceFrame &fr, const Hi
   f3 smoothNormal = normalize(F3((n0.x * uvw.x + n1.x * uvw.y) + n2.x * uvw.z,
                                  (n0.y * uvw.x + n1.y * uvw.y) + n2.y * uvw.z,
                                  (n0.z * uvw.x + n1.z * uvw.y) + n2.z * uvw.z));
-  f3 angles = F3(flx_acos(flx_abs(dot(geometryNormal, n0))), flx_acos(flx_abs(dot(geometryNormal, n1))),
-                 flx_acos(flx_abs(dot(geometryNormal, n2))));
-  f3 angleTan = F3(flx_clamp(flx_tan(angles.x), 0.0f, 1.0f), flx_clamp(flx_tan(angles.y), 0.0f, 1.0f),
-                   flx_clamp(flx_tan(angles.z), 0.0f, 1.0f));
+  f3 angleTan;
+  if (sc.angle_tan) { const float4 t = sc.angle_tan[hit.triangleId]; angleTan = F3(t.x, t.y, t.z); }      /* the same floats, computed at the upload (k_angle_tan) */
+  else angleTan = triangleAngleTan(t0v, t1v, t2v, n0, n1, n2);
   sf.geometryOffset = dot(diffs * angleTan, uvw);
   /* uv0 = a2.yz, uv1 = (a2.w, a3.x), uv2 = a3.yz */
   float bu = (a2.y * uvw.x + a2.w * uvw.y) + a3.y * uvw.z;

@@ -83,6 +83,7 @@ void launch_fxaa(const uint32_t *plane, float4 *out, int W, int H, hipStream_t s
 void launch_taa(const uint32_t *const planes[9], float4 *out, int W, int H, hipStream_t stream);
 /* float4 plane -> RGBA8 plane (a render-target store) */
 void launch_quantize(const float4 *src, uint32_t *dst, size_t n, hipStream_t stream);
+void launch_angle_tan(const DeviceScene &sc, float4 *out, hipStream_t stream);      /* DeviceScene::angle_tan for the scene as it stands */
 /* the chain over planes whose slot 0 (R[0], Ip[0], O[0], Id[0], OId) holds the frame */
 void launch_filter_chain(const FilterPlanes &pl, float4 *out, int W, int H, int hdr, hipStream_t stream);
 /* temporal accumulation (pathtracerWGL2.js:571-662) over rings of n RGBA8 planes, slot 0 = newest:

@@ -323,6 +323,25 @@ __global__ __launch_bounds__(256) void k_resolve(DeviceFrame fr, const float4 *_
   out[o] = color;
 }
 
+/* DeviceScene::angle_tan: per triangle entry what every shade of it would compute (flx_device.h: triangleAngleTanOf), once per scene / transform upload */
+__global__ __launch_bounds__(256) void k_angle_tan(DeviceScene sc, float4 *__restrict__ out) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= sc.n_entries) return;
+  float4 r = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  const float kind = sc.geometry[3 * (size_t)i + 2].z;
+  if (kind != 0.0f && kind != 1.0f) {                         /* a triangle entry (1: a box, 0: the end of the list / padding) — flx_api.hip: build_threaded reads the kind the same way */
+    const f3 t = triangleAngleTanOf(sc, (int)i);
+    r = make_float4(t.x, t.y, t.z, 0.0f);
+  }
+  out[i] = r;
+}
+void launch_angle_tan(const DeviceScene &sc, float4 *out, hipStream_t stream) {
+  if (sc.n_entries == 0u) return;
+  DeviceScene s = sc;
+  s.angle_tan = nullptr;
+  hipLaunchKernelGGL(k_angle_tan, dim3((sc.n_entries + 255u) / 256u), dim3(256), 0, stream, s, out);
+}
+
 uint64_t path_item_count64(const DeviceFrame &fr) {
   return (uint64_t)((fr.width + 7u) >> 3) * ((fr.rows + 7u) >> 3) * (uint64_t)fr.samples * 64u;
 }

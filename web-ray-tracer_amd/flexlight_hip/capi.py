@@ -29,7 +29,7 @@ EXPORTS = [
     "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
     "flx_frame_server_takes", "flx_frame_target_set", "flx_frame_target_index", "flx_debug_set_server_groups",
     "flx_share_create", "flx_share_join", "flx_share_leave", "flx_frame_begin_shared", "flx_frame_end_shared",
-    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8",
+    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table",
 ]
 
 
@@ -142,6 +142,7 @@ def _load():
         "flx_group_render": (C.c_int, [vp, C.POINTER(FrameParams), u32, u32, fp, C.POINTER(Counters)]),
         "flx_group_render_rgba8": (C.c_int, [vp, C.POINTER(FrameParams), u32, u32, C.POINTER(C.c_uint8), C.POINTER(Counters)]),
         "flx_render_gathered_rgba8_device": (C.c_int, [vp, C.POINTER(FrameParams), u32, C.c_int, vp]),
+        "flx_debug_set_angle_table": (C.c_int, [vp, C.c_int]),
         "flx_group_frame_begin": (C.c_int, [vp, C.POINTER(FrameParams), u32, C.c_int]),
         "flx_group_frame_end": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
         "flx_group_frames_in_flight": (C.c_int, [vp]),
@@ -345,6 +346,10 @@ class Context:
         ptr, n, ms = C.c_void_p(), C.c_size_t(), C.c_float()
         self._check(LIB.flx_frame_end_shared(self._h, C.byref(ptr), C.byref(n), C.byref(ms)), "flx_frame_end_shared")
         return ptr.value, ms.value
+
+    def set_angle_table(self, on):
+        """the shading's per-triangle table on (default) or off (every shade computes the values itself: the same floats)"""
+        self._check(LIB.flx_debug_set_angle_table(self._h, int(bool(on))), "flx_debug_set_angle_table")
 
     def set_server_groups(self, groups):
         """rehearsal: the frame server's launch takes only `groups` CUs (0: all)"""
