@@ -219,6 +219,10 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
                                                float4 *__restrict__ sampleRadiance, float4 *__restrict__ lastOriginal,
                                                uint32_t *__restrict__ queue, uint32_t total_items,
                                                unsigned long long *__restrict__ counters) {
+  /* this kernel's shading computes the per-triangle angle terms itself (the table's load is one more dependent fetch in a kernel that hides its latencies with waves, and its
+   * arithmetic runs beside them: theater 9.96 ms without the table, 10.03 with it, tools/angle_table_time.py / profiles/r04_angle_table.txt); a constant here, so the
+   * other branch is not compiled into it */
+  sc.angle_tan = nullptr;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t S = (uint32_t)fr.samples;
   const size_t P = (size_t)fr.rows * fr.width;
