@@ -209,6 +209,9 @@ int flx_frame_server_takes(flx_context *ctx, const flx_frame_params *params);
  * must be ones the server takes and FLX_FRAME_DEVICE; flx_frame_end hands out the image's address.  n_images = 0: the launch's own buffers again.  Frames in
  * flight are completed where they were begun. */
 flx_status flx_frame_target_set(flx_context *ctx, void *const *d_images, uint32_t n_images);
+/* ... images of the canvas' RGBA8 — uint8[height][width][4], the bytes flx_present stores: the launch quantises its tiles as it resolves them (a quarter of the bytes
+ * every GPU of a group writes).  Without a target the server does the same for frames begun as FLX_FRAME_RGBA8. */
+flx_status flx_frame_target_set8(flx_context *ctx, void *const *d_images, uint32_t n_images);
 int flx_frame_target_index(const flx_context *ctx);      /* which of the images the frame begun last goes to (-1: none) */
 /* Device faults reach the status code.  The frame kernels' wait loops have watchdogs (seconds); a wave that gives up — or finds a ring slot that never
  * fills — sets a bit in the context's device error word (pinned host memory), and the next call in which the host waits for frames (flx_render,
@@ -335,7 +338,8 @@ flx_status flx_group_render_rgba8(flx_group *group, const flx_frame_params *para
 /* The group's frame loop — what the reference's render loop is to its one context (pathtracerWGL2.js:254-303: a frame per animation callback, the host
  * never waits for the GPU).  flx_group_frame_begin posts the frame to every context's frame server (flx_set_frame_chain) and returns; every server renders
  * its context's strips and resolves them straight into ONE image the group owns — pinned host memory that every GPU writes over its own PCIe link
- * (FLX_FRAME_FLOAT), or context 0's device memory through the peer mapping (FLX_FRAME_DEVICE) — so a frame needs no exchange, no reassembly and no copy.
+ * (FLX_FRAME_FLOAT; FLX_FRAME_RGBA8: the canvas' bytes, quantised by the servers as they resolve their tiles), or context 0's device memory through the peer mapping
+ * (FLX_FRAME_DEVICE) — so a frame needs no exchange, no reassembly and no copy.
  * flx_group_frame_end waits for the oldest frame's completion words (no stream is synchronised) and hands the image out: float4[height][width], valid until
  * `lanes` more frames have been begun; ms: the slowest context's time from the post to its word, on the host's clock.  Up to `lanes` frames (2 or 3,
  * default 3) are in flight; frames complete in order and equal flx_render's bit for bit.  Frames the server does not take (filter and temporal frames,

@@ -145,3 +145,30 @@ def test_a_frame_target_of_the_callers(hip, scenes):
         hip.frame_target_set([])
         hip.set_frame_lanes(2)
         hip.set_frame_chain(2)
+
+
+def test_group_loop_hands_out_the_canvas_bytes(pair, hip, oracle, scenes):
+    """FLX_FRAME_RGBA8: the group's image is the canvas' RGBA8 in pinned host memory, every context's server quantising the tiles it resolves (a quarter of the bytes
+    every GPU writes); frames the servers do not take (a filter frame, a small scene) come out as the same bytes the other way"""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    pair.update_scene(sc)
+    ps = [moving(sc, f, width=640, height=368) for f in range(7)]
+    want = [oracle.present(hip.render(p)[0]) for p in ps]
+    for lanes in (3, 2):
+        pair.set_frame_lanes(lanes)
+        got = run_loop(pair, ps, lanes, rgba8=True)
+        for f in range(7):
+            assert got[f].dtype == np.uint8 and np.array_equal(got[f], want[f]), (lanes, f)
+    # float frames after it: the target is made again
+    pair.set_frame_lanes(3)
+    gotf = run_loop(pair, ps[:3], 3)
+    for f in range(3):
+        assert bit_mismatches(gotf[f], hip.render(ps[f])[0]) == 0
+    # a filter frame between frames of the loop
+    flt = sc.frame_params(width=640, height=368, use_filter=1, samples=1, max_reflections=2)
+    pair.frame_begin(ps[0], rgba8=True)
+    pair.frame_begin(flt, rgba8=True)
+    a = pair.frame_end()[0]
+    b = pair.frame_end()[0]
+    assert np.array_equal(a, want[0]) and np.array_equal(b, oracle.present(hip.render(flt)[0]))

@@ -186,8 +186,9 @@ def test_group_frame_loop_through_node(hip, oracle, scenes, tmp_path, move_scene
 
 
 def test_group_presents_rgba8_through_node(hip, oracle, scenes, tmp_path):
-    """a group whose renderer presents the canvas' RGBA8 (renderer.present8 with devices): flx_group_render_rgba8 — the strips quantised on their GPUs, a quarter
-    of the bytes gathered — hands the loop the bytes flx_present / the oracle store for the float frame of the same tick"""
+    """a group whose renderer presents the canvas' RGBA8 (renderer.present8 with devices): the group's frame loop with FLX_FRAME_RGBA8 — every context's frame server
+    quantises the tiles it resolves into the pinned image, a quarter of the bytes — hands the loop the bytes flx_present / the oracle store for the float frame of
+    the same tick"""
     node = shutil.which("node")
     w, h, spp, bounces = 320, 180, 2, 3
     prefix = str(tmp_path / "g8")

@@ -123,8 +123,36 @@ def test_an_upload_of_unchanged_lights_and_transforms_is_nothing(served, scenes)
         served.update_primary_light_sources(sc.arrays["lights"])
 
 
+def test_the_server_hands_out_the_canvas_bytes(served, oracle, scenes):
+    """frames begun as FLX_FRAME_RGBA8 go to the server too: its workgroups quantise the tiles they resolve (ServerArgs::out8) — the bytes are flx_present's of the
+    float frame; a change of format ends the launch and starts another"""
+    sc = scenes("dragon")
+    served.update_scene(sc)
+    served.set_frame_lanes(3)
+    ps = [moving(sc, f, width=480, height=272) for f in range(6)]
+    want = [served.render(p)[0] for p in ps]
+    got, kinds = loop(served, ps, 3, rgba8=True)
+    assert kinds == [3] * 6, kinds
+    for f in range(6):
+        assert got[f].dtype == np.uint8 and np.array_equal(got[f], oracle.present(want[f])), f
+    mixed, kinds = [], []
+    for f, p in enumerate(ps):
+        if served.frames_in_flight() == 3:
+            mixed.append(served.frame_end()[0])
+        served.frame_begin(p, rgba8=(f % 2 == 1))
+        kinds.append(served.last_chained())
+    while served.frames_in_flight():
+        mixed.append(served.frame_end()[0])
+    assert kinds == [3] * 6
+    for f in range(6):
+        if f % 2:
+            assert np.array_equal(mixed[f], oracle.present(want[f])), f
+        else:
+            assert bit_mismatches(mixed[f], want[f]) == 0, f
+
+
 def test_frames_the_server_does_not_take(served, scenes):
-    """a scene of fewer than 129 entries, the canvas' RGBA8 format: rendered the other ways, and right"""
+    """a scene of fewer than 129 entries: rendered the other ways, and right; RGBA8 frames through the server equal the ones quantised by the kernel of their own"""
     sc = scenes("cornell_obj")
     served.update_scene(sc)
     served.set_frame_lanes(2)

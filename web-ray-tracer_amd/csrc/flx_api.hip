@@ -1522,13 +1522,13 @@ static flx_status server_allocate(flx_context *ctx, const DeviceFrame &frOne, ui
   return FLX_OK;
 }
 
-static bool server_continues(flx_context *ctx, const flx_frame_params *params) {      /* the running launch takes this frame as it is */
+static bool server_continues(flx_context *ctx, const flx_frame_params *params, bool out8) {      /* the running launch takes this frame as it is */
   const uint32_t depth = ctx->frame_lanes == 3 ? 3u : 2u;
-  return ctx->sv_running && ctx->sv_depth == depth && chain_same_shape(ctx->sv_params, *params) && ctx->sv_scene_version == ctx->scene_version;
+  return ctx->sv_running && ctx->sv_depth == depth && chain_same_shape(ctx->sv_params, *params) && ctx->sv_scene_version == ctx->scene_version && ctx->sv_out8 == out8;
 }
 /* For a device group (flx_group_frame_begin): would flx_frame_begin of this frame have to end or start a launch?  And the memory a launch needs, made while
  * NO launch of the group runs — where contexts share a device, an allocation in one waits for the launch of the other. */
-int flx_server_continues(flx_context *ctx, const flx_frame_params *params) { return server_continues(ctx, params) ? 1 : 0; }
+int flx_server_continues(flx_context *ctx, const flx_frame_params *params) { return server_continues(ctx, params, ctx->sv_target_slots != 0u && ctx->sv_target8) ? 1 : 0; }
 flx_status flx_server_prepare(flx_context *ctx, const flx_frame_params *params) {
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   DeviceScene sc; DeviceFrame fr;
@@ -1541,11 +1541,11 @@ flx_status flx_server_prepare(flx_context *ctx, const flx_frame_params *params) 
   return FLX_OK;
 }
 
-static flx_status server_post(flx_context *ctx, const flx_frame_params *params, const DeviceScene &sc, const DeviceFrame &frOne, uint32_t *seqOut, uint32_t *slotOut) {
+static flx_status server_post(flx_context *ctx, const flx_frame_params *params, const DeviceScene &sc, const DeviceFrame &frOne, uint32_t *seqOut, uint32_t *slotOut, bool out8) {
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
   const uint32_t depth = ctx->frame_lanes == 3 ? 3u : 2u;
   flx_status s;
-  if (ctx->sv_running && !server_continues(ctx, params))
+  if (ctx->sv_running && !server_continues(ctx, params, out8))
     if ((s = server_stop(ctx))) return s;
   if (!ctx->sv_running) {
     if (ctx->sv_stream) FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));      /* a launch that was told to end reads the mailbox until it has */
@@ -1581,9 +1581,11 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
     for (uint32_t i = 0; i < depth; i++) sa.out[i] = ctx->d_sv_out + (size_t)i * P1;
     if (ctx->sv_target_slots) {
       /* the frames are this context's row strips of images somebody else owns: resolved straight into them, each row where the image has it */
-      for (uint32_t i = 0; i < depth; i++) sa.out[i] = ctx->sv_target[i] + (size_t)params->tile_index * params->tile_rows * params->width;
+      const size_t first = (size_t)params->tile_index * params->tile_rows * params->width;      /* pixels in front of this context's first strip */
+      for (uint32_t i = 0; i < depth; i++) sa.out[i] = out8 ? (float4 *)((uint32_t *)ctx->sv_target[i] + first) : ctx->sv_target[i] + first;
       sa.outStripRows = params->tile_rows; sa.outStripStep = params->tile_rows * params->tile_count; sa.outSystem = 1u;
     }
+    sa.out8 = out8 ? 1u : 0u;
     sa.tileLists = ctx->d_sv_tiles; sa.tileListCap = (uint32_t)ctx->sv_tile_cap;
     sa.idleExit = 200000000u;                                /* 2 s at 100 MHz: a safety net, the host always says when to stop */
     sa.error = ctx->d_dev_error;
@@ -1593,7 +1595,7 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
     if (launch_server(sc, fr, wb, sa, cusWalk, ctx->sv_stream) != 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the frame server does not take this scene");
     FLX_HIP(ctx, hipGetLastError());
     ctx->sv_running = true; ctx->sv_depth = depth; ctx->sv_next_seq = seq0; ctx->sv_next_slot = slot0;
-    ctx->sv_params = *params; ctx->sv_scene_version = ctx->scene_version;
+    ctx->sv_params = *params; ctx->sv_scene_version = ctx->scene_version; ctx->sv_out8 = out8;
   }
   const uint32_t seq = ctx->sv_next_seq++, slot = ctx->sv_next_slot;
   ctx->sv_next_slot = (slot + 1u) % depth;
@@ -1665,7 +1667,7 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
   if (ctx->sv_running && ((!served && (ctx->slot_capacity[k] < (pixels ? pixels : 1) || !ctx->d_slot[k])) || (format != FLX_FRAME_DEVICE && (ctx->h_slot_capacity[k] < bytes || !ctx->h_slot[k]))))
     if ((s = flx_server_stop(ctx))) return s;
   if (!served && (s = flx_ensure_pixels(ctx, &ctx->d_slot[k], &ctx->slot_capacity[k], pixels ? pixels : 1))) return s;
-  if (format == FLX_FRAME_RGBA8 && ctx->slot8_capacity[k] < pixels) {
+  if (format == FLX_FRAME_RGBA8 && !served && ctx->slot8_capacity[k] < pixels) {      /* (a frame of the server is quantised where it is resolved) */
     ctx->slot8_capacity[k] = 0;
     if (ctx->d_slot8[k]) { FLX_HIP(ctx, hipFree(ctx->d_slot8[k])); ctx->d_slot8[k] = nullptr; }
     FLX_HIP(ctx, hipMalloc(&ctx->d_slot8[k], (pixels ? pixels : 1) * sizeof(uint32_t)));
@@ -1680,7 +1682,7 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
   if (served) {
     /* the frame server: the frame is posted to the running launch; flx_frame_end takes it (server_take) */
     uint32_t seq = 0, sslot = 0;
-    if ((s = server_post(ctx, params, sc, fr, &seq, &sslot))) return s;
+    if ((s = server_post(ctx, params, sc, fr, &seq, &sslot, ctx->sv_target_slots ? ctx->sv_target8 : format == FLX_FRAME_RGBA8))) return s;
     ctx->sv_pending[k].valid = true; ctx->sv_pending[k].seq = seq; ctx->sv_pending[k].slot = sslot; ctx->sv_pending[k].format = format; ctx->sv_pending[k].fr = fr;
     ctx->sv_pending[k].posted = std::chrono::steady_clock::now();
     ctx->slot_host[k] = format != FLX_FRAME_DEVICE;
@@ -1833,7 +1835,14 @@ extern "C" flx_status flx_frame_target_set(flx_context *ctx, void *const *d_imag
   for (uint32_t i = 0; i < 3u; i++) ctx->sv_target[i] = i < n_images ? (float4 *)d_images[i] : nullptr;
   for (uint32_t i = 0; i < n_images; i++) if (!ctx->sv_target[i]) { ctx->sv_target_slots = 0; return fail(ctx, FLX_ERR_INVALID, "flx_frame_target_set: an image is NULL"); }
   ctx->sv_target_slots = n_images;
+  ctx->sv_target8 = false;
   return FLX_OK;
+}
+/* ... images of the canvas' RGBA8 (uint32 per pixel): the launch quantises its tiles as it resolves them */
+extern "C" flx_status flx_frame_target_set8(flx_context *ctx, void *const *d_images, uint32_t n_images) {
+  const flx_status s = flx_frame_target_set(ctx, d_images, n_images);
+  if (!s) ctx->sv_target8 = n_images != 0u;
+  return s;
 }
 /* the image (index into flx_frame_target_set's) the frame begun last will be in */
 extern "C" int flx_frame_target_index(const flx_context *ctx) {
@@ -1891,7 +1900,6 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
       if (chained == 3) chained = 2;
     }
   }
-  if (chained == 2 && format == FLX_FRAME_RGBA8) chained = 0;      /* (the 8-bit store is a kernel of its own: not beside the server's launch) */
   if (ctx->sv_target_slots && (chained != 2 || format != FLX_FRAME_DEVICE || ctx->sv_target_slots != (ctx->frame_lanes == 3 ? 3u : 2u)))
     return fail(ctx, FLX_ERR_INVALID, "flx_frame_begin: a frame target is set (flx_frame_target_set) — the frame must be one the frame server takes (flx_frame_server_takes), FLX_FRAME_DEVICE, and the target must have as many images as the loop has frames in flight");
   if (chained == 0) ctx->last_chained = 0;

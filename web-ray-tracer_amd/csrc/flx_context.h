@@ -191,6 +191,8 @@ struct flx_context {
   uint32_t sv_depth = 0, sv_next_seq = 0, sv_next_slot = 0, sv_counter = 0;
   flx_frame_params sv_params = {};               /* the shape of the frames the running launch takes */
   uint64_t sv_scene_version = 0;
+  bool sv_out8 = false;                          /* the running launch resolves RGBA8 (ServerArgs::out8) */
+  bool sv_target8 = false;                       /* flx_frame_target_set8: the target images are uint32 RGBA8 per pixel */
   float4 *sv_target[3] = { nullptr, nullptr, nullptr };      /* flx_frame_target_set: whole images the launch resolves this context's strips into (a peer GPU's memory, pinned host memory, ..) */
   uint32_t sv_target_slots = 0;                  /* 0: none — the launch's own d_sv_out */
   flx_share *share = nullptr;

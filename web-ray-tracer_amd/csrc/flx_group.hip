@@ -280,7 +280,7 @@ struct flx_group {
    * (FLX_FRAME_DEVICE) or in pinned host memory (FLX_FRAME_FLOAT) — so a frame needs no exchange, no reassembly and no copy */
   int lanes = 3;
   bool peer_ok = true;                  /* every context's GPU can write context 0's memory */
-  struct Target { void *base = nullptr; bool host = false; size_t pixels = 0; uint32_t n = 0; };
+  struct Target { void *base = nullptr; bool host = false; size_t pixels = 0; uint32_t n = 0; size_t texel = sizeof(float4); /* bytes per pixel: float4, or 4 for the canvas' RGBA8 */ };
   Target target;                        /* target.n images of target.pixels float4 */
   std::vector<Target> retired;          /* targets of an earlier frame shape that frames in flight still live in */
   flx_frame_params shape = {};          /* what the target was made for */
@@ -514,7 +514,9 @@ static bool group_same_shape(const flx_frame_params &a, const flx_frame_params &
 
 /* the target for frames of this shape and format exists and every context resolves into it */
 static flx_status group_target(flx_group *g, const flx_frame_params *p, uint32_t tile_rows, int format) {
-  const bool host = format == FLX_FRAME_FLOAT;
+  const bool host = format != FLX_FRAME_DEVICE;
+  const bool rgba8 = format == FLX_FRAME_RGBA8;
+  const size_t texel = rgba8 ? sizeof(uint32_t) : sizeof(float4);
   const size_t pixels = (size_t)p->width * p->height;
   flx_frame_params want = *p; want.tile_rows = tile_rows;
   if (g->target.base && g->shape_format == format && group_same_shape(g->shape, want) && g->target.n == (uint32_t)g->lanes) return FLX_OK;
@@ -524,16 +526,16 @@ static flx_status group_target(flx_group *g, const flx_frame_params *p, uint32_t
   for (int r = 0; r < n; r++) if ((s = flx_frame_target_set(g->ctx[r], nullptr, 0))) { g->err = flx_last_error(g->ctx[r]); return s; }
   if (g->target.base) { if (g->fifo_n) g->retired.push_back(g->target); else group_free_target(g, g->target); g->target = flx_group::Target(); }
   flx_group::Target t;
-  t.host = host; t.pixels = pixels; t.n = (uint32_t)g->lanes;
+  t.host = host; t.pixels = pixels; t.n = (uint32_t)g->lanes; t.texel = texel;
   (void)hipSetDevice(g->ctx[0]->device);
-  const size_t bytes = (size_t)t.n * pixels * sizeof(float4);
+  const size_t bytes = (size_t)t.n * pixels * texel;
   const hipError_t e = host ? hipHostMalloc(&t.base, bytes, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) : hipMalloc(&t.base, bytes);
   if (e != hipSuccess) { g->err = std::string("flx_group_frame_begin: the frames' images: ") + hipGetErrorString(e); return FLX_ERR_DEVICE; }
   g->target = t; g->shape = want; g->shape_format = format;
   for (int r = 0; r < n; r++) {
     void *img[3] = { nullptr, nullptr, nullptr };
     for (uint32_t i = 0; i < t.n; i++) {
-      void *at = (char *)t.base + (size_t)i * pixels * sizeof(float4);
+      void *at = (char *)t.base + (size_t)i * pixels * texel;
       if (host) {
         (void)hipSetDevice(g->ctx[r]->device);
         void *dp = nullptr;
@@ -542,7 +544,7 @@ static flx_status group_target(flx_group *g, const flx_frame_params *p, uint32_t
       }
       img[i] = at;
     }
-    if ((s = flx_frame_target_set(g->ctx[r], img, t.n))) { g->err = flx_last_error(g->ctx[r]); return s; }
+    if ((s = rgba8 ? flx_frame_target_set8(g->ctx[r], img, t.n) : flx_frame_target_set(g->ctx[r], img, t.n))) { g->err = flx_last_error(g->ctx[r]); return s; }
   }
   return FLX_OK;
 }
@@ -550,13 +552,13 @@ static flx_status group_target(flx_group *g, const flx_frame_params *p, uint32_t
 extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params *params, uint32_t tile_rows, int format) {
   if (!g) return FLX_ERR_INVALID;
   if (!params || tile_rows == 0u) { g->err = "flx_group_frame_begin: params and tile_rows"; return FLX_ERR_INVALID; }
-  if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_DEVICE) { g->err = "flx_group_frame_begin: format is FLX_FRAME_FLOAT (the frame in pinned host memory) or FLX_FRAME_DEVICE (in context 0's device memory)"; return FLX_ERR_INVALID; }
+  if (format != FLX_FRAME_FLOAT && format != FLX_FRAME_DEVICE && format != FLX_FRAME_RGBA8) { g->err = "flx_group_frame_begin: format is FLX_FRAME_FLOAT (the frame in pinned host memory), FLX_FRAME_RGBA8 (the canvas' bytes there) or FLX_FRAME_DEVICE (in context 0's device memory)"; return FLX_ERR_INVALID; }
   if (g->fifo_n >= g->lanes) { g->err = "flx_group_frame_begin: as many frames are in flight as the loop has lanes (flx_group_set_frame_lanes), take one with flx_group_frame_end first"; return FLX_ERR_INVALID; }
   const int n = (int)g->ctx.size();
   if (g->fifo_n == 0) for (auto &t : g->retired) group_free_target(g, t);
   if (g->fifo_n == 0) g->retired.clear();
   std::vector<flx_frame_params> p((size_t)n, *params);
-  bool server = format == FLX_FRAME_FLOAT || g->peer_ok;
+  bool server = format != FLX_FRAME_DEVICE || g->peer_ok;
   flx_status s;
   for (int r = 0; r < n; r++) {
     p[r].tile_rows = tile_rows; p[r].tile_index = (uint32_t)r; p[r].tile_count = (uint32_t)n;
@@ -581,8 +583,17 @@ extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params
       g->h_sync_pixels[b] = pixels;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    if (format == FLX_FRAME_RGBA8) {
+      /* the canvas' bytes of a frame the servers do not take: a filter / temporal frame is rendered as floats and quantised by context 0 (flx_present's store);
+       * anything else is gathered as RGBA8 (flx_group_render_rgba8) */
+      if (params->use_filter || params->is_temporal) {
+        std::vector<float> tmp(pixels * 4u);
+        if ((s = flx_group_render(g, params, 1, tile_rows, tmp.data(), nullptr))) return s;
+        if ((s = flx_present(g->ctx[0], params->width, params->height, tmp.data(), (uint8_t *)g->h_sync[b]))) { g->err = flx_last_error(g->ctx[0]); return s; }
+      } else if ((s = flx_group_render_rgba8(g, params, 1, tile_rows, (uint8_t *)g->h_sync[b], nullptr))) return s;
+    } else
     if ((s = flx_group_render(g, params, 1, tile_rows, (float *)g->h_sync[b], nullptr))) return s;
-    slot.kind = 0; slot.bytes = pixels * sizeof(float4);
+    slot.kind = 0; slot.bytes = pixels * (format == FLX_FRAME_RGBA8 ? sizeof(uint32_t) : sizeof(float4));
     slot.pixels = (const void *)g->h_sync[b];
     slot.ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     g->fifo_n++;
@@ -607,7 +618,7 @@ extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params
     else if (at != image) { g->err = "flx_group_frame_begin: internal: the contexts' servers disagree about the frame's image"; return FLX_ERR_DEVICE; }
   }
   if (image < 0) { g->err = "flx_group_frame_begin: internal: no image"; return FLX_ERR_DEVICE; }
-  slot.kind = 1; slot.bytes = g->target.pixels * sizeof(float4);
+  slot.kind = 1; slot.bytes = g->target.pixels * g->target.texel;
   slot.pixels = (const char *)g->target.base + (size_t)image * slot.bytes;
   slot.ms = 0.f;
   g->fifo_n++;

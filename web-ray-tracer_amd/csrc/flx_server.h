@@ -39,6 +39,7 @@ struct ServerArgs {
   uint32_t outStripRows, outStripStep;         /* 0, or: the frame is a rank's row strips and out[] the WHOLE image from the rank's first strip on — row r of the frame is row
                                                 * (r / outStripRows) x outStripStep + r % outStripRows there (strips of outStripRows rows, the rank's next one outStripStep rows on) */
   uint32_t outSystem;                          /* out[] is not this GPU's memory (a peer's, or the host's): a workgroup's part is released at system scope */
+  uint32_t out8;                               /* out[] holds the canvas' RGBA8 (uint32 per pixel: flx_present's bytes, pack_rgba8) instead of float4: the tiles are quantised as they are resolved */
   uint32_t *tileLists;                         /* [workgroup][slot] x tileListCap: the screen tiles the workgroup made of the frame in the slot */
   uint32_t tileListCap;
   uint32_t idleExit;                           /* 100 MHz ticks without anything to do after which a workgroup gives up (an error: the host always says when to stop) */

@@ -227,7 +227,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           const float4 c = resolve_pixel(fr, wb.hits, wb.sampleRadiance, wb.lastOriginal, o, stride);
           uint32_t row = k - P * fr.frame_rows;
           if (sa.outStripRows) { const uint32_t strip = row / sa.outStripRows; row = strip * sa.outStripStep + (row - strip * sa.outStripRows); }
-          sa.out[P][(size_t)row * fr.width + px] = c;
+          if (sa.out8) ((uint32_t *)sa.out[P])[(size_t)row * fr.width + px] = pack_rgba8(c.x, c.y, c.z, c.w);
+          else sa.out[P][(size_t)row * fr.width + px] = c;
         }
       }
       /* this workgroup's part of the frame is in its XCD's L2 at the latest: written back (to the memory of whoever owns the frame), then counted */

@@ -29,7 +29,7 @@ EXPORTS = [
     "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
     "flx_frame_server_takes", "flx_frame_target_set", "flx_frame_target_index", "flx_debug_set_server_groups",
     "flx_share_create", "flx_share_join", "flx_share_leave", "flx_frame_begin_shared", "flx_frame_end_shared",
-    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table",
+    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table", "flx_frame_target_set8",
 ]
 
 
@@ -143,6 +143,7 @@ def _load():
         "flx_group_render_rgba8": (C.c_int, [vp, C.POINTER(FrameParams), u32, u32, C.POINTER(C.c_uint8), C.POINTER(Counters)]),
         "flx_render_gathered_rgba8_device": (C.c_int, [vp, C.POINTER(FrameParams), u32, C.c_int, vp]),
         "flx_debug_set_angle_table": (C.c_int, [vp, C.c_int]),
+        "flx_frame_target_set8": (C.c_int, [vp, C.POINTER(vp), u32]),
         "flx_group_frame_begin": (C.c_int, [vp, C.POINTER(FrameParams), u32, C.c_int]),
         "flx_group_frame_end": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
         "flx_group_frames_in_flight": (C.c_int, [vp]),
@@ -679,20 +680,22 @@ class Group:
     def frames_in_flight(self):
         return int(LIB.flx_group_frames_in_flight(self._h))
 
-    def frame_begin(self, params, tile_rows=8, device=False):
+    def frame_begin(self, params, tile_rows=8, device=False, rgba8=False):
         self._pending = getattr(self, "_pending", [])
-        self._check(LIB.flx_group_frame_begin(self._h, C.byref(params), tile_rows, 2 if device else 0), "flx_group_frame_begin")
-        self._pending.append((params.height, params.width, device))
+        self._check(LIB.flx_group_frame_begin(self._h, C.byref(params), tile_rows, 2 if device else (1 if rgba8 else 0)), "flx_group_frame_begin")
+        self._pending.append((params.height, params.width, device, rgba8))
 
     def frame_end(self):
         """-> (pixels [H, W, 4] float32: a COPY of the pinned image — or, for a frame begun with device=True, its address in context 0's memory —, ms)"""
         ptr, n, ms = C.c_void_p(), C.c_size_t(), C.c_float()
         rc = LIB.flx_group_frame_end(self._h, C.byref(ptr), C.byref(n), C.byref(ms))
         if rc != 1 or self._pending:
-            h, w, device = self._pending.pop(0)
+            h, w, device, rgba8 = self._pending.pop(0)
         self._check(rc, "flx_group_frame_end")
         if device:
             return ptr.value, ms.value
+        if rgba8:                                   # the canvas' bytes: uint8 [H, W, 4]
+            return np.frombuffer((C.c_uint8 * (h * w * 4)).from_address(ptr.value), np.uint8).reshape(h, w, 4).copy(), ms.value
         buf = (C.c_float * (h * w * 4)).from_address(ptr.value)
         return np.frombuffer(buf, np.float32).reshape(h, w, 4).copy(), ms.value
 

@@ -257,7 +257,7 @@ class PathTracerHIP {
    * taken (flx_frame_end) and handed to canvas.onFrame — `pixels` is a view of that pinned memory (Float32Array, or the canvas'
    * RGBA8 as a Uint8ClampedArray with this.present8), valid until the frame after the next is begun.  A group of GPUs (`devices`) runs the
    * same loop through flx_group_frame_begin / _end with up to this.groupLanes (3) frames in flight, `pixels` valid until the next frame is begun.
-   * Anti-aliasing passes, tiles and a group with present8 take the synchronous renderFrame() per cycle instead.  `fps` as in pathtracerWGL2.js:293-298;
+   * Anti-aliasing passes and tiles take the synchronous renderFrame() per cycle instead.  `fps` as in pathtracerWGL2.js:293-298;
    * `gpuMs` = GPU time of the last frame taken. */
   async render () {
     if (!this._halt) return;                              // already running (the WebGPU renderer guards the same way)
@@ -278,7 +278,7 @@ class PathTracerHIP {
     };
     const take = () => {
       const q = pending.shift();
-      const r = q.group ? native().groupFrameEnd(this._group) : native().frameEnd(this._ctx, q.rgba8);
+      const r = q.group ? native().groupFrameEnd(this._group, q.rgba8) : native().frameEnd(this._ctx, q.rgba8);
       this._inFlight--;
       this.gpuMs = r.gpuMs;
       deliver({ width: q.width, height: q.height, rows: q.rows, radiance: q.rgba8 ? undefined : r.pixels, rgba8: q.rgba8 ? r.pixels : undefined, pixels: r.pixels, frameMs: r.gpuMs });
@@ -289,7 +289,7 @@ class PathTracerHIP {
         const aa = this._antialiasing();
         /* a group of GPUs (flx_group_frame_begin / _end): every GPU's frame server resolves its strips straight into one image in pinned host memory, up to
          * three frames in flight, nothing waits for a GPU inside a frame; `pixels` is a view of that image, the frame's until the next frame is begun */
-        const grouped = !!this._devices && !this._tile && !aa && !this.present8;
+        const grouped = !!this._devices && !this._tile && !aa;      // (present8: the servers quantise their tiles as they resolve them — the canvas' bytes, a quarter of what every GPU writes)
         const pipelined = !this._devices && !this._tile && !aa;
         if (grouped) {
           this._uploadFrameState();
@@ -301,9 +301,9 @@ class PathTracerHIP {
           }
           if (this._inFlight === this.groupLanes) take();
           if (this._halt) return;                           // (the application halted the renderer from its onFrame)
-          native().groupFrameBegin(this._group, p, this._tileRows);
+          native().groupFrameBegin(this._group, p, this._tileRows, this.present8);
           this._inFlight++;
-          pending.push({ width: p.width, height: p.height, rows: p.height, rgba8: false, group: true });
+          pending.push({ width: p.width, height: p.height, rows: p.height, rgba8: this.present8, group: true });
           this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);
         } else if (pipelined) {
           this._uploadFrameState();
@@ -313,14 +313,6 @@ class PathTracerHIP {
           pending.push({ width: p.width, height: p.height, rows: p.height, rgba8: this.present8 });
           this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);
           if (this._inFlight === 2) take();
-        } else if (this._devices && this.present8 && !this._tile && !aa && !this.config.filter && !this.config.temporal) {
-          /* a group that presents the canvas' RGBA8: every GPU quantises its strips and a quarter of the bytes is gathered (flx_group_render_rgba8) */
-          while (this._inFlight > 0) take();
-          this._uploadFrameState();
-          const p = this.frameParams();
-          if (!this._out8 || this._out8.length !== p.width * p.height * 4) this._out8 = new Uint8ClampedArray(p.width * p.height * 4);
-          const info = native().groupRenderRgba8(this._group, p, this._tileRows, this._out8);
-          deliver({ width: p.width, height: p.height, rows: p.height, rgba8: this._out8, pixels: this._out8, frameMs: info.frameMs });
         } else {
           while (this._inFlight > 0) take();
           deliver(this.renderFrame({ reuse: true }));

@@ -794,29 +794,33 @@ static napi_value GroupRenderRgba8(napi_env env, napi_callback_info info) {
   return res;
 }
 
-/* ---- the group's frame loop: groupFrameBegin(handle, params, tileRows) / groupFrameEnd(handle) -> { pixels, gpuMs } --------------------
+/* ---- the group's frame loop: groupFrameBegin(handle, params, tileRows, rgba8) / groupFrameEnd(handle, rgba8) -> { pixels, gpuMs } ------
  * flx_group_frame_begin / _end: every GPU's frame server resolves its strips straight into ONE image in pinned host memory; `pixels` is a Float32Array
- * over that image (no copy), the frame's until the NEXT groupFrameBegin — which may be the frame that re-uses the image — detaches it (and
+ * (or, rgba8, a Uint8ClampedArray of the canvas' bytes: the servers quantise as they resolve) over that image (no copy), the frame's until the NEXT groupFrameBegin — which may be the frame that re-uses the image — detaches it (and
  * groupSetFrameLanes, destroyGroup). */
 static napi_value GroupFrameBegin(napi_env env, napi_callback_info info) {
-  napi_value argv[3];
-  if (!get_args(env, info, 3, argv)) return nullptr;
+  napi_value argv[4];
+  if (!get_args(env, info, 4, argv)) return nullptr;
   GroupBox *box = get_group_box(env, argv[0]);
   if (!box) return nullptr;
   flx_frame_params p;
   if (!read_params(env, argv[1], &p)) return nullptr;
   uint32_t tileRows = 8;
   NAPI_OK(env, napi_get_value_uint32(env, argv[2], &tileRows));
+  bool rgba8 = false;
+  napi_get_value_bool(env, argv[3], &rgba8);
   detach_group_views(env, box);
-  flx_status rc = flx_group_frame_begin(box->g, &p, tileRows, FLX_FRAME_FLOAT);
+  flx_status rc = flx_group_frame_begin(box->g, &p, tileRows, rgba8 ? FLX_FRAME_RGBA8 : FLX_FRAME_FLOAT);
   if (rc != FLX_OK) return gfail(env, box->g, "flx_group_frame_begin", rc);
   return nullptr;
 }
 static napi_value GroupFrameEnd(napi_env env, napi_callback_info info) {
-  napi_value argv[1];
-  if (!get_args(env, info, 1, argv)) return nullptr;
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
   GroupBox *box = get_group_box(env, argv[0]);
   if (!box) return nullptr;
+  bool rgba8 = false;
+  napi_get_value_bool(env, argv[1], &rgba8);
   const void *pixels = nullptr; size_t bytes = 0; float ms = 0.f;
   flx_status rc = flx_group_frame_end(box->g, &pixels, &bytes, &ms);
   if (rc != FLX_OK) return gfail(env, box->g, "flx_group_frame_end", rc);
@@ -828,7 +832,8 @@ static napi_value GroupFrameEnd(napi_env env, napi_callback_info info) {
     NAPI_OK(env, napi_create_reference(env, buf, 0, &view.ref));
     box->views.push_back(view);
   }
-  NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, bytes / 4, buf, 0, &arr));
+  if (rgba8) NAPI_OK(env, napi_create_typedarray(env, napi_uint8_clamped_array, bytes, buf, 0, &arr));
+  else NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, bytes / 4, buf, 0, &arr));
   napi_set_named_property(env, res, "pixels", arr);
   napi_create_double(env, ms, &v); napi_set_named_property(env, res, "gpuMs", v);
   return res;
