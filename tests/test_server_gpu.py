@@ -151,6 +151,55 @@ def test_the_server_hands_out_the_canvas_bytes(served, oracle, scenes):
             assert bit_mismatches(mixed[f], want[f]) == 0, f
 
 
+def test_a_scene_that_moves_goes_to_the_lanes(hip, oracle, scenes):
+    """the default mode (flx_set_frame_chain(2)): the server for a rank's share of a frame while the scene stands still; a frame that follows an upload of changed
+    transforms goes to the two lanes (the launch would end and start again around it: tools/dynamic_scene_time.py); every frame is the oracle's for its arrays"""
+    import copy
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    hip.set_frame_lanes(3)
+    hip.set_frame_chain(2)
+    try:
+        p = sc.frame_params(use_filter=0, width=640, height=360, tile=(8, 1, 2))
+        rot0 = np.array(sc.arrays["rotation"], np.float32).reshape(-1, 2, 12)
+
+        def arrays(f):
+            r = rot0.copy()
+            c, s_ = np.cos(0.05 * f), np.sin(0.05 * f)
+            R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]) * 2.0
+            Ri = np.linalg.inv(R)
+            for m, M in ((0, R), (1, Ri)):
+                for col in range(3):
+                    r[2, m, 4 * col:4 * col + 3] = M[:, col]
+            return r.reshape(-1)
+        hip.frame_begin(p)                                    # (the frame that follows update_scene itself goes to the lanes)
+        hip.frame_end()
+        kinds, got = [], []
+        for f in range(6):
+            if hip.frames_in_flight() == 2:
+                got.append(hip.frame_end()[0])
+            if f >= 3:
+                hip.update_transforms(arrays(f), sc.arrays["shift"])
+            hip.frame_begin(p)
+            kinds.append(hip.last_chained())
+        while hip.frames_in_flight():
+            got.append(hip.frame_end()[0])
+        assert kinds[:3] == [3, 3, 3] and kinds[3:] == [0, 0, 0], kinds
+        for f in (0, 4, 5):
+            moved = copy.copy(sc)
+            moved.arrays = dict(sc.arrays, rotation=arrays(f) if f >= 3 else sc.arrays["rotation"])
+            want = oracle.render(moved, p)[0]
+            assert bit_mismatches(got[f], want) == 0, f
+        hip.frame_begin(p)                                    # the scene stands still again: back to the server
+        hip.frame_begin(p)
+        assert hip.last_chained() == 3
+        while hip.frames_in_flight():
+            hip.frame_end()
+    finally:
+        hip.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+        hip.set_frame_lanes(2)
+
+
 def test_frames_the_server_does_not_take(served, scenes):
     """a scene of fewer than 129 entries: rendered the other ways, and right; RGBA8 frames through the server equal the ones quantised by the kernel of their own"""
     sc = scenes("cornell_obj")

@@ -174,6 +174,7 @@ struct flx_context {
   flx_frame_params chain_params = {};            /* its shape: a frame continues the chain only with the same one */
   uint64_t chain_scene_version = 0;              /* ... and the same scene */
   uint64_t scene_version = 0;                    /* bumped by every upload */
+  uint64_t begin_scene_version = 0;              /* ... as the last flx_frame_begin found it (0: no frame begun yet) */
   int last_chained = 0;                          /* flx_last_chained: 0 the last frame of the loop was not chained, 1 it began a chain, 2 it continued one */
   /* the frame server (flx_server.hip): one persistent launch renders the loop's frames as they are posted (flx_set_frame_chain mode 2) */
   flx::ServerSlot *d_sv_slots = nullptr;

@@ -284,6 +284,7 @@ struct flx_group {
   Target target;                        /* target.n images of target.pixels float4 */
   std::vector<Target> retired;          /* targets of an earlier frame shape that frames in flight still live in */
   flx_frame_params shape = {};          /* what the target was made for */
+  std::vector<uint64_t> seen_version;   /* per context: its scene_version at the group's last flx_group_frame_begin */
   int shape_format = -1;
   struct InFlight { int kind; /* 1: through the servers, 0: rendered synchronously (frames the server does not take) */ const void *pixels; size_t bytes; float ms; };
   InFlight fifo[3] = {};
@@ -567,6 +568,11 @@ extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params
       if (c->fifo_n == 0) { c->frame_lanes = g->lanes; c->frame_chain = 3; }      /* (every frame the server can take, whatever its size: the target says where it goes) */
     }
     if (!flx_frame_server_takes(c, &p[r])) server = false;
+    /* a scene that changed since the frame before: the servers' launches would end and start again around it (2.5 ms per frame on a rank's eighth of the dragon frame
+     * against 1.8 for its own launches, tools/dynamic_scene_time.py) — such a frame is rendered by flx_group_render, like the ones the servers do not take */
+    if (g->seen_version.size() != (size_t)n) g->seen_version.assign((size_t)n, 0);
+    if (g->seen_version[(size_t)r] != 0 && g->seen_version[(size_t)r] != c->scene_version && format != FLX_FRAME_DEVICE) server = false;      /* (a frame for context 0's memory stays with the servers) */
+    g->seen_version[(size_t)r] = c->scene_version;
   }
   auto &slot = g->fifo[g->fifo_n];
   if (!server && format == FLX_FRAME_DEVICE) { g->err = "flx_group_frame_begin: FLX_FRAME_DEVICE takes only frames the frame server takes (flx_frame_server_takes) on GPUs that can write context 0's memory; FLX_FRAME_FLOAT takes every frame"; return FLX_ERR_INVALID; }
