@@ -172,3 +172,50 @@ def test_group_loop_hands_out_the_canvas_bytes(pair, hip, oracle, scenes):
     a = pair.frame_end()[0]
     b = pair.frame_end()[0]
     assert np.array_equal(a, want[0]) and np.array_equal(b, oracle.present(hip.render(flt)[0]))
+
+
+@pytest.mark.parametrize("rgba8", [False, True])
+def test_group_loop_with_a_scene_that_moves(pair, hip, oracle, scenes, rgba8):
+    """the transforms change before every frame (examples/dragon.js): such frames do not go to the servers — floats run on the contexts' two lanes and their strips are
+    copied into the frame's image when it is taken, the canvas' bytes go through flx_group_render_rgba8 — and the loop goes back to the servers when the scene stands still;
+    every frame equals one context's render with the same arrays"""
+    sc = scenes("dragon")
+    pair.update_scene(sc)
+    hip.update_scene(sc)
+    rot0 = np.array(sc.arrays["rotation"], np.float32).reshape(-1, 2, 12)
+
+    def arrays(f):
+        r = rot0.copy()
+        c, s_ = np.cos(0.07 * f), np.sin(0.07 * f)
+        R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]) * 2.0
+        Ri = np.linalg.inv(R)
+        for m, M in ((0, R), (1, Ri)):
+            for col in range(3):
+                r[2, m, 4 * col:4 * col + 3] = M[:, col]
+        return r.reshape(-1)
+    ps = [moving(sc, f, width=640, height=368) for f in range(9)]
+    moves = [f for f in range(9) if 2 <= f < 7]                    # frames 2 .. 6 follow an upload of changed transforms
+    pair.set_frame_lanes(3)
+    got = []
+    try:
+        for f, p in enumerate(ps):
+            if pair.frames_in_flight() == 3:
+                got.append(pair.frame_end()[0])
+            if f in moves:
+                pair.update_transforms(arrays(f), sc.arrays["shift"])
+            pair.frame_begin(p, rgba8=rgba8)
+        while pair.frames_in_flight():
+            got.append(pair.frame_end()[0])
+        last = None
+        for f, p in enumerate(ps):
+            if f in moves:
+                last = arrays(f)
+            hip.update_transforms(last if last is not None else sc.arrays["rotation"], sc.arrays["shift"])
+            want = hip.render(p)[0]
+            if rgba8:
+                assert np.array_equal(got[f], oracle.present(want)), f
+            else:
+                assert bit_mismatches(got[f], want) == 0, f
+    finally:
+        hip.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+        pair.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])

@@ -285,8 +285,10 @@ struct flx_group {
   std::vector<Target> retired;          /* targets of an earlier frame shape that frames in flight still live in */
   flx_frame_params shape = {};          /* what the target was made for */
   std::vector<uint64_t> seen_version;   /* per context: its scene_version at the group's last flx_group_frame_begin */
+  std::vector<hipStream_t> strip_copy;  /* per context: the stream its strips of a frame of the lanes (InFlight::kind 2) are copied into the frame's image on */
   int shape_format = -1;
-  struct InFlight { int kind; /* 1: through the servers, 0: rendered synchronously (frames the server does not take) */ const void *pixels; size_t bytes; float ms; };
+  struct InFlight { int kind; /* 1: through the servers, 0: rendered synchronously (frames the server does not take), 2: on the contexts' two lanes (a scene that moves): the strips are
+                               * copied into the image when the frame is taken */ const void *pixels; size_t bytes; float ms; flx_frame_params params; uint32_t tile_rows; };
   InFlight fifo[3] = {};
   int fifo_n = 0;
   float4 *h_sync[3] = { nullptr, nullptr, nullptr };      /* pinned: frames rendered synchronously (as many as may be in flight) */
@@ -316,6 +318,7 @@ extern "C" void flx_group_destroy(flx_group *g) {
   for (size_t r = 0; r < g->ctx.size(); r++) {
     if (!g->ctx[r]) continue;
     (void)hipSetDevice(g->ctx[r]->device);
+    if (r < g->strip_copy.size() && g->strip_copy[r]) { (void)hipStreamSynchronize(g->strip_copy[r]); (void)hipStreamDestroy(g->strip_copy[r]); }
     (void)hipStreamSynchronize(g->ctx[r]->stream);
     if (r < g->comms.size() && g->comms[r]) (void)ncclCommDestroy(g->comms[r]);
     g->ctx[r]->comm = nullptr;
@@ -559,21 +562,24 @@ extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params
   if (g->fifo_n == 0) for (auto &t : g->retired) group_free_target(g, t);
   if (g->fifo_n == 0) g->retired.clear();
   std::vector<flx_frame_params> p((size_t)n, *params);
-  bool server = format != FLX_FRAME_DEVICE || g->peer_ok;
+  bool server = format != FLX_FRAME_DEVICE || g->peer_ok, moved = false;
   flx_status s;
   for (int r = 0; r < n; r++) {
     p[r].tile_rows = tile_rows; p[r].tile_index = (uint32_t)r; p[r].tile_count = (uint32_t)n;
     flx_context *c = g->ctx[r];
-    if (c->frame_lanes != g->lanes || c->frame_chain != 3) {
-      if (c->fifo_n == 0) { c->frame_lanes = g->lanes; c->frame_chain = 3; }      /* (every frame the server can take, whatever its size: the target says where it goes) */
-    }
+    if (c->frame_lanes != g->lanes && c->fifo_n == 0) c->frame_lanes = g->lanes;
+    c->frame_chain = 3;                    /* (every frame the server can take, whatever its size: the target says where it goes; read by flx_frame_begin only) */
     if (!flx_frame_server_takes(c, &p[r])) server = false;
-    /* a scene that changed since the frame before: the servers' launches would end and start again around it (2.5 ms per frame on a rank's eighth of the dragon frame
-     * against 1.8 for its own launches, tools/dynamic_scene_time.py) — such a frame is rendered by flx_group_render, like the ones the servers do not take */
+    /* a scene that changed since the frame before: the servers' launches would end and start again around it (2.4 ms per frame on a rank's eighth of the dragon frame
+     * against 1.4 on two lanes, tools/dynamic_scene_time.py): such a frame does not go to the servers */
     if (g->seen_version.size() != (size_t)n) g->seen_version.assign((size_t)n, 0);
-    if (g->seen_version[(size_t)r] != 0 && g->seen_version[(size_t)r] != c->scene_version && format != FLX_FRAME_DEVICE) server = false;      /* (a frame for context 0's memory stays with the servers) */
+    if (g->seen_version[(size_t)r] != 0 && g->seen_version[(size_t)r] != c->scene_version && format != FLX_FRAME_DEVICE) moved = true;      /* (a frame for context 0's memory stays with the servers) */
     g->seen_version[(size_t)r] = c->scene_version;
   }
+  /* ... as floats on the contexts' two lanes (every lane keeps its own copy of the lights and transforms; nothing waits for a GPU here), its strips copied into the frame's
+   * image when the frame is taken; the canvas' bytes through flx_group_render_rgba8 */
+  const bool lanes = moved && server && format == FLX_FRAME_FLOAT;
+  if (moved) server = false;
   auto &slot = g->fifo[g->fifo_n];
   if (!server && format == FLX_FRAME_DEVICE) { g->err = "flx_group_frame_begin: FLX_FRAME_DEVICE takes only frames the frame server takes (flx_frame_server_takes) on GPUs that can write context 0's memory; FLX_FRAME_FLOAT takes every frame"; return FLX_ERR_INVALID; }
   if (!server) {
@@ -587,6 +593,20 @@ extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params
       g->h_sync[b] = nullptr; g->h_sync_pixels[b] = 0;
       if (hipHostMalloc((void **)&g->h_sync[b], pixels * sizeof(float4), hipHostMallocDefault) != hipSuccess) { g->err = "flx_group_frame_begin: pinned memory for the frame"; return FLX_ERR_DEVICE; }
       g->h_sync_pixels[b] = pixels;
+    }
+    if (lanes) {
+      if (g->strip_copy.size() != (size_t)n) {
+        g->strip_copy.assign((size_t)n, nullptr);
+        for (int r = 0; r < n; r++) { (void)hipSetDevice(g->ctx[r]->device); if (hipStreamCreateWithFlags(&g->strip_copy[(size_t)r], hipStreamNonBlocking) != hipSuccess) { g->err = "flx_group_frame_begin: a copy stream"; return FLX_ERR_DEVICE; } }
+      }
+      for (int r = 0; r < n; r++) {
+        flx_context *c = g->ctx[r];
+        c->frame_chain = 0;                /* its own launches, alternating between the context's two lanes */
+        if ((s = flx_frame_begin(c, &p[r], FLX_FRAME_DEVICE))) { g->err = flx_last_error(c); return s; }
+      }
+      slot.kind = 2; slot.bytes = pixels * sizeof(float4); slot.pixels = (const void *)g->h_sync[b]; slot.ms = 0.f; slot.params = *params; slot.tile_rows = tile_rows;
+      g->fifo_n++;
+      return FLX_OK;
     }
     const auto t0 = std::chrono::steady_clock::now();
     if (format == FLX_FRAME_RGBA8) {
@@ -645,6 +665,30 @@ extern "C" flx_status flx_group_frame_end(flx_group *g, const void **pixels, siz
       if (s && !first) { first = s; g->err = flx_last_error(c); }
       if (one > worst) worst = one;
     }
+    f.ms = worst;
+  }
+  if (f.kind == 2) {
+    /* every context's frame of its lanes is complete in ITS device memory (packed strips); each strip goes where the image has it — one copy per strip, all contexts'
+     * at once over their own PCIe links — and the frame is handed out when the last byte is there */
+    float worst = 0.f;
+    const int n = (int)g->ctx.size();
+    const uint32_t W = f.params.width, H = f.params.height, tr = f.tile_rows;
+    for (int r = 0; r < n; r++) {
+      flx_context *c = g->ctx[r];
+      const void *dptr = nullptr; size_t got = 0; float one = 0.f;
+      const flx_status s = flx_frame_end(c, &dptr, &got, &one);
+      if (s) { if (!first) { first = s; g->err = flx_last_error(c); } continue; }
+      if (one > worst) worst = one;
+      (void)hipSetDevice(c->device);
+      uint32_t packed = 0;
+      for (uint32_t strip = (uint32_t)r; (size_t)strip * tr < H && !first; strip += (uint32_t)n) {
+        const uint32_t row0 = strip * tr, rows = row0 + tr <= H ? tr : H - row0;
+        if (hipMemcpyAsync((char *)const_cast<void *>(f.pixels) + (size_t)row0 * W * sizeof(float4), (const char *)dptr + (size_t)packed * W * sizeof(float4),
+                           (size_t)rows * W * sizeof(float4), hipMemcpyDeviceToHost, g->strip_copy[(size_t)r]) != hipSuccess) { first = FLX_ERR_DEVICE; g->err = "flx_group_frame_end: copying a strip into the frame's image"; }
+        packed += rows;
+      }
+    }
+    for (int r = 0; r < n; r++) { (void)hipSetDevice(g->ctx[r]->device); if (hipStreamSynchronize(g->strip_copy[(size_t)r]) != hipSuccess && !first) { first = FLX_ERR_DEVICE; g->err = "flx_group_frame_end: the strips' copies"; } }
     f.ms = worst;
   }
   if (first) return first;
