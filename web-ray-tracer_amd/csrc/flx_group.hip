@@ -578,8 +578,10 @@ extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params
   }
   /* ... as floats on the contexts' two lanes (every lane keeps its own copy of the lights and transforms; nothing waits for a GPU here), its strips copied into the frame's
    * image when the frame is taken; the canvas' bytes through flx_group_render_rgba8 */
-  const bool lanes = moved && server && format == FLX_FRAME_FLOAT;
   if (moved) server = false;
+  /* (... and so does every other float frame the servers do not take — a scene of <= 128 entries, strips that are no multiple of 8 rows —; filter and temporal frames need
+   * the whole frame in one context: flx_group_render) */
+  const bool lanes = !server && format == FLX_FRAME_FLOAT && !params->use_filter && !params->is_temporal;
   auto &slot = g->fifo[g->fifo_n];
   if (!server && format == FLX_FRAME_DEVICE) { g->err = "flx_group_frame_begin: FLX_FRAME_DEVICE takes only frames the frame server takes (flx_frame_server_takes) on GPUs that can write context 0's memory; FLX_FRAME_FLOAT takes every frame"; return FLX_ERR_INVALID; }
   if (!server) {
