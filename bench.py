@@ -381,7 +381,7 @@ def shared_loop(args, dist, capi, scene, params, full, rank, world, local_rank, 
     import numpy as np
     import torch
     W, H = full.width, full.height
-    err, ctx_s, handle, last_ptr, lat = None, None, None, None, []
+    err, ctx_s, handle, last_ptr, lat, served = None, None, None, None, [], None
 
     def agree(ok):
         t = torch.tensor([1 if ok else 0], dtype=torch.int32)
@@ -408,8 +408,11 @@ def shared_loop(args, dist, capi, scene, params, full, rank, world, local_rank, 
         ctx_s.update_scene(scene)
         if args.one_device:                      # rehearsal on one GPU: every rank's server launch takes its part of the CUs, so that they run at once
             ctx_s.set_server_groups(max(1, ctx_s.device_info()[1] // world))
-        if not ctx_s.frame_server_takes(params):
-            raise RuntimeError("not a frame the frame server takes (flx_frame_server_takes)")
+        served = True                                  # (else: every rank's two lanes, its strips copied into the image when the frame is taken; the library decides from every rank's share)
+        for r in range(world):
+            q = type(params).from_buffer_copy(params)
+            q.tile_index = r
+            served = served and ctx_s.frame_server_takes(q)
         if rank == 0:
             handle = ctx_s.share_create(W, H, lanes, world, 0)
     except Exception as e:                       # noqa: BLE001 — reported in the line
@@ -476,10 +479,11 @@ def shared_loop(args, dist, capi, scene, params, full, rank, world, local_rank, 
         return None
     if not ok or dt is None:
         return {"error": "; ".join("rank %d: %s" % (r, e) for r, e in enumerate(errs) if e) or "a rank failed", "frames_in_flight": lanes}
-    return {"frames_in_flight": lanes, "ms_per_frame": dt / frames * 1e3, "frames": frames, "frame_gpu_ms_median": float(np.median(lat[-frames:])) if lat else None,
+    return {"frames_in_flight": lanes, "frame_server": bool(served), "ms_per_frame": dt / frames * 1e3, "frames": frames, "frame_gpu_ms_median": float(np.median(lat[-frames:])) if lat else None,
             "image_equals_single_context_frame": equal, "error": err,
             "note": "flx_frame_begin_shared / flx_frame_end_shared on every rank: each rank's frame server (one persistent launch, %d frames in flight) resolves its strips straight "
-                    "into one image in rank 0's device memory (hipIpc mapping, stores over xGMI) — no collective, no reassembly kernel, no copy; rank 0 hands a frame out when every "
+                    "into one image in rank 0's device memory (hipIpc mapping, stores over xGMI) — no collective, no reassembly kernel, no copy (`frame_server` false: a frame the "
+                    "server does not take — every rank's two lanes, its strips copied into that image when the frame is taken); rank 0 hands a frame out when every "
                     "rank's strips of it are complete%s" % (lanes, "; REHEARSAL on one device: every rank's launch takes 1/%d of the CUs" % world if args.one_device else "")}
 
 

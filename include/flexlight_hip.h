@@ -295,7 +295,9 @@ flx_status flx_frame_begin_gathered(flx_context *ctx, const flx_frame_params *pa
  * allocates n_images (2 or 3 = frames in flight) images and exports them (flx_share_create: a hipIpcMemHandle and the name of a page of POSIX shared memory
  * in `handle`, which the caller hands to the other ranks — bench.py broadcasts it over torch.distributed); the others map them (flx_share_join: their stores
  * go over xGMI); every rank's launch resolves its row strips where the image has them.  The loop is the frame loop's: flx_frame_begin_shared (params.tile_count
- * = the ranks, .tile_index = this rank; a frame the frame server takes) / flx_frame_end_shared, up to n_images frames in flight on every rank; on the root
+ * = the ranks, .tile_index = this rank) / flx_frame_end_shared, up to n_images frames in flight on every rank — a frame the frame server does not take (a scene of <= 128
+ * entries, a last strip cut by the frame's edge; not filter / temporal frames) is rendered on the rank's two lanes and its strips are copied into the image when the frame is
+ * taken (the two kinds cannot be in flight together) —; on the root
  * flx_frame_end_shared waits until every rank has completed its strips of the frame and hands out the image (device memory; valid until the root's next
  * flx_frame_begin_shared — no rank overwrites an image before that), elsewhere it returns NULL / 0 bytes.  Frames equal flx_render of one context bit for bit.
  * A rank that fails or does not answer within 5 s makes every rank's next call return FLX_ERR_DEVICE instead of waiting.  The root is the context that

@@ -40,6 +40,12 @@ struct flx_share {
   uint32_t width = 0, height = 0, n_images = 0;
   float4 *images = nullptr;            /* the root's allocation, or this rank's mapping of it */
   uint64_t begun = 0, ended = 0;
+  /* frames the frame server does not take (a scene of <= 128 entries, strips that are no multiple of 8 rows): rendered on the context's two lanes and copied, strip by
+   * strip, into the image when the frame is taken — the same image on every rank: frame g of such a run goes to image g % n_images */
+  bool lanes_mode = false;             /* the frames in flight are of that kind (the kinds do not mix in flight) */
+  hipStream_t copy = nullptr;
+  struct Pending { uint32_t image; uint32_t tile_rows; } fifo[3] = {};
+  int fifo_n = 0;
 };
 
 struct ShareHandle {                   /* FLX_SHARE_HANDLE_BYTES */
@@ -67,6 +73,7 @@ extern "C" flx_status flx_share_leave(flx_context *ctx) {
   (void)hipSetDevice(ctx->device);
   while (ctx->fifo_n) (void)flx_frame_end(ctx, nullptr, nullptr, nullptr);
   (void)flx_frame_target_set(ctx, nullptr, 0);
+  if (sh->copy) { (void)hipStreamSynchronize(sh->copy); (void)hipStreamDestroy(sh->copy); sh->copy = nullptr; }
   if (sh->page) {
     if (sh->root) __atomic_store_n(&sh->page->released, ~0ull >> 1, __ATOMIC_RELEASE);      /* nobody waits for a root that has left */
     else __atomic_store_n(&sh->page->done[sh->rank], ~0ull >> 1, __ATOMIC_RELEASE);
@@ -167,7 +174,26 @@ extern "C" flx_status flx_frame_begin_shared(flx_context *ctx, const flx_frame_p
   if (!params || params->width != sh->width || params->height != sh->height || (int)params->tile_count != sh->n_ranks || (int)params->tile_index != sh->rank)
     return share_fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_shared: the frame must have the images' size, tile_count = the ranks and tile_index = this rank");
   if (share_broken(sh)) return share_fail(ctx, FLX_ERR_DEVICE, "flx_frame_begin_shared: a rank of the share has failed");
-  if (!flx_frame_server_takes(ctx, params)) return share_fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_shared: not a frame the frame server takes (flx_frame_server_takes)");
+  if (params->use_filter || params->is_temporal) return share_fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_shared: filter and temporal frames need the whole frame in one context (flx_render_gathered_root_device)");
+  /* the frame server where it takes the frame; else the context's two lanes and a copy of the strips into the image (the same choice on every rank: it depends on the
+   * scene and on the frame's shape only) */
+  bool lanes = false;
+  for (int r = 0; r < sh->n_ranks && !lanes; r++) {          /* (EVERY rank's share: a frame whose last strip is cut by the frame's edge is one the server does not take on the rank that owns that strip) */
+    flx_frame_params q = *params;
+    q.tile_index = (uint32_t)r;
+    if (!flx_frame_server_takes(ctx, &q)) lanes = true;
+  }
+  if (lanes != sh->lanes_mode) {
+    if (ctx->fifo_n) return share_fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_shared: frames the frame server takes and frames it does not take cannot be in flight together: take the frames in flight first");
+    flx_status ts = FLX_OK;
+    if (lanes) {
+      ts = flx_frame_target_set(ctx, nullptr, 0);                    /* (the lanes' frames stay in this context's memory until they are copied) */
+      if (!ts) ts = flx_set_frame_chain(ctx, 0);
+      if (!ts && !sh->copy && hipStreamCreateWithFlags(&sh->copy, hipStreamNonBlocking) != hipSuccess) ts = share_fail(ctx, FLX_ERR_DEVICE, "flx_frame_begin_shared: a copy stream");
+    } else ts = share_attach(ctx, sh);
+    if (ts) { __atomic_store_n(&sh->page->error[sh->rank], 1u, __ATOMIC_RELEASE); return ts; }
+    sh->lanes_mode = lanes;
+  }
   if (sh->root) {
     /* the root is through with every frame it has been handed (the caller begins the next one): their images are free */
     __atomic_store_n(&sh->page->released, sh->ended, __ATOMIC_RELEASE);
@@ -181,6 +207,7 @@ extern "C" flx_status flx_frame_begin_shared(flx_context *ctx, const flx_frame_p
   }
   const flx_status s = flx_frame_begin(ctx, params, FLX_FRAME_DEVICE);
   if (s) { __atomic_store_n(&sh->page->error[sh->rank], 1u, __ATOMIC_RELEASE); return s; }
+  if (sh->fifo_n < 3) { sh->fifo[sh->fifo_n].image = (uint32_t)(sh->begun % sh->n_images); sh->fifo[sh->fifo_n].tile_rows = params->tile_rows; sh->fifo_n++; }
   sh->begun++;
   return FLX_OK;
 }
@@ -192,6 +219,23 @@ extern "C" flx_status flx_frame_end_shared(flx_context *ctx, const void **image,
   const void *p = nullptr;
   const flx_status s = flx_frame_end(ctx, &p, nullptr, ms);      /* this rank's strips are in the image (written back at system scope by the launch) */
   if (s) { __atomic_store_n(&sh->page->error[sh->rank], 1u, __ATOMIC_RELEASE); return s; }
+  flx_share::Pending pf = sh->fifo[0];
+  if (sh->fifo_n) { sh->fifo[0] = sh->fifo[1]; sh->fifo[1] = sh->fifo[2]; sh->fifo_n--; }
+  if (sh->lanes_mode) {
+    /* a frame of the lanes: this rank's packed strips (its own device memory) go where the image has them — the root's memory, through the mapping: over xGMI */
+    float4 *image = sh->images + (size_t)pf.image * sh->width * sh->height;
+    const uint32_t tr = pf.tile_rows ? pf.tile_rows : 8u;
+    uint32_t packed = 0;
+    hipError_t e = hipSuccess;
+    for (uint32_t strip = (uint32_t)sh->rank; (size_t)strip * tr < sh->height && e == hipSuccess; strip += (uint32_t)sh->n_ranks) {
+      const uint32_t row0 = strip * tr, rows = row0 + tr <= sh->height ? tr : sh->height - row0;
+      e = hipMemcpyAsync(image + (size_t)row0 * sh->width, (const float4 *)p + (size_t)packed * sh->width, (size_t)rows * sh->width * sizeof(float4), hipMemcpyDeviceToDevice, sh->copy);
+      packed += rows;
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(sh->copy);
+    if (e != hipSuccess) { __atomic_store_n(&sh->page->error[sh->rank], 1u, __ATOMIC_RELEASE); ctx->err = std::string("flx_frame_end_shared: copying the strips into the image: ") + hipGetErrorString(e); return FLX_ERR_DEVICE; }
+    p = image;
+  }
   sh->ended++;
   __atomic_store_n(&sh->page->done[sh->rank], sh->ended, __ATOMIC_RELEASE);
   if (image) *image = nullptr;
