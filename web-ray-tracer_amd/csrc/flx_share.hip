@@ -44,7 +44,7 @@ struct flx_share {
    * strip, into the image when the frame is taken — the same image on every rank: frame g of such a run goes to image g % n_images */
   bool lanes_mode = false;             /* the frames in flight are of that kind (the kinds do not mix in flight) */
   hipStream_t copy = nullptr;
-  struct Pending { uint32_t image; uint32_t tile_rows; } fifo[3] = {};
+  struct Pending { uint32_t image; flx_frame_params params; } fifo[3] = {};
   int fifo_n = 0;
 };
 
@@ -207,7 +207,7 @@ extern "C" flx_status flx_frame_begin_shared(flx_context *ctx, const flx_frame_p
   }
   const flx_status s = flx_frame_begin(ctx, params, FLX_FRAME_DEVICE);
   if (s) { __atomic_store_n(&sh->page->error[sh->rank], 1u, __ATOMIC_RELEASE); return s; }
-  if (sh->fifo_n < 3) { sh->fifo[sh->fifo_n].image = (uint32_t)(sh->begun % sh->n_images); sh->fifo[sh->fifo_n].tile_rows = params->tile_rows; sh->fifo_n++; }
+  if (sh->fifo_n < 3) { sh->fifo[sh->fifo_n].image = (uint32_t)(sh->begun % sh->n_images); sh->fifo[sh->fifo_n].params = *params; sh->fifo_n++; }
   sh->begun++;
   return FLX_OK;
 }
@@ -224,13 +224,15 @@ extern "C" flx_status flx_frame_end_shared(flx_context *ctx, const void **image,
   if (sh->lanes_mode) {
     /* a frame of the lanes: this rank's packed strips (its own device memory) go where the image has them — the root's memory, through the mapping: over xGMI */
     float4 *image = sh->images + (size_t)pf.image * sh->width * sh->height;
-    const uint32_t tr = pf.tile_rows ? pf.tile_rows : 8u;
-    uint32_t packed = 0;
+    /* runs of consecutive image rows among this rank's packed rows (flx_tile_row_at: the tile policy itself says where a packed row lives) */
+    const uint32_t mine = flx_tile_row_count(&pf.params);
     hipError_t e = hipSuccess;
-    for (uint32_t strip = (uint32_t)sh->rank; (size_t)strip * tr < sh->height && e == hipSuccess; strip += (uint32_t)sh->n_ranks) {
-      const uint32_t row0 = strip * tr, rows = row0 + tr <= sh->height ? tr : sh->height - row0;
-      e = hipMemcpyAsync(image + (size_t)row0 * sh->width, (const float4 *)p + (size_t)packed * sh->width, (size_t)rows * sh->width * sizeof(float4), hipMemcpyDeviceToDevice, sh->copy);
-      packed += rows;
+    for (uint32_t k = 0; k < mine && e == hipSuccess;) {
+      const uint32_t row0 = flx_tile_row_at(&pf.params, k);
+      uint32_t run = 1;
+      while (k + run < mine && flx_tile_row_at(&pf.params, k + run) == row0 + run) run++;
+      e = hipMemcpyAsync(image + (size_t)row0 * sh->width, (const float4 *)p + (size_t)k * sh->width, (size_t)run * sh->width * sizeof(float4), hipMemcpyDeviceToDevice, sh->copy);
+      k += run;
     }
     if (e == hipSuccess) e = hipStreamSynchronize(sh->copy);
     if (e != hipSuccess) { __atomic_store_n(&sh->page->error[sh->rank], 1u, __ATOMIC_RELEASE); ctx->err = std::string("flx_frame_end_shared: copying the strips into the image: ") + hipGetErrorString(e); return FLX_ERR_DEVICE; }
