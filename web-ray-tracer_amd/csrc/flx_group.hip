@@ -627,6 +627,16 @@ extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params
     g->fifo_n++;
     return FLX_OK;
   }
+  /* frames of the lanes still in flight: their launches complete before a server's does — a persistent launch that got the CUs first would hold them, waiting for the host,
+   * while the host waits for those frames (where the contexts share one GPU: for one another's) */
+  for (int i = 0; i < g->fifo_n; i++) if (g->fifo[i].kind == 2) {
+    for (int r = 0; r < n; r++) {
+      flx_context *c = g->ctx[r];
+      (void)hipSetDevice(c->device);
+      if (hipStreamSynchronize(c->stream) != hipSuccess || (c->twin && hipStreamSynchronize(c->twin->stream) != hipSuccess)) { g->err = "flx_group_frame_begin: waiting for the frames of the lanes"; return FLX_ERR_DEVICE; }
+    }
+    break;
+  }
   if ((s = group_target(g, params, tile_rows, format))) return s;
   /* A launch that has to end or start allocates (and hipMalloc / hipFree wait for the device): where contexts share a device that must not happen while
    * another context's launch runs — it would wait for a launch that waits for the host.  So if ANY context cannot simply post, all launches end first (their
