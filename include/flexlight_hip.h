@@ -191,7 +191,8 @@ flx_status flx_set_frame_lanes(flx_context *ctx, int lanes);
  *      others: ONE persistent launch renders the loop's frames as flx_frame_begin posts them (the view goes through pinned memory; nothing is launched per
  *      frame), every workgroup works on the oldest frame first and fills its idle lanes with the next ones, resolves the screen tiles it made and the last
  *      one through with a frame tells the host.  With three frames in flight a rank's eighth of the 1080p dragon frame completes every 0.93 - 0.98 ms (all
- *      eight ranks; two lanes: 1.29, one frame at a time: 1.65; profiles/r04_share_scaling.txt).  The launch ends when the loop runs empty, or when a frame
+ *      eight ranks; two lanes: 1.29, one frame at a time: 1.65; profiles/r04_share_scaling.txt).  The launch ends when the loop runs empty (or, by itself, when the host has
+ *      said nothing for two seconds: frames in flight that are complete by then are handed out as usual and the next frame starts another launch), or when a frame
  *      of another shape, a scene upload, a synchronous render or flx_sync needs the device;
  *   3  the frame server for every frame it can take, whatever its size (a whole 1080p frame: 6.46 ms against 6.32 on two lanes).
  * The chained modes take frames without filter and temporal accumulation, scenes of more than 128 entries, strips of a multiple of 8 rows, float or

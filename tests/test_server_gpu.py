@@ -200,6 +200,27 @@ def test_a_scene_that_moves_goes_to_the_lanes(hip, oracle, scenes):
         hip.set_frame_lanes(2)
 
 
+def test_a_host_that_pauses_loses_nothing(served, scenes):
+    """the launch waits for the host; after two seconds without a word it ends by itself (a safety net: the host normally says when to stop).  An application that
+    pauses with frames in flight — all of them complete by then — must find them when it comes back, no error, and the loop goes on with a new launch"""
+    import time
+    sc = scenes("dragon")
+    served.update_scene(sc)
+    served.set_frame_lanes(3)
+    ps = [moving(sc, f, width=480, height=272) for f in range(6)]
+    want = [served.render(p)[0] for p in ps]
+    for p in ps[:3]:
+        served.frame_begin(p)
+    time.sleep(2.6)
+    got = [served.frame_end()[0] for _ in range(3)]
+    for p in ps[3:]:
+        served.frame_begin(p)
+        assert served.last_chained() == 3
+    got += [served.frame_end()[0] for _ in range(3)]
+    for f in range(6):
+        assert bit_mismatches(got[f], want[f]) == 0, f
+
+
 def test_frames_the_server_does_not_take(served, scenes):
     """a scene of fewer than 129 entries: rendered the other ways, and right; RGBA8 frames through the server equal the ones quantised by the kernel of their own"""
     sc = scenes("cornell_obj")

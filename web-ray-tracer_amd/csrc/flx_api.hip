@@ -526,12 +526,30 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, DeviceSce
 
 /* Did a frame kernel's watchdog trip (WavefrontBuffers::error, ChainArgs::error)?  Asked wherever the host has just waited for frames: the frame that was
  * being rendered — and whatever a chained kernel had worked ahead on — is incomplete.  Never reached by a healthy frame; tests force it (flx_debug_inject_fault). */
+/* The frame server's launch ended by itself because the HOST did nothing for seconds (an application that paused with frames in flight) — and every frame it had been
+ * given is complete in its image: nothing is lost, the next frame starts another launch.  (Anything else in the error word, or a frame that was posted and not
+ * completed, is an error.) */
+static bool server_idled_with_nothing_owed(const flx_context *ctx) {
+  if (!ctx->h_dev_error || !ctx->h_sv_mail) return false;
+  if (__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != WF_ERR_SERVER_IDLE) return false;
+  if (ctx->twin && ctx->twin->h_dev_error && __atomic_load_n(&ctx->twin->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u) return false;
+  for (uint32_t k = 0; k < SV_MAX_DEPTH; k++)
+    if (__atomic_load_n(&ctx->h_sv_mail->posted[k], __ATOMIC_ACQUIRE) != __atomic_load_n(&ctx->h_sv_mail->done[k], __ATOMIC_ACQUIRE)) return false;
+  return true;
+}
+
 flx_status flx_check_device_error(flx_context *ctx) {
   flx_context *owner = ctx;
   if (!owner->h_dev_error) return FLX_OK;
   uint32_t bits = __atomic_load_n(&owner->h_dev_error[0], __ATOMIC_ACQUIRE);
   if (ctx->twin && ctx->twin->h_dev_error) { bits |= __atomic_load_n(&ctx->twin->h_dev_error[0], __ATOMIC_ACQUIRE); }
   if (bits == 0u) return FLX_OK;
+  if (server_idled_with_nothing_owed(ctx)) {
+    ctx->sv_running = false;                                 /* (the frames still pending are complete: server_take hands them out) */
+    if (ctx->sv_stream) (void)hipStreamSynchronize(ctx->sv_stream);
+    ctx->h_dev_error[0] = 0u;
+    return FLX_OK;
+  }
   if (ctx->sv_stream) {                                      /* a frame server that is still up: it ends, whatever it holds */
     if (ctx->h_sv_mail) __atomic_store_n(&ctx->h_sv_mail->stopAfter, 1u, __ATOMIC_RELEASE);
     ctx->sv_running = false;
@@ -1621,7 +1639,7 @@ static flx_status server_take(flx_context *ctx, int k) {
       break;
     }
   }
-  if (__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u) {
+  if (__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u && !server_idled_with_nothing_owed(ctx)) {
     /* the launch gave up (or never answered): tell it to end, then report */
     __atomic_store_n(&ctx->h_sv_mail->stopAfter, 1u, __ATOMIC_RELEASE);
     ctx->sv_running = false;
