@@ -22,30 +22,53 @@ lanes, shape = 3, shapes[0]
 ctx.set_frame_lanes(lanes)
 inflight, checked, bad, served, t0 = [], 0, 0, 0, time.time()
 f = 0
+ops = []
+lights_gen = 0
+def fail_dump():
+    print('\n'.join(ops[-16:]), flush=True)
+import atexit
 while f < N or inflight:
     r = rnd.random()
     if f < N and len(inflight) < lanes and (r < 0.6 or not inflight):
         p = frame(f, shape)
-        ctx.frame_begin(p)
+        r8 = rnd.random() < 0.3                              # the canvas' bytes: the launch quantises as it resolves (another format: another launch)
+        ops.append('begin %d %dx%d rgba8 %d lanes %d' % (f, p.width, p.height, r8, lanes))
+        try:
+            ctx.frame_begin(p, rgba8=r8)
+        except capi.FlexLightHipError:
+            fail_dump(); raise
         served += ctx.last_chained() == 3
-        inflight.append((f, p))
+        inflight.append((f, p, r8, lights_gen))
         f += 1
     elif inflight:
-        g, p = inflight.pop(0)
-        got = ctx.frame_end()[0]
-        if g % 37 == 0 and not inflight:                     # (the comparison render would end the launch anyway: only when nothing is in flight)
+        g, p, r8, gen = inflight.pop(0)
+        ops.append('end %d' % g)
+        try:
+            got = ctx.frame_end()[0]
+        except capi.FlexLightHipError:
+            fail_dump(); raise
+        if g % 37 == 0 and not inflight and gen == lights_gen:                     # (the comparison render would end the launch anyway: only when nothing is in flight)
             want = ctx.render(p)[0]
             checked += 1
-            bad += not np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            ok = np.array_equal(got, ctx.present(want)) if r8 else np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            if not ok:
+                bad += 1
+                d = (got != ctx.present(want)).any(axis=2) if r8 else (got.view(np.uint32) != want.view(np.uint32)).any(axis=2)
+                print("frame %d differs: %d pixels, rows %s, rgba8 %d, shape %dx%d tile %d/%d" % (g, int(d.sum()), np.nonzero(d.any(axis=1))[0][:6], r8, p.width, p.height, p.tile_index, p.tile_count)); fail_dump()
     if rnd.random() < 0.01:
         time.sleep(rnd.random() * 0.01)                      # the host pauses: the launch waits for posts
     if rnd.random() < 0.004 and not inflight:
-        lanes = rnd.choice([2, 3]); ctx.set_frame_lanes(lanes)
+        lanes = rnd.choice([2, 3]); ctx.set_frame_lanes(lanes); ops.append('lanes %d' % lanes)
     if rnd.random() < 0.006:
-        shape = rnd.choice(shapes)                           # frames of another shape: the launch ends, another begins
+        ops.append('shape'); shape = rnd.choice(shapes)                           # frames of another shape: the launch ends, another begins
     if rnd.random() < 0.003:
-        ctx.update_primary_light_sources(sc.arrays["lights"])
+        lights_gen += 1; ctx.update_primary_light_sources(sc.arrays["lights"])    # (the scene's own lights: the same again — nothing — unless they had been changed)
+    if rnd.random() < 0.003:
+        dim = np.array(sc.arrays["lights"], np.float32).copy(); dim.reshape(-1, 6)[:, 3] *= rnd.choice([0.5, 1.0, 2.0])
+        ops.append('lights changed'); lights_gen += 1; ctx.update_primary_light_sources(dim)                # other lights: the launch ends, the frames after are rendered with them (and compared with them)
+    if rnd.random() < 0.0005 and inflight:
+        ops.append('pause 2.3 s'); time.sleep(2.3)                                      # the host pauses for longer than the launch waits: nothing may be lost
     if rnd.random() < 0.002:
-        ctx.render(frame(f, shapes[3]))                      # a synchronous render while frames are in flight
+        ops.append('sync render'); ctx.render(frame(f, shapes[3]))                      # a synchronous render while frames are in flight
 print("%d frames (%d through the server) in %.1f s, %d compared with their own render, %d differ" % (N, served, time.time() - t0, checked, bad))
 sys.exit(1 if bad else 0)

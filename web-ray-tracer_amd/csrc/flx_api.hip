@@ -1565,8 +1565,20 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
   flx_status s;
   if (ctx->sv_running && !server_continues(ctx, params, out8))
     if ((s = server_stop(ctx))) return s;
+  if (ctx->sv_running && server_idled_with_nothing_owed(ctx)) {      /* the launch ended by itself while the host was away (nothing owed): another begins */
+    ctx->sv_running = false;
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));
+    __atomic_store_n(&ctx->h_dev_error[0], 0u, __ATOMIC_RELEASE);
+  }
   if (!ctx->sv_running) {
     if (ctx->sv_stream) FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));      /* a launch that was told to end reads the mailbox until it has */
+    if (server_idled_with_nothing_owed(ctx)) __atomic_store_n(&ctx->h_dev_error[0], 0u, __ATOMIC_RELEASE);
+    /* frames of the launch before that nobody has taken yet (it ended by itself while the host was away): taken now, before the mailbox becomes the new launch's */
+    for (int i = 0; i < ctx->fifo_n; i++) {
+      if (ctx->fifo[i].lane != ctx) continue;
+      const int kp = ctx->fifo[i].slot;
+      if (ctx->sv_pending[kp].valid && (s = server_take(ctx, kp))) return s;
+    }
     DeviceFrame fr = frOne;                                 /* the slots stacked like a batch of frames; the views come through the mailbox */
     fr.frames = depth; fr.rows = depth * frOne.frame_rows;
     for (uint32_t i = 0; i < depth; i++) memset(&fr.view[i], 0, sizeof(FrameView));
@@ -1639,7 +1651,14 @@ static flx_status server_take(flx_context *ctx, int k) {
       break;
     }
   }
-  if (__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u && !server_idled_with_nothing_owed(ctx)) {
+  if (server_idled_with_nothing_owed(ctx)) {
+    /* the launch ended by itself while the host was away, this frame and every other it had been given complete: forgiven HERE, while the mailbox still is that
+     * launch's (a later launch's posts must not be held against it) */
+    ctx->sv_running = false;
+    FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));
+    __atomic_store_n(&ctx->h_dev_error[0], 0u, __ATOMIC_RELEASE);
+  }
+  if (__atomic_load_n(&ctx->h_dev_error[0], __ATOMIC_ACQUIRE) != 0u) {
     /* the launch gave up (or never answered): tell it to end, then report */
     __atomic_store_n(&ctx->h_sv_mail->stopAfter, 1u, __ATOMIC_RELEASE);
     ctx->sv_running = false;
