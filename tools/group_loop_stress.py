@@ -72,6 +72,8 @@ while done < N:
             g.update_transforms(cur, sc.arrays["shift"]); ops.append('transforms changed')
         elif rnd.random() < 0.3:
             g.update_transforms(cur, sc.arrays["shift"])          # the same arrays again: nothing
+        if inflight and rnd.random() < 0.02:
+            ops.append('pause 2.3 s'); time.sleep(2.3)              # longer than the servers' launches wait for the host: nothing may be lost
         rgba8 = rnd.random() < 0.4
         flt = rnd.random() < 0.08
         p = sc.frame_params(use_filter=1 if flt else 0, **shape)
