@@ -456,6 +456,12 @@ struct SurfaceCtx {
   Material material;
 };
 
+/* Who reads the per-triangle table (DeviceScene::angle_tan) is decided per source file: the per-pixel kernel gains 4.5 % from it; the persistent kernels — whose paths' chains
+ * walk -> shade -> walk set the pace of a thin share — lose to the extra dependent load (a rank's eighth through the frame server with two frames in flight 1.235 -> 1.351 ms,
+ * k_paths + 1 %: profiles/r04_angle_table.txt) and keep computing the terms.  (As FLX_SINCOS_TABLE: one definition per translation unit.) */
+#ifndef FLX_ANGLE_TABLE
+#define FLX_ANGLE_TABLE 0
+#endif
 /* fragment:500-512 from the triangle's transformed vertices and vertex normals: independent of the ray (DeviceScene::angle_tan) */
 FLX_DEV f3 triangleAngleTan(f3 t0v, f3 t1v, f3 t2v, f3 n0, f3 n1, f3 n2) {
   f3 geometryNormal = normalize(cross(t0v - t1v, t0v - t2v));
@@ -497,7 +503,7 @@ FLX_DEV void shadeSurface(const DeviceScene &sc, const DeviceFrame &fr, const Hi
                                  (n0.y * uvw.x + n1.y * uvw.y) + n2.y * uvw.z,
                                  (n0.z * uvw.x + n1.z * uvw.y) + n2.z * uvw.z));
   f3 angleTan;
-  if (sc.angle_tan) { const float4 t = sc.angle_tan[hit.triangleId]; angleTan = F3(t.x, t.y, t.z); }      /* the same floats, computed at the upload (k_angle_tan) */
+  if (FLX_ANGLE_TABLE && sc.angle_tan) { const float4 t = sc.angle_tan[hit.triangleId]; angleTan = F3(t.x, t.y, t.z); }      /* the same floats, computed at the upload (k_angle_tan) */
   else angleTan = triangleAngleTan(t0v, t1v, t2v, n0, n1, n2);
   sf.geometryOffset = dot(diffs * angleTan, uvw);
   /* uv0 = a2.yz, uv1 = (a2.w, a3.x), uv2 = a3.yz */

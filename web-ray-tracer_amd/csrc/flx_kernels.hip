@@ -10,6 +10,7 @@
  * 10.22 -> 10.10 ms, cornell.obj filter frame 1.055 -> 1.021 ms); the wavefront pipeline's dense shade kernels keep the selects
  * (dragon 8.07 against 8.18 ms with the table) */
 #define FLX_SINCOS_TABLE 1
+#define FLX_ANGLE_TABLE 1                  /* k_trace_pixels reads the per-triangle table (flx_device.h); k_paths sets the pointer to null for itself */
 #include "flx_kernels.h"
 #include "flx_kernel_util.h"
 
