@@ -201,6 +201,14 @@ flx_status flx_set_frame_lanes(flx_context *ctx, int lanes);
 flx_status flx_set_frame_chain(flx_context *ctx, int mode);
 /* The last frame begun in the loop: 0 its own launches, 1 it began a chain of launches, 2 it continued one, 3 it went to the frame server. */
 flx_status flx_last_chained(flx_context *ctx, int *chained);
+/* A scene that MOVES in the frame server.  The reference refills its transform UBO and its light texture before every frame (modules/pathtracerWGL2.js:258-262,
+ * 361-365) and an example like examples/dragon.js turns an object every tick.  Once flx_transforms_upload / flx_lights_upload has brought CHANGED contents of the
+ * same counts, the server's next launch takes those arrays WITH every frame — they are posted with the frame's view, a version per frame in flight, and a later
+ * upload no longer ends the launch (round 4 before this: every changed upload ended it and the frames went to the lanes).  Scenes whose 32 words per transform + 6
+ * per light exceed 1024 keep the old behaviour, and so does flx_set_server_moving_scenes(ctx, 0).  Frames are bit-identical either way.
+ * flx_server_moving: 1 while a launch of that kind is running. */
+flx_status flx_set_server_moving_scenes(flx_context *ctx, int on);
+int flx_server_moving(const flx_context *ctx);
 /* Would flx_frame_begin hand this frame to the frame server (under flx_set_frame_chain(ctx, 3): whatever its size)?  1 / 0. */
 int flx_frame_server_takes(flx_context *ctx, const flx_frame_params *params);
 /* The frame server resolves the loop's frames straight into images the CALLER owns: d_images[i] (n_images = 2 or 3 = the loop's frames in flight;

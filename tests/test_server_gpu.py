@@ -159,6 +159,7 @@ def test_a_scene_that_moves_goes_to_the_lanes(hip, oracle, scenes):
     hip.update_scene(sc)
     hip.set_frame_lanes(3)
     hip.set_frame_chain(2)
+    hip.set_server_moving_scenes(0)                           # (the behaviour before the server took moving scenes — and that of scenes whose arrays do not fit a post)
     try:
         p = sc.frame_params(use_filter=0, width=640, height=360, tile=(8, 1, 2))
         rot0 = np.array(sc.arrays["rotation"], np.float32).reshape(-1, 2, 12)
@@ -197,6 +198,81 @@ def test_a_scene_that_moves_goes_to_the_lanes(hip, oracle, scenes):
             hip.frame_end()
     finally:
         hip.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+        hip.set_frame_lanes(2)
+        hip.set_server_moving_scenes(1)
+
+
+def _turned(sc, f):
+    """the dragon scene's third transform (its monkey) turned by 0.05 f, as examples/dragon.js does every tick"""
+    r = np.array(sc.arrays["rotation"], np.float32).reshape(-1, 2, 12).copy()
+    c, s_ = np.cos(0.05 * f), np.sin(0.05 * f)
+    R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]) * 2.0
+    Ri = np.linalg.inv(R)
+    for m, M in ((0, R), (1, Ri)):
+        for col in range(3):
+            r[2, m, 4 * col:4 * col + 3] = M[:, col]
+    return r.reshape(-1)
+
+
+def _lit(sc, f):
+    lt = np.array(sc.arrays["lights"], np.float32).reshape(-1, 6).copy()
+    lt[0, 0] += 0.4 * f
+    lt[0, 3] *= 1.0 + 0.1 * (f % 3)
+    return lt.reshape(-1)
+
+
+@pytest.mark.parametrize("lanes", [2, 3])
+def test_a_scene_that_moves_stays_with_the_server(hip, oracle, scenes, lanes):
+    """transforms AND lights that change before every frame: after the first changed upload the server's launch takes them with every frame (ServerMail::blob, a
+    version per frame in flight) and goes on over the uploads — ONE launch for all the frames that follow; every frame is its own flx_render with its own arrays,
+    and the oracle's"""
+    import copy
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    hip.set_frame_lanes(lanes)
+    hip.set_frame_chain(2)
+    try:
+        p = sc.frame_params(use_filter=0, width=640, height=360, tile=(8, 1, 2))
+        N = 9
+        hip.frame_begin(p)                                    # (the frame that follows update_scene itself goes to the lanes)
+        hip.frame_end()
+        kinds, got, moving = [], [], []
+        for f in range(N):
+            if hip.frames_in_flight() == lanes:
+                got.append(hip.frame_end()[0].copy())
+            if f >= 2:
+                hip.update_transforms(_turned(sc, f), sc.arrays["shift"])
+            if f >= 4:
+                hip.update_primary_light_sources(_lit(sc, f))
+            q = copy.copy(p)
+            q.random_seed = float(f % 3)
+            hip.frame_begin(q)
+            kinds.append(hip.last_chained())
+            moving.append(hip.server_moving())
+        while hip.frames_in_flight():
+            got.append(hip.frame_end()[0].copy())
+        assert kinds == [3] * N, kinds
+        assert moving == [False, False] + [True] * (N - 2), moving
+        for f in range(N):
+            hip.update_transforms(_turned(sc, f) if f >= 2 else sc.arrays["rotation"], sc.arrays["shift"])
+            hip.update_primary_light_sources(_lit(sc, f) if f >= 4 else sc.arrays["lights"])
+            q = copy.copy(p)
+            q.random_seed = float(f % 3)
+            want = hip.render(q)[0]
+            assert bit_mismatches(got[f], want) == 0, f
+            if f in (3, 8):
+                moved = copy.copy(sc)
+                moved.arrays = dict(sc.arrays, rotation=_turned(sc, f), lights=_lit(sc, f) if f >= 4 else sc.arrays["lights"])
+                assert bit_mismatches(got[f], oracle.render(moved, q)[0]) == 0, f
+        # another count of lights is another scene: the launch ends, the frame is right
+        two = np.concatenate([_lit(sc, 1), _lit(sc, 2)])
+        hip.update_primary_light_sources(two)
+        hip.frame_begin(p)
+        g = hip.frame_end()[0].copy()
+        assert bit_mismatches(g, hip.render(p)[0]) == 0
+    finally:
+        hip.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+        hip.update_primary_light_sources(sc.arrays["lights"])
         hip.set_frame_lanes(2)
 
 

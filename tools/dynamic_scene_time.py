@@ -24,11 +24,16 @@ def rot(f):
         for col in range(3): r[2, m, 4 * col:4 * col + 3] = M[:, col]
     return r.reshape(-1)
 N = 100
-for label, lanes, chain, moving in (("frame server, 3 in flight, static scene", 3, 3, False), ("frame server, 3 in flight, transforms change every frame", 3, 3, True),
+ctx.set_server_moving_scenes(0)
+for label, lanes, chain, moving in (("frame server, 3 in flight, static scene", 3, 3, False), ("frame server, 3 in flight, transforms change every frame: every upload ends the launch (flx_set_server_moving_scenes(0))", 3, 3, True),
                                     ("two lanes (own launches), static scene", 2, 0, False), ("two lanes (own launches), transforms change every frame", 2, 0, True),
                                     ("one lane, transforms change every frame", 1, 0, True),
                                     ("the default (flx_set_frame_chain(2)), 3 in flight, static scene", 3, 2, False),
-                                    ("the default, transforms change every frame: frames go to the lanes", 3, 2, True)):
+                                    ("flx_set_server_moving_scenes(0), the default mode, transforms change every frame: frames go to the lanes", 3, 2, True),
+                                    ("MOVING SCENES IN THE SERVER (the default): 3 in flight, transforms change every frame", 3, 2, "server"),
+                                    ("   ... 2 in flight", 2, 2, "server"),
+                                    ("   ... the same launch, the scene standing still again", 3, 2, "still")):
+    if moving in ("server", "still"): ctx.set_server_moving_scenes(1)
     ctx.set_frame_lanes(lanes); ctx.set_frame_chain(chain)
     best = 1e9
     for rep in range(3):
@@ -37,9 +42,9 @@ for label, lanes, chain, moving in (("frame server, 3 in flight, static scene", 
             if f == 6: t0 = time.perf_counter()
             if ctx.frames_in_flight() == max(lanes, 1) or (lanes == 1 and ctx.frames_in_flight() == 1):
                 ctx.frame_end()
-            if moving: ctx.update_transforms(rot(f), sc.arrays["shift"])
+            if moving and moving != "still": ctx.update_transforms(rot(f), sc.arrays["shift"])
             ctx.frame_begin(p, device=True)
         while ctx.frames_in_flight(): ctx.frame_end()
         best = min(best, (time.perf_counter() - t0) * 1e3 / N)
-    print("%-64s %.3f ms per frame" % (label, best), flush=True)
+    print("%-64s %.3f ms per frame%s" % (label, best, "   (launch takes the arrays per frame)" if ctx.server_moving() else ""), flush=True)
 ctx.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])

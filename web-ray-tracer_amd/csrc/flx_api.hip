@@ -128,7 +128,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   if (ctx->stage) (void)hipHostFree(ctx->stage);
   if (ctx->h_chain_mail) (void)hipHostFree(ctx->h_chain_mail);
   if (ctx->h_sv_mail) (void)hipHostFree(ctx->h_sv_mail);
-  for (void *b : { (void *)ctx->d_sv_slots, (void *)ctx->d_sv_relay, (void *)ctx->d_sv_rings, (void *)ctx->d_sv_stats, (void *)ctx->d_sv_out, (void *)ctx->d_sv_tiles }) if (b) (void)hipFree(b);
+  for (void *b : { (void *)ctx->d_sv_slots, (void *)ctx->d_sv_relay, (void *)ctx->d_sv_rings, (void *)ctx->d_sv_stats, (void *)ctx->d_sv_out, (void *)ctx->d_sv_tiles, (void *)ctx->d_sv_versions }) if (b) (void)hipFree(b);
   if (ctx->sv_stream) (void)hipStreamDestroy(ctx->sv_stream);
   for (void *b : { (void *)ctx->d_chain_slots, (void *)ctx->d_chain_relay, (void *)ctx->d_chain_lists, (void *)ctx->d_chain_rings, (void *)ctx->d_chain_stats, (void *)ctx->d_chain_susp, (void *)ctx->d_chain_order, (void *)ctx->d_chain_cost }) if (b) (void)hipFree(b);
   if (ctx->h_dev_error) (void)hipHostFree(ctx->h_dev_error);
@@ -164,6 +164,7 @@ static flx_status shared_upload_end(flx_context *ctx) {
 template <typename T>
 static flx_status upload(flx_context *ctx, T **dst, const void *src, size_t bytes) {
   { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }      /* (a running frame server reads the scene) */
+  ctx->structure_version++;              /* (the uploads a launch for a scene that moves goes on over do not come through here: flx_transforms_upload) */
   ctx->scene_version++;                  /* (a chain of frames does not go on over a changed scene: flx_chain.hip) */
   size_t &cap = ctx->upload_capacity[(void **)dst];
   if (bytes == 0) {                      /* "none": the kernels test the pointer */
@@ -326,6 +327,7 @@ extern "C" flx_status flx_scene_upload(flx_context *ctx, const float *geometry, 
   if (n_ids && !ids) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: ids is NULL");
   if (n_entries_padded > LINK_INDEX) return fail(ctx, FLX_ERR_INVALID, "flx_scene_upload: more than 2^28 - 1 entries");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
+  ctx->sv_want_ver = false;                 /* (another scene: it has not moved yet) */
   /* Validate the skip list on the host: a skip that leaves the array would make the walk read out of
    * bounds on the GPU (the shader's texelFetch would be robust-access clamped; we refuse instead). */
   uint32_t max_transform = 0;
@@ -390,10 +392,23 @@ extern "C" flx_status flx_transforms_upload(flx_context *ctx, const float *rotat
       memcmp(ctx->h_rotation.data(), rotation, (size_t)n_transforms * 96) == 0 && memcmp(ctx->h_shift.data(), shift, (size_t)n_transforms * 32) == 0) return FLX_OK;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   flx_status s;
+  /* the same transforms, moved: the scene moves (the frame server's next launch takes them per frame; one that does already goes on) */
+  const bool moved = !ctx->is_twin && ctx->have_transforms && ctx->n_transforms == n_transforms && ctx->d_rotation && ctx->d_shift;
+  if (moved && ctx->sv_moving) ctx->sv_want_ver = true;
+  if (moved && ctx->sv_running && ctx->sv_ver) {
+    /* the running launch takes the transforms with every frame (server_post: from the host's copy) and does not read the device's arrays: they follow when the
+     * launch has ended (dyn_flush) — a copy on this context's stream now would wait for that end */
+    ctx->transforms_version++; ctx->scene_version++; ctx->dyn_version++;
+    ctx->h_rotation.assign(rotation, rotation + (size_t)n_transforms * 24);
+    ctx->h_shift.assign(shift, shift + (size_t)n_transforms * 8);
+    ctx->dyn_device_stale |= 1u;
+    return FLX_OK;
+  }
   ctx->have_transforms = false;             /* (until both arrays are in: a failed upload must not pass for the arrays it replaced) */
   ctx->transforms_version++;
   if ((s = upload(ctx, &ctx->d_rotation, rotation, (size_t)n_transforms * 96))) return s;
   if ((s = upload(ctx, &ctx->d_shift, shift, (size_t)n_transforms * 32))) return s;
+  ctx->dyn_device_stale &= ~1u;
   ctx->n_transforms = n_transforms;
   ctx->have_transforms = true;
   if (!ctx->is_twin) {                      /* kept for the frame loop's second lane (flx_frame_begin) */
@@ -411,8 +426,17 @@ extern "C" flx_status flx_lights_upload(flx_context *ctx, const float *lights, u
       (n_lights == 0 || memcmp(ctx->h_lights.data(), lights, (size_t)n_lights * 24) == 0)) return FLX_OK;      /* (as flx_transforms_upload: the same lights again) */
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   flx_status s;
+  const bool moved = !ctx->is_twin && ctx->have_lights && ctx->n_lights == n_lights && n_lights != 0 && ctx->d_lights;      /* (as flx_transforms_upload) */
+  if (moved && ctx->sv_moving) ctx->sv_want_ver = true;
+  if (moved && ctx->sv_running && ctx->sv_ver) {
+    ctx->scene_version++; ctx->dyn_version++;
+    ctx->h_lights.assign(lights, lights + (size_t)n_lights * 6);
+    ctx->dyn_device_stale |= 2u;
+    return FLX_OK;
+  }
   ctx->have_lights = false;
   if ((s = upload(ctx, &ctx->d_lights, lights, (size_t)n_lights * 24))) return s;
+  ctx->dyn_device_stale &= ~2u;
   ctx->n_lights = n_lights;
   if (!ctx->is_twin) { ctx->h_lights.assign(lights, lights + (size_t)n_lights * 6); ctx->dyn_version++; ctx->have_lights = true; }
   return FLX_OK;
@@ -488,22 +512,7 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, DeviceSce
   sc.walk = ctx->d_walk; sc.walk_entries = ctx->walk_entries; sc.walk_hot = ctx->walk_hot; sc.walk_root = ctx->walk_root; sc.walk_fast_boxes = ctx->walk_fast_boxes;
   sc.fwd = ctx->d_fwd; sc.fwd_entries = ctx->fwd_entries; sc.fwd_root = ctx->fwd_root;
   sc.lock = ctx->d_fwd; sc.lock_entries = (ctx->lock_ok && ctx->lock_use) ? ctx->fwd_entries : 0u; sc.lock_root = ctx->fwd_root;
-  /* the per-triangle table of the shading (DeviceScene::angle_tan): made again, on this context's stream and so in front of whatever this frame launches
-   * there (the frame server synchronises with the stream before its launch), when the geometry, the attributes or this context's transforms were uploaded
-   * since it was made */
-  sc.angle_tan = nullptr;
-  if (ctx->angle_table && ctx->n_entries != 0u) {
-    const uint64_t key = ((uint64_t)ctx->geometry_version << 32) | ctx->transforms_version;
-    if (key != ctx->angle_key || !ctx->d_angle_tan) {
-      FLX_HIP(ctx, hipSetDevice(ctx->device));
-      flx_status es = flx_ensure_pixels(ctx, &ctx->d_angle_tan, &ctx->angle_capacity, ctx->n_entries);
-      if (es) return es;
-      launch_angle_tan(sc, ctx->d_angle_tan, ctx->stream);
-      FLX_HIP(ctx, hipGetLastError());
-      ctx->angle_key = key;
-    }
-    sc.angle_tan = ctx->d_angle_tan;
-  }
+  sc.angle_tan = nullptr;                  /* (the per-pixel kernel's table: flx_run_frame makes it where that kernel is launched) */
   uint32_t tr, ti, tc;
   tile_normalise(p, tr, ti, tc);
   fr.width = p->width; fr.height = p->height;
@@ -693,8 +702,23 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame0, ctx->stream));
   if (cnt) FLX_HIP(ctx, hipMemsetAsync(cnt, 0, FLX_COUNTER_SLOTS * sizeof(unsigned long long), ctx->stream));
   if (pipeline == 1) {
+    /* the per-triangle table of the shading (DeviceScene::angle_tan; read by this kernel only): made again, on this context's stream and so in front of the
+     * launch, when the geometry, the attributes or this context's transforms were uploaded since it was made */
+    DeviceScene scT = sc;
+    scT.angle_tan = nullptr;
+    if (ctx->angle_table && ctx->n_entries != 0u) {
+      const uint64_t key = ((uint64_t)ctx->geometry_version << 32) | ctx->transforms_version;
+      if (key != ctx->angle_key || !ctx->d_angle_tan) {
+        flx_status es = flx_ensure_pixels(ctx, &ctx->d_angle_tan, &ctx->angle_capacity, ctx->n_entries);
+        if (es) return es;
+        launch_angle_tan(scT, ctx->d_angle_tan, ctx->stream);
+        FLX_HIP(ctx, hipGetLastError());
+        ctx->angle_key = key;
+      }
+      scT.angle_tan = ctx->d_angle_tan;
+    }
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    launch_trace_pixels(sc, fr, d_out, gb, cnt, ctx->stream);
+    launch_trace_pixels(scT, fr, d_out, gb, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   } else if (pipeline == 2) {
@@ -1465,8 +1489,28 @@ static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *para
 #define FLX_SERVER_TILE_LIST_MIN 64         /* .. this many at the least; a workgroup whose list is full leaves the rest of the frame's tiles to the others */
 #endif
 static flx_status server_take(flx_context *ctx, int k);
+/* the device's transforms and lights follow the host's copies (uploads that a launch for a scene that moves went on over): before anything else reads them */
+static flx_status dyn_flush(flx_context *ctx) {
+  const uint32_t stale = ctx->dyn_device_stale;
+  if (!stale || ctx->sv_running) return FLX_OK;
+  ctx->dyn_device_stale = 0u;
+  flx_status s;
+  const uint64_t sv = ctx->scene_version, dv = ctx->dyn_version;
+  const uint32_t tv = ctx->transforms_version;
+  if (stale & 1u) {
+    const std::vector<float> r = ctx->h_rotation, sh = ctx->h_shift;
+    if ((s = upload(ctx, &ctx->d_rotation, r.data(), r.size() * sizeof(float)))) return s;
+    if ((s = upload(ctx, &ctx->d_shift, sh.data(), sh.size() * sizeof(float)))) return s;
+  }
+  if (stale & 2u) {
+    const std::vector<float> l = ctx->h_lights;
+    if ((s = upload(ctx, &ctx->d_lights, l.data(), l.size() * sizeof(float)))) return s;
+  }
+  ctx->scene_version = sv; ctx->dyn_version = dv; ctx->transforms_version = tv;      /* (the same contents the versions were counted for) */
+  return FLX_OK;
+}
 flx_status flx_server_stop(flx_context *ctx) {
-  if (!ctx->sv_running && !(ctx->sv_pending[0].valid || ctx->sv_pending[1].valid || ctx->sv_pending[2].valid)) return FLX_OK;
+  if (!ctx->sv_running && !(ctx->sv_pending[0].valid || ctx->sv_pending[1].valid || ctx->sv_pending[2].valid)) return dyn_flush(ctx);
   if (ctx->sv_running) {
     /* every frame posted is completed before the launch ends */
     __atomic_store_n(&ctx->h_sv_mail->stopAfter, ctx->sv_next_seq - 1u, __ATOMIC_RELEASE);
@@ -1480,7 +1524,7 @@ flx_status flx_server_stop(flx_context *ctx) {
     if (ctx->sv_pending[k].valid) { flx_status s = server_take(ctx, k); if (s) return s; }
   }
   FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return FLX_OK;
+  return dyn_flush(ctx);
 }
 static flx_status server_stop(flx_context *ctx) { return flx_server_stop(ctx); }
 
@@ -1507,6 +1551,7 @@ static flx_status server_allocate(flx_context *ctx, const DeviceFrame &frOne, ui
     FLX_HIP(ctx, hipMalloc(&ctx->d_sv_rings, ringWords * sizeof(uint32_t)));
     FLX_HIP(ctx, hipMemsetAsync(ctx->d_sv_rings, 0xff, ringWords * sizeof(uint32_t), ctx->stream));      /* WF_INVALID everywhere; a launch leaves them so */
     FLX_HIP(ctx, hipMalloc(&ctx->d_sv_stats, SV_STAT_TOTAL * sizeof(unsigned long long)));
+    FLX_HIP(ctx, hipMalloc(&ctx->d_sv_versions, (size_t)cus * SV_MAX_DEPTH * SV_BLOB_WORDS * sizeof(uint32_t)));      /* (3 MB at 256 CUs) */
   }
   int chains = 1;
   if ((s = ensure_workspace(ctx, fr, 3, false, chains))) return s;
@@ -1540,9 +1585,16 @@ static flx_status server_allocate(flx_context *ctx, const DeviceFrame &frOne, ui
   return FLX_OK;
 }
 
+/* the lights and transforms of this scene can travel with the frames of a launch */
+static bool server_versions_fit(const flx_context *ctx) {
+  return ctx->sv_moving && ctx->have_transforms && ctx->n_transforms != 0 && server_blob_words(ctx->n_transforms, ctx->n_lights) <= SV_BLOB_WORDS &&
+         ctx->h_rotation.size() == (size_t)ctx->n_transforms * 24 && ctx->h_shift.size() == (size_t)ctx->n_transforms * 8 && ctx->h_lights.size() == (size_t)ctx->n_lights * 6;
+}
 static bool server_continues(flx_context *ctx, const flx_frame_params *params, bool out8) {      /* the running launch takes this frame as it is */
   const uint32_t depth = ctx->frame_lanes == 3 ? 3u : 2u;
-  return ctx->sv_running && ctx->sv_depth == depth && chain_same_shape(ctx->sv_params, *params) && ctx->sv_scene_version == ctx->scene_version && ctx->sv_out8 == out8;
+  /* (a launch that takes the lights and transforms per frame goes on over their uploads; one that read them at its start does not) */
+  const bool same_scene = ctx->sv_ver ? ctx->sv_structure_version == ctx->structure_version : ctx->sv_scene_version == ctx->scene_version;
+  return ctx->sv_running && ctx->sv_depth == depth && chain_same_shape(ctx->sv_params, *params) && same_scene && ctx->sv_out8 == out8;
 }
 /* For a device group (flx_group_frame_begin): would flx_frame_begin of this frame have to end or start a launch?  And the memory a launch needs, made while
  * NO launch of the group runs — where contexts share a device, an allocation in one waits for the launch of the other. */
@@ -1571,6 +1623,7 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
     __atomic_store_n(&ctx->h_dev_error[0], 0u, __ATOMIC_RELEASE);
   }
   if (!ctx->sv_running) {
+    if ((s = dyn_flush(ctx))) return s;
     if (ctx->sv_stream) FLX_HIP(ctx, hipStreamSynchronize(ctx->sv_stream));      /* a launch that was told to end reads the mailbox until it has */
     if (server_idled_with_nothing_owed(ctx)) __atomic_store_n(&ctx->h_dev_error[0], 0u, __ATOMIC_RELEASE);
     /* frames of the launch before that nobody has taken yet (it ended by itself while the host was away): taken now, before the mailbox becomes the new launch's */
@@ -1622,15 +1675,32 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
     sa.stats = ctx->d_sv_stats;
     uint32_t cusWalk = cus > 4u * FLX_SERVER_RESERVED_CUS ? cus - FLX_SERVER_RESERVED_CUS : cus;
     if (ctx->sv_groups && ctx->sv_groups < cusWalk) cusWalk = ctx->sv_groups;
-    if (launch_server(sc, fr, wb, sa, cusWalk, ctx->sv_stream) != 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the frame server does not take this scene");
+    /* a scene that moves: the launch reads the lights and transforms of every frame from versions of its own, filled from what is posted with the frame */
+    const bool ver = ctx->sv_want_ver && server_versions_fit(ctx);
+    DeviceScene scL = sc;
+    if (ver) {
+      const size_t versions = (size_t)cusWalk * depth;
+      sa.blobWords = server_blob_words(ctx->n_transforms, ctx->n_lights);
+      scL.rotation = (const float4 *)ctx->d_sv_versions;
+      scL.shift = (const float4 *)(ctx->d_sv_versions + versions * ctx->n_transforms * 24u);
+      scL.lights = (const float *)(ctx->d_sv_versions + versions * ctx->n_transforms * 32u);
+    }
+    if (launch_server(scL, fr, wb, sa, cusWalk, ctx->sv_stream) != 0) return fail(ctx, FLX_ERR_DEVICE, "internal: the frame server does not take this scene");
     FLX_HIP(ctx, hipGetLastError());
     ctx->sv_running = true; ctx->sv_depth = depth; ctx->sv_next_seq = seq0; ctx->sv_next_slot = slot0;
     ctx->sv_params = *params; ctx->sv_scene_version = ctx->scene_version; ctx->sv_out8 = out8;
+    ctx->sv_ver = ver; ctx->sv_structure_version = ctx->structure_version;
   }
   const uint32_t seq = ctx->sv_next_seq++, slot = ctx->sv_next_slot;
   ctx->sv_next_slot = (slot + 1u) % depth;
   /* post: the view, then the number that says whose view it is.  (The frame that was in this slot was taken by flx_frame_end `depth` frames ago.) */
   memcpy((void *)&ctx->h_sv_mail->view[slot], &frOne.view[0], sizeof(FrameView));
+  if (ctx->sv_ver) {                                         /* ... and the frame's transforms and lights (as the host holds them: what the last uploads said) */
+    uint32_t *b = (uint32_t *)ctx->h_sv_mail->blob[slot];
+    memcpy(b, ctx->h_rotation.data(), (size_t)ctx->n_transforms * 96);
+    memcpy(b + (size_t)ctx->n_transforms * 24, ctx->h_shift.data(), (size_t)ctx->n_transforms * 32);
+    if (ctx->n_lights) memcpy(b + (size_t)ctx->n_transforms * 32, ctx->h_lights.data(), (size_t)ctx->n_lights * 24);
+  }
   __atomic_store_n(&ctx->h_sv_mail->posted[slot], seq, __ATOMIC_RELEASE);
   *seqOut = seq; *slotOut = slot;
   ctx->last_pipeline = 3; ctx->last_organisation = 5; ctx->last_chained = 3;
@@ -1907,6 +1977,17 @@ extern "C" flx_status flx_debug_set_server_groups(flx_context *ctx, uint32_t gro
   return FLX_OK;
 }
 
+extern "C" flx_status flx_set_server_moving_scenes(flx_context *ctx, int on) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_set_server_moving_scenes: frames are in flight");
+  flx_status s = flx_server_stop(ctx);
+  if (s) return s;
+  ctx->sv_moving = on ? 1 : 0;
+  if (!on) ctx->sv_want_ver = false;
+  return FLX_OK;
+}
+extern "C" int flx_server_moving(const flx_context *ctx) { return ctx && ctx->sv_running && ctx->sv_ver ? 1 : 0; }
+
 extern "C" flx_status flx_set_frame_lanes(flx_context *ctx, int lanes) {
   if (!ctx) return FLX_ERR_INVALID;
   if (lanes < 1 || lanes > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_lanes: 1 (frames one after the other), 2 (two frames overlap on the GPU) or 3 (three frames in flight where the loop is chained: flx_set_frame_chain; as 2 elsewhere)");
@@ -1934,10 +2015,12 @@ static flx_status frame_begin(flx_context *ctx, const flx_frame_params *params, 
        * workgroup (a rank's eighth of a 1080p frame has 16, a whole 1080p frame 127: 6.46 ms per frame through the server against 6.32 on two lanes,
        * profiles/r04_server.txt); mode 3 takes every frame it can. */
       if (chained == 2 && !ctx->sv_target_slots && path_item_count64(frT) / ((uint64_t)frT.samples * 64u) >= (uint64_t)FLX_SERVER_MAX_TILES_PER_CU * (uint64_t)ctx->prop.multiProcessorCount) chained = 0;
-      /* ... and only while the scene stands still: the launch reads ONE scene, so an upload of changed lights or transforms ends it (its frames in flight complete
-       * first) and the next frame starts another — a rank's eighth of the dragon frame with its monkey turning every tick: 2.51 ms per frame through the server against
-       * 1.42 on two lanes, each of which keeps its own copy of those arrays (tools/dynamic_scene_time.py).  A frame that follows an upload goes to the lanes. */
-      if (chained == 2 && !ctx->sv_target_slots && ctx->begin_scene_version != 0 && ctx->begin_scene_version != ctx->scene_version) chained = 0;
+      /* ... and a scene that moves — lights or transforms that change from frame to frame, examples/dragon.js turns its monkey every tick — goes through a launch
+       * that takes those arrays with every frame (flx_server.hip: VER; a rank's eighth of the dragon frame with the monkey turning: 2.51 ms per frame when every
+       * upload ended the launch, 1.42 on two lanes with their own copies of the arrays: tools/dynamic_scene_time.py).  Where they do not fit a post
+       * (SV_BLOB_WORDS), a frame that follows an upload goes to the lanes. */
+      if (chained == 2 && !ctx->sv_target_slots && ctx->begin_scene_version != 0 && ctx->begin_scene_version != ctx->scene_version &&
+          !(ctx->sv_want_ver && server_versions_fit(ctx))) chained = 0;
       if (chained == 3) chained = 2;
     }
   }

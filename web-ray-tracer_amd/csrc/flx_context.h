@@ -192,6 +192,15 @@ struct flx_context {
   uint32_t sv_depth = 0, sv_next_seq = 0, sv_next_slot = 0, sv_counter = 0;
   flx_frame_params sv_params = {};               /* the shape of the frames the running launch takes */
   uint64_t sv_scene_version = 0;
+  /* A scene that MOVES (changed lights / transforms of the same counts, frame after frame): the launch takes those arrays with every frame (ServerMail::blob) and
+   * goes on over their uploads. */
+  uint64_t structure_version = 0;                /* bumped by every upload but those (scene_version counts them all) */
+  uint64_t sv_structure_version = 0;
+  bool sv_ver = false;                           /* the running launch takes the lights and transforms per frame */
+  uint32_t dyn_device_stale = 0;                 /* bit 0 / 1: d_rotation + d_shift / d_lights are behind h_rotation .. (uploads the launch went on over): dyn_flush */
+  bool sv_want_ver = false;                      /* the scene has moved since it was uploaded: the next launch does */
+  int sv_moving = 1;                             /* flx_set_server_moving_scenes: 0 = never (every changed upload ends the launch, as before round 4) */
+  uint32_t *d_sv_versions = nullptr;             /* [3 arrays][workgroup x depth + slot]: the launch's versions of rotation / shift / lights */
   bool sv_out8 = false;                          /* the running launch resolves RGBA8 (ServerArgs::out8) */
   bool sv_target8 = false;                       /* flx_frame_target_set8: the target images are uint32 RGBA8 per pixel */
   float4 *sv_target[3] = { nullptr, nullptr, nullptr };      /* flx_frame_target_set: whole images the launch resolves this context's strips into (a peer GPU's memory, pinned host memory, ..) */

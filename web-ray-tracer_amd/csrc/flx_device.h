@@ -371,6 +371,7 @@ struct PixelState {
   f4 renderId, renderOriginalId;
   float ndc_x, ndc_y;
   float seed;                   /* randomSeed of the pixel's frame */
+  uint32_t lightBase = 0;       /* floats in front of this frame's lights in DeviceScene::lights (the frame server with a scene that moves keeps a version per frame slot: flx_server.hip; else 0) */
 };
 
 /* State of one path between bounces (what lightTrace keeps in locals, fragment:464-474). */
@@ -407,7 +408,7 @@ FLX_DEV void reservoirPick(const DeviceScene &sc, const DeviceFrame &fr, PixelSt
   float lastRandomX = n0.x, lastRandomY = n0.y;
   const int size = (int)sc.n_lights;
   for (int j = 0; j < size; j++) {
-    const float *lt = sc.lights + 6 * j;
+    const float *lt = sc.lights + 6 * j + ps.lightBase;
     float strength = lt[3], variation = lt[4];
     if (strength <= 0.0f) continue;
     reservoirLength += 1.0f;
@@ -780,12 +781,12 @@ extern "C" __device__ unsigned int __ockl_wfred_min_u32(unsigned int);
 #endif
 typedef __attribute__((address_space(4))) const flx_v4f_ fwd_cf4;
 FLX_DEV void primaryVisit(const DeviceScene &sc, const Ray &ray, float viewDepthPerS, WalkState &w, int &cachedTI, Hit &hit, uint32_t &nxt,
-                          float4 e0, float4 e1, float4 e2) {
+                          float4 e0, float4 e1, float4 e2, int xfBase = 0 /* matrices in front of this frame's version of the transforms (PixelState::lightBase) */) {
   const int meta = __float_as_int(e2.z);
   if ((meta & 3) == 0) { nxt = WALK_END; return; }          /* terminator (its fetch counts, fragment:208) */
   const int tI = (meta >> 2) << 1;
   if (tI != cachedTI) {
-    const int iI = tI + 1;
+    const int iI = tI + 1 + xfBase;
     const M3 rotationII = rotation_at(sc, iI);
     cachedTI = tI;
     w.tR.origin = mul(rotationII, ray.origin + shift_at(sc, iI));
@@ -804,7 +805,7 @@ FLX_DEV void primaryVisit(const DeviceScene &sc, const Ray &ray, float viewDepth
   }
 }
 /* every lane of the wave calls this (active = the lane has a pixel) */
-FLX_DEV Hit primaryWalkF(const DeviceScene &sc, bool active, const Ray &ray, float viewDepthPerS, uint32_t &visits) {
+FLX_DEV Hit primaryWalkF(const DeviceScene &sc, bool active, const Ray &ray, float viewDepthPerS, uint32_t &visits, int xfBase = 0) {
   Hit hit; hit.suv = F3(0.0f, 0.0f, 0.0f); hit.transformId = 0; hit.triangleId = -1;
   WalkState w;
   w.tR = ray; w.minLen = POW32;
@@ -823,7 +824,7 @@ FLX_DEV Hit primaryWalkF(const DeviceScene &sc, bool active, const Ray &ray, flo
     const bool mine = nxt == i;
     if (mine) {
       visits++;
-      primaryVisit(sc, ray, viewDepthPerS, w, cachedTI, hit, nxt, make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), make_float4(c.x, c.y, c.z, c.w));
+      primaryVisit(sc, ray, viewDepthPerS, w, cachedTI, hit, nxt, make_float4(a.x, a.y, a.z, a.w), make_float4(b.x, b.y, b.z, b.w), make_float4(c.x, c.y, c.z, c.w), xfBase);
     }
     thin = (uint32_t)__popcll(flx_ballot(mine)) < (uint32_t)FLX_PRIMARY_LOCK_MIN ? thin + 1u : 0u;
     if (thin >= 2u) break;
@@ -858,7 +859,7 @@ FLX_DEV Hit primaryWalkF(const DeviceScene &sc, bool active, const Ray &ray, flo
     const size_t i = (size_t)nxt * 3u;
     const float4 e0 = sc.fwd[i], e1 = sc.fwd[i + 1], e2 = sc.fwd[i + 2];
     visits++;
-    primaryVisit(sc, ray, viewDepthPerS, w, cachedTI, hit, nxt, e0, e1, e2);
+    primaryVisit(sc, ray, viewDepthPerS, w, cachedTI, hit, nxt, e0, e1, e2, xfBase);
   }
 #endif
   return hit;

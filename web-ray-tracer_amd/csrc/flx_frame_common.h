@@ -52,9 +52,14 @@ FLX_DEV FrameArgsP kernel_frame_args() { return (FrameArgsP)__builtin_amdgcn_ker
  * material (shadeSurface) — is computed once and the per-sample rest (shadeSample) runs `samples` times.  Every path gets the
  * record the per-path kernel would have written, bit for bit. */
 /* (the lane's pixel of screen tile `tile`; h = its primary hit: suv + triangle id as bits, -1 for none; returns whether the pixel's paths run) */
-template <bool COUNT, bool LV = false>
+/* VER (the frame server with a scene that moves, flx_server.hip): DeviceScene::rotation / shift / lights hold one version of those arrays per (workgroup, frame
+ * slot) — version blockIdx.x x frames + the frame's slot — and a path reads its frame's. */
+template <bool VER>
+FLX_DEV uint32_t scene_version_of(const DeviceFrame &fr, uint32_t frameIdx) { return VER ? blockIdx.x * fr.frames + frameIdx : 0u; }
+
+template <bool COUNT, bool LV = false, bool VER = false>
 FLX_DEV bool shade0_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, float4 h, WorkCounters &cnt, const FrameView *lv = nullptr) {
-  uint32_t S, frameIdx;
+  uint32_t S, frameIdx, lightBase = 0;
   int tri;
   bool alive, compact;
   f3 camera;
@@ -76,6 +81,7 @@ FLX_DEV bool shade0_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, float4 h, 
   compact = wb.rec0 != nullptr;
   if (alive) {
     hit.transformId = (int)sc.geometry[3 * tri + 2].y << 1;
+    if (VER) { const uint32_t ver = scene_version_of<VER>(fr, frameIdx); hit.transformId += (int)(ver * 2u * sc.n_transforms); lightBase = ver * 6u * sc.n_lights; }
     const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
     float viewDepthPerS;
     Ray pr;
@@ -106,6 +112,7 @@ FLX_DEV bool shade0_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, float4 h, 
     ps.renderOriginalId = ps.renderId;
     ps.ndc_x = ndcX; ps.ndc_y = ndcY;
     ps.seed = view_at<LV>(fr, lv, frameIdx).random_seed;
+    ps.lightBase = lightBase;
     ps.originalColor = F3(1.0f, 1.0f, 1.0f);
     p.hit = hit;
     p.lastHitPoint = camera;
@@ -145,7 +152,7 @@ FLX_DEV bool shade0_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, float4 h, 
 
 /* The primary ray of the lane's pixel of screen tile `tile` (what k_primary does for it, flx_kernels.hip): the wave walks the forward-ordered copy
  * together.  -> suv + triangle id as bits (-1: no hit, or no pixel), also stored for k_resolve. */
-template <bool COUNT, bool LV = false>
+template <bool COUNT, bool LV = false, bool VER = false>
 FLX_DEV float4 primary_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, WorkCounters &cnt, const FrameView *lv = nullptr) {
   FLX_ARGS_OF(ab);
   float4 *__restrict__ hits = const_cast<float4 *>(wb.hits);
@@ -154,14 +161,16 @@ FLX_DEV float4 primary_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, WorkCou
   const bool inImage = px < fr.width && k < fr.rows;
   float nx, ny, viewDepthPerS = 0.0f;
   Ray pr; pr.origin = F3(0.0f, 0.0f, 0.0f); pr.dir = F3(0.0f, 0.0f, 1.0f);
+  int xfBase = 0;
   if (inImage) {
     const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
     const uint32_t frameIdx = frame_index(fr, k);
+    if (VER) xfBase = (int)(scene_version_of<VER>(fr, frameIdx) * 2u * sc.n_transforms);      /* (per lane, from the lane's own row: vector loads — the scalar cache is not coherent with the stores that filled the version) */
     const FrameView &v = view_at<LV>(fr, lv, frameIdx);
     pr.dir = primary_dir_v(fr, v, px, py_gl, nx, ny, viewDepthPerS);
     pr.origin = view_camera(v);
   }
-  const Hit hp = primaryWalkF(sc, inImage, pr, viewDepthPerS, cnt.primary_visits);
+  const Hit hp = primaryWalkF(sc, inImage, pr, viewDepthPerS, cnt.primary_visits, xfBase);
   float4 h = make_float4(hp.suv.x, hp.suv.y, hp.suv.z, __int_as_float(inImage ? hp.triangleId : -1));
   if (inImage) {
     if (COUNT && hp.triangleId != -1) cnt.primary_hits++;
@@ -171,7 +180,7 @@ FLX_DEV float4 primary_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, WorkCou
 }
 
 /* One path's shading for its next bounce (fragment:476-589): the record the last walk left -> the record the next walk reads. */
-template <bool COUNT, bool LV = false>
+template <bool COUNT, bool LV = false, bool VER = false>
 FLX_DEV void shade_path(FrameArgsP ab, uint32_t pathId, WorkCounters &cnt, const FrameView *lv = nullptr) {
   FLX_ARGS_OF(ab);
   float4 *rec = wb.rec + (size_t)pathId * 8;
@@ -192,6 +201,7 @@ FLX_DEV void shade_path(FrameArgsP ab, uint32_t pathId, WorkCounters &cnt, const
   p.hit.suv = F3(q2.x, q2.y, q2.z);
   p.hit.triangleId = __float_as_int(q2.w);
   p.hit.transformId = (int)sc.geometry[3 * p.hit.triangleId + 2].y << 1;
+  if (VER) { const uint32_t ver = scene_version_of<VER>(fr, frameIdx); p.hit.transformId += (int)(ver * 2u * sc.n_transforms); ps.lightBase = ver * 6u * sc.n_lights; }
   p.dontFilter = (__float_as_int(q0.w) & RF_DONT_FILTER) != 0;
   p.importancyFactor = F3(q6.x, q6.y, q6.z);
   ps.originalColor = F3(q7.x, q7.y, q7.z);

@@ -12,6 +12,8 @@ constexpr uint32_t SV_MAX_DEPTH = 3;           /* most frame slots = most frames
 #define FLX_SERVER_RESERVE 2048           /* places of a workgroup's rings that only paths of an older frame may take: the r-th oldest frame draws up to FQ_ALIVE_MAX - r x this */
 #endif
 constexpr uint32_t SV_RINGS = 3 * SV_MAX_DEPTH;   /* rings of a workgroup: (to shade, to walk, fresh units) x slot */
+constexpr uint32_t SV_BLOB_WORDS = 1024;       /* most words of a frame's lights and transforms that travel with it (ServerMail::blob): 32 per transform + 6 per light */
+inline uint32_t server_blob_words(uint32_t n_transforms, uint32_t n_lights) { return n_transforms * 32u + n_lights * 6u; }
 
 /* Device memory: what the workgroups of the launch share about a slot. */
 struct ServerSlot {
@@ -27,6 +29,8 @@ struct ServerMail {
   uint32_t pad[3];
   uint32_t done[4];                            /* [slot] device -> host: sequence number of the last frame completed in the slot */
   FrameView view[SV_MAX_DEPTH];
+  uint32_t blob[SV_MAX_DEPTH][SV_BLOB_WORDS];  /* [slot] a scene that moves: the frame's transforms and lights (written with the view, before the number): rotation (2 x 3 float4 per
+                                                * transform), shift (2 float4 per transform), lights (6 floats each) */
 };
 struct ServerArgs {
   ServerSlot *slots;                           /* [depth], zeroed before the launch */
@@ -43,6 +47,8 @@ struct ServerArgs {
   uint32_t *tileLists;                         /* [workgroup][slot] x tileListCap: the screen tiles the workgroup made of the frame in the slot */
   uint32_t tileListCap;
   uint32_t idleExit;                           /* 100 MHz ticks without anything to do after which a workgroup gives up (an error: the host always says when to stop) */
+  uint32_t blobWords;                          /* 0, or: the scene moves — words of ServerMail::blob that hold a frame's transforms and lights; DeviceScene::rotation / shift / lights
+                                                * of the launch then are its version buffers ([workgroup x depth + slot] versions of each array) */
   uint32_t *error;                             /* the context's device error word (pinned host memory) */
   unsigned long long *stats;                   /* or nullptr: SV_STAT_WORDS diagnostics of the launch */
 };
@@ -51,7 +57,7 @@ enum { SVS_START = 0, SVS_END, SVS_FRAMES, SVS_TILES, SVS_BATCHES, SVS_BATCH_LAN
        SV_DUMP_MAX = 4, SV_DUMP_WORDS = 72 /* blockIdx, wave, 64 control words, ... */, SV_STAT_TOTAL = SV_STAT_WORDS + SV_DUMP_MAX * SV_DUMP_WORDS };
 struct ServerKernelArgs { FrameArgs fa; ServerArgs sa; };
 
-bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes);
+bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes, uint32_t xfSlots = 1u /* depth for a scene that moves */);
 size_t server_rings_per_group();
 /* fr: the slots stacked (frames = depth); its views are NOT used (they come through the mailbox).  0, or -1 if the kernel does not fit */
 int launch_server(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, const ServerArgs &sa, uint32_t compute_units, hipStream_t stream);

@@ -59,25 +59,30 @@ FLX_DEV const ServerArgs &server_args(FrameArgsP p) {
 }
 #define FLX_SERVER_ARGS() FLX_ARGS_OF(ab); const ServerArgs &sa = server_args(ab); (void)sa
 
+/* VER: the scene MOVES — the lights and the transforms travel with the frame (ServerMail::blob: the host posts them with the view).  The launch keeps one version
+ * of those arrays per (workgroup, slot): DeviceScene::rotation / shift / lights point at the launch's own version buffer, written by the wave that brings the slot's
+ * view into the workgroup and read by that workgroup alone (plain loads: one CU, one vector L1; the inverse transforms of the walk waves go to LDS per slot). */
+template <bool VER>
 __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_server(ServerKernelArgs /* read through kernel_frame_args() */, uint32_t ldsCount, uint32_t nTransforms,
                                                                                      uint32_t shadeWaves, uint32_t readyUnits) {
   const FrameArgsP ab = kernel_frame_args();
   constexpr uint32_t WAVES = FLX_WF_WALK_THREADS / 64u;
   const uint32_t WALK_WAVES = WAVES - shadeWaves;
-  /* LDS: [tree top][inverse transforms][control words][the slots' views][per walk thread: nTransforms x 40 B of rays] */
+  uint32_t samples, depth, itemsPerSlot, tilesPerSlot;
+  { FLX_SERVER_ARGS(); samples = (uint32_t)fr.samples; depth = sa.depth; itemsPerSlot = sa.itemsPerSlot; tilesPerSlot = sa.tilesPerSlot; }
+  /* LDS: [tree top][inverse transforms (VER: per slot)][control words][the slots' views][per walk thread: nTransforms x 40 B of rays] */
   extern __shared__ float4 ldsAll[];
   float4 *ldsEntries = ldsAll;
   float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u;
-  uint32_t *ctl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);
+  uint32_t *ctl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u * (VER ? depth : 1u));
   FrameView *lv = (FrameView *)(ctl + SC_WORDS);
   float2 *raysBase = (float2 *)(ctl + SC_WORDS + SC_VIEW_WORDS);
-  uint32_t samples, depth, itemsPerSlot, tilesPerSlot;
   uint32_t *rings;
   {
     FLX_SERVER_ARGS();
-    samples = (uint32_t)fr.samples; depth = sa.depth; itemsPerSlot = sa.itemsPerSlot; tilesPerSlot = sa.tilesPerSlot;
     rings = wb.frameRings + (size_t)blockIdx.x * SV_RINGS * FQ_SIZE;
     for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_WF_WALK_THREADS) ldsEntries[t] = sc.walk[t];
+    if (!VER)
     for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_WF_WALK_THREADS) {
       const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
       ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
@@ -139,6 +144,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           const uint32_t v = __hip_atomic_load((const uint32_t *)&sa.mail->view[slot] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __hip_atomic_store((uint32_t *)&sa.relay->view[slot] + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (VER)
+          for (uint32_t t = lane; t < sa.blobWords; t += 64u)
+            __hip_atomic_store(&sa.relay->blob[slot][t], __hip_atomic_load(&sa.mail->blob[slot][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) __hip_atomic_store(&sa.relay->posted[slot], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -150,6 +158,29 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     seq = __builtin_amdgcn_readfirstlane(seq);
     if (seq != want) return false;
     if (lane < 19u) ((uint32_t *)&lv[slot])[lane] = __hip_atomic_load((const uint32_t *)&sa.relay->view[slot] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (VER) {
+      /* the frame's lights and transforms: into this workgroup's version of the slot (global memory it alone reads and writes) and, the inverse transforms, into LDS.
+       * Blob: [rotation: 2 x 3 float4 per transform][shift: 2 float4 per transform][lights: 6 floats each] */
+      const uint32_t nRot = nTransforms * 24u, nSh = nTransforms * 8u, ver = blockIdx.x * depth + slot;
+      uint32_t *rotW = (uint32_t *)const_cast<float4 *>(sc.rotation) + (size_t)ver * nRot;
+      uint32_t *shW = (uint32_t *)const_cast<float4 *>(sc.shift) + (size_t)ver * nSh;
+      uint32_t *ltW = (uint32_t *)const_cast<float *>(sc.lights) + (size_t)ver * 6u * sc.n_lights;
+      uint32_t *xfW = (uint32_t *)(ldsXf + (size_t)slot * nTransforms * 4u);
+      for (uint32_t t = lane; t < sa.blobWords; t += 64u) {
+        const uint32_t v = __hip_atomic_load(&sa.relay->blob[slot][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < nRot) {
+          rotW[t] = v;
+          const uint32_t q = t >> 2, i = q / 3u, k = q - 3u * i;
+          if (i & 1u) xfW[((i >> 1) * 4u + k) * 4u + (t & 3u)] = v;
+        } else if (t < nRot + nSh) {
+          const uint32_t u = t - nRot, i = u >> 2;
+          shW[u] = v;
+          if (i & 1u) xfW[((i >> 1) * 4u + 3u) * 4u + (u & 3u)] = v;
+        } else {
+          ltW[t - nRot - nSh] = v;
+        }
+      }
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (lane == 0) __hip_atomic_store(&ctl[SC_SAVAIL + slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      /* (the slot's frame cannot change while its view is not here: a rotation needs it) */
     return true;
@@ -188,8 +219,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       if (at < sa.tileListCap) sa.tileLists[((size_t)blockIdx.x * SV_S + slot) * sa.tileListCap + at] = tile;
       else __hip_atomic_fetch_or(sa.error, WF_ERR_LIST, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    const float4 h = primary_tile<false, true>(ab, tile, lane, cnt, lv);
-    const bool runs = shade0_tile<false, true>(ab, tile, lane, h, cnt, lv);
+    const float4 h = primary_tile<false, true, VER>(ab, tile, lane, cnt, lv);
+    const bool runs = shade0_tile<false, true, VER>(ab, tile, lane, h, cnt, lv);
     if (flx_ballot(runs) == 0ull) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");            /* (what the tile's dead pixels stored, before the count) */
       if (lane == 0) atomicSub(&ctl[SC_ALIVE + slot], perTile);
@@ -322,7 +353,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           const long long tb0 = wall_clock64();
           const bool mine = lane < got && id != WF_INVALID;
           statAdd(SVS_BATCHES, 1ull); statAdd(SVS_BATCH_LANES, got);
-          if (mine) shade_path<false, true>(ab, id, cnt, lv);
+          if (mine) shade_path<false, true, VER>(ab, id, cnt, lv);
           const uint32_t slotMine = slotOf(id);
           for (uint32_t sl = 0; sl < depth; sl++) fq_push(ring(RK_WALK, sl), rctl(RK_WALK, sl), mine && slotMine == sl, id, lane);
           tBatch += wall_clock64() - tb0;
@@ -509,7 +540,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         if (st == P_SETUP) {
           const bool shadowMode = w.mode == 0;
           const Ray src = shadowMode ? shadowRay : nextRay;
-          walkSetupRays(sc, nTransforms, ldsXf, myRays, src, shadowMode);
+          walkSetupRays(sc, nTransforms, VER ? ldsXf + (size_t)slotOf(pathId) * nTransforms * 4u : ldsXf, myRays, src, shadowMode);
           w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
           reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);
           st = P_WALKING;
@@ -542,10 +573,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   leave();
 }
 
-bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes) {
+bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes, uint32_t xfSlots) {
   const uint32_t T = sc.n_transforms;
   const uint32_t walkThreads = FLX_WF_WALK_THREADS - 64u * (uint32_t)FLX_SERVER_SHADERS;
-  const uint32_t fixed = walkThreads * T * 40u + T * 64u + (SC_WORDS + SC_VIEW_WORDS) * 4u;
+  const uint32_t fixed = walkThreads * T * 40u + xfSlots * T * 64u + (SC_WORDS + SC_VIEW_WORDS) * 4u;
   if (fixed + 4096u > (uint32_t)FLX_WF_LDS_TOTAL) return false;
   ldsCount = ((uint32_t)FLX_WF_LDS_TOTAL - fixed) / 48u;
   if (ldsCount > sc.walk_hot) ldsCount = sc.walk_hot;
@@ -557,20 +588,24 @@ size_t server_rings_per_group() { return (size_t)SV_RINGS * FQ_SIZE; }
 
 int launch_server(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, const ServerArgs &sa, uint32_t compute_units, hipStream_t stream) {
   uint32_t ldsCount = 0, ldsBytes = 0;
-  if (!server_kernel_fits(sc, ldsCount, ldsBytes)) return -1;
+  const bool ver = sa.blobWords != 0u;                         /* the scene moves: its lights and transforms come with every frame */
   if (sa.depth < 2u || sa.depth > SV_MAX_DEPTH) return -1;
+  if (!server_kernel_fits(sc, ldsCount, ldsBytes, ver ? sa.depth : 1u)) return -1;
+  if (ver && (sa.blobWords > SV_BLOB_WORDS || sa.blobWords != server_blob_words(sc.n_transforms, sc.n_lights))) return -1;
   static std::once_flag once[64];
   static bool ok[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
-  std::call_once(once[dev], [&]() { ok[dev] = hipFuncSetAttribute((const void *)k_wf_server, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; });
+  std::call_once(once[dev], [&]() { ok[dev] = hipFuncSetAttribute((const void *)k_wf_server<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+                                              hipFuncSetAttribute((const void *)k_wf_server<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess; });
   if (!ok[dev]) return -1;
   ServerKernelArgs ka;
   ka.fa.sc = sc; ka.fa.fr = fr; ka.fa.wb = wb; ka.sa = sa;
   const uint32_t tilesPerGroup = sa.tilesPerSlot / compute_units;
   uint32_t readyUnits = tilesPerGroup >= 48u ? (uint32_t)FLX_FRAME_READY_UNITS : tilesPerGroup / 2u;
   readyUnits = readyUnits < (uint32_t)FLX_FRAME_READY_UNITS / 4u ? (uint32_t)FLX_FRAME_READY_UNITS / 4u : (readyUnits > (uint32_t)FLX_FRAME_READY_UNITS ? (uint32_t)FLX_FRAME_READY_UNITS : readyUnits);
-  hipLaunchKernelGGL(k_wf_server, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, (uint32_t)FLX_SERVER_SHADERS, readyUnits);
+  if (ver) hipLaunchKernelGGL(k_wf_server<true>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, (uint32_t)FLX_SERVER_SHADERS, readyUnits);
+  else hipLaunchKernelGGL(k_wf_server<false>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, (uint32_t)FLX_SERVER_SHADERS, readyUnits);
   return 0;
 }
 

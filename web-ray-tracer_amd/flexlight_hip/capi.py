@@ -23,7 +23,7 @@ EXPORTS = [
     "flx_mesh_scale", "flx_mesh_set_material", "flx_mesh_bounding", "flx_mesh_flatten", "flx_transforms_pack", "flx_fxaa_device", "flx_taa_device", "flx_fxaa", "flx_taa", "flx_taa_reset", "flx_present", "flx_present_device",
     "flx_comm_unique_id", "flx_comm_init_rank", "flx_comm_destroy", "flx_render_gathered_device",
     "flx_group_create", "flx_group_destroy", "flx_group_last_error", "flx_group_size", "flx_group_uses_rccl", "flx_group_context",
-    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_get_tail_diag", "flx_set_frame_chain", "flx_last_chained", "flx_debug_inject_fault", "flx_set_chain_stats", "flx_get_chain_stats", "flx_get_server_stats", "flx_get_server_dump", "flx_set_chain_order", "flx_set_chain_cost", "flx_get_chain_cost",
+    "flx_frame_begin", "flx_frame_end", "flx_frames_in_flight", "flx_set_frame_lanes", "flx_set_server_moving_scenes", "flx_server_moving", "flx_get_tail_diag", "flx_set_frame_chain", "flx_last_chained", "flx_debug_inject_fault", "flx_set_chain_stats", "flx_get_chain_stats", "flx_get_server_stats", "flx_get_server_dump", "flx_set_chain_order", "flx_set_chain_cost", "flx_get_chain_cost",
     "flx_render_gathered_root_device", "flx_comm_count", "flx_frame_begin_gathered", "flx_group_set_gather", "flx_frame_host_slots", "flx_has_experiments", "flx_set_wavefront_organisation", "flx_set_frame_front", "flx_last_organisation",
     "flx_group_scene_upload", "flx_group_transforms_upload", "flx_group_lights_upload", "flx_group_atlas_upload", "flx_group_scene_upload_view", "flx_group_render",
     "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
@@ -106,6 +106,8 @@ def _load():
         "flx_frames_in_flight": (C.c_int, [vp]),
         "flx_set_frame_lanes": (C.c_int, [vp, C.c_int]),
         "flx_set_frame_chain": (C.c_int, [vp, C.c_int]),
+        "flx_set_server_moving_scenes": (C.c_int, [vp, C.c_int]),
+        "flx_server_moving": (C.c_int, [vp]),
         "flx_last_chained": (C.c_int, [vp, C.POINTER(C.c_int)]),
         "flx_debug_inject_fault": (C.c_int, [vp, u32, u32]),
         "flx_set_chain_stats": (C.c_int, [vp, C.c_int]),
@@ -314,6 +316,14 @@ class Context:
     def set_frame_chain(self, mode):
         """0 every frame its own launches; 1 a chain of launches (flx_chain.hip); 2 (default) the frame server (flx_server.hip) for thin frames; 3 the server for every frame it takes"""
         self._check(LIB.flx_set_frame_chain(self._h, int(mode)), "flx_set_frame_chain")
+
+    def set_server_moving_scenes(self, on):
+        """1 (default): once the lights / transforms have changed, the frame server takes them with every frame; 0: every changed upload ends its launch"""
+        self._check(LIB.flx_set_server_moving_scenes(self._h, int(bool(on))), "flx_set_server_moving_scenes")
+
+    def server_moving(self):
+        """a launch of the frame server that takes lights and transforms per frame is running"""
+        return bool(LIB.flx_server_moving(self._h))
 
     def frame_server_takes(self, params):
         return bool(LIB.flx_frame_server_takes(self._h, C.byref(params)))
