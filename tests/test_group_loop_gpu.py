@@ -174,14 +174,18 @@ def test_group_loop_hands_out_the_canvas_bytes(pair, hip, oracle, scenes):
     assert np.array_equal(a, want[0]) and np.array_equal(b, oracle.present(hip.render(flt)[0]))
 
 
+@pytest.mark.parametrize("servers", [True, False])
 @pytest.mark.parametrize("rgba8", [False, True])
-def test_group_loop_with_a_scene_that_moves(pair, hip, oracle, scenes, rgba8):
-    """the transforms change before every frame (examples/dragon.js): such frames do not go to the servers — floats run on the contexts' two lanes and their strips are
-    copied into the frame's image when it is taken, the canvas' bytes go through flx_group_render_rgba8 — and the loop goes back to the servers when the scene stands still;
-    every frame equals one context's render with the same arrays"""
+def test_group_loop_with_a_scene_that_moves(pair, hip, oracle, scenes, rgba8, servers):
+    """the transforms change before every frame (examples/dragon.js).  servers: the contexts' launches take the transforms with every frame and go on (flx_server.hip:
+    VER) — the frames still complete ONE image with no exchange.  Not servers (flx_set_server_moving_scenes(0): what a scene whose arrays do not fit a post gets): such
+    frames do not go to the servers — floats run on the contexts' two lanes and their strips are copied into the frame's image when it is taken, the canvas' bytes go
+    through flx_group_render_rgba8 — and the loop goes back to the servers when the scene stands still.  Every frame equals one context's render with the same arrays"""
     sc = scenes("dragon")
     pair.update_scene(sc)
     hip.update_scene(sc)
+    for r in range(2):
+        pair.context(r).set_server_moving_scenes(servers)
     rot0 = np.array(sc.arrays["rotation"], np.float32).reshape(-1, 2, 12)
 
     def arrays(f):
@@ -204,6 +208,8 @@ def test_group_loop_with_a_scene_that_moves(pair, hip, oracle, scenes, rgba8):
             if f in moves:
                 pair.update_transforms(arrays(f), sc.arrays["shift"])
             pair.frame_begin(p, rgba8=rgba8)
+            if f == 5:
+                assert [pair.context(r).server_moving() for r in range(2)] == [servers, servers]
         while pair.frames_in_flight():
             got.append(pair.frame_end()[0])
         last = None

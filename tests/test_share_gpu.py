@@ -24,7 +24,19 @@ def _moving(sc, f, **kw):
     return p
 
 
-def _rank_main(rank, conn, tile_rows, scene_name="dragon"):
+def _turned(sc, f):
+    """the dragon scene's third transform (its monkey) turned, as examples/dragon.js does every tick"""
+    r = np.array(sc.arrays["rotation"], np.float32).reshape(-1, 2, 12).copy()
+    c, s_ = np.cos(0.06 * f), np.sin(0.06 * f)
+    R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]) * 2.0
+    Ri = np.linalg.inv(R)
+    for m, M in ((0, R), (1, Ri)):
+        for col in range(3):
+            r[2, m, 4 * col:4 * col + 3] = M[:, col]
+    return r.reshape(-1)
+
+
+def _rank_main(rank, conn, tile_rows, scene_name="dragon", moves=False):
     """one rank: rank 0 creates the share and sends the handle up; the others receive it from the parent"""
     try:
         from flexlight_hip import capi
@@ -35,7 +47,12 @@ def _rank_main(rank, conn, tile_rows, scene_name="dragon"):
         ctx.set_server_groups(ctx.device_info()[1] // RANKS)
         want = None
         if rank == 0:
-            want = [ctx.render(_moving(sc, f))[0] for f in range(FRAMES)]      # (before any launch of the other rank holds CUs)
+            want = []
+            for f in range(FRAMES):                                           # (before any launch of the other rank holds CUs)
+                if moves and f >= 2:
+                    ctx.update_transforms(_turned(sc, f), sc.arrays["shift"])
+                want.append(ctx.render(_moving(sc, f))[0])
+            ctx.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
             conn.send(ctx.share_create(W, H, LANES, RANKS, 0))
             assert conn.recv() == "go"
         else:
@@ -61,8 +78,11 @@ def _rank_main(rank, conn, tile_rows, scene_name="dragon"):
         for f in range(FRAMES):
             if len(inflight) == LANES:
                 take()
+            if moves and f >= 2:                                              # every rank turns the monkey before the frame: its launch takes the transforms with the frame and goes on
+                ctx.update_transforms(_turned(sc, f), sc.arrays["shift"])
             ctx.frame_begin_shared(_moving(sc, f, tile=(tile_rows, rank, RANKS)))
             assert ctx.last_chained() == (3 if scene_name == "dragon" else 0)      # (a scene of <= 128 entries: the lanes, its strips copied into the image)
+            assert ctx.server_moving() or not (moves and f >= 2)            # (rank 0's scene has moved before the loop: its first launch is of that kind already)
             inflight.append(f)
         while inflight:
             take()
@@ -77,12 +97,13 @@ def _rank_main(rank, conn, tile_rows, scene_name="dragon"):
         conn.send(("error", traceback.format_exc() + repr(e)))
 
 
-@pytest.mark.parametrize("tile_rows,scene_name", [(8, "dragon"), (16, "dragon"), (8, "theater")])
-def test_two_processes_complete_one_image(tile_rows, scene_name):
-    """... the theater (23 entries: not a scene the frame server takes): every rank renders on its two lanes and copies its strips into the root's image when the frame is taken"""
+@pytest.mark.parametrize("tile_rows,scene_name,moves", [(8, "dragon", False), (16, "dragon", False), (8, "theater", False), (8, "dragon", True)])
+def test_two_processes_complete_one_image(tile_rows, scene_name, moves):
+    """... the theater (23 entries: not a scene the frame server takes): every rank renders on its two lanes and copies its strips into the root's image when the frame is taken;
+    moves: every rank uploads changed transforms before every frame from the third on — the ranks' launches take them with the frames"""
     mpc = mp.get_context("spawn")
     pipes = [mpc.Pipe() for _ in range(RANKS)]
-    procs = [mpc.Process(target=_rank_main, args=(r, pipes[r][1], tile_rows, scene_name)) for r in range(RANKS)]
+    procs = [mpc.Process(target=_rank_main, args=(r, pipes[r][1], tile_rows, scene_name, moves)) for r in range(RANKS)]
     for p in procs:
         p.start()
     try:

@@ -20,10 +20,21 @@ def frame(f, shape):
     return p
 lanes, shape = 3, shapes[0]
 ctx.set_frame_lanes(lanes)
-inflight, checked, bad, served, t0 = [], 0, 0, 0, time.time()
+inflight, checked, bad, served, served_moving, t0 = [], 0, 0, 0, 0, time.time()
 f = 0
 ops = []
 lights_gen = 0
+cur_lights = np.array(sc.arrays["lights"], np.float32).copy()
+cur_rot = np.array(sc.arrays["rotation"], np.float32).copy()
+moving = False                                               # a stretch of frames with the monkey turning (and the light flickering) before every frame: the launch takes the arrays per frame
+def turned(f):
+    r = np.array(sc.arrays["rotation"], np.float32).reshape(-1, 2, 12).copy()
+    c, s_ = np.cos(0.013 * f), np.sin(0.013 * f)
+    R = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]) * 2.0
+    Ri = np.linalg.inv(R)
+    for m, M in ((0, R), (1, Ri)):
+        for col in range(3): r[2, m, 4 * col:4 * col + 3] = M[:, col]
+    return r.reshape(-1)
 def fail_dump():
     print('\n'.join(ops[-16:]), flush=True)
 import atexit
@@ -31,6 +42,11 @@ while f < N or inflight:
     r = rnd.random()
     if f < N and len(inflight) < lanes and (r < 0.6 or not inflight):
         p = frame(f, shape)
+        if moving:
+            cur_rot = turned(f); ctx.update_transforms(cur_rot, sc.arrays["shift"])
+            if rnd.random() < 0.5:
+                cur_lights = np.array(sc.arrays["lights"], np.float32).copy(); cur_lights.reshape(-1, 6)[:, 3] *= 1.0 + 0.01 * (f % 50); cur_lights.reshape(-1, 6)[0, 0] += 0.02 * (f % 31)
+                ctx.update_primary_light_sources(cur_lights)
         r8 = rnd.random() < 0.3                              # the canvas' bytes: the launch quantises as it resolves (another format: another launch)
         ops.append('begin %d %dx%d rgba8 %d lanes %d' % (f, p.width, p.height, r8, lanes))
         try:
@@ -38,7 +54,8 @@ while f < N or inflight:
         except capi.FlexLightHipError:
             fail_dump(); raise
         served += ctx.last_chained() == 3
-        inflight.append((f, p, r8, lights_gen))
+        served_moving += ctx.last_chained() == 3 and ctx.server_moving()
+        inflight.append((f, p, r8, (cur_lights.copy(), cur_rot.copy())))
         f += 1
     elif inflight:
         g, p, r8, gen = inflight.pop(0)
@@ -47,8 +64,10 @@ while f < N or inflight:
             got = ctx.frame_end()[0]
         except capi.FlexLightHipError:
             fail_dump(); raise
-        if g % 37 == 0 and not inflight and gen == lights_gen:                     # (the comparison render would end the launch anyway: only when nothing is in flight)
+        if (g % 37 == 0 or (moving and g % 7 == 0)) and not inflight:              # (the comparison render would end the launch anyway: only when nothing is in flight)
+            ctx.update_primary_light_sources(gen[0]); ctx.update_transforms(gen[1], sc.arrays["shift"])      # the arrays the frame was begun with
             want = ctx.render(p)[0]
+            ctx.update_primary_light_sources(cur_lights); ctx.update_transforms(cur_rot, sc.arrays["shift"])
             checked += 1
             ok = np.array_equal(got, ctx.present(want)) if r8 else np.array_equal(got.view(np.uint32), want.view(np.uint32))
             if not ok:
@@ -62,13 +81,17 @@ while f < N or inflight:
     if rnd.random() < 0.006:
         ops.append('shape'); shape = rnd.choice(shapes)                           # frames of another shape: the launch ends, another begins
     if rnd.random() < 0.003:
-        lights_gen += 1; ctx.update_primary_light_sources(sc.arrays["lights"])    # (the scene's own lights: the same again — nothing — unless they had been changed)
+        cur_lights = np.array(sc.arrays["lights"], np.float32).copy(); ctx.update_primary_light_sources(cur_lights)    # (the scene's own lights: the same again — nothing — unless they had been changed)
     if rnd.random() < 0.003:
-        dim = np.array(sc.arrays["lights"], np.float32).copy(); dim.reshape(-1, 6)[:, 3] *= rnd.choice([0.5, 1.0, 2.0])
-        ops.append('lights changed'); lights_gen += 1; ctx.update_primary_light_sources(dim)                # other lights: the launch ends, the frames after are rendered with them (and compared with them)
+        cur_lights = np.array(sc.arrays["lights"], np.float32).copy(); cur_lights.reshape(-1, 6)[:, 3] *= rnd.choice([0.5, 1.0, 2.0])
+        ops.append('lights changed'); ctx.update_primary_light_sources(cur_lights)                # other lights: the frames after are rendered with them (and compared with them)
+    if rnd.random() < 0.004:
+        moving = not moving; ops.append('moving %d' % moving)
+    if rnd.random() < 0.001 and not inflight:
+        ops.append('scene again'); ctx.update_scene(sc); cur_lights = np.array(sc.arrays["lights"], np.float32).copy(); cur_rot = np.array(sc.arrays["rotation"], np.float32).copy()      # the scene uploaded again: it has not moved yet
     if rnd.random() < 0.0005 and inflight:
         ops.append('pause 2.3 s'); time.sleep(2.3)                                      # the host pauses for longer than the launch waits: nothing may be lost
     if rnd.random() < 0.002:
         ops.append('sync render'); ctx.render(frame(f, shapes[3]))                      # a synchronous render while frames are in flight
-print("%d frames (%d through the server) in %.1f s, %d compared with their own render, %d differ" % (N, served, time.time() - t0, checked, bad))
+print("%d frames (%d through the server, %d of them by a launch that takes lights and transforms per frame) in %.1f s, %d compared with their own render, %d differ" % (N, served, served_moving, time.time() - t0, checked, bad))
 sys.exit(1 if bad else 0)

@@ -1598,6 +1598,7 @@ static bool server_continues(flx_context *ctx, const flx_frame_params *params, b
 }
 /* For a device group (flx_group_frame_begin): would flx_frame_begin of this frame have to end or start a launch?  And the memory a launch needs, made while
  * NO launch of the group runs — where contexts share a device, an allocation in one waits for the launch of the other. */
+int flx_server_takes_moving_scene(const flx_context *ctx) { return ctx->sv_want_ver && server_versions_fit(ctx) ? 1 : 0; }
 int flx_server_continues(flx_context *ctx, const flx_frame_params *params) { return server_continues(ctx, params, ctx->sv_target_slots != 0u && ctx->sv_target8) ? 1 : 0; }
 flx_status flx_server_prepare(flx_context *ctx, const flx_frame_params *params) {
   FLX_HIP(ctx, hipSetDevice(ctx->device));

@@ -237,6 +237,7 @@ flx_status flx_make_frame(flx_context *ctx, const flx_frame_params *p, flx::Devi
 flx_status flx_make_batch(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, flx::DeviceScene &sc, flx::DeviceFrame &fr);
 flx_status flx_run_frame(flx_context *ctx, const flx::DeviceScene &sc, const flx::DeviceFrame &fr, float4 *d_out, const flx::GBufferPtrs &gb);
 flx_status flx_ensure_pixels(flx_context *ctx, float4 **buf, size_t *cap, size_t pixels);
+int flx_server_takes_moving_scene(const flx_context *ctx);                       /* the scene has moved and its lights and transforms fit a post: the server's launches take them per frame */
 int flx_server_continues(flx_context *ctx, const flx_frame_params *params);      /* the running launch of the frame server takes this frame as it is */
 flx_status flx_server_prepare(flx_context *ctx, const flx_frame_params *params); /* the launch ends; everything a launch for frames like this needs is allocated */
 flx_status flx_server_stop(flx_context *ctx);      /* the frame server's launch ends (after the frames posted to it), the frames in flight are resolved into their output slots */

@@ -570,10 +570,11 @@ extern "C" flx_status flx_group_frame_begin(flx_group *g, const flx_frame_params
     if (c->frame_lanes != g->lanes && c->fifo_n == 0) c->frame_lanes = g->lanes;
     c->frame_chain = 3;                    /* (every frame the server can take, whatever its size: the target says where it goes; read by flx_frame_begin only) */
     if (!flx_frame_server_takes(c, &p[r])) server = false;
-    /* a scene that changed since the frame before: the servers' launches would end and start again around it (2.4 ms per frame on a rank's eighth of the dragon frame
-     * against 1.4 on two lanes, tools/dynamic_scene_time.py): such a frame does not go to the servers */
+    /* a scene that changed since the frame before: lights and transforms that move travel with the frames of the servers' launches (flx_server.hip: VER); where they
+     * do not fit a post, or something else was uploaded, the launches would end and start again around the frame (2.4 ms per frame on a rank's eighth of the dragon
+     * frame against 1.4 on two lanes, tools/dynamic_scene_time.py): such a frame does not go to the servers */
     if (g->seen_version.size() != (size_t)n) g->seen_version.assign((size_t)n, 0);
-    if (g->seen_version[(size_t)r] != 0 && g->seen_version[(size_t)r] != c->scene_version && format != FLX_FRAME_DEVICE) moved = true;      /* (a frame for context 0's memory stays with the servers) */
+    if (g->seen_version[(size_t)r] != 0 && g->seen_version[(size_t)r] != c->scene_version && format != FLX_FRAME_DEVICE && !flx_server_takes_moving_scene(c)) moved = true;      /* (a frame for context 0's memory stays with the servers) */
     g->seen_version[(size_t)r] = c->scene_version;
   }
   /* ... as floats on the contexts' two lanes (every lane keeps its own copy of the lights and transforms; nothing waits for a GPU here), its strips copied into the frame's
