@@ -48,3 +48,28 @@ for label, lanes, chain, moving in (("frame server, 3 in flight, static scene", 
         best = min(best, (time.perf_counter() - t0) * 1e3 / N)
     print("%-64s %.3f ms per frame%s" % (label, best, "   (launch takes the arrays per frame)" if ctx.server_moving() else ""), flush=True)
 ctx.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+if "--all-ranks" in sys.argv:
+    # every rank's eighth, the monkey turning before every frame: the server (3 and 2 in flight) against the two lanes
+    print("\nall eight ranks of configs[2], transforms change before every frame, ms per frame (wall clock over %d frames, best of 3):" % N)
+    print("rank   server 3 in flight   server 2 in flight   two lanes")
+    rows = []
+    for i in range(8):
+        p.tile_index = i
+        row = []
+        for lanes, chain, on in ((3, 2, 1), (2, 2, 1), (2, 0, 1)):
+            ctx.set_server_moving_scenes(on); ctx.set_frame_lanes(lanes); ctx.set_frame_chain(chain)
+            best = 1e9
+            for rep in range(3):
+                for f in range(N + 6):
+                    if f == 6: t0 = time.perf_counter()
+                    if ctx.frames_in_flight() == lanes: ctx.frame_end()
+                    ctx.update_transforms(rot(f), sc.arrays["shift"])
+                    ctx.frame_begin(p, device=True)
+                while ctx.frames_in_flight(): ctx.frame_end()
+                best = min(best, (time.perf_counter() - t0) * 1e3 / N)
+            row.append(best)
+        rows.append(row)
+        print("%4d   %18.3f   %18.3f   %9.3f" % (i, *row), flush=True)
+    a = np.array(rows)
+    print(" max   %18.3f   %18.3f   %9.3f     (the slowest rank paces the frame)" % tuple(a.max(axis=0)))
+    ctx.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
