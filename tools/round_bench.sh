@@ -19,7 +19,8 @@ import json, sys, glob, os
 for f in sorted(glob.glob(sys.argv[1] + "/bench_*.json")):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1]); r = d["roofline"]
-        print("%-34s %9.1f Mray/s %8.3f ms  pipelined %s  batched %s | %s %.3f ms frac %s lane %s" % (os.path.basename(f), d["value"], d["ms_per_step"],
+        print("%-34s %9.1f Mray/s %8.3f ms (%s)  one at a time %s  pipelined %s  batched %s | %s %.3f ms frac %s lane %s" % (os.path.basename(f), d["value"], d["ms_per_step"], d.get("headline", {}).get("mode", "one_frame_per_pass"),
+              ("%.3f" % d["one_frame_per_pass"]["ms_per_step"]) if d.get("one_frame_per_pass") else "-",
               ("%.3f" % d["pipelined"]["ms_per_frame"]) if d.get("pipelined") else "-", ("%.3f" % d["batched"]["ms_per_frame"]) if d.get("batched") else "-",
               r["kernel"].split(" ")[0], r["kernel_ms"], r["frac"] and round(r["frac"], 3), r["valu_lane_utilisation"] and round(r["valu_lane_utilisation"], 3)))
     except Exception as e:
