@@ -276,6 +276,38 @@ def test_a_scene_that_moves_stays_with_the_server(hip, oracle, scenes, lanes):
         hip.set_frame_lanes(2)
 
 
+def test_a_rank_s_eighth_of_the_baseline_frame_with_the_scene_moving(hip, scenes):
+    """BASELINE configs[2] at full size, tile 3 of 8 (what one of eight GPUs renders), three frames in flight, the monkey turning and the light moving before every
+    frame: one launch takes them all; every frame equals its own flx_render with its own arrays"""
+    import copy
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    hip.set_frame_lanes(3)
+    hip.set_frame_chain(2)
+    try:
+        p = sc.frame_params(use_filter=0, tile=(8, 3, 8))
+        assert (p.width, p.height, p.samples, p.max_reflections) == (1920, 1080, 8, 4)
+        N = 7
+        got = []
+        for f in range(N):
+            if hip.frames_in_flight() == 3:
+                got.append(hip.frame_end()[0].copy())
+            hip.update_transforms(_turned(sc, f + 1), sc.arrays["shift"])
+            hip.update_primary_light_sources(_lit(sc, f + 1))
+            hip.frame_begin(p)
+            assert hip.last_chained() == 3 and (f == 0 or hip.server_moving())
+        while hip.frames_in_flight():
+            got.append(hip.frame_end()[0].copy())
+        for f in range(N):
+            hip.update_transforms(_turned(sc, f + 1), sc.arrays["shift"])
+            hip.update_primary_light_sources(_lit(sc, f + 1))
+            assert bit_mismatches(got[f], hip.render(p)[0]) == 0, f
+    finally:
+        hip.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+        hip.update_primary_light_sources(sc.arrays["lights"])
+        hip.set_frame_lanes(2)
+
+
 def test_a_host_that_pauses_loses_nothing(served, scenes):
     """the launch waits for the host; after two seconds without a word it ends by itself (a safety net: the host normally says when to stop).  An application that
     pauses with frames in flight — all of them complete by then — must find them when it comes back, no error, and the loop goes on with a new launch"""
