@@ -155,8 +155,8 @@ def test_group_frame_loop_through_node(hip, oracle, scenes, tmp_path, move_scene
     """new FlexLight(canvas, { devices: [0, 0] }).renderer.render(): the renderer's frame loop over a GROUP of contexts — flx_group_frame_begin / _end, every
     context's frame server resolving its strips straight into one pinned image, three frames in flight, nothing waits for a GPU inside a frame (round-3 review,
     item 5; pathtracerWGL2.js:191, 254-303).  Frames of a moving camera equal the oracle's frames for their ticks, with the scene's transforms static (the
-    servers' launches live on across the frames: an upload of unchanged lights / transforms is nothing) and with the monkey turning every tick (the launches
-    end and start again at every change of the scene)."""
+    servers' launches live on across the frames: an upload of unchanged lights / transforms is nothing) and with the monkey turning every tick (from the
+    first changed upload on the launches take the transforms with every frame: flx_server.hip, VER)."""
     import copy
     node = shutil.which("node")
     w, h, spp, bounces = 320, 176, 2, 3            # (176 rows: strips of whole 8 x 8 tiles for both contexts — frames the server takes)
