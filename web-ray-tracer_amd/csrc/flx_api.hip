@@ -40,6 +40,9 @@ using namespace flx;
 
 thread_local std::string g_create_error;
 
+#ifndef FLX_PATHS_LOCK_MIN_BOXES
+#define FLX_PATHS_LOCK_MIN_BOXES 0          /* k_paths walks in lockstep from this many boxes on (flx_run_frame): always, since the kernel runs at 4 waves per SIMD (flx_kernels.hip: FLX_PATHS_WAVES) */
+#endif
 flx_status flx_fail(flx_context *ctx, flx_status code, const char *msg) {
   if (ctx) ctx->err = msg;
   return code;
@@ -728,10 +731,11 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     /* persistent grid: enough workgroups to fill every CU at the kernel's occupancy; surplus ones find the queue dry */
     /* The lockstep walk pays where a wave's lanes stand at boxes and at triangles in the same trip of the lane walk.  A nearly flat
-     * tree (the theater: 3 boxes over 20 triangles) has few such trips, and this kernel's seven waves per SIMD hide the lane walk's
-     * fetches: there the lane walk measures 2 % faster (10.70 vs 10.91 ms; cornell.obj, 13 boxes: 1.30 vs 1.19 ms). */
+     * tree (the theater: 3 boxes over 20 triangles) has few such trips, and at seven waves per SIMD — which hide the lane walk's
+     * fetches — the lane walk measured 2 % faster there (round 2: 10.70 vs 10.91 ms).  At the kernel's four waves per SIMD (late round 4) the
+     * lockstep walk wins everywhere: theater 9.13 against 9.54 ms (profiles/r04_paths_occupancy.txt). */
     DeviceScene scPaths = sc;
-    if (ctx->lock_boxes < 8u) scPaths.lock_entries = 0u;
+    if (ctx->lock_boxes < (uint32_t)FLX_PATHS_LOCK_MIN_BOXES) scPaths.lock_entries = 0u;
     launch_paths(scPaths, fr, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue, cus * 8u, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));

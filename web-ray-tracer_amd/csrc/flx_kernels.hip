@@ -211,9 +211,11 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
 }
 
 #ifndef FLX_PATHS_WAVES
-#define FLX_PATHS_WAVES 7                  /* k_paths: 163 VGPRs / 3 waves per SIMD left to itself; theater 1080p 16 spp 6 bounces by waves per SIMD:
-                                            * 11.74 (3) 11.37 (4) 11.14 (5) 10.50 (6) 10.25 (7) 11.04 ms (8) — the shading's latency wants waves more
-                                            * than registers (profiles/r02_ab_occupancy.txt) */
+#define FLX_PATHS_WAVES 4                  /* k_paths: 163 VGPRs / 3 waves per SIMD left to itself.  Theater 1080p 16 spp 6 bounces by waves per SIMD, round 2 (lane walk):
+                                            * 11.74 (3) 11.37 (4) 11.14 (5) 10.50 (6) 10.25 (7) 11.04 ms (8) (profiles/r02_ab_occupancy.txt) — and swept again late in round 4, the
+                                            * kernel leaner by then (profiles/r04_paths_occupancy.txt, one box): lane walk 9.54 (4) 10.31 (5) 10.03 (6) 10.17 ms (7); with the
+                                            * wave's lockstep walk 10.19 (3) 9.13 (4) 9.50 (5) 9.80 (6) 9.92 ms (7): 128 registers and the lockstep walk, which needs no waves to
+                                            * hide a fetch behind */
 #endif
 template <bool COUNT, bool LOCK>
 __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, DeviceFrame fr, const float4 *__restrict__ hits,
