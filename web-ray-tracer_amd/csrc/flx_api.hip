@@ -671,6 +671,23 @@ static flx_status ensure_workspace(flx_context *ctx, const DeviceFrame &fr, int 
   return FLX_OK;
 }
 
+/* sc.angle_tan: the context's per-triangle table, made again first when the geometry, the attributes or this context's transforms were uploaded since it was made */
+static flx_status angle_table(flx_context *ctx, DeviceScene &scT) {
+  scT.angle_tan = nullptr;
+  if (ctx->angle_table && ctx->n_entries != 0u) {
+    const uint64_t key = ((uint64_t)ctx->geometry_version << 32) | ctx->transforms_version;
+    if (key != ctx->angle_key || !ctx->d_angle_tan) {
+      flx_status es = flx_ensure_pixels(ctx, &ctx->d_angle_tan, &ctx->angle_capacity, ctx->n_entries);
+      if (es) return es;
+      launch_angle_tan(scT, ctx->d_angle_tan, ctx->stream);
+      FLX_HIP(ctx, hipGetLastError());
+      ctx->angle_key = key;
+    }
+    scT.angle_tan = ctx->d_angle_tan;
+  }
+  return FLX_OK;
+}
+
 flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFrame &fr, float4 *d_out, const GBufferPtrs &gb) {
   { flx_status ss = flx_server_stop(ctx); if (ss) return ss; }      /* (the frame server renders into the same workspace) */
   ctx->chain_seq = 0;                    /* this frame's kernels use the workspace a chain of frames keeps its state in: the chain ends here */
@@ -708,18 +725,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     /* the per-triangle table of the shading (DeviceScene::angle_tan; read by this kernel only): made again, on this context's stream and so in front of the
      * launch, when the geometry, the attributes or this context's transforms were uploaded since it was made */
     DeviceScene scT = sc;
-    scT.angle_tan = nullptr;
-    if (ctx->angle_table && ctx->n_entries != 0u) {
-      const uint64_t key = ((uint64_t)ctx->geometry_version << 32) | ctx->transforms_version;
-      if (key != ctx->angle_key || !ctx->d_angle_tan) {
-        flx_status es = flx_ensure_pixels(ctx, &ctx->d_angle_tan, &ctx->angle_capacity, ctx->n_entries);
-        if (es) return es;
-        launch_angle_tan(scT, ctx->d_angle_tan, ctx->stream);
-        FLX_HIP(ctx, hipGetLastError());
-        ctx->angle_key = key;
-      }
-      scT.angle_tan = ctx->d_angle_tan;
-    }
+    { flx_status es = angle_table(ctx, scT); if (es) return es; }
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
     launch_trace_pixels(scT, fr, d_out, gb, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());
@@ -735,6 +741,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
      * fetches — the lane walk measured 2 % faster there (round 2: 10.70 vs 10.91 ms).  At the kernel's four waves per SIMD (late round 4) the
      * lockstep walk wins everywhere: theater 9.13 against 9.54 ms (profiles/r04_paths_occupancy.txt). */
     DeviceScene scPaths = sc;
+    if (FLX_PATHS_ANGLE_TABLE) { flx_status es = angle_table(ctx, scPaths); if (es) return es; }
     if (ctx->lock_boxes < (uint32_t)FLX_PATHS_LOCK_MIN_BOXES) scPaths.lock_entries = 0u;
     launch_paths(scPaths, fr, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue, cus * 8u, cnt, ctx->stream);
     FLX_HIP(ctx, hipGetLastError());

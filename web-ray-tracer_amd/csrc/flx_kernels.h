@@ -4,6 +4,10 @@
 
 #include "flx_device.h"
 
+#ifndef FLX_PATHS_ANGLE_TABLE
+#define FLX_PATHS_ANGLE_TABLE 1        /* k_paths reads the shading's per-triangle table too (DeviceScene::angle_tan): at the seven waves per SIMD it ran at first the table's dependent load cost it 1 %,
+                                        * at four it gains 5 % — theater 9.29 -> 8.80 ms (profiles/r04_paths_occupancy.txt) */
+#endif
 namespace flx {
 
 struct GBufferPtrs {

@@ -10,7 +10,7 @@
  * 10.22 -> 10.10 ms, cornell.obj filter frame 1.055 -> 1.021 ms); the wavefront pipeline's dense shade kernels keep the selects
  * (dragon 8.07 against 8.18 ms with the table) */
 #define FLX_SINCOS_TABLE 1
-#define FLX_ANGLE_TABLE 1                  /* k_trace_pixels reads the per-triangle table (flx_device.h); k_paths sets the pointer to null for itself */
+#define FLX_ANGLE_TABLE 1                  /* k_trace_pixels and k_paths read the per-triangle table (flx_device.h; k_paths: FLX_PATHS_ANGLE_TABLE) */
 #include "flx_kernels.h"
 #include "flx_kernel_util.h"
 
@@ -222,10 +222,9 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
                                                float4 *__restrict__ sampleRadiance, float4 *__restrict__ lastOriginal,
                                                uint32_t *__restrict__ queue, uint32_t total_items,
                                                unsigned long long *__restrict__ counters) {
-  /* this kernel's shading computes the per-triangle angle terms itself (the table's load is one more dependent fetch in a kernel that hides its latencies with waves, and its
-   * arithmetic runs beside them: theater 9.96 ms without the table, 10.03 with it, tools/angle_table_time.py / profiles/r04_angle_table.txt); a constant here, so the
-   * other branch is not compiled into it */
-  sc.angle_tan = nullptr;
+  /* (round 4 at first: this kernel's shading computed the per-triangle angle terms itself — at seven waves per SIMD the table's load was one more dependent fetch in a kernel that hid
+   * its latencies with waves: theater 9.96 ms without the table, 10.03 with it, profiles/r04_angle_table.txt.  At four waves per SIMD the arithmetic saved counts: flx_kernels.h) */
+  if (!FLX_PATHS_ANGLE_TABLE) sc.angle_tan = nullptr;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t S = (uint32_t)fr.samples;
   const size_t P = (size_t)fr.rows * fr.width;
