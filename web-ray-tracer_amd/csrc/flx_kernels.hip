@@ -20,11 +20,14 @@
 
 namespace flx {
 
+#ifndef FLX_TRACE_BLOCK
+#define FLX_TRACE_BLOCK 256                /* threads of a k_trace_pixels workgroup: 256 = a 16 x 16 pixel tile, 64 = one of its four 8 x 8 quarters per workgroup (A/B) */
+#endif
 __device__ __forceinline__ void tile_pixel(const DeviceFrame &fr, uint32_t &px, uint32_t &k) {
   const uint32_t tiles_x = (fr.width + 15u) >> 4;
-  const uint32_t tile = blockIdx.x;
+  const uint32_t tile = FLX_TRACE_BLOCK == 256 ? blockIdx.x : blockIdx.x >> 2;
   const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
-  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+  const uint32_t wave = FLX_TRACE_BLOCK == 256 ? threadIdx.x >> 6 : blockIdx.x & 3u, lane = threadIdx.x & 63u;
   px = (tx << 4) + ((wave & 1u) << 3) + (lane & 7u);
   k = (ty << 4) + ((wave >> 1) << 3) + (lane >> 3);
 }
@@ -40,7 +43,7 @@ __device__ __forceinline__ void tile_pixel(const DeviceFrame &fr, uint32_t &px, 
                                             * 1080p 8 spp 4 bounces filter frame 15.26 (4) 14.24 (5) 13.68 ms (6) */
 #endif
 template <bool COUNT, bool LOCK>
-__global__ __launch_bounds__(256, LOCK ? FLX_TRACE_WAVES : FLX_TRACE_WAVES_BIG) void k_trace_pixels(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
+__global__ __launch_bounds__(FLX_TRACE_BLOCK, LOCK ? FLX_TRACE_WAVES : FLX_TRACE_WAVES_BIG) void k_trace_pixels(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
                                                       unsigned long long *__restrict__ counters) {
   uint32_t px, k;
   tile_pixel(fr, px, k);
@@ -148,11 +151,11 @@ void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *o
   const uint32_t tiles = ((fr.width + 15u) >> 4) * ((fr.rows + 15u) >> 4);
   const bool lock = FLX_LOCKSTEP && sc.lock_entries != 0u;      /* small scene in one object space: the variant with the wave-wide walk */
   if (lock) {
-    if (counters) hipLaunchKernelGGL((k_trace_pixels<true, true>), dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
-    else hipLaunchKernelGGL((k_trace_pixels<false, true>), dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+    if (counters) hipLaunchKernelGGL((k_trace_pixels<true, true>), dim3(tiles * (256u / FLX_TRACE_BLOCK)), dim3(FLX_TRACE_BLOCK), 0, stream, sc, fr, out, gb, counters);
+    else hipLaunchKernelGGL((k_trace_pixels<false, true>), dim3(tiles * (256u / FLX_TRACE_BLOCK)), dim3(FLX_TRACE_BLOCK), 0, stream, sc, fr, out, gb, counters);
   } else {
-    if (counters) hipLaunchKernelGGL((k_trace_pixels<true, false>), dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
-    else hipLaunchKernelGGL((k_trace_pixels<false, false>), dim3(tiles), dim3(256), 0, stream, sc, fr, out, gb, counters);
+    if (counters) hipLaunchKernelGGL((k_trace_pixels<true, false>), dim3(tiles * (256u / FLX_TRACE_BLOCK)), dim3(FLX_TRACE_BLOCK), 0, stream, sc, fr, out, gb, counters);
+    else hipLaunchKernelGGL((k_trace_pixels<false, false>), dim3(tiles * (256u / FLX_TRACE_BLOCK)), dim3(FLX_TRACE_BLOCK), 0, stream, sc, fr, out, gb, counters);
   }
 }
 
