@@ -99,6 +99,23 @@ __device__ __forceinline__ bool texel_of_thread(int W, int H, int &x, int &y_gl)
   return x < W && row < H;
 }
 
+/* The first filter's workgroup: its 37 taps are gathers of one texel per lane, up to 42 texels away — what a gather costs is the number of 128-byte lines the wave's 64 texels lie
+ * in, so its waves are 32 x 2 texels (two lines per gather) instead of the 16 x 4 of the other kernels (four half lines).  FLX_FILTER_FIRST_SHAPE: 0 = 16 x 16 workgroup of
+ * 16 x 4 waves, 1 = 64 x 4 workgroup of 64 x 1 waves, 2 = 32 x 8 workgroup of 32 x 2 waves: the cornell.obj filter frame 0.930 (0) 0.915 (1) 0.910 ms (2), 5 us per pass
+ * (profiles/r04_paths_occupancy.txt; taps in flight: 8 stays — 4: 0.940, 13: 0.951). */
+#ifndef FLX_FILTER_FIRST_SHAPE
+#define FLX_FILTER_FIRST_SHAPE 2
+#endif
+constexpr int FF_W = FLX_FILTER_FIRST_SHAPE == 1 ? 64 : FLX_FILTER_FIRST_SHAPE == 2 ? 32 : 16, FF_H = 256 / FF_W;
+__device__ __forceinline__ bool texel_of_thread_first(int W, int H, int &x, int &y_gl) {
+  const int tiles_x = (W + FF_W - 1) / FF_W;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  x = tx * FF_W + (int)(threadIdx.x % FF_W);
+  const int row = ty * FF_H + (int)(threadIdx.x / FF_W);
+  y_gl = H - 1 - row;
+  return x < W && row < H;
+}
+
 /* a float4 plane of the path-trace pass -> the RGBA8 target it renders into */
 __global__ __launch_bounds__(256) void k_quantize(const float4 *__restrict__ src, uint32_t *__restrict__ dst, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -167,7 +184,7 @@ __global__ __launch_bounds__(256) void k_temporal(TemporalRings r, int W, int H,
 __global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, uint32_t *dColor, uint32_t *dIp,
                                                       uint32_t *dId, int W, int H) {
   int x, y;
-  if (!texel_of_thread(W, H, x, y)) return;
+  if (!texel_of_thread_first(W, H, x, y)) return;
   const f4 centerColor = unpack(fetchRaw(tColor, W, H, x, y));
   const uint32_t rCenterIp = fetchRaw(tIp, W, H, x, y), rCenterOColor = fetchRaw(tOColor, W, H, x, y);
   const uint32_t rCenterId = fetchRaw(tId, W, H, x, y), rCenterOId = fetchRaw(tOId, W, H, x, y);
@@ -216,7 +233,10 @@ __global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex t
     const size_t centre = (size_t)(H - 1 - y) * W + x;
     const uint32_t *pId = tId.p ? tId.p : tColor.p, *pOId = tOId.p ? tOId.p : tColor.p, *pIp = tIp.p ? tIp.p : tColor.p;      /* (tColor is always bound) */
     const uint32_t mId = tId.p ? ~0u : 0u, mOId = tOId.p ? ~0u : 0u, mIp = tIp.p ? ~0u : 0u;
-    constexpr int CH = 8;
+#ifndef FLX_FILTER_FIRST_CH
+#define FLX_FILTER_FIRST_CH 8
+#endif
+    constexpr int CH = FLX_FILTER_FIRST_CH;
     for (int base = 0; base < 37; base += CH) {
       size_t at[CH]; bool in[CH], pass[CH];
       uint32_t id[CH], oid[CH], rc[CH], rip[CH];
@@ -503,7 +523,7 @@ void launch_filter_chain(const FilterPlanes &pl, float4 *out, int W, int H, int 
     if (3 <= i - 2) third = pl.O[npOriginal];
     else if (np < 2) third = pl.Id[np];                       /* IdRenderTexture[2], [3] do not exist: output dropped */
     Tex tColor = { pl.R[cur] }, tIp = { pl.Ip[cur] }, tOColor = { pl.O[nOriginal] }, tId = { pl.Id[nId] }, tOId = { pl.OId };
-    if (cur < 2) hipLaunchKernelGGL(k_filter_first, grid, block, 0, stream, tColor, tIp, tOColor, tId, tOId, pl.R[np], pl.Ip[np], third, W, H);
+    if (cur < 2) hipLaunchKernelGGL(k_filter_first, dim3(((W + FF_W - 1) / FF_W) * ((H + FF_H - 1) / FF_H)), block, 0, stream, tColor, tIp, tOColor, tId, tOId, pl.R[np], pl.Ip[np], third, W, H);
     else hipLaunchKernelGGL(k_filter_second, grid, block, 0, stream, tColor, tIp, tOColor, tId, tOId, pl.R[np], pl.Ip[np], third, W, H);
     cur = np;
     if (3 <= i) nOriginal = npOriginal; else nId = np;
