@@ -308,6 +308,62 @@ def test_a_rank_s_eighth_of_the_baseline_frame_with_the_scene_moving(hip, scenes
         hip.set_frame_lanes(2)
 
 
+def test_what_else_reads_the_arrays_beside_a_launch_that_takes_them_per_frame(hip, scenes):
+    """uploads beside such a launch touch only the host's copies; the device's arrays follow when the launch ends — before a synchronous render with yet other
+    transforms, before the per-pixel kernel's table of a filter frame, across flx_sync; and a context is destroyed with such frames in flight"""
+    from flexlight_hip import capi
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    hip.set_frame_lanes(3)
+    hip.set_frame_chain(2)
+    try:
+        p = sc.frame_params(use_filter=0, width=640, height=360, tile=(8, 1, 2))
+        for f in range(3):
+            hip.update_transforms(_turned(sc, f + 1), sc.arrays["shift"])
+            hip.frame_begin(p)
+        assert hip.server_moving() and hip.frames_in_flight() == 3
+        hip.sync()                                                       # flx_sync in mid-loop: the frames are complete, and handed out as usual
+        got = [hip.frame_end()[0].copy() for _ in range(3)]
+        for f in range(3):
+            hip.update_transforms(_turned(sc, f + 1), sc.arrays["shift"])
+            assert bit_mismatches(got[f], hip.render(p)[0]) == 0, f
+        for f in range(2):
+            hip.update_transforms(_turned(sc, 10 + f), sc.arrays["shift"])
+            hip.frame_begin(p)
+        hip.update_transforms(_turned(sc, 20), sc.arrays["shift"])       # (beside the launch: the host's copy only)
+        want20 = hip.render(p)[0].copy()                                 # ends the launch; renders with the transforms of the LAST upload
+        g = [hip.frame_end()[0].copy() for _ in range(2)]
+        hip.update_scene(sc)
+        hip.update_transforms(_turned(sc, 20), sc.arrays["shift"])
+        assert bit_mismatches(want20, hip.render(p)[0]) == 0
+        for f in range(2):
+            hip.update_transforms(_turned(sc, 10 + f), sc.arrays["shift"])
+            assert bit_mismatches(g[f], hip.render(p)[0]) == 0, f
+        pf = sc.frame_params(use_filter=1, width=320, height=200)
+        for f in range(3):
+            hip.update_transforms(_turned(sc, 30 + f), sc.arrays["shift"])
+            hip.frame_begin(p)
+        a = hip.render(pf)[0].copy()                                     # the per-pixel kernel's table: made from the transforms of the last upload
+        while hip.frames_in_flight():
+            hip.frame_end()
+        hip.set_angle_table(0)
+        b = hip.render(pf)[0].copy()
+        hip.set_angle_table(1)
+        assert bit_mismatches(a, b) == 0
+        other = capi.Context(0)
+        other.update_scene(sc)
+        other.set_frame_lanes(3)
+        other.set_server_groups(other.device_info()[1] // 2)
+        for f in range(3):
+            other.update_transforms(_turned(sc, 40 + f), sc.arrays["shift"])
+            other.frame_begin(p)
+        assert other.server_moving()
+        other.close()                                                    # with three such frames in flight
+    finally:
+        hip.update_transforms(sc.arrays["rotation"], sc.arrays["shift"])
+        hip.set_frame_lanes(2)
+
+
 def test_a_host_that_pauses_loses_nothing(served, scenes):
     """the launch waits for the host; after two seconds without a word it ends by itself (a safety net: the host normally says when to stop).  An application that
     pauses with frames in flight — all of them complete by then — must find them when it comes back, no error, and the loop goes on with a new launch"""
