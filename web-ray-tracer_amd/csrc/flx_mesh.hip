@@ -149,7 +149,7 @@ std::unique_ptr<Node> split(flx_mesh &m, std::unique_ptr<Node> objs, int depth, 
     for (auto &c : objs->children) if (!fitsInBound(upper, c->bounding) && !fitsInBound(lower, c->bounding)) n += 1;
     if (fewest >= n && room > minWidth) { axis = a; fewest = n; }
   }
-  if (fewest == INFINITY) return objs;                /* "OPTIMIZATION failed for subtree": left as it is */
+  if (fewest == INFINITY) return objs;                /* no axis splits it: the subtree stays a flat list (modules/scene.js:128-132) */
   double b0[6], b1[6];
   std::memcpy(b0, bb, sizeof b0); std::memcpy(b1, bb, sizeof b1);
   b0[axis * 2] = centre[axis];

@@ -402,8 +402,8 @@ class Scene {
         if (fewest >= n && room > minWidth) { axis = a; fewest = n; }
       }
       if (fewest === Infinity) {
-        console.error('OPTIMIZATION failed for subtree!', objs.length);
-        console.log(tried);
+        // no axis splits this subtree (every candidate plane leaves no room): it stays a flat list, as in the reference (modules/scene.js:128-132, which also logs it)
+        console.warn('flexlight-hip: BVH builder keeps a subtree of ' + objs.length + ' primitives flat (straddlers per axis: ' + tried.join(', ') + ')');
         return objs;
       }
       const bounds = [bb, bb.concat(), bb.concat()];           // bucket 0 shares (and narrows) the parent's array, like the reference
