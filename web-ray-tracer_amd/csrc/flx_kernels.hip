@@ -220,17 +220,30 @@ __global__ __launch_bounds__(256) void k_primary(DeviceScene sc, DeviceFrame fr,
                                             * wave's lockstep walk 10.19 (3) 9.13 (4) 9.50 (5) 9.80 (6) 9.92 ms (7): 128 registers and the lockstep walk, which needs no waves to
                                             * hide a fetch behind */
 #endif
+/* FLX_PATHS_KERNARG: the scene and the frame stay in the kernarg segment and are read where they are used (what flx_frame_common.h does for the frame kernels: by-value structs are
+ * loaded whole at the kernel's entry and kept — here 83 spilled scalar registers, 182 lane reads / writes in the bounce loop) */
+#ifndef FLX_PATHS_KERNARG
+#define FLX_PATHS_KERNARG 0
+#endif
+struct PathsArgs { DeviceScene sc; DeviceFrame fr; };
+typedef const __attribute__((address_space(4))) PathsArgs *PathsArgsP;
+__device__ __forceinline__ const PathsArgs &paths_args(PathsArgsP p) { asm volatile("" : "+s"(p)); return *(const PathsArgs *)p; }
+#if FLX_PATHS_KERNARG
+#define PATHS_ARGS() const PathsArgs &PA_ = paths_args((PathsArgsP)__builtin_amdgcn_kernarg_segment_ptr()); const DeviceScene &sc = PA_.sc; const DeviceFrame &fr = PA_.fr; (void)sc; (void)fr
+#else
+#define PATHS_ARGS() const DeviceScene &sc = pa.sc; const DeviceFrame &fr = pa.fr; (void)sc; (void)fr
+#endif
 template <bool COUNT, bool LOCK>
-__global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, DeviceFrame fr, const float4 *__restrict__ hits,
+__global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(PathsArgs pa /* the kernel's FIRST parameter: offset 0 of the kernarg segment */, const float4 *__restrict__ hits,
                                                float4 *__restrict__ sampleRadiance, float4 *__restrict__ lastOriginal,
                                                uint32_t *__restrict__ queue, uint32_t total_items,
                                                unsigned long long *__restrict__ counters) {
   /* (round 4 at first: this kernel's shading computed the per-triangle angle terms itself — at seven waves per SIMD the table's load was one more dependent fetch in a kernel that hid
    * its latencies with waves: theater 9.96 ms without the table, 10.03 with it, profiles/r04_angle_table.txt.  At four waves per SIMD the arithmetic saved counts: flx_kernels.h) */
-  if (!FLX_PATHS_ANGLE_TABLE) sc.angle_tan = nullptr;
+  if (!FLX_PATHS_ANGLE_TABLE && !FLX_PATHS_KERNARG) pa.sc.angle_tan = nullptr;
   const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t S = (uint32_t)fr.samples;
-  const size_t P = (size_t)fr.rows * fr.width;
+  uint32_t S; size_t P;
+  { PATHS_ARGS(); S = (uint32_t)fr.samples; P = (size_t)fr.rows * fr.width; }
   f3 camera = F3(0.0f, 0.0f, 0.0f);             /* of the frame the lane's path belongs to */
   uint32_t frameIdx = 0;
   WorkCounters cnt = {};
@@ -244,6 +257,7 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
   uint32_t chunkNext = 0, chunkEnd = 0;      /* wave-uniform */
   bool itemsLeft = true;                     /* wave-uniform */
   auto finishPath = [&]() {                  /* fragment:598 + what main() needs from the last sample */
+    PATHS_ARGS();
     const f3 r = p.finalColor + p.importancyFactor * frame_ambient(fr, frameIdx);
     sampleRadiance[slot] = make_float4(r.x, r.y, r.z, 1.0f);
     if (sampleIdx == S - 1u)
@@ -255,6 +269,7 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
     for (;;) {
       const unsigned long long idle = __ballot(!alive);
       if (idle == 0ull) break;
+      PATHS_ARGS();
       if (chunkNext == chunkEnd) {
         if (!itemsLeft) break;
         uint32_t base = 0;
@@ -313,6 +328,7 @@ __global__ __launch_bounds__(256, FLX_PATHS_WAVES) void k_paths(DeviceScene sc, 
 
     /* -- one bounce for every live lane (fragment:475-596) ------------------------------------------ */
     if (alive) {
+      PATHS_ARGS();
       bool cont = bounce<COUNT, LOCK>(sc, fr, ps, p, camera, cosSampleN, bounceIdx, cnt);
       bounceIdx++;
       if (cont) cont = bounceIdx < fr.max_reflections && length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3;
@@ -367,12 +383,15 @@ void launch_paths(const DeviceScene &sc, const DeviceFrame &fr, const float4 *hi
                   uint32_t *queue, uint32_t blocks, unsigned long long *counters, hipStream_t stream) {
   const uint32_t total = path_item_count(fr);
   const bool lock = FLX_LOCKSTEP && sc.lock_entries != 0u;
+  PathsArgs pa;
+  pa.sc = sc; pa.fr = fr;
+  if (FLX_PATHS_KERNARG && !FLX_PATHS_ANGLE_TABLE) pa.sc.angle_tan = nullptr;
   if (lock) {
-    if (counters) hipLaunchKernelGGL((k_paths<true, true>), dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
-    else hipLaunchKernelGGL((k_paths<false, true>), dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+    if (counters) hipLaunchKernelGGL((k_paths<true, true>), dim3(blocks), dim3(256), 0, stream, pa, hits, sampleRadiance, lastOriginal, queue, total, counters);
+    else hipLaunchKernelGGL((k_paths<false, true>), dim3(blocks), dim3(256), 0, stream, pa, hits, sampleRadiance, lastOriginal, queue, total, counters);
   } else {
-    if (counters) hipLaunchKernelGGL((k_paths<true, false>), dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
-    else hipLaunchKernelGGL((k_paths<false, false>), dim3(blocks), dim3(256), 0, stream, sc, fr, hits, sampleRadiance, lastOriginal, queue, total, counters);
+    if (counters) hipLaunchKernelGGL((k_paths<true, false>), dim3(blocks), dim3(256), 0, stream, pa, hits, sampleRadiance, lastOriginal, queue, total, counters);
+    else hipLaunchKernelGGL((k_paths<false, false>), dim3(blocks), dim3(256), 0, stream, pa, hits, sampleRadiance, lastOriginal, queue, total, counters);
   }
 }
 
