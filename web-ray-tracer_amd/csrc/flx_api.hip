@@ -1504,6 +1504,7 @@ static flx_status server_take(flx_context *ctx, int k);
 static flx_status dyn_flush(flx_context *ctx) {
   const uint32_t stale = ctx->dyn_device_stale;
   if (!stale || ctx->sv_running) return FLX_OK;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));      /* (a group ends its contexts' launches one after the other from one thread) */
   ctx->dyn_device_stale = 0u;
   flx_status s;
   const uint64_t sv = ctx->scene_version, dv = ctx->dyn_version;
