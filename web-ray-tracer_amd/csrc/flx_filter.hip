@@ -12,6 +12,7 @@
  * pass sit in the XCD L2s / Infinity Cache; taps are 4-byte gathers, neighbouring threads hit the
  * same cache lines.  Threads are mapped 16x16 to keep a workgroup's taps together.
  */
+#include <type_traits>
 #include "flx_kernels.h"
 #include "flx_kernel_util.h"
 
@@ -107,6 +108,19 @@ __device__ __forceinline__ bool texel_of_thread(int W, int H, int &x, int &y_gl)
 #define FLX_FILTER_FIRST_SHAPE 2
 #endif
 constexpr int FF_W = FLX_FILTER_FIRST_SHAPE == 1 ? 64 : FLX_FILTER_FIRST_SHAPE == 2 ? 32 : 16, FF_H = 256 / FF_W;
+/* The first filter's taps lie (int)(stencil x k^2 x 3.5) texels from the centre, stencil in -3 .. 3, k = 1 + originalColor.w in 1 .. 2: up to 42 texels — but on a frame like
+ * BASELINE configs[1] the median k of the pixels that have taps is 1.10 (12 texels) and a quarter of them sit at k = 2.  FLX_FILTER_FIRST_LDS: a workgroup that has pixels whose
+ * taps stay within FF_HALO texels stages its four planes with that halo in LDS once (coalesced rows) and those pixels take their 37 x 4 gathers from there; the others gather
+ * from memory as before.  Same values, same order of the sums. */
+/* MEASURED AND OFF (profiles/r04_paths_occupancy.txt): the cornell.obj filter frame 0.914 -> 0.99 - 1.00 ms whatever the share of workgroups that stage (FLX_FILTER_FIRST_LDS_MIN 32 .. 224) —
+ * the 31.5 KB of LDS per workgroup cost the waves that hide the far gathers' latency; the near gathers were mostly cache hits already. */
+#ifndef FLX_FILTER_FIRST_LDS
+#define FLX_FILTER_FIRST_LDS 0
+#endif
+#ifndef FLX_FILTER_FIRST_LDS_MIN
+#define FLX_FILTER_FIRST_LDS_MIN 96
+#endif
+constexpr int FF_HALO = 13, FF_TW = FF_W + 2 * FF_HALO, FF_TH = FF_H + 2 * FF_HALO;
 __device__ __forceinline__ bool texel_of_thread_first(int W, int H, int &x, int &y_gl) {
   const int tiles_x = (W + FF_W - 1) / FF_W;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -180,11 +194,81 @@ __global__ __launch_bounds__(256) void k_temporal(TemporalRings r, int W, int H,
   }
 }
 
+#ifndef FLX_FILTER_FIRST_CH
+#define FLX_FILTER_FIRST_CH 8
+#endif
+/* the 37 taps of one texel (k_filter_first), TILE: from the workgroup's staged planes */
+struct FirstTapsIn {
+  const uint32_t *pId, *pOId, *pIp, *pColor;
+  uint32_t mId, mOId, mIp;
+  size_t centre;
+  int x, y, W, H, x0, r0;
+  float k;
+  uint32_t rCenterId, rCenterOId;
+  int centerLightNum, centerShadow;
+};
+template <bool TILE, typename TILES>
+__device__ __forceinline__ void first_filter_taps(const FirstTapsIn &t, const TILES &ftile, f4 &color, float &count) {
+  const int x = t.x, y = t.y, W = t.W, H = t.H, x0 = t.x0, r0 = t.r0;
+  const float k = t.k;
+  const size_t centre = t.centre;
+  const uint32_t *pId = t.pId, *pOId = t.pOId, *pIp = t.pIp;
+  const uint32_t mId = t.mId, mOId = t.mOId, mIp = t.mIp, rCenterId = t.rCenterId, rCenterOId = t.rCenterOId;
+  const int centerLightNum = t.centerLightNum, centerShadow = t.centerShadow;
+  (void)x0; (void)r0; (void)ftile;
+  constexpr int CH = FLX_FILTER_FIRST_CH;
+  for (int base = 0; base < 37; base += CH) {
+    size_t at[CH]; bool in[CH], pass[CH];
+    uint32_t id[CH], oid[CH], rc[CH], rip[CH];
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+      const int i = base + j < 37 ? base + j : 36;
+      const int cx = x + (int)(STENCIL3_37[i][0] * k * k * 3.5f);
+      const int cy = y + (int)(STENCIL3_37[i][1] * k * k * 3.5f);
+      in[j] = base + j < 37 && cx >= 0 && cy >= 0 && cx < W && cy < H;
+#if FLX_FILTER_FIRST_LDS
+      if constexpr (TILE) {                               /* (a tap outside the image: the centre's place in the tile, its value is not used) */
+        at[j] = in[j] ? (size_t)((H - 1 - cy) - r0) * FF_TW + (size_t)(cx - x0) : (size_t)((H - 1 - y) - r0) * FF_TW + (size_t)(x - x0);
+        id[j] = ftile[0][at[j]]; oid[j] = ftile[1][at[j]];
+      } else
+#endif
+      {
+        at[j] = in[j] ? (size_t)(H - 1 - cy) * W + cx : centre;
+        id[j] = pId[at[j]]; oid[j] = pOId[at[j]];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; j++) {
+      const uint32_t idj = in[j] ? id[j] & mId : 0u, oidj = in[j] ? oid[j] & mOId : 0u;
+      const int idW = (int)rawW(idj);
+      pass[j] = base + j < 37 && rawEq3(rCenterId, idj) && rCenterOId == oidj && (centerLightNum != idW / 2 || centerShadow == idW % 2);
+#if FLX_FILTER_FIRST_LDS
+      if constexpr (TILE) { rc[j] = ftile[2][at[j]]; rip[j] = ftile[3][at[j]]; } else
+#endif
+      {
+        const size_t a = pass[j] ? at[j] : centre;
+        rc[j] = t.pColor[a]; rip[j] = pIp[a];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CH; j++) if (pass[j]) {
+      const f4 nextColor = unpack(in[j] ? rc[j] : 0u);
+      const f4 nextColorIp = unpack(in[j] ? rip[j] & mIp : 0u);
+      color = add4(color, add4(nextColor, scale4(nextColorIp, 256.0f)));
+      count += 1.0f;
+    }
+  }
+}
+
 /* pathtracer_first_filter.glsl:18-123 */
 __global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex tOColor, Tex tId, Tex tOId, uint32_t *dColor, uint32_t *dIp,
                                                       uint32_t *dId, int W, int H) {
   int x, y;
-  if (!texel_of_thread_first(W, H, x, y)) return;
+  const bool inside = texel_of_thread_first(W, H, x, y);
+  if (!FLX_FILTER_FIRST_LDS && !inside) return;              /* (with the tile every thread of the workgroup reaches the barriers; fetchRaw() gives 0 outside the image) */
+#if FLX_FILTER_FIRST_LDS
+  __shared__ uint32_t ftile[4][FF_TW * FF_TH];               /* id, original id, colour, colour's integer part: the workgroup's texels and FF_HALO around them */
+#endif
   const f4 centerColor = unpack(fetchRaw(tColor, W, H, x, y));
   const uint32_t rCenterIp = fetchRaw(tIp, W, H, x, y), rCenterOColor = fetchRaw(tOColor, W, H, x, y);
   const uint32_t rCenterId = fetchRaw(tId, W, H, x, y), rCenterOId = fetchRaw(tOId, W, H, x, y);
@@ -220,51 +304,52 @@ __global__ __launch_bounds__(256) void k_filter_first(Tex tColor, Tex tIp, Tex t
     rRenderId = idNumber == 0 ? ids[0] : idNumber == 1 ? ids[1] : idNumber == 2 ? ids[2] : ids[3];
     renderColorIp.w = flx_max(1.0f - flx_sign((float)maxVote), 0.0f);
   }
-  if (rawW(rCenterOColor) == 0u) {
+  const bool wantTaps = inside && rawW(rCenterOColor) != 0u;
+  const float k = 1.0f + unorm8(rawW(rCenterOColor));
+#if FLX_FILTER_FIRST_LDS
+  /* (the farthest tap: |stencil| = 3; the same float expression as the taps', monotone in |stencil|) */
+  bool small = wantTaps && (int)(3.0f * k * k * 3.5f) <= FF_HALO;
+  const int tilesX = (W + FF_W - 1) / FF_W;
+  const int x0 = (int)(blockIdx.x % tilesX) * FF_W - FF_HALO, r0 = (int)(blockIdx.x / tilesX) * FF_H - FF_HALO;      /* the tile's first column and first memory row */
+  /* (staging costs ~31 loads per thread: it pays from FLX_FILTER_FIRST_LDS_MIN texels with near taps on) */
+  const bool staged = __syncthreads_count(small) >= FLX_FILTER_FIRST_LDS_MIN;
+  small = small && staged;
+  if (staged) {
+    for (int idx = threadIdx.x; idx < FF_TW * FF_TH; idx += 256) {
+      const int lr = idx / FF_TW, lc = idx - lr * FF_TW;
+      const int gx = x0 + lc, gr = r0 + lr;
+      const bool in = gx >= 0 && gr >= 0 && gx < W && gr < H;
+      const size_t off = in ? (size_t)gr * W + gx : 0;
+      ftile[0][idx] = in && tId.p ? tId.p[off] : 0u;
+      ftile[1][idx] = in && tOId.p ? tOId.p[off] : 0u;
+      ftile[2][idx] = in ? tColor.p[off] : 0u;
+      ftile[3][idx] = in && tIp.p ? tIp.p[off] : 0u;
+    }
+    __syncthreads();
+  }
+#else
+  const bool small = false;
+#endif
+  if (!inside) return;
+  if (!wantTaps) {
     color = centerColor;
     count = 1.0f;
   } else {
-    const float k = 1.0f + unorm8(rawW(rCenterOColor));
-    /* The 37 taps reach up to 42 texels from the centre — too far for an LDS tile — and each is two gathers, a decision, two more
-     * gathers.  Taken one tap after the other that is 37 round trips to L2 per texel; the taps do not depend on each other, so they
+    /* The 37 taps reach up to 42 texels from the centre and each is two gathers, a decision, two more
+     * gathers.  Taken one tap after the other that is 37 round trips per texel; the taps do not depend on each other, so they
      * go eight at a time: the sixteen id gathers in flight together, then the colours of the taps that passed (a tap that did
      * not re-reads the centre texel: its value is not used), then the sums in tap order as the shader adds them.
      * fetchRaw()'s "0 outside the image or from an unbound plane" as arithmetic, so that every load is unconditional: */
     const size_t centre = (size_t)(H - 1 - y) * W + x;
     const uint32_t *pId = tId.p ? tId.p : tColor.p, *pOId = tOId.p ? tOId.p : tColor.p, *pIp = tIp.p ? tIp.p : tColor.p;      /* (tColor is always bound) */
     const uint32_t mId = tId.p ? ~0u : 0u, mOId = tOId.p ? ~0u : 0u, mIp = tIp.p ? ~0u : 0u;
-#ifndef FLX_FILTER_FIRST_CH
-#define FLX_FILTER_FIRST_CH 8
+    FirstTapsIn t = { pId, pOId, pIp, tColor.p, mId, mOId, mIp, centre, x, y, W, H, 0, 0, k, rCenterId, rCenterOId, centerLightNum, centerShadow };
+#if FLX_FILTER_FIRST_LDS
+    t.x0 = x0; t.r0 = r0;
+    if (small) first_filter_taps<true>(t, ftile, color, count); else first_filter_taps<false>(t, ftile, color, count);
+#else
+    first_filter_taps<false>(t, 0, color, count);
 #endif
-    constexpr int CH = FLX_FILTER_FIRST_CH;
-    for (int base = 0; base < 37; base += CH) {
-      size_t at[CH]; bool in[CH], pass[CH];
-      uint32_t id[CH], oid[CH], rc[CH], rip[CH];
-#pragma unroll
-      for (int j = 0; j < CH; j++) {
-        const int i = base + j < 37 ? base + j : 36;
-        const int cx = x + (int)(STENCIL3_37[i][0] * k * k * 3.5f);
-        const int cy = y + (int)(STENCIL3_37[i][1] * k * k * 3.5f);
-        in[j] = base + j < 37 && cx >= 0 && cy >= 0 && cx < W && cy < H;
-        at[j] = in[j] ? (size_t)(H - 1 - cy) * W + cx : centre;
-        id[j] = pId[at[j]]; oid[j] = pOId[at[j]];
-      }
-#pragma unroll
-      for (int j = 0; j < CH; j++) {
-        const uint32_t idj = in[j] ? id[j] & mId : 0u, oidj = in[j] ? oid[j] & mOId : 0u;
-        const int idW = (int)rawW(idj);
-        pass[j] = base + j < 37 && rawEq3(rCenterId, idj) && rCenterOId == oidj && (centerLightNum != idW / 2 || centerShadow == idW % 2);
-        const size_t a = pass[j] ? at[j] : centre;
-        rc[j] = tColor.p[a]; rip[j] = pIp[a];
-      }
-#pragma unroll
-      for (int j = 0; j < CH; j++) if (pass[j]) {
-        const f4 nextColor = unpack(in[j] ? rc[j] : 0u);
-        const f4 nextColorIp = unpack(in[j] ? rip[j] & mIp : 0u);
-        color = add4(color, add4(nextColor, scale4(nextColorIp, 256.0f)));
-        count += 1.0f;
-      }
-    }
   }
   const float invCount = 1.0f / count;
   const float sg = flx_sign(centerColor.w);
