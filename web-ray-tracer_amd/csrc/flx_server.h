@@ -57,7 +57,7 @@ enum { SVS_START = 0, SVS_END, SVS_FRAMES, SVS_TILES, SVS_BATCHES, SVS_BATCH_LAN
        SV_DUMP_MAX = 4, SV_DUMP_WORDS = 72 /* blockIdx, wave, 64 control words, ... */, SV_STAT_TOTAL = SV_STAT_WORDS + SV_DUMP_MAX * SV_DUMP_WORDS };
 struct ServerKernelArgs { FrameArgs fa; ServerArgs sa; };
 
-bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes, uint32_t xfSlots = 1u /* depth for a scene that moves */);
+bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes, uint32_t xfSlots = 1u /* depth for a scene that moves */, uint32_t shadeWaves = 0u /* 0: the default of three slots */);
 size_t server_rings_per_group();
 /* fr: the slots stacked (frames = depth); its views are NOT used (they come through the mailbox).  0, or -1 if the kernel does not fit */
 int launch_server(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontBuffers &wb, const ServerArgs &sa, uint32_t compute_units, hipStream_t stream);

@@ -36,6 +36,13 @@ namespace flx {
 #ifndef FLX_SERVER_SHADERS
 #define FLX_SERVER_SHADERS FLX_FRAME_SHADERS_FRONT      /* shade waves of a server workgroup (they also make the fresh paths) */
 #endif
+#ifndef FLX_SERVER_SHADERS_DEPTH2_MAX_TILES
+#define FLX_SERVER_SHADERS_DEPTH2_MAX_TILES 24         /* ... of at most this many screen tiles per workgroup and frame */
+#endif
+#ifndef FLX_SERVER_SHADERS_DEPTH2
+#define FLX_SERVER_SHADERS_DEPTH2 2                    /* ... of a launch with two frame slots: a rank's eighth with two frames in flight 1.23 -> 1.18 ms (with three slots two shade waves lose: 0.975 -> 1.11;
+                                                        * profiles/r04_paths_occupancy.txt) */
+#endif
 #ifndef FLX_SERVER_SHADE_PRIO
 #define FLX_SERVER_SHADE_PRIO 0              /* issue priority of the shade waves (s_setprio 0 .. 3) */
 #endif
@@ -573,9 +580,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   leave();
 }
 
-bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes, uint32_t xfSlots) {
+bool server_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes, uint32_t xfSlots, uint32_t shadeWaves) {
   const uint32_t T = sc.n_transforms;
-  const uint32_t walkThreads = FLX_WF_WALK_THREADS - 64u * (uint32_t)FLX_SERVER_SHADERS;
+  if (shadeWaves == 0u) shadeWaves = (uint32_t)FLX_SERVER_SHADERS;
+  const uint32_t walkThreads = FLX_WF_WALK_THREADS - 64u * shadeWaves;
   const uint32_t fixed = walkThreads * T * 40u + xfSlots * T * 64u + (SC_WORDS + SC_VIEW_WORDS) * 4u;
   if (fixed + 4096u > (uint32_t)FLX_WF_LDS_TOTAL) return false;
   ldsCount = ((uint32_t)FLX_WF_LDS_TOTAL - fixed) / 48u;
@@ -590,7 +598,9 @@ int launch_server(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontB
   uint32_t ldsCount = 0, ldsBytes = 0;
   const bool ver = sa.blobWords != 0u;                         /* the scene moves: its lights and transforms come with every frame */
   if (sa.depth < 2u || sa.depth > SV_MAX_DEPTH) return -1;
-  if (!server_kernel_fits(sc, ldsCount, ldsBytes, ver ? sa.depth : 1u)) return -1;
+  /* (two slots of THIN frames: a whole frame through two slots wants its three shade waves, 6.49 against 7.23 ms) */
+  const uint32_t shadeWaves = sa.depth == 2u && sa.tilesPerSlot / compute_units <= (uint32_t)FLX_SERVER_SHADERS_DEPTH2_MAX_TILES ? (uint32_t)FLX_SERVER_SHADERS_DEPTH2 : (uint32_t)FLX_SERVER_SHADERS;
+  if (!server_kernel_fits(sc, ldsCount, ldsBytes, ver ? sa.depth : 1u, shadeWaves)) return -1;
   if (ver && (sa.blobWords > SV_BLOB_WORDS || sa.blobWords != server_blob_words(sc.n_transforms, sc.n_lights))) return -1;
   static std::once_flag once[64];
   static bool ok[64];
@@ -604,8 +614,8 @@ int launch_server(const DeviceScene &sc, const DeviceFrame &fr, const WavefrontB
   const uint32_t tilesPerGroup = sa.tilesPerSlot / compute_units;
   uint32_t readyUnits = tilesPerGroup >= 48u ? (uint32_t)FLX_FRAME_READY_UNITS : tilesPerGroup / 2u;
   readyUnits = readyUnits < (uint32_t)FLX_FRAME_READY_UNITS / 4u ? (uint32_t)FLX_FRAME_READY_UNITS / 4u : (readyUnits > (uint32_t)FLX_FRAME_READY_UNITS ? (uint32_t)FLX_FRAME_READY_UNITS : readyUnits);
-  if (ver) hipLaunchKernelGGL(k_wf_server<true>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, (uint32_t)FLX_SERVER_SHADERS, readyUnits);
-  else hipLaunchKernelGGL(k_wf_server<false>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, (uint32_t)FLX_SERVER_SHADERS, readyUnits);
+  if (ver) hipLaunchKernelGGL(k_wf_server<true>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, shadeWaves, readyUnits);
+  else hipLaunchKernelGGL(k_wf_server<false>, dim3(compute_units), dim3(FLX_WF_WALK_THREADS), ldsBytes, stream, ka, ldsCount, sc.n_transforms, shadeWaves, readyUnits);
   return 0;
 }
 
