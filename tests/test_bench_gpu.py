@@ -44,20 +44,19 @@ def test_bench_line_single_gpu():
     assert d["counters"]["primary_hits"] > 0
 
 
-def test_bench_headline_is_the_fastest_verified_loop():
-    """`value` / `ms_per_step`: the K frames of the fastest frame loop whose last frame equals one frame per pass bit for bit; the line says which and keeps the others"""
+def test_bench_value_is_one_frame_per_pass_and_the_loops_stand_beside_it():
+    """`value` / `ms_per_step` are ALWAYS the timed region (one frame per pass); the frame loops are named entries with their own `value`, the fastest verified one
+    repeated as `throughput_best`; and `ms_per_step` is not below the dominant kernel's own time per step"""
     args = [a if a != "6" else "12" for a in SMALL]
     d = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "0", "--no-pmc"] + args, timeout=900, stderr=subprocess.DEVNULL))
     one, pl = d["one_frame_per_pass"], d["pipelined"]
     assert d["steps"] == 12 and pl["frames"] == 12 and pl["last_frame_equals_one_frame_per_pass"] is True
-    best = min(one["ms_per_step"], pl["ms_per_frame"])
-    assert abs(d["ms_per_step"] - best) < 1e-9 and d["headline"]["mode"] == ("pipelined" if pl["ms_per_frame"] < one["ms_per_step"] else "one_frame_per_pass")
+    assert d["headline"]["mode"] == "one_frame_per_pass" and d["ms_per_step"] == one["ms_per_step"] and d["value"] == one["value"]
     assert abs(d["value"] - d["config"]["rays_per_frame"] / (d["ms_per_step"] * 1e-3) / 1e6) < 1e-6 * d["value"]
-    if d["headline"]["mode"] == "pipelined":
-        assert d["headline"]["frames_in_flight"] == 2 and d["headline"]["frames"] == 12 and "2 in flight" in d["config"]["frames"]
-    # ... and K frames one at a time on request
-    d1 = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "0", "--no-pmc", "--headline", "one_frame_per_pass"] + args, timeout=900, stderr=subprocess.DEVNULL))
-    assert d1["headline"]["mode"] == "one_frame_per_pass" and d1["ms_per_step"] == d1["one_frame_per_pass"]["ms_per_step"] and d1["pipelined"]["ms_per_frame"] > 0
+    tb = d["throughput_best"]
+    assert tb["mode"] == "pipelined" and tb["frames_in_flight"] == 2 and tb["frames"] == 12 and tb["value"] == pl["value"] and tb["ms_per_frame"] == pl["ms_per_frame"]
+    r = d["roofline"]
+    assert d["ms_per_step"] >= r["kernel_ms"] * r.get("launches_per_step", 1) * 0.999, (d["ms_per_step"], r["kernel_ms"])      # the dominant kernel's time per step fits in the step
 
 
 def test_bench_two_ranks_gather_the_frame():
@@ -84,12 +83,12 @@ def test_bench_two_ranks_complete_one_image_without_a_collective():
     assert d["gathered_frame_equals_single_context_frame"] is True
     assert sh["frame_server"] is True
     assert sh["frames"] == 20 and d["headline"]["mode"] == "one_frame_per_pass"      # (K = 6: the loop timed 20 frames)
-    # K = 12: the shared loop times exactly K frames and — two ranks' servers beside each other on one GPU against a gloo gather — is the headline
+    # K = 12: the shared loop times exactly K frames; it is a named entry and `throughput_best`, never `value`
     args12 = [a if a != "6" else "12" for a in args]
     d = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--batch", "0", "--no-pmc"] + args12, timeout=1200, env=env, stderr=subprocess.DEVNULL))
     assert d["shared"]["frames"] == 12 and d["shared"]["image_equals_single_context_frame"] is True
-    if d["shared"]["ms_per_frame"] < d["one_frame_per_pass"]["ms_per_step"]:
-        assert d["headline"]["mode"] == "shared" and d["headline"]["frames_in_flight"] == 3 and d["ms_per_step"] == d["shared"]["ms_per_frame"] and d["value"] == d["shared"]["value"]
+    assert d["headline"]["mode"] == "one_frame_per_pass" and d["ms_per_step"] == d["one_frame_per_pass"]["ms_per_step"]
+    assert d["throughput_best"]["mode"] in ("shared", "pipelined") and d["throughput_best"]["ms_per_frame"] <= d["shared"]["ms_per_frame"]
     # a frame the server does not take (a last strip of 6 rows): every rank's two lanes, the strips copied into the image
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--batch", "0", "--no-pmc"] + SMALL, timeout=1200, env=env, stderr=subprocess.DEVNULL)
     sh = _last_json(out)["shared"]

@@ -36,7 +36,7 @@ def _turned(sc, f):
     return r.reshape(-1)
 
 
-def _rank_main(rank, conn, tile_rows, scene_name="dragon", moves=False):
+def _rank_main(rank, conn, tile_rows, scene_name="dragon", moves=False, in_flight=LANES):
     """one rank: rank 0 creates the share and sends the handle up; the others receive it from the parent"""
     try:
         from flexlight_hip import capi
@@ -63,12 +63,16 @@ def _rank_main(rank, conn, tile_rows, scene_name="dragon", moves=False):
             hiprt = ctypes.CDLL("libamdhip64.so")
         except OSError:
             hiprt = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
-        bad, inflight = [], []
+        bad, inflight, ptrs = [], [], []
 
         def take():
             ptr, _ = ctx.frame_end_shared()
             f = inflight.pop(0)
             if rank == 0:
+                if in_flight == 1:                                            # the other rank may begin (and finish) the next frame before this one is read: it must not be in this image
+                    import time
+                    time.sleep(0.03)
+                    ptrs.append(ptr)
                 out = np.empty((H, W, 4), np.float32)
                 assert hiprt.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(ptr), ctypes.c_size_t(H * W * 16), 2) == 0
                 if not np.array_equal(out.view(np.uint32), want[f].view(np.uint32)):
@@ -76,7 +80,7 @@ def _rank_main(rank, conn, tile_rows, scene_name="dragon", moves=False):
             else:
                 assert ptr is None
         for f in range(FRAMES):
-            if len(inflight) == LANES:
+            if len(inflight) == in_flight:
                 take()
             if moves and f >= 2:                                              # every rank turns the monkey before the frame: its launch takes the transforms with the frame and goes on
                 ctx.update_transforms(_turned(sc, f), sc.arrays["shift"])
@@ -86,6 +90,8 @@ def _rank_main(rank, conn, tile_rows, scene_name="dragon", moves=False):
             inflight.append(f)
         while inflight:
             take()
+        if ptrs:                                                              # frame g in image g % n
+            assert all(ptrs[g] == ptrs[0] + (g % LANES) * W * H * 16 for g in range(len(ptrs))), ptrs
         # a frame of another size is refused, a second share too
         with pytest.raises(capi.FlexLightHipError):
             ctx.frame_begin_shared(sc.frame_params(use_filter=0, width=W, height=H - 8, tile=(tile_rows, rank, RANKS)))
@@ -115,6 +121,35 @@ def test_two_processes_complete_one_image(tile_rows, scene_name, moves):
             assert pipes[r][0].poll(120), "rank %d did not join" % r
             got = pipes[r][0].recv()
             assert got == "joined", got
+        for r in range(RANKS):
+            pipes[r][0].send("go")
+        for r in range(RANKS):
+            assert pipes[r][0].poll(120), "rank %d did not finish" % r
+            status, detail = pipes[r][0].recv()
+            assert status == "ok", detail
+            assert detail == [], "frames %s differ from one context's render" % detail
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():
+                p.kill()
+
+
+def test_frames_begun_and_ended_one_at_a_time_keep_their_images():
+    """every rank begins and ends ONE frame at a time, so every frame is a launch of its own that starts on an empty loop (such a launch always began at image 0
+    and a non-root rank could write frame g into the image the root was still reading frame g - 1 from): frame g must land in image g % n on every rank — the root copies
+    each frame it is handed AFTER the other rank has been allowed to begin the next one, and every one of them must equal one context's render (moving camera)"""
+    mpc = mp.get_context("spawn")
+    pipes = [mpc.Pipe() for _ in range(RANKS)]
+    procs = [mpc.Process(target=_rank_main, args=(r, pipes[r][1], 8, "dragon", False, 1)) for r in range(RANKS)]
+    for p in procs:
+        p.start()
+    try:
+        assert pipes[0][0].poll(120), "rank 0 did not create the share"
+        handle = pipes[0][0].recv()
+        assert isinstance(handle, bytes), handle
+        pipes[1][0].send(handle)
+        assert pipes[1][0].poll(120) and pipes[1][0].recv() == "joined"
         for r in range(RANKS):
             pipes[r][0].send("go")
         for r in range(RANKS):

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <sched.h>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
@@ -1670,7 +1671,10 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
     ServerArgs sa = {};
     sa.slots = ctx->d_sv_slots; sa.mail = ctx->d_sv_mail; sa.relay = ctx->d_sv_relay;
     /* frames of the launch before may still be in its images (taken, not yet handed out): this launch goes on with the slot after them */
-    const uint32_t slot0 = (ctx->fifo_n && ctx->sv_depth == depth) ? ctx->sv_next_slot % depth : 0u;
+    /* with a frame target the image IS the slot, and the caller was promised "image i takes the frames begun i-th, (i + n)-th, ..": a launch that starts on an empty
+     * loop (frames begun and ended one at a time end the launch every frame) goes on counting where the last one stopped — flx_share's ranks reuse the image of
+     * frame g - n for frame g and would otherwise all write image 0 while the root still reads it */
+    const uint32_t slot0 = ctx->sv_target_slots ? (uint32_t)(ctx->sv_target_posted % depth) : ((ctx->fifo_n && ctx->sv_depth == depth) ? ctx->sv_next_slot % depth : 0u);
     sa.depth = depth; sa.slot0 = slot0; sa.seq0 = seq0;
     sa.tilesPerSlot = (uint32_t)(itemsPerSlot / ((size_t)fr.samples * 64u));
     sa.itemsPerSlot = (uint32_t)itemsPerSlot;
@@ -1706,6 +1710,7 @@ static flx_status server_post(flx_context *ctx, const flx_frame_params *params, 
   }
   const uint32_t seq = ctx->sv_next_seq++, slot = ctx->sv_next_slot;
   ctx->sv_next_slot = (slot + 1u) % depth;
+  if (ctx->sv_target_slots) ctx->sv_target_posted++;
   /* post: the view, then the number that says whose view it is.  (The frame that was in this slot was taken by flx_frame_end `depth` frames ago.) */
   memcpy((void *)&ctx->h_sv_mail->view[slot], &frOne.view[0], sizeof(FrameView));
   if (ctx->sv_ver) {                                         /* ... and the frame's transforms and lights (as the host holds them: what the last uploads said) */
@@ -1733,6 +1738,9 @@ static flx_status server_take(flx_context *ctx, int k) {
       __atomic_fetch_or(&ctx->h_dev_error[0], WF_ERR_SERVER_TIMEOUT, __ATOMIC_RELEASE);
       break;
     }
+    /* back off: a pause per poll while the word is about to come, then the core goes to whoever else wants it (eight ranks' hosts share a box's cores; the
+     * Node host waits on a worker thread, napi/flexlight_napi.cc frameEndAsync) */
+    if (spins < 4096u) __builtin_ia32_pause(); else sched_yield();
   }
   if (server_idled_with_nothing_owed(ctx)) {
     /* the launch ended by itself while the host was away, this frame and every other it had been given complete: forgiven HERE, while the mailbox still is that
@@ -1955,6 +1963,7 @@ extern "C" flx_status flx_frame_target_set(flx_context *ctx, void *const *d_imag
   for (uint32_t i = 0; i < 3u; i++) ctx->sv_target[i] = i < n_images ? (float4 *)d_images[i] : nullptr;
   for (uint32_t i = 0; i < n_images; i++) if (!ctx->sv_target[i]) { ctx->sv_target_slots = 0; return fail(ctx, FLX_ERR_INVALID, "flx_frame_target_set: an image is NULL"); }
   ctx->sv_target_slots = n_images;
+  ctx->sv_target_posted = 0;
   ctx->sv_target8 = false;
   return FLX_OK;
 }

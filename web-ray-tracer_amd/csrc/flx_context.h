@@ -204,6 +204,7 @@ struct flx_context {
   bool sv_out8 = false;                          /* the running launch resolves RGBA8 (ServerArgs::out8) */
   bool sv_target8 = false;                       /* flx_frame_target_set8: the target images are uint32 RGBA8 per pixel */
   float4 *sv_target[3] = { nullptr, nullptr, nullptr };      /* flx_frame_target_set: whole images the launch resolves this context's strips into (a peer GPU's memory, pinned host memory, ..) */
+  uint64_t sv_target_posted = 0;                 /* frames posted since flx_frame_target_set: frame g goes to image g % n, whatever launch takes it */
   uint32_t sv_target_slots = 0;                  /* 0: none — the launch's own d_sv_out */
   flx_share *share = nullptr;
   uint32_t sv_groups = 0;                        /* flx_debug_set_server_groups: workgroups of the launch (0: one per CU) — two launches beside each other on one GPU, to rehearse a device group */

@@ -147,7 +147,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       if (lane == 0) { seq = __hip_atomic_load(&sa.mail->posted[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); stop = __hip_atomic_load(&sa.mail->stopAfter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
       if (lane == 0 && stop != 0u) __hip_atomic_store(&sa.relay->stopAfter, stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (__builtin_amdgcn_readfirstlane(seq) == want) {
-        if (lane < 19u) {                                                 /* (the view was written before the number) */
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                    /* (system scope: the host wrote the view and the blob before the number) */
+        if (lane < 19u) {
           const uint32_t v = __hip_atomic_load((const uint32_t *)&sa.mail->view[slot] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           __hip_atomic_store((uint32_t *)&sa.relay->view[slot] + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -156,7 +157,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             __hip_atomic_store(&sa.relay->blob[slot][t], __hip_atomic_load(&sa.mail->blob[slot][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&sa.relay->posted[slot], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        /* seqlock: a wave that was held up in the middle of the copy (its siblings relayed the frame, the frame completed, the host posted the slot again) has copied a mix
+         * of two posts — it says nothing then, and never moves the relay's number back */
+        uint32_t again = 0;
+        if (lane == 0) again = __hip_atomic_load(&sa.mail->posted[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const bool still = __builtin_amdgcn_readfirstlane(again) == want && fq_load(&ctl[SC_SEQ + slot]) == want;
+        if (still && lane == 0) __hip_atomic_store(&sa.relay->posted[slot], want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     uint32_t seq = 0, stop = 0;
@@ -164,6 +170,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     if (lane == 0 && stop != 0u) __hip_atomic_store(&ctl[SC_STOPAFTER], stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     seq = __builtin_amdgcn_readfirstlane(seq);
     if (seq != want) return false;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                     /* the relay's view and blob were stored before its number */
+    if (fq_load(&ctl[SC_SAVAIL + slot]) == 1u) return true;                 /* a sibling wave got here first: the view is in place, nothing to copy twice */
     if (lane < 19u) ((uint32_t *)&lv[slot])[lane] = __hip_atomic_load((const uint32_t *)&sa.relay->view[slot] + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (VER) {
       /* the frame's lights and transforms: into this workgroup's version of the slot (global memory it alone reads and writes) and, the inverse transforms, into LDS.
@@ -189,6 +197,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (fq_load(&ctl[SC_SEQ + slot]) != want) return false;                /* (the slot went on to its next frame while this wave was copying: that frame's view is not this one) */
     if (lane == 0) __hip_atomic_store(&ctl[SC_SAVAIL + slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      /* (the slot's frame cannot change while its view is not here: a rotation needs it) */
     return true;
   };

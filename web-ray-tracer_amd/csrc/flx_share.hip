@@ -63,6 +63,7 @@ static flx_status share_attach(flx_context *ctx, flx_share *sh) {
   flx_status s = flx_set_frame_lanes(ctx, (int)sh->n_images);
   if (!s) s = flx_set_frame_chain(ctx, 3);
   if (!s) s = flx_frame_target_set(ctx, img, sh->n_images);
+  if (!s) ctx->sv_target_posted = sh->begun;      /* frame g of the share goes to image g % n on every rank, whichever launch takes it and whatever ran on the lanes before */
   return s;
 }
 
@@ -76,7 +77,7 @@ extern "C" flx_status flx_share_leave(flx_context *ctx) {
   if (sh->copy) { (void)hipStreamSynchronize(sh->copy); (void)hipStreamDestroy(sh->copy); sh->copy = nullptr; }
   if (sh->page) {
     if (sh->root) __atomic_store_n(&sh->page->released, ~0ull >> 1, __ATOMIC_RELEASE);      /* nobody waits for a root that has left */
-    else __atomic_store_n(&sh->page->done[sh->rank], ~0ull >> 1, __ATOMIC_RELEASE);
+    else if (sh->rank >= 0) __atomic_store_n(&sh->page->error[sh->rank], 2u, __ATOMIC_RELEASE);      /* left: the root's next call fails instead of handing out images without this rank's strips */
     munmap(sh->page, sizeof(SharePage));
   }
   if (sh->images) { if (sh->root) (void)hipFree(sh->images); else (void)hipIpcCloseMemHandle(sh->images); }
@@ -126,7 +127,7 @@ extern "C" flx_status flx_share_join(flx_context *ctx, const uint8_t *handle, in
   ShareHandle h;
   memcpy(&h, handle, sizeof h);
   h.name[sizeof h.name - 1] = 0;
-  if (rank < 0 || rank >= (int)h.n_ranks || (h.n_images != 2u && h.n_images != 3u) || h.name[0] != '/') return share_fail(ctx, FLX_ERR_INVALID, "flx_share_join: not a handle of flx_share_create, or rank out of range");
+  if (h.n_ranks < 1u || h.n_ranks > 64u || rank < 0 || rank >= (int)h.n_ranks || (h.n_images != 2u && h.n_images != 3u) || h.name[0] != '/' || h.width == 0u || h.height == 0u) return share_fail(ctx, FLX_ERR_INVALID, "flx_share_join: not a handle of flx_share_create, or rank out of range");
   FLX_HIP(ctx, hipSetDevice(ctx->device));
   flx_share *sh = new flx_share();
   sh->root = false; sh->rank = rank; sh->n_ranks = (int)h.n_ranks; sh->width = h.width; sh->height = h.height; sh->n_images = h.n_images;
@@ -136,7 +137,8 @@ extern "C" flx_status flx_share_join(flx_context *ctx, const uint8_t *handle, in
   if (fd >= 0) close(fd);
   if (m == MAP_FAILED) { flx_share_leave(ctx); return share_fail(ctx, FLX_ERR_DEVICE, "flx_share_join: the ranks' page (shm_open / mmap): is the root on this host?"); }
   sh->page = (SharePage *)m;
-  if (__atomic_load_n(&sh->page->magic, __ATOMIC_ACQUIRE) != SHARE_MAGIC) { flx_share_leave(ctx); return share_fail(ctx, FLX_ERR_DEVICE, "flx_share_join: the ranks' page is not initialised"); }
+  if (__atomic_load_n(&sh->page->magic, __ATOMIC_ACQUIRE) != SHARE_MAGIC) { sh->rank = -1; flx_share_leave(ctx); return share_fail(ctx, FLX_ERR_DEVICE, "flx_share_join: the ranks' page is not initialised"); }
+  if (sh->page->n_ranks != h.n_ranks || sh->page->n_images != h.n_images) { sh->rank = -1; flx_share_leave(ctx); return share_fail(ctx, FLX_ERR_INVALID, "flx_share_join: the handle's ranks / images are not the page's"); }
   void *p = nullptr;
   const hipError_t e = hipIpcOpenMemHandle(&p, h.mem, hipIpcMemLazyEnablePeerAccess);
   if (e != hipSuccess) {
@@ -151,8 +153,14 @@ extern "C" flx_status flx_share_join(flx_context *ctx, const uint8_t *handle, in
   return s;
 }
 
+/* error[r]: 1 = rank r failed; 2 = rank r has left in good order (flx_share_leave): the frames it completed stay completed, no later frame will ever have its strips */
 static bool share_broken(const flx_share *sh) {
-  for (int r = 0; r < sh->n_ranks; r++) if (__atomic_load_n(&sh->page->error[r], __ATOMIC_ACQUIRE) != 0u) return true;
+  for (int r = 0; r < sh->n_ranks; r++) if (__atomic_load_n(&sh->page->error[r], __ATOMIC_ACQUIRE) == 1u) return true;
+  return false;
+}
+static bool share_gone(const flx_share *sh, uint64_t want) {      /* a rank has left before it completed frame number `want` (counted from 1) */
+  for (int r = 0; r < sh->n_ranks; r++)
+    if (__atomic_load_n(&sh->page->error[r], __ATOMIC_ACQUIRE) == 2u && __atomic_load_n(&sh->page->done[r], __ATOMIC_ACQUIRE) < want) return true;
   return false;
 }
 template <class F> static bool share_wait(const flx_share *sh, F ready) {      /* false: a rank failed, or nothing happened for 5 s */
@@ -160,7 +168,7 @@ template <class F> static bool share_wait(const flx_share *sh, F ready) {      /
   for (uint32_t spins = 0;; spins++) {
     if (ready()) return true;
     if ((spins & 255u) == 255u) {
-      if (share_broken(sh)) return false;
+      if (share_broken(sh) || share_gone(sh, sh->ended)) return false;
       if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) return false;
     }
     __builtin_ia32_pause();
@@ -174,6 +182,7 @@ extern "C" flx_status flx_frame_begin_shared(flx_context *ctx, const flx_frame_p
   if (!params || params->width != sh->width || params->height != sh->height || (int)params->tile_count != sh->n_ranks || (int)params->tile_index != sh->rank)
     return share_fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_shared: the frame must have the images' size, tile_count = the ranks and tile_index = this rank");
   if (share_broken(sh)) return share_fail(ctx, FLX_ERR_DEVICE, "flx_frame_begin_shared: a rank of the share has failed");
+  if (sh->root && share_gone(sh, sh->begun + 1u)) return share_fail(ctx, FLX_ERR_DEVICE, "flx_frame_begin_shared: a rank of the share has left: this frame would never have its strips");
   if (params->use_filter || params->is_temporal) return share_fail(ctx, FLX_ERR_INVALID, "flx_frame_begin_shared: filter and temporal frames need the whole frame in one context (flx_render_gathered_root_device)");
   /* the frame server where it takes the frame; else the context's two lanes and a copy of the strips into the image (the same choice on every rank: it depends on the
    * scene and on the frame's shape only) */
