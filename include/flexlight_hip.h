@@ -148,9 +148,6 @@ flx_status flx_render_batch_device(flx_context *ctx, const flx_frame_params *par
 flx_status flx_sync(flx_context *ctx);
 /* Use an existing hipStream_t (e.g. torch's current stream) instead of the context's own. NULL restores it. */
 flx_status flx_set_stream(flx_context *ctx, void *hip_stream);
-/* Counters of the last flx_render_device frame (collected only when enabled; costs atomics). */
-flx_status flx_set_counters_enabled(flx_context *ctx, int enabled);
-flx_status flx_get_counters(flx_context *ctx, flx_counters *out);
 /* GPU time of the last frame between HIP events on the context's stream, and of its dominant
  * (trace) kernel alone; milliseconds. */
 flx_status flx_last_frame_ms(flx_context *ctx, float *frame_ms, float *trace_kernel_ms);
@@ -185,8 +182,8 @@ flx_status flx_set_frame_lanes(flx_context *ctx, int lanes);
  * (modules/pathtracerWGL2.js:254-303); a frame's own launches, though, end in a drain — the last paths of the frame keep a few waves busy while the
  * other CUs idle — and for a short frame (a rank's eighth of a 1080p frame: 0.8 ms of work, 1.65 ms from launch to end) the drain is half of the time.
  *   0  every frame has its own launches, on the lanes of flx_set_frame_lanes;
- *   1  a chain of launches (csrc/flx_chain.hip): the frame kernel of frame k works ahead on frame k + 1, whose camera flx_frame_begin posts to it while it
- *      runs, and hands what it holds of that frame to the next launch.  Correct and kept for comparison; the relaunch per frame costs what the overlap gains;
+ *   1  (only in `make EXPERIMENTS=1`'s library; refused by the shipped one) a chain of launches (csrc/flx_chain.hip): the frame kernel of frame k works ahead on
+ *      frame k + 1 and hands what it holds of it to the next launch.  Measured: the relaunch per frame costs what the overlap gains;
  *   2  (default) the frame server (csrc/flx_server.hip) for frames of fewer than 64 8 x 8 screen tiles per CU — a rank's share of a frame — and mode 0 for the
  *      others: ONE persistent launch renders the loop's frames as flx_frame_begin posts them (the view goes through pinned memory; nothing is launched per
  *      frame), every workgroup works on the oldest frame first and fills its idle lanes with the next ones, resolves the screen tiles it made and the last
@@ -199,18 +196,6 @@ flx_status flx_set_frame_lanes(flx_context *ctx, int lanes);
  * device output, work counters off; any other frame runs as in mode 0.  Frames are bit-identical to their own flx_render and complete in order.  A
  * watchdog that trips inside a launch makes flx_frame_end return FLX_ERR_DEVICE. */
 flx_status flx_set_frame_chain(flx_context *ctx, int mode);
-/* The last frame begun in the loop: 0 its own launches, 1 it began a chain of launches, 2 it continued one, 3 it went to the frame server. */
-flx_status flx_last_chained(flx_context *ctx, int *chained);
-/* A scene that MOVES in the frame server.  The reference refills its transform UBO and its light texture before every frame (modules/pathtracerWGL2.js:258-262,
- * 361-365) and an example like examples/dragon.js turns an object every tick.  Once flx_transforms_upload / flx_lights_upload has brought CHANGED contents of the
- * same counts, the server's next launch takes those arrays WITH every frame — they are posted with the frame's view, a version per frame in flight, and a later
- * upload no longer ends the launch (round 4 before this: every changed upload ended it and the frames went to the lanes).  Scenes whose 32 words per transform + 6
- * per light exceed 1024 keep the old behaviour, and so does flx_set_server_moving_scenes(ctx, 0).  Frames are bit-identical either way.
- * flx_server_moving: 1 while a launch of that kind is running. */
-flx_status flx_set_server_moving_scenes(flx_context *ctx, int on);
-int flx_server_moving(const flx_context *ctx);
-/* Would flx_frame_begin hand this frame to the frame server (under flx_set_frame_chain(ctx, 3): whatever its size)?  1 / 0. */
-int flx_frame_server_takes(flx_context *ctx, const flx_frame_params *params);
 /* The frame server resolves the loop's frames straight into images the CALLER owns: d_images[i] (n_images = 2 or 3 = the loop's frames in flight;
  * float4[height][width]; addresses this context's GPU can write — its own memory, a peer GPU's through the peer mapping, pinned host memory) takes the frames
  * begun i-th, (i + n)-th, ...  With params.tile_count > 1 the context writes its row strips where the image has them, so the contexts of a device group
@@ -225,29 +210,7 @@ int flx_frame_target_index(const flx_context *ctx);      /* which of the images 
 /* Device faults reach the status code.  The frame kernels' wait loops have watchdogs (seconds); a wave that gives up — or finds a ring slot that never
  * fills — sets a bit in the context's device error word (pinned host memory), and the next call in which the host waits for frames (flx_render,
  * flx_render_batch, flx_frame_end, flx_sync) returns FLX_ERR_DEVICE with the bits in flx_last_error and clears the word: the frame is incomplete.  A healthy
- * frame never gets there; this hook forces it for tests: the next frames' kernels give up after `watchdog_polls` polls (0: the built-in limit) and, with
- * FLX_INJECT_NO_SHADING, their shade waves drop every batch they pop, so that the walk waves wait for paths that never come back. */
-#define FLX_INJECT_NO_SHADING 1u
-flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog_polls, uint32_t flags);
-/* The shading keeps a per-triangle table of what fragment:500-512 derives from a triangle and its transform alone (three acos and three tan per shade otherwise),
- * made again at scene / transform uploads.  0: every shade computes the values itself — the same floats; for A/B runs. */
-flx_status flx_debug_set_angle_table(flx_context *ctx, int on);
-/* Rehearsal of a device group on ONE GPU: the frame server's launch takes `groups` CUs only (0: all), so that the launches of several contexts run beside
- * each other. */
-flx_status flx_debug_set_server_groups(flx_context *ctx, uint32_t groups);
-/* diagnostics of the frame server's last launch (csrc/flx_server.h: SVS_*): start, end, frames completed, tiles, batches, rotations, ... */
-flx_status flx_get_server_stats(flx_context *ctx, uint64_t *out /* [16] */);
-/* the control words of up to four workgroups of the frame server that gave up (72 words each: workgroup, wave, its 64 LDS control words, the relayed posts, the slots' tile cursors) */
-flx_status flx_get_server_dump(flx_context *ctx, uint64_t *out /* [4 * 72] */);
-/* Diagnostics of the chained launches of mode 1 (tools/chain_stats.py): 64 launches (by sequence number mod 64) x 64 words — when the launch started and ended,
- * when the next frame's view was seen, when its own frame was complete, tiles made for either frame, paths handed to the next kernel, walks abandoned. */
-flx_status flx_set_chain_stats(flx_context *ctx, int on);
-flx_status flx_get_chain_stats(flx_context *ctx, uint64_t *out /* [64 * 64] */);
-/* Experiments with the order in which a chained frame's 8 x 8 screen tiles are drawn (tools/chain_order.py): an explicit permutation of the frame's tiles
- * (n = 0: the row-major default), and per-tile counts of the shadings its paths took after bounce 0 (n tiles per slot; 2 x n words out). */
-flx_status flx_set_chain_order(flx_context *ctx, const uint32_t *order, uint32_t n);
-flx_status flx_set_chain_cost(flx_context *ctx, uint32_t n);
-flx_status flx_get_chain_cost(flx_context *ctx, uint32_t *out);
+ * frame never gets there (flexlight_hip_debug.h: flx_debug_inject_fault forces it for tests). */
 
 /* Filter frames on several GPUs.  The path-trace pass is per pixel and shards by row strips like a frame
  * without filter; the denoise chain reads up to ~194 rows around a pixel and runs on the whole frame.  So every rank
@@ -291,8 +254,6 @@ flx_status flx_render_gathered_root_device(flx_context *ctx, const flx_frame_par
  * 1080p frame in all instead of 33 MB; 33 instead of 133 MB at 4K).  d_frames_rgba8 = uint8[n_frames][height][width][4] in device memory.  root < 0: all-gather,
  * every rank gets the frames; root >= 0: that rank alone (NULL elsewhere).  Frames without the filter (a filter frame's exchange is its five render targets). */
 flx_status flx_render_gathered_rgba8_device(flx_context *ctx, const flx_frame_params *params, uint32_t n_frames, int root, void *d_frames_rgba8);
-/* ranks of the context's communicator as RCCL reports them (ncclCommCount); 0: the context belongs to none */
-int flx_comm_count(const flx_context *ctx);
 /* The frame loop (flx_frame_begin / flx_frame_end) over the communicator: every rank begins the same frame with its own
  * tile_index; the frames alternate between the context's two lanes, the second lane gathering over a communicator of its own
  * (ncclCommSplit of the first, made by flx_comm_init_rank), so that frame k + 1's kernels fill the CUs the tails of frame k's
@@ -322,11 +283,11 @@ flx_status flx_frame_end_shared(flx_context *ctx, const void **image, size_t *by
  * `devices` may name one GPU more than once — a rehearsal on a one-GPU box, where RCCL refuses two ranks on a device: the
  * strips are then exchanged with device-to-device copies, everything else is unchanged (flx_group_uses_rccl says which). */
 typedef struct flx_group flx_group;
+int flx_group_uses_rccl(const flx_group *group);
 flx_status flx_group_create(int n, const int *devices, flx_group **out);
 void flx_group_destroy(flx_group *group);
 const char *flx_group_last_error(const flx_group *group);   /* group may be NULL: last creation error */
 int flx_group_size(const flx_group *group);
-int flx_group_uses_rccl(const flx_group *group);
 /* to_root = 1 (default): only context 0 — the one flx_group_render hands the frame out from — receives the strips (ncclSend / ncclRecv,
  * or copies into context 0 alone); 0: all-gather, every context ends up with the frame. */
 flx_status flx_group_set_gather(flx_group *group, int to_root);
@@ -378,49 +339,6 @@ flx_status flx_taa_reset(flx_context *ctx);
 flx_status flx_present_device(flx_context *ctx, uint32_t width, uint32_t height, const void *d_in_rgba, void *d_out_rgba8);
 flx_status flx_present(flx_context *ctx, uint32_t width, uint32_t height, const float *in_rgba, uint8_t *out_rgba8);
 
-/* Kernel organisation of the path-trace pass.  0 = automatic: the sample-sequential per-pixel kernel when use_filter /
- * is_temporal need the cross-sample G-buffer state; for scenes of up to 128 entries the per-pixel kernel too, or — from 32 bounce
- * iterations per pixel (4 with four or more lights) in frames of at least 2^20 paths — the persistent path kernel; the wavefront
- * pipeline for everything larger; 1 = per-pixel kernel, 2 = persistent path kernel, 3 = wavefront pipeline.
- * Results are identical; the explicit values are for A/B timing and tests.  flx_last_pipeline: what the last frame ran. */
-flx_status flx_set_pipeline(flx_context *ctx, int pipeline);
-flx_status flx_last_pipeline(flx_context *ctx, int *pipeline);
-/* Scenes of at most 128 entries that all stand in transform 0 (cornell, cornell.obj, the theater) are walked by the wave in
- * lockstep over the entries in the reference's order instead of lane by lane over the threaded copy (per-pixel and persistent
- * path kernels; same entries per ray, same arithmetic, same counters).  on = 0 switches that off, for A/B timing and tests. */
-flx_status flx_set_lockstep(flx_context *ctx, int on);
-/* Wavefront pipeline: run the bounce loop as 1..4 independent chains of screen-tile ranges on separate HIP
- * streams (default 1: more chains measured slower, profiles/r01_ab_stream_groups.txt), so that the tail of one chain's persistent walk kernel overlaps the other's work. */
-flx_status flx_set_wavefront_groups(flx_context *ctx, int groups);
-/* Wavefront pipeline: how the bounce loop is laid out on the GPU.  0 (default): automatic — ONE persistent launch for all bounces
- * (k_wf_frame: the walk waves and shade waves of a workgroup pass paths to each other through LDS rings; no kernel boundary, hence no
- * tail, between the bounces) where the scene's object spaces leave room in LDS, rounds otherwise; 1: rounds, a shade + walk kernel
- * pair per bounce (the round-1/2 organisation); 2: the frame kernel where it fits.  Frames and work counters are identical. */
-flx_status flx_set_wavefront_organisation(flx_context *ctx, int organisation);
-/* Wavefront pipeline: who traces the primary rays and shades bounce 0.  0: two kernels in front of the bounce loop (k_primary, k_wf_shade0); 3: ONE kernel in
- * front (k_wf_front: a wave traces the primary rays of its 8 x 8 screen tile and shades it straight away); 2: the frame kernel itself wherever it runs — its shade waves
- * make the fresh paths one screen tile at a time while its walk waves walk the earlier ones — and one kernel in front elsewhere; 1 (default): automatic — the frame
- * kernel itself where a workgroup gets at least 32 screen tiles (a whole 1080p frame: yes, a rank's eighth of one: no), else one kernel in front up to 128 M paths
- * a pass, two beyond.  Frames and work counters are identical. */
-flx_status flx_set_frame_front(flx_context *ctx, int mode);
-/* What the wavefront pipeline ran for the last frame: 1 rounds, 2 the frame kernel, 3 the frame kernel with the front of the frame inside it;
- * 0 when another pipeline rendered it (flx_last_pipeline). */
-flx_status flx_last_organisation(flx_context *ctx, int *organisation);
-/* Wavefront pipeline: how the bounce walks are scheduled.  Every mode walks every ray through the same entries with the
- * same arithmetic (frames and work counters are identical); they differ in speed and exist for A/B measurements
- * (profiles/r01_ab_tail_schedulers.txt).
- *   scheduler      FLX_WALK_LANES (default): one walk per lane, lanes refilled as walks end (k_wf_walk_pre)
- *                  FLX_WALK_QUEUES: walk states in LDS, waves take 64 walks that need the same test (flx_walkq.hip)
- *                  FLX_WALK_LANES_FINISHER: as FLX_WALK_LANES, suspended walks are finished a wave per walk (flx_walkcoop.hip)
- *   suspend_walks  FLX_WALK_LANES*: a walk workgroup that has found the queue dry and is down to this many walks hands
- *                  them over (to the next round's walk kernel, or to the finisher) instead of finishing them; 0 = never */
-#define FLX_WALK_LANES 0
-#define FLX_WALK_QUEUES 1
-#define FLX_WALK_LANES_FINISHER 2
-flx_status flx_set_walk_scheduler(flx_context *ctx, int scheduler, uint32_t suspend_walks);
-/* 1 when the library carries the experimental schedulers above (`make EXPERIMENTS=1`: libflexlight_hip_experiments.so); the
- * shipped library returns 0 and its flx_set_walk_scheduler accepts (FLX_WALK_LANES, 0) only. */
-int flx_has_experiments(void);
 
 /* ---- native scene import (host only, needs no GPU and no context) ---------------------------------
  * One imported object: Scene.importMtl + Scene.importObj of the reference (modules/scene.js:330-487) including the
@@ -454,35 +372,12 @@ flx_status flx_mesh_flatten(const flx_mesh *mesh, float *geometry, float *attrib
  * positions: 3 per transform; out: rotation 24 floats and shift 8 floats per transform, ready for flx_transforms_upload. */
 flx_status flx_transforms_pack(uint32_t n_transforms, const double *matrices, const double *positions, float *rotation, float *shift);
 
-/* ---- diagnostics --------------------------------------------------------------------------------- */
-/* Evaluate one of include/flx_math.h's routines on the GPU for n inputs (b may be NULL for unary
- * functions); used by tests to prove CPU/GPU bit equality.  fn: 0 sin 1 cos 2 tan 3 acos 4 atan2
- * 5 exp 6 pow 7 tanh 8 floor 9 sqrt 10 div. */
-flx_status flx_debug_math(flx_context *ctx, int fn, const float *a, const float *b, float *out, uint32_t n);
-/* Evaluate one of the intersection routines on the GPU, AS THE KERNELS CALL IT, for n rows; used by tests to hold the device code against literal
- * answers computed from the shader text (tests/golden/intersect_kat.json.gz).  fn 0: moellerTrumbore (fragment:123-140) through the walk kernels'
- * routine over stored edges (exact 1/det from v_rcp_f32, branch-free acceptance), 1: moellerTrumboreCull (:143-158) through the same routine, 2: rayCuboid
- * (:161-167) through the walk kernels' box test (interval test, exact quotients by reciprocal, IEEE division where their preconditions fail); 3, 4, 5: the
- * same three as the per-pixel kernel calls them.  Rows: triangles 16 floats (a, b, c, origin, direction, l), boxes 13 (l, origin, direction, min, max);
- * out: 3 floats per row for fn 0 and 3 ((s, u, v) of a hit, zeros otherwise), else one float 0 / 1. */
-flx_status flx_debug_intersect(flx_context *ctx, int fn, const float *in, float *out, uint32_t n);
-/* Walk n rays through the uploaded scene on the GPU, AS THE KERNELS DO, one ray per lane: rayTracer (fragment:172-227) and shadowTest (:230-279) of each ray;
- * used by tests to hold the device walks against literal answers computed from the shader text (tests/golden/walk_kat.json.gz).  variant 0: the wavefront
- * pipeline's lane walk over the threaded, hot-first copy with the rays pre-transformed into every object space; 1: the per-pixel / persistent kernels' lane
- * walk; 2: their wave-wide lockstep walk (scenes of at most 128 entries in one object space).  rays: 7 floats each (origin, direction, shadowTest's l);
- * out: 8 floats each: s, u, v, 2 x transform number and entry index of the closest hit (zeros and -1 for none), entries that walk fetched, shadowTest's
- * answer (0 / 1), entries the shadow walk fetched. */
-flx_status flx_debug_walk(flx_context *ctx, int variant, const float *rays, float *out, uint32_t n);
-/* Scheduler statistics of the last counted frame (wavefront pipeline): for bounce b = 0..3 (3 = all
- * later ones) out[2b] = wave-iterations of the walk kernel, out[2b+1] = fold/refill batches. */
-flx_status flx_get_diag(flx_context *ctx, uint64_t out[32]);   /* out[8..12]: bounce-0 walk kernel stamps: fold, refill, step cycles, wave lifetime, waves; out[16+3b..]: per bounce sum / count / max of wave lifetimes */
-/* Tail profile of the last counted frame (wavefront pipeline, walk kernel of the round given to the build by FLX_TAIL_DIAG_ROUND, default 0):
- * for k = 0 .. 11 out[3k], out[3k+1], out[3k+2] = sum / count / max over the walk workgroups of the shader cycles since the workgroup's start
- * at which its walks in flight first numbered <= 2^k; out[36..38] the same for the moment the workgroup found the walk queue dry. */
-flx_status flx_get_tail_diag(flx_context *ctx, uint64_t out[40]);
 /* Device name / CU count of the context's GPU. */
 flx_status flx_device_info(flx_context *ctx, char *name, uint32_t name_len, uint32_t *compute_units);
 const char *flx_version(void);
+
+/* Work counters, kernel-organisation knobs for A/B runs, fault injection, device-side evaluators of single routines and the launch diagnostics are NOT part of
+ * this boundary: include/flexlight_hip_debug.h (same library, same ABI rules; used by tests/, tools/ and bench.py). */
 
 #ifdef __cplusplus
 }

@@ -7,21 +7,39 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "flexlight_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(flx_[a-z0-9_]+)\s*\(", text)))
+def declared_functions(headers=("flexlight_hip.h", "flexlight_hip_debug.h"), experiments=False):
+    """every function the boundary (flexlight_hip.h) and the instrumentation header (flexlight_hip_debug.h) declare; what the latter keeps under
+    #ifdef FLX_EXPERIMENTS exists in `make EXPERIMENTS=1`'s library only"""
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        if not experiments:
+            text = re.sub(r"#ifdef FLX_EXPERIMENTS.*?#endif", "", text, flags=re.S)
+        names.update(re.findall(r"\b(flx_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_symbols_are_exported():
     from flexlight_hip import capi
-    names = declared_functions()
+    names = declared_functions(experiments=capi.has_experiments())
     assert len(names) >= 20
     for name in names:
         assert hasattr(capi.LIB, name), "libflexlight_hip.so does not export %s" % name
-    assert sorted(capi.EXPORTS) == [n for n in names if n in capi.EXPORTS]
-    missing = [n for n in names if n not in capi.EXPORTS]
+    every = declared_functions(experiments=True)
+    assert sorted(capi.EXPORTS) == [n for n in every if n in capi.EXPORTS]
+    missing = [n for n in every if n not in capi.EXPORTS]
     assert not missing, "capi.EXPORTS lacks %s" % missing
+    # the drop-in boundary stays small (SURVEY.md 8b sketches a dozen calls; round 4's header had grown to 110): what a host binds is flexlight_hip.h alone
+    boundary = declared_functions(headers=("flexlight_hip.h",))
+    assert len(boundary) <= 80, len(boundary)
+    assert not [n for n in boundary if n.startswith("flx_debug_") or n.startswith("flx_get_") or "chain_" in n], boundary
+    # ... and the shipped library exports nothing that no header declares
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], stdout=subprocess.PIPE, universal_newlines=True).stdout
+    exported = sorted(set(re.findall(r" T (flx_[a-z0-9_]+)$", out, flags=re.M)))
+    if exported:
+        assert not [n for n in exported if n not in names], [n for n in exported if n not in names]
 
 
 def test_no_cpu_fallback():

@@ -32,6 +32,9 @@ def loop(ctx, ps):
     return got, kinds
 
 
+chain_of_launches = pytest.mark.experiments      # flx_set_frame_chain(ctx, 1): csrc/flx_chain.hip is in `make EXPERIMENTS=1`'s library only (the frame server replaced it)
+
+
 @pytest.fixture()
 def chained(hip):
     hip.set_frame_lanes(2)
@@ -40,6 +43,7 @@ def chained(hip):
     hip.set_frame_chain(2)
 
 
+@chain_of_launches
 @pytest.mark.parametrize("shape", [dict(width=640, height=360), dict(width=1920, height=1080, tile=(8, 3, 8)), dict(width=500, height=264, samples=3)])
 def test_chained_frames_equal_their_own_render(chained, scenes, shape):
     """a camera that moves from frame to frame, a seed that changes: whole frames, a rank's strips of the BASELINE frame, an odd width with three samples"""
@@ -54,6 +58,7 @@ def test_chained_frames_equal_their_own_render(chained, scenes, shape):
         assert bit_mismatches(got[f], want[f]) == 0, "frame %d differs from its own render" % f
 
 
+@chain_of_launches
 def test_a_chain_ends_where_the_frames_change(chained, scenes):
     """another frame shape, a scene upload, a synchronous render in between: each starts a new chain (kind 1) and every frame is still its own render"""
     sc = scenes("dragon")
@@ -97,6 +102,7 @@ def test_a_chain_ends_where_the_frames_change(chained, scenes):
     assert bit_mismatches(g0, want[0]) == 0 and bit_mismatches(g1, want[1]) == 0 and bit_mismatches(g2, want[2]) == 0
 
 
+@chain_of_launches
 def test_frames_the_chain_does_not_take_run_on_two_lanes(chained, scenes):
     """a scene of fewer than 129 entries (another pipeline), a filter frame, strips that are not a multiple of 8 rows: not chained, still right"""
     sc = scenes("cornell_obj")

@@ -92,7 +92,6 @@ def test_an_upload_of_unchanged_lights_and_transforms_is_nothing(served, scenes)
     sc = scenes("dragon")
     served.update_scene(sc)
     served.set_frame_lanes(3)
-    served.set_chain_stats(True)
     try:
         ps = [moving(sc, f, width=480, height=272) for f in range(8)]
         want = [served.render(p)[0] for p in ps]
@@ -119,7 +118,6 @@ def test_an_upload_of_unchanged_lights_and_transforms_is_nothing(served, scenes)
         served.frame_begin(ps[0])
         assert bit_mismatches(served.frame_end()[0], want[0]) == 0
     finally:
-        served.set_chain_stats(False)
         served.update_primary_light_sources(sc.arrays["lights"])
 
 

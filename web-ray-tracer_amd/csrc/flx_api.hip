@@ -574,7 +574,9 @@ flx_status flx_check_device_error(flx_context *ctx) {
   ctx->h_dev_error[0] = 0u;
   ctx->chain_seq = 0;
   /* the kernels' rings may hold ids nobody popped: back to "empty" for the next launch */
+#if FLX_EXPERIMENTS
   if (ctx->d_chain_rings) (void)hipMemsetAsync(ctx->d_chain_rings, 0xff, (size_t)ctx->prop.multiProcessorCount * chain_rings_per_group() * sizeof(uint32_t), ctx->stream);
+#endif
   if (ctx->d_sv_rings) (void)hipMemsetAsync(ctx->d_sv_rings, 0xff, (size_t)ctx->prop.multiProcessorCount * server_rings_per_group() * sizeof(uint32_t), ctx->stream);
   for (flx_context *c : { ctx, ctx->twin })
     if (c && c->d_frame_rings) (void)hipMemsetAsync(c->d_frame_rings, 0xff, (size_t)c->frame_rings_chains * c->prop.multiProcessorCount * WF_FRAME_RINGS * WF_FRAME_RING * sizeof(uint32_t), c->stream);
@@ -1380,9 +1382,13 @@ static bool chain_wanted(flx_context *ctx, const flx_frame_params *p, const Devi
   if (path_item_count64(fr) * (uint64_t)(ctx->frame_lanes == 3 ? 3 : 2) >= (1ull << 31)) return false;
   if ((uint32_t)fr.samples * 64u * 2u + 2u * (uint32_t)FLX_CHAIN_RESERVE > (uint32_t)WF_FRAME_RING - 256u) return false;
   uint32_t a = 0, b = 0;
-  return chain_kernel_fits(sc, a, b);
+#if FLX_EXPERIMENTS
+  if (ctx->frame_chain == 1) return chain_kernel_fits(sc, a, b);
+#endif
+  return server_kernel_fits(sc, a, b, SV_MAX_DEPTH);          /* (with room for a moving scene's transforms per slot) */
 }
 
+#if FLX_EXPERIMENTS      /* the chain of launches (mode 1) was measured and lost to the frame server: only `make EXPERIMENTS=1` carries it (Makefile) */
 static flx_status chain_resources(flx_context *ctx, size_t itemsPerSlot) {
   const uint32_t cus = (uint32_t)ctx->prop.multiProcessorCount;
   if (!ctx->d_chain_slots) {
@@ -1485,6 +1491,7 @@ static flx_status chain_run_frame(flx_context *ctx, const flx_frame_params *para
   ctx->chain_seq = seq; ctx->chain_slot = slotP; ctx->chain_depth = depth; ctx->chain_params = *params; ctx->chain_scene_version = ctx->scene_version;
   return FLX_OK;
 }
+#endif /* FLX_EXPERIMENTS */
 
 
 /* ---- the frame server (flx_server.hip) -------------------------------------------------------------------------------------
@@ -1828,8 +1835,10 @@ static flx_status frame_begin_on(flx_context *ctx, const flx_frame_params *param
   } else if (pixels) {
     if (params->use_filter || params->is_temporal) {
       s = run_post_frame(ctx, sc, fr, params, ctx->d_slot[k]);
+#if FLX_EXPERIMENTS
     } else if (chained == 1) {
       s = chain_run_frame(ctx, params, sc, fr, ctx->d_slot[k]);
+#endif
     } else {
       GBufferPtrs gb = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
       s = flx_run_frame(ctx, sc, fr, ctx->d_slot[k], gb);
@@ -1865,10 +1874,14 @@ extern "C" flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog
 extern "C" flx_status flx_set_frame_chain(flx_context *ctx, int mode) {
   if (!ctx) return FLX_ERR_INVALID;
   if (mode < 0 || mode > 3) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: 0 (every frame its own launches), 1 (a chain of launches that work ahead on each other's frames), 2 (the frame server — one persistent launch takes the loop's frames as they are posted — for frames of fewer than 64 screen tiles per CU) or 3 (the frame server for every frame it can take)");
+#if !FLX_EXPERIMENTS
+  if (mode == 1) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: the chain of launches (mode 1) is not in the shipped library (make EXPERIMENTS=1; it lost to the frame server, modes 2 / 3)");
+#endif
   if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_set_frame_chain: frames are in flight");
   ctx->frame_chain = mode; ctx->chain_seq = 0;
   return FLX_OK;
 }
+#if FLX_EXPERIMENTS
 extern "C" flx_status flx_set_chain_stats(flx_context *ctx, int on) {
   if (!ctx) return FLX_ERR_INVALID;
   FLX_HIP(ctx, hipSetDevice(ctx->device));
@@ -1921,6 +1934,7 @@ extern "C" flx_status flx_get_chain_cost(flx_context *ctx, uint32_t *out /* [2 *
   FLX_HIP(ctx, hipMemcpy(out, ctx->d_chain_cost, 2 * ctx->chain_cost_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return FLX_OK;
 }
+#endif /* FLX_EXPERIMENTS */
 extern "C" flx_status flx_get_server_dump(flx_context *ctx, uint64_t *out /* [4 * 72] */) {
   if (!ctx || !out || !ctx->d_sv_stats) return FLX_ERR_INVALID;
   FLX_HIP(ctx, hipSetDevice(ctx->device));

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "flexlight_hip.h"
+#include "flexlight_hip_debug.h"
 #include "flx_kernels.h"
 #include "flx_chain.h"
 #include "flx_server.h"
