@@ -205,3 +205,26 @@ def test_group_presents_rgba8_through_node(hip, oracle, scenes, tmp_path):
         want = oracle.present(oracle.render(sc, p)[0])
         got = np.fromfile(prefix + "%d.f32" % k, np.uint8).reshape(h, w, 4)
         assert np.array_equal(got, want), "frame %d" % k
+
+
+def test_the_frame_loop_leaves_the_main_thread_in_the_event_loop(tmp_path):
+    """SURVEY 8b ("a napi_async_work worker for the non-blocking variant") / pathtracerWGL2.js:300-302 (the reference's loop returns to the event loop every frame):
+    PathTracerHIP.render() waits for a frame on a worker thread (frameEndAsync), so an application timer of 1 ms fires on time while whole 1080p frames (6.4 ms each) are
+    traced; with the blocking flx_frame_end of round 4 the same timer is late by most of a frame.  Frames are the same bytes either way."""
+    node = shutil.which("node")
+    assert node
+    out = {}
+    for mode in ("0", "1"):
+        prefix = str(tmp_path / ("lag%s_" % mode))
+        cmd = [node, os.path.join(ROOT, "tools", "js_loop.js"), os.path.join(ROOT, "tests", "golden", "ref_dragon.flxs.gz"), "--frames", "40", "--move", "1",
+               "--blocking", mode, "--dump", prefix, "--dump-frames", "3"]
+        out[mode] = json.loads(subprocess.check_output(cmd, timeout=600).decode().splitlines()[-1])
+    a, b = out["0"], out["1"]
+    assert a["frameEnd"].startswith("async") and b["frameEnd"] == "blocking"
+    assert a["eventLoopLagMs"]["samples"] > 40 and a["eventLoopLagMs"]["median"] < 1.0, a["eventLoopLagMs"]
+    assert b["eventLoopLagMs"]["median"] > 2.0 * max(a["eventLoopLagMs"]["median"], 0.25), (a["eventLoopLagMs"], b["eventLoopLagMs"])      # the blocking loop holds the thread for the frame
+    assert a["fps"] > 0.9 * b["fps"], (a["fps"], b["fps"])                                         # ... and the worker thread costs the loop next to nothing
+    for k in range(3):
+        fa = np.fromfile(str(tmp_path / ("lag0_%d.f32" % k)), np.float32)
+        fb = np.fromfile(str(tmp_path / ("lag1_%d.f32" % k)), np.float32)
+        assert fa.size == 1920 * 1080 * 4 and np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), k

@@ -6,7 +6,9 @@
  *   node tools/js_loop.js tests/golden/ref_dragon.flxs.gz [--frames N] [--move 1] [--present8 1] [--width W --height H --spp S --bounces B]
  *                         [--devices 0,1,..  (a group of GPUs in this process; a number may repeat: rehearsal on one GPU)  --lanes 2|3]
  *                         [--dump PREFIX --dump-frames K]    (the first K frames as PREFIX<k>.f32 + the camera / transforms used, for the parity test)
- * Prints one JSON line: frames, seconds, fps (wall clock over the loop), the renderer's own fps counter, median GPU ms per frame.
+ *                         [--blocking 1]   (flx_frame_end on the main thread, as before round 5, instead of frameEndAsync on a worker thread)
+ * Prints one JSON line: frames, seconds, fps (wall clock over the loop), the renderer's own fps counter, median GPU ms per frame, and how late a 1 ms
+ * timer of the application fires while the loop runs (eventLoopLagMs: the main thread is in the event loop while a worker waits for the GPU).
  */
 const fs = require('fs');
 const path = require('path');
@@ -52,6 +54,15 @@ engine.renderer = 'pathtracer';
 engine.renderer.scene = replay;
 engine.renderer.present8 = Number(opt('--present8', 0)) === 1;
 if (devices) engine.renderer.groupLanes = Number(opt('--lanes', 3));
+engine.renderer.blockingFrameEnd = Number(opt('--blocking', 0)) === 1;
+/* the application's own timer: how late does it fire?  (setInterval(…, 1) asks for 1 ms; what comes on top is the time the main thread was not in the event loop) */
+const lag = [];
+let lastTick = 0;
+const lagTimer = setInterval(() => {
+  const now = Number(process.hrtime.bigint()) / 1e6;
+  if (lastTick && got > 0) lag.push(Math.max(0, now - lastTick - 1));
+  lastTick = now;
+}, 1);
 
 const gpuMs = [];
 const log = [];
@@ -81,10 +92,14 @@ canvas.onFrame = f => {
     const seconds = (Date.now() - t0) / 1000;
     const rendererFps = engine.renderer.fps;
     engine.renderer.halt();
+    clearInterval(lagTimer);
+    lag.sort((a, b) => a - b);
+    const lagStats = lag.length ? { samples: lag.length, mean: lag.reduce((a, b) => a + b, 0) / lag.length, median: lag[lag.length >> 1], p99: lag[Math.floor(lag.length * 0.99)], max: lag[lag.length - 1] } : null;
     gpuMs.sort((a, b) => a - b);
     if (dumpPrefix) fs.writeFileSync(dumpPrefix + 'log.json', JSON.stringify(log));
     console.log(JSON.stringify({ scene: meta.name, width: canvas.width, height: canvas.height, spp: engine.config.samplesPerRay, bounces: engine.config.maxReflections,
-      frames, seconds, fps: frames / seconds, rendererFps: Number(rendererFps), gpuMsMedian: gpuMs[gpuMs.length >> 1], present8: engine.renderer.present8, moving: move, devices: devices ? devices.split(',').map(Number) : null, lanes: devices ? engine.renderer.groupLanes : 2 }));
+      frames, seconds, fps: frames / seconds, rendererFps: Number(rendererFps), gpuMsMedian: gpuMs[gpuMs.length >> 1], present8: engine.renderer.present8, moving: move, devices: devices ? devices.split(',').map(Number) : null, lanes: devices ? engine.renderer.groupLanes : 2,
+      frameEnd: engine.renderer.blockingFrameEnd ? 'blocking' : 'async (worker thread)', eventLoopLagMs: lagStats }));
   }
 };
 engine.renderer.render().catch(e => { console.error(e); process.exit(1); });

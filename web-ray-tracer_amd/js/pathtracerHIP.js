@@ -93,6 +93,11 @@ class PathTracerHIP {
 
   halt () {                                               // pathtracerWGL2.js:70-77
     this._halt = true;
+    if (this._pendingEnd) { this._releaseWhenIdle = true; return; }      // a frame is being waited for on a worker thread (render()'s frameEndAsync): released when it settles
+    this._release();
+  }
+
+  _release () {
     if (this._ctx) {
       try { native().destroyContext(this._ctx); } catch (e) { console.warn('Unable to release the GPU context', e.message); }
       this._ctx = null;
@@ -276,14 +281,26 @@ class PathTracerHIP {
         frames = 0; windowStart = now;
       }
     };
-    const take = () => {
+    /* flx_frame_end waits for the GPU: on a worker thread (frameEndAsync: napi_async_work), so that this thread is back in the event loop for most of every frame,
+     * as the reference's is (pathtracerWGL2.js:300-302).  this.blockingFrameEnd = true: the synchronous call, for measurements. */
+    const take = async () => {
       const q = pending.shift();
-      const r = q.group ? native().groupFrameEnd(this._group, q.rgba8) : native().frameEnd(this._ctx, q.rgba8);
+      let r;
+      if (this.blockingFrameEnd) r = q.group ? native().groupFrameEnd(this._group, q.rgba8) : native().frameEnd(this._ctx, q.rgba8);
+      else {
+        this._pendingEnd = q.group ? native().groupFrameEndAsync(this._group, q.rgba8) : native().frameEndAsync(this._ctx, q.rgba8);
+        try { r = await this._pendingEnd; } finally { this._pendingEnd = null; }
+      }
       this._inFlight--;
+      if (this._releaseWhenIdle) {                          // halt() came while the frame was being waited for: its memory goes now
+        this._releaseWhenIdle = false;
+        this._release();
+        return;
+      }
       this.gpuMs = r.gpuMs;
       deliver({ width: q.width, height: q.height, rows: q.rows, radiance: q.rgba8 ? undefined : r.pixels, rgba8: q.rgba8 ? r.pixels : undefined, pixels: r.pixels, frameMs: r.gpuMs });
     };
-    const cycle = () => {
+    const cycle = async () => {
       if (this._halt) return;
       try {
         const aa = this._antialiasing();
@@ -295,11 +312,12 @@ class PathTracerHIP {
           this._uploadFrameState();
           const p = this.frameParams();
           if (this._lanesSet !== this.groupLanes) {         // (the library's default is 3)
-            while (this._inFlight > 0) take();
+            while (this._inFlight > 0 && !this._halt) await take();
+            if (this._halt) return;
             native().groupSetFrameLanes(this._group, this.groupLanes);
             this._lanesSet = this.groupLanes;
           }
-          if (this._inFlight === this.groupLanes) take();
+          if (this._inFlight === this.groupLanes) await take();
           if (this._halt) return;                           // (the application halted the renderer from its onFrame)
           native().groupFrameBegin(this._group, p, this._tileRows, this.present8);
           this._inFlight++;
@@ -312,9 +330,10 @@ class PathTracerHIP {
           this._inFlight++;
           pending.push({ width: p.width, height: p.height, rows: p.height, rgba8: this.present8 });
           this._temporalFrame = (this._temporalFrame + 1) % Math.max(1, this.config.temporalSamples);
-          if (this._inFlight === 2) take();
+          if (this._inFlight === 2) await take();
         } else {
-          while (this._inFlight > 0) take();
+          while (this._inFlight > 0 && !this._halt) await take();
+          if (this._halt) return;
           deliver(this.renderFrame({ reuse: true }));
         }
       } catch (e) {
@@ -322,6 +341,7 @@ class PathTracerHIP {
         this._halt = true;
         return;
       }
+      if (this._halt) return;
       if (this.fpsLimit === Infinity) setImmediate(cycle);
       else setTimeout(cycle, 1000 / this.fpsLimit);
     };

@@ -45,6 +45,7 @@ struct CtxBox {
   flx_context *ctx = nullptr;              /* first member: a handle also reads as flx_context ** */
   struct View { const void *ptr; napi_ref ref; };
   std::vector<View> views;
+  bool busy = false;                       /* a frameEndAsync is waiting for the GPU on a worker thread: the context is that thread's until its promise settles */
 };
 static void detach_view(napi_env env, CtxBox::View &v) {
   napi_value buf = nullptr;
@@ -62,6 +63,7 @@ static CtxBox *get_box(napi_env env, napi_value v) {
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a context handle"); return nullptr; }
   CtxBox *box = static_cast<CtxBox *>(p);
   if (!box->ctx) { napi_throw_error(env, nullptr, "context was halted"); return nullptr; }
+  if (box->busy) { napi_throw_error(env, nullptr, "a frameEndAsync of this context is pending: await it first"); return nullptr; }
   return box;
 }
 static flx_context *get_ctx(napi_env env, napi_value v) {
@@ -145,6 +147,7 @@ static napi_value DestroyContext(napi_env env, napi_callback_info info) {
   void *p = nullptr;
   if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
     CtxBox *box = static_cast<CtxBox *>(p);
+    if (box->busy) { napi_throw_error(env, nullptr, "destroyContext: a frameEndAsync is pending: await it first"); return nullptr; }
     detach_views(env, box, [](const void *) { return false; });      /* the pinned slots are about to be freed */
     if (box->ctx) { flx_context_destroy(box->ctx); box->ctx = nullptr; }
   }
@@ -560,6 +563,22 @@ static napi_value FrameBegin(napi_env env, napi_callback_info info) {
   return nullptr;
 }
 static void no_free(napi_env, void *, void *) {}
+/* { pixels, gpuMs } over the pinned slot (or the group's image) the frame is in */
+static napi_value frame_result(napi_env env, std::vector<CtxBox::View> &views, const void *pixels, size_t bytes, float ms, bool rgba8) {
+  napi_value res, buf, arr, v;
+  NAPI_OK(env, napi_create_object(env, &res));
+  NAPI_OK(env, napi_create_external_arraybuffer(env, const_cast<void *>(pixels), bytes, no_free, nullptr, &buf));
+  {
+    CtxBox::View view = { pixels, nullptr };
+    NAPI_OK(env, napi_create_reference(env, buf, 0, &view.ref));      /* weak: the view lives as long as JavaScript holds it */
+    views.push_back(view);
+  }
+  if (rgba8) NAPI_OK(env, napi_create_typedarray(env, napi_uint8_clamped_array, bytes, buf, 0, &arr));
+  else NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, bytes / 4, buf, 0, &arr));
+  napi_set_named_property(env, res, "pixels", arr);
+  napi_create_double(env, ms, &v); napi_set_named_property(env, res, "gpuMs", v);
+  return res;
+}
 static napi_value FrameEnd(napi_env env, napi_callback_info info) {
   napi_value argv[2];
   if (!get_args(env, info, 2, argv)) return nullptr;
@@ -571,22 +590,11 @@ static napi_value FrameEnd(napi_env env, napi_callback_info info) {
   const void *pixels = nullptr; size_t bytes = 0; float ms = 0.f;
   flx_status rc = flx_frame_end(ctx, &pixels, &bytes, &ms);
   if (rc != FLX_OK) return fail(env, ctx, "flx_frame_end", rc);
-  napi_value res, buf, arr, v;
-  NAPI_OK(env, napi_create_object(env, &res));
   /* the slot now holds THIS frame: an older frame's view of the same memory (two frames back on this lane) is detached */
   detach_views(env, box, [&](const void *q) { return q != pixels; });
-  NAPI_OK(env, napi_create_external_arraybuffer(env, const_cast<void *>(pixels), bytes, no_free, nullptr, &buf));
-  {
-    CtxBox::View view = { pixels, nullptr };
-    NAPI_OK(env, napi_create_reference(env, buf, 0, &view.ref));      /* weak: the view lives as long as JavaScript holds it */
-    box->views.push_back(view);
-  }
-  if (rgba8) NAPI_OK(env, napi_create_typedarray(env, napi_uint8_clamped_array, bytes, buf, 0, &arr));
-  else NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, bytes / 4, buf, 0, &arr));
-  napi_set_named_property(env, res, "pixels", arr);
-  napi_create_double(env, ms, &v); napi_set_named_property(env, res, "gpuMs", v);
-  return res;
+  return frame_result(env, box->views, pixels, bytes, ms, rgba8);
 }
+
 static napi_value FramesInFlight(napi_env env, napi_callback_info info) {
   napi_value argv[1];
   if (!get_args(env, info, 1, argv)) return nullptr;
@@ -603,6 +611,7 @@ static napi_value FramesInFlight(napi_env env, napi_callback_info info) {
 struct GroupBox {
   flx_group *g = nullptr;                  /* first member: a handle also reads as flx_group ** */
   std::vector<CtxBox::View> views;
+  bool busy = false;                       /* a groupFrameEndAsync is pending */
 };
 static void detach_group_views(napi_env env, GroupBox *box) {
   for (auto &v : box->views) detach_view(env, v);
@@ -619,6 +628,7 @@ static GroupBox *get_group_box(napi_env env, napi_value v) {
   if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a group handle"); return nullptr; }
   GroupBox *box = static_cast<GroupBox *>(p);
   if (!box->g) { napi_throw_error(env, nullptr, "group was halted"); return nullptr; }
+  if (box->busy) { napi_throw_error(env, nullptr, "a groupFrameEndAsync of this group is pending: await it first"); return nullptr; }
   return box;
 }
 static flx_group *get_group(napi_env env, napi_value v) {
@@ -655,6 +665,7 @@ static napi_value DestroyGroup(napi_env env, napi_callback_info info) {
   void *p = nullptr;
   if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
     GroupBox *box = static_cast<GroupBox *>(p);
+    if (box->busy) { napi_throw_error(env, nullptr, "destroyGroup: a groupFrameEndAsync is pending: await it first"); return nullptr; }
     detach_group_views(env, box);          /* the images are freed with the group: whoever still holds a frame reads an empty array */
     if (box->g) { flx_group_destroy(box->g); box->g = nullptr; }
   }
@@ -824,20 +835,86 @@ static napi_value GroupFrameEnd(napi_env env, napi_callback_info info) {
   const void *pixels = nullptr; size_t bytes = 0; float ms = 0.f;
   flx_status rc = flx_group_frame_end(box->g, &pixels, &bytes, &ms);
   if (rc != FLX_OK) return gfail(env, box->g, "flx_group_frame_end", rc);
-  napi_value res, buf, arr, v;
-  NAPI_OK(env, napi_create_object(env, &res));
-  NAPI_OK(env, napi_create_external_arraybuffer(env, const_cast<void *>(pixels), bytes, no_free, nullptr, &buf));
-  {
-    CtxBox::View view = { pixels, nullptr };
-    NAPI_OK(env, napi_create_reference(env, buf, 0, &view.ref));
-    box->views.push_back(view);
-  }
-  if (rgba8) NAPI_OK(env, napi_create_typedarray(env, napi_uint8_clamped_array, bytes, buf, 0, &arr));
-  else NAPI_OK(env, napi_create_typedarray(env, napi_float32_array, bytes / 4, buf, 0, &arr));
-  napi_set_named_property(env, res, "pixels", arr);
-  napi_create_double(env, ms, &v); napi_set_named_property(env, res, "gpuMs", v);
-  return res;
+  return frame_result(env, box->views, pixels, bytes, ms, rgba8);
 }
+/* ---- frameEndAsync(handle, rgba8) / groupFrameEndAsync(handle, rgba8) -> Promise<{ pixels, gpuMs }> ------------------------------------------
+ * The reference's loop hands the frame to the browser and returns to the event loop (modules/pathtracerWGL2.js:300-302); flx_frame_end WAITS for the GPU.
+ * Here the wait happens on a libuv worker thread (napi_async_work) and the promise settles on the main thread, which meanwhile runs timers, I/O and the
+ * application's own code.  While the promise is pending the context (group) belongs to the worker: every other call on it throws. */
+struct EndWork {
+  napi_async_work work = nullptr;
+  napi_deferred deferred = nullptr;
+  napi_ref handle = nullptr;               /* keeps the context / group handle alive */
+  CtxBox *box = nullptr;
+  GroupBox *gbox = nullptr;
+  bool rgba8 = false;
+  flx_status rc = FLX_OK;
+  const void *pixels = nullptr; size_t bytes = 0; float ms = 0.f;
+  std::string err;
+};
+static void end_execute(napi_env, void *data) {      /* worker thread: no N-API calls here */
+  EndWork *w = static_cast<EndWork *>(data);
+  if (w->box) {
+    w->rc = flx_frame_end(w->box->ctx, &w->pixels, &w->bytes, &w->ms);
+    if (w->rc != FLX_OK) w->err = std::string("flx_frame_end failed (") + std::to_string(w->rc) + "): " + flx_last_error(w->box->ctx);
+  } else {
+    w->rc = flx_group_frame_end(w->gbox->g, &w->pixels, &w->bytes, &w->ms);
+    if (w->rc != FLX_OK) w->err = std::string("flx_group_frame_end failed (") + std::to_string(w->rc) + "): " + flx_group_last_error(w->gbox->g);
+  }
+}
+static void end_complete(napi_env env, napi_status status, void *data) {      /* main thread */
+  EndWork *w = static_cast<EndWork *>(data);
+  if (w->box) w->box->busy = false; else w->gbox->busy = false;
+  napi_value out = nullptr;
+  if (status == napi_ok && w->rc == FLX_OK) {
+    if (w->box) detach_views(env, w->box, [&](const void *q) { return q != w->pixels; });
+    out = frame_result(env, w->box ? w->box->views : w->gbox->views, w->pixels, w->bytes, w->ms, w->rgba8);
+  }
+  if (out) napi_resolve_deferred(env, w->deferred, out);
+  else {
+    bool pending = false;
+    napi_is_exception_pending(env, &pending);
+    napi_value ex = nullptr;
+    if (pending) napi_get_and_clear_last_exception(env, &ex);
+    if (!ex) {
+      napi_value msg;
+      napi_create_string_utf8(env, w->err.empty() ? "frameEndAsync: cancelled" : w->err.c_str(), NAPI_AUTO_LENGTH, &msg);
+      napi_create_error(env, nullptr, msg, &ex);
+    }
+    napi_reject_deferred(env, w->deferred, ex);
+  }
+  napi_delete_reference(env, w->handle);
+  napi_delete_async_work(env, w->work);
+  delete w;
+}
+static napi_value end_async(napi_env env, napi_callback_info info, bool group) {
+  napi_value argv[2];
+  if (!get_args(env, info, 2, argv)) return nullptr;
+  CtxBox *box = group ? nullptr : get_box(env, argv[0]);
+  GroupBox *gbox = group ? get_group_box(env, argv[0]) : nullptr;
+  if (!box && !gbox) return nullptr;
+  EndWork *w = new EndWork();
+  w->box = box; w->gbox = gbox;
+  napi_get_value_bool(env, argv[1], &w->rgba8);
+  napi_value promise, name;
+  if (napi_create_promise(env, &w->deferred, &promise) != napi_ok || napi_create_reference(env, argv[0], 1, &w->handle) != napi_ok ||
+      napi_create_string_utf8(env, group ? "flx_group_frame_end" : "flx_frame_end", NAPI_AUTO_LENGTH, &name) != napi_ok ||
+      napi_create_async_work(env, nullptr, name, end_execute, end_complete, w, &w->work) != napi_ok) {
+    delete w;
+    napi_throw_error(env, nullptr, "frameEndAsync: could not create the work item");
+    return nullptr;
+  }
+  if (box) box->busy = true; else gbox->busy = true;
+  if (napi_queue_async_work(env, w->work) != napi_ok) {
+    if (box) box->busy = false; else gbox->busy = false;
+    napi_delete_reference(env, w->handle); napi_delete_async_work(env, w->work); delete w;
+    napi_throw_error(env, nullptr, "frameEndAsync: could not queue the work item");
+    return nullptr;
+  }
+  return promise;
+}
+static napi_value FrameEndAsync(napi_env env, napi_callback_info info) { return end_async(env, info, false); }
+static napi_value GroupFrameEndAsync(napi_env env, napi_callback_info info) { return end_async(env, info, true); }
 static napi_value GroupFramesInFlight(napi_env env, napi_callback_info info) {
   napi_value argv[1];
   if (!get_args(env, info, 1, argv)) return nullptr;
@@ -874,7 +951,7 @@ static napi_value Init(napi_env env, napi_value exports) {
     { "meshImport", MeshImport }, { "meshCounts", MeshCounts }, { "meshSetTransform", MeshSetTransform }, { "meshMove", MeshMove },
     { "meshScale", MeshScale }, { "meshSetMaterial", MeshSetMaterial }, { "meshFlatten", MeshFlatten }, { "meshBounding", MeshBounding }, { "packTransforms", PackTransforms },
     { "present", Present }, { "fxaa", Fxaa }, { "taa", Taa }, { "taaReset", TaaReset },
-    { "frameBegin", FrameBegin }, { "frameEnd", FrameEnd }, { "framesInFlight", FramesInFlight },
+    { "frameBegin", FrameBegin }, { "frameEnd", FrameEnd }, { "frameEndAsync", FrameEndAsync }, { "groupFrameEndAsync", GroupFrameEndAsync }, { "framesInFlight", FramesInFlight },
     { "createGroup", CreateGroup }, { "destroyGroup", DestroyGroup }, { "groupInfo", GroupInfo }, { "groupUploadScene", GroupUploadScene },
     { "groupUploadTransforms", GroupUploadTransforms }, { "groupUploadLights", GroupUploadLights }, { "groupUploadAtlas", GroupUploadAtlas },
     { "groupRender", GroupRender }, { "groupRenderRgba8", GroupRenderRgba8 }, { "groupFrameBegin", GroupFrameBegin }, { "groupFrameEnd", GroupFrameEnd }, { "groupFramesInFlight", GroupFramesInFlight },
