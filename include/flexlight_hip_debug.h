@@ -44,6 +44,10 @@ flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog_polls, uin
 /* The shading keeps a per-triangle table of what fragment:500-512 derives from a triangle and its transform alone (three acos and three tan per shade otherwise),
  * made again at scene / transform uploads.  0: every shade computes the values itself — the same floats; for A/B runs. */
 flx_status flx_debug_set_angle_table(flx_context *ctx, int on);
+/* Walk jobs per lane of the frame kernel's walk waves: 1 = k_wf_frame (1 024-thread workgroups, a path's walks per lane), 2 = k_wf_frame2 (512-thread workgroups, two
+ * independent jobs per lane, a box phase and a triangle phase per trip; only where the front of the frame is inside the launch), 0 = the library's default.  Frames and
+ * work counters are identical; for A/B runs (profiles/r05_two_walks.txt). */
+flx_status flx_debug_set_walk_jobs(flx_context *ctx, int jobs);
 /* Rehearsal of a device group on ONE GPU: the frame server's launch takes `groups` CUs only (0: all), so that the launches of several contexts run beside
  * each other. */
 flx_status flx_debug_set_server_groups(flx_context *ctx, uint32_t groups);

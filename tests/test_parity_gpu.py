@@ -488,6 +488,37 @@ def test_walk_schedulers_do_not_change_the_frame(hip, oracle, scenes, name, w, h
         hip.set_walk_scheduler(0, 0)
 
 
+@pytest.mark.experiments
+@pytest.mark.parametrize("w,h,spp,bounces", [(480, 270, 2, 4), (640, 368, 8, 4), (200, 120, 3, 6)])
+def test_two_walk_jobs_per_lane_do_not_change_the_frame(hip, oracle, scenes, w, h, spp, bounces):
+    """k_wf_frame2 (round 5, measured slower, `make EXPERIMENTS=1` only): the walk waves of the frame kernel hold two independent jobs per lane and step them in a box phase
+    and a triangle phase — another order of the same work: same bits, same work counters as the oracle"""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=w, height=h, samples=spp, max_reflections=bounces, use_filter=0)
+    key = ("dragon", w, h, spp, bounces)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = oracle.render(sc, p)[:2]
+    want, want_cnt = _ORACLE_CACHE[key]
+    try:
+        hip.set_pipeline(3)
+        hip.set_wavefront_organisation(2)
+        hip.set_frame_front(2)                                  # the front of the frame inside the launch whatever the frame's size: the kernel the two-job variant replaces
+        hip.set_walk_jobs(2)
+        for _ in range(2):
+            got, cnt, _ = hip.render(p, counters=True)
+            assert hip.last_organisation() == 3
+            assert np.array_equal(got, want, equal_nan=True)
+            assert cnt == want_cnt
+        got, _, _ = hip.render(p)
+        assert np.array_equal(got, want, equal_nan=True)
+    finally:
+        hip.set_walk_jobs(1)
+        hip.set_pipeline(0)
+        hip.set_wavefront_organisation(0)
+        hip.set_frame_front(1)
+
+
 def test_walk_scheduler_arguments(hip):
     from flexlight_hip import capi
     for args in ((3, 0), (-1, 0), (0, 513), (1, 8)):
@@ -498,6 +529,8 @@ def test_walk_scheduler_arguments(hip):
         for args in ((1, 0), (2, 16), (0, 16)):
             with pytest.raises(capi.FlexLightHipError, match="EXPERIMENTS"):
                 hip.set_walk_scheduler(*args)
+        with pytest.raises(capi.FlexLightHipError, match="EXPERIMENTS"):
+            hip.set_walk_jobs(2)
 
 
 def test_errors_are_reported_not_thrown(hip, scenes):

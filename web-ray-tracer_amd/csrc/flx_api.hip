@@ -66,6 +66,9 @@ extern "C" flx_status flx_context_create(int device, flx_context **out) {
   if (device < 0 || device >= n) { g_create_error = "flx_context_create: device index out of range"; return FLX_ERR_INVALID; }
   flx_context *ctx = new flx_context();
   ctx->device = device;
+#if FLX_EXPERIMENTS
+  if (const char *wj = getenv("FLX_WALK_JOBS")) { if (wj[0] == '1' || wj[0] == '2') ctx->walk_jobs = (uint32_t)(wj[0] - '0'); }      /* A/B runs of whole test suites and bench.py (flx_debug_set_walk_jobs) */
+#endif
   auto bail = [&](const char *what, hipError_t err) {
     g_create_error = std::string(what) + ": " + hipGetErrorString(err);
     delete ctx;
@@ -795,7 +798,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
       wb.frameRings = ctx->d_frame_rings + (size_t)g * cus * WF_FRAME_RINGS * WF_FRAME_RING;
       wb.front = front ? 1u : (fusedFront ? 2u : 0u);
-      wb.error = ctx->d_dev_error; wb.watchdog = ctx->inject_watchdog; wb.inject = ctx->inject_flags;
+      wb.error = ctx->d_dev_error; wb.watchdog = ctx->inject_watchdog; wb.inject = ctx->inject_flags; wb.walkJobs = ctx->walk_jobs;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
       wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
@@ -1991,6 +1994,17 @@ extern "C" flx_status flx_frame_target_set8(flx_context *ctx, void *const *d_ima
 extern "C" int flx_frame_target_index(const flx_context *ctx) {
   if (!ctx || !ctx->sv_target_slots || !ctx->sv_running) return -1;
   return (int)((ctx->sv_next_slot + ctx->sv_depth - 1u) % ctx->sv_depth);
+}
+/* walk jobs per lane of the frame kernel's walk waves (1: k_wf_frame, 2: k_wf_frame2 where the front of the frame is inside the launch); for A/B runs */
+extern "C" flx_status flx_debug_set_walk_jobs(flx_context *ctx, int jobs) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (jobs < 0 || jobs > 2) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_walk_jobs: 0 (the default), 1 or 2");
+#if !FLX_EXPERIMENTS
+  if (jobs == 2) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_walk_jobs: two jobs per lane (k_wf_frame2) measured slower and is not in the shipped library (make EXPERIMENTS=1)");
+#endif
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_walk_jobs: frames are in flight");
+  ctx->walk_jobs = jobs ? (uint32_t)jobs : (uint32_t)FLX_WALK_JOBS_DEFAULT;
+  return FLX_OK;
 }
 /* the shading's per-triangle table (DeviceScene::angle_tan) off: every shade computes the values itself, as before round 4 — for A/B runs and the test that both agree */
 extern "C" flx_status flx_debug_set_angle_table(flx_context *ctx, int on) {

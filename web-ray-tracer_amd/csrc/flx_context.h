@@ -25,6 +25,9 @@ typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept 
 #endif
 constexpr int WF_MAX_GROUPS = 4;
 #ifndef FLX_FRAME_CHAIN_DEFAULT
+#ifndef FLX_WALK_JOBS_DEFAULT
+#define FLX_WALK_JOBS_DEFAULT 1
+#endif
 #define FLX_FRAME_CHAIN_DEFAULT 2      /* flx_set_frame_chain's default: the frame server where a frame is a rank's thin share */
 #endif
 constexpr int FLX_COUNTER_SLOTS = 80;          /* 8 work counters + 32 scheduler diagnostics (flx_get_diag) + 40 tail profile (flx_get_tail_diag) */
@@ -52,6 +55,7 @@ struct flx_context {
   bool lock_use = true;                          /* flx_set_lockstep */
   bool gb_float_wanted = false;                  /* flx_render was given `gbuffers`: the filter frame keeps its float G-buffers */
   int walk_scheduler = 0;
+  uint32_t walk_jobs = FLX_WALK_JOBS_DEFAULT;    /* flx_debug_set_walk_jobs: walk jobs per lane of the frame kernel's walk waves */
   int32_t *d_ids = nullptr;
   float *d_lights = nullptr;
   uchar4 *d_atlas[3] = { nullptr, nullptr, nullptr };

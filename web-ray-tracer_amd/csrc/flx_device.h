@@ -948,6 +948,21 @@ FLX_DEV bool walkTriT(WalkState &w, const WalkEntry &cur) {
   w.i = __float_as_int(cur.e2.y);
   return ended;
 }
+/* walkTriT's second half on its own: what a triangle test's answer does to the walk (fragment:217-222 / :270-273) and the link it leaves by — for callers that run the
+ * test on operands they picked themselves (the two-job walk waves, flx_wavefront.hip: k_wf_frame2) */
+FLX_DEV bool walkTriApply(WalkState &w, const WalkEntry &cur, bool hit, f3 suv) {
+  bool ended = false;
+  if (hit) {
+    if (w.mode == 0) { w.shadowed = true; ended = true; }
+    else if (suv.x != 0.0f) {                        /* fragment:217 */
+      w.suv = suv; w.hitTI = (__float_as_int(cur.e2.z) >> 2) << 1; w.tri = __float_as_int(cur.e2.w);
+      w.minLen = suv.x;
+    }
+  }
+  w.i = __float_as_int(cur.e2.y);
+  return ended;
+}
+FLX_DEV f3 sel3(bool c, f3 a, f3 b) { return F3(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z); }
 FLX_DEV void walkStartT(const DeviceScene &sc, WalkState &w, int mode, const Ray &ray, float len) {
   w.mode = mode; w.src = ray; w.tR = ray; w.cachedTI = 0; w.minLen = len; w.i = (int)sc.walk_root;
   walkPrepareRay(sc, w);

@@ -56,6 +56,7 @@ struct WavefrontBuffers {
   uint32_t *error;              /* the context's device error word (pinned host memory, WF_ERR_* bits), or nullptr: a watchdog that trips says so here (flx_status FLX_ERR_DEVICE at the next point the host waits) */
   uint32_t watchdog;            /* frame kernels: polls after which a wave that waits gives up (0: FQ_WATCHDOG, seconds); fault injection sets it low */
   uint32_t inject;              /* fault injection (flx_debug_inject_fault): WF_INJECT_* */
+  uint32_t walkJobs;            /* frame kernel with its front inside: 2 = two walk jobs per lane (k_wf_frame2); else one (k_wf_frame) */
 };
 /* the arguments of the shade kernels and the frame kernels, read from the kernarg segment where they are used (flx_frame_common.h) */
 struct FrameArgs { DeviceScene sc; DeviceFrame fr; WavefrontBuffers wb; };

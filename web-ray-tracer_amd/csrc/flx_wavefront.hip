@@ -1213,6 +1213,454 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #undef FLX_FRAME_ARGS
 }
 
+/* ---- the frame kernel with TWO WALK JOBS PER LANE (round 5; profiles/r05_two_walks.txt) ------------------------------------------------------------
+ * What bounds k_wf_frame is instruction issue with half of the lanes masked (VALU issue 0.48 priced as FMAs, 0.68 by class; lane utilisation 0.54): nearly every
+ * trip of a walk wave has lanes at boxes AND lanes at triangles, so both test bodies run, each for part of the lanes, and the ~25 % of the lanes that stand at a
+ * triangle pay for a 97-instruction body.  Making the lanes wait for company lost (profiles/r01_ab_deferred_triangles.txt: a lane that waits lengthens its chain).
+ * Here a lane holds TWO independent jobs (each what a lane of k_wf_frame holds: a path's shadow walk, then its closest-hit walk), and a trip has two phases:
+ *   box phase       every lane with a job at a box advances ONE such job (the one it did not advance last, when both are);
+ *   triangle phase  only when at least FLX_FRAME2_TRI_MIN lanes have a job at a triangle (or no lane is at a box, or they have waited FLX_FRAME2_TRI_WAIT trips):
+ *                   every such lane advances one — a lane that waits at a triangle with one job goes on at boxes with the other.
+ * Links carry nothing new: a job's next entry is fetched right after its step, as before; the operands of a phase are picked from the two jobs with selects.
+ * Per path nothing changes (entries, order, arithmetic, counters).  Half the waves: 512-thread workgroups at two waves per SIMD and 256 VGPRs — the LDS rays of a
+ * workgroup stay what they are (2 jobs x 384 walk threads x T x 40 B), and the front's 164 - 167 live values fit (no spills).
+ * tests/analysis/walk_sim2.py replays the oracle's traces through this policy: -14 % instructions per visit over the dragon frame's bounces.
+ * MEASURED AND LOST (profiles/r05_two_walks.txt): bit-identical, 14.07 ms against 6.40 for the dragon's 1080p frame.  The compiler's trip is 872 instructions (553 vector,
+ * 225 scalar: selects of the operands, masks around four arms) where k_wf_frame's is 401 for 1.35 steps per lane instead of 1, and two waves per SIMD do not hide the
+ * fetches.  Not in the shipped library: `make EXPERIMENTS=1` carries it (flx_debug_set_walk_jobs(ctx, 2)), tests run it under the `experiments` marker. */
+#if FLX_EXPERIMENTS
+
+#ifndef FLX_FRAME2_THREADS
+#define FLX_FRAME2_THREADS 512
+#endif
+#ifndef FLX_FRAME2_WAVES_PER_EU
+#define FLX_FRAME2_WAVES_PER_EU 2
+#endif
+#ifndef FLX_FRAME2_SHADERS
+#define FLX_FRAME2_SHADERS 2                /* shade waves of the eight */
+#endif
+#ifndef FLX_FRAME2_TRI_MIN
+#define FLX_FRAME2_TRI_MIN 20
+#endif
+#ifndef FLX_FRAME2_TRI_WAIT
+#define FLX_FRAME2_TRI_WAIT 4
+#endif
+#ifndef FLX_FRAME2_BATCH
+#define FLX_FRAME2_BATCH 48                 /* parked jobs (of a wave's 128) that trigger a fold + refill */
+#endif
+#ifndef FLX_FRAME2_PROLOGUE_WAVES
+#define FLX_FRAME2_PROLOGUE_WAVES 1
+#endif
+template <typename T> FLX_DEV T selv(bool c, T a, T b) { return c ? a : b; }      /* operands by VALUE: a select of two loaded values, never of two addresses (that would put the jobs in scratch memory) */
+struct WalkJob {
+  int st; uint32_t pathId; int flags; int pathBounce; float base;
+  Ray nextRay, shadowRay; float shadowLen;
+  WalkState w; WalkEntry cur; float2 *rays;
+};
+template <bool COUNT>
+__global__ __launch_bounds__(FLX_FRAME2_THREADS, FLX_FRAME2_WAVES_PER_EU) void k_wf_frame2(FrameArgs /* read through argBase */, uint32_t total_items,
+                                                                                       uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves, uint32_t readyUnits) {
+  const uint32_t n = total_items;
+  if (n == 0u) return;
+  const FrameArgsP argBase = kernel_frame_args();
+#define FLX_FRAME_ARGS() FLX_ARGS_OF(argBase)
+  const uint32_t WALK_WAVES = FLX_FRAME2_THREADS / 64u - shadeWaves;
+  uint32_t *frameRings; uint32_t samples; bool compactRecs;
+  { FLX_FRAME_ARGS(); frameRings = wb.frameRings; samples = (uint32_t)fr.samples; compactRecs = wb.rec0 != nullptr; }
+  /* LDS: [tree top][inverse transforms][control words][per walk thread: 2 jobs x nTransforms x 40 B of rays] */
+  extern __shared__ float4 ldsAll[];
+  float4 *ldsEntries = ldsAll;
+  float4 *ldsXf = ldsAll + (size_t)ldsCount * 3u;
+  uint32_t *ctl = (uint32_t *)(ldsXf + (size_t)nTransforms * 4u);
+  uint32_t *shadeRing = frameRings + (size_t)blockIdx.x * WF_FRAME_RINGS * FQ_SIZE, *walkRing = shadeRing + FQ_SIZE, *readyRing = walkRing + FQ_SIZE;
+  const uint32_t perTile = samples * 64u;
+  float2 *raysBase = (float2 *)(ctl + FC_WORDS);
+  {
+    FLX_FRAME_ARGS();
+    for (uint32_t t = threadIdx.x; t < ldsCount * 3u; t += FLX_FRAME2_THREADS) ldsEntries[t] = sc.walk[t];
+    for (uint32_t t = threadIdx.x; t < nTransforms * 4u; t += FLX_FRAME2_THREADS) {
+      const uint32_t tr = t >> 2, k = t & 3u, iI = 2u * tr + 1u;
+      ldsXf[t] = k < 3u ? sc.rotation[3u * iI + k] : sc.shift[iI];
+    }
+  }
+  if (threadIdx.x < (uint32_t)FC_WORDS) ctl[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  WorkCounters cnt = {};
+
+  const uint32_t nTiles = n / perTile;
+  auto makeTile = [&]() -> uint32_t {                          /* k_wf_frame's makeTile, word for word */
+    FLX_FRAME_ARGS();
+    uint32_t take = 0, tile = 0;
+    if (lane == 0 && fq_load(&ctl[FC_RQ + 2]) < readyUnits) {
+      const uint32_t before = atomicAdd(&ctl[FC_ALIVE], perTile);
+      if (before + perTile > FQ_ALIVE_MAX) atomicSub(&ctl[FC_ALIVE], perTile);
+      else { tile = atomicAdd(wb.walkQueue, 1u); take = 1; }
+    }
+    take = __builtin_amdgcn_readfirstlane(take);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (take == 0u) return 0u;
+    if (tile >= nTiles) {
+      if (lane == 0) atomicSub(&ctl[FC_ALIVE], perTile);
+      return 2u;
+    }
+    tile += wb.item_base / perTile;
+    const float4 h = primary_tile<COUNT>(argBase, tile, lane, cnt);
+    const bool runs = shade0_tile<COUNT>(argBase, tile, lane, h, cnt);
+    if (flx_ballot(runs) == 0ull) {
+      if (lane == 0) atomicSub(&ctl[FC_ALIVE], perTile);
+    } else {
+      for (uint32_t s0 = 0; s0 < samples; s0 += 64u)
+        fq_push(readyRing, ctl + FC_RQ, s0 + lane < samples, tile * samples + s0 + lane, lane);
+    }
+    return 1u;
+  };
+
+  if (wave >= WALK_WAVES) {
+    /* ================================ shade wave (as in k_wf_frame<COUNT, true>) ================================ */
+    uint32_t idle = 0;
+    bool frontDone = false;
+    uint32_t inject; { FLX_FRAME_ARGS(); inject = wb.inject; } asm volatile("" : "+s"(inject));
+    const long long tStartShade = COUNT ? clock64() : 0;
+    for (;;) {
+      FLX_FRAME_ARGS();
+      const bool dry = fq_load(&ctl[FC_DRY]) != 0u;
+      uint32_t id = WF_INVALID;
+      const uint32_t got = fq_pop(shadeRing, ctl + FC_SQ, ~0ull, 64u, dry ? 1u : 64u, lane, id);
+      if (got == 0u && !frontDone) {
+        const uint32_t made = makeTile();
+        if (made == 2u) {
+          if (lane == 0 && atomicAdd(&ctl[FC_FRONT_DONE], 1u) + 1u == shadeWaves) {
+            atomicExch(&ctl[FC_DRY], 1u);
+            if (COUNT) {
+              const unsigned long long now = (unsigned long long)(clock64() - tStartShade);
+              atomicAdd(wb.counters + 60, now); atomicMax(wb.counters + 61, now); atomicAdd(wb.counters + 62, 1ull);
+              atomicAdd(wb.counters + 63, (unsigned long long)fq_load(&ctl[FC_ALIVE]));
+            }
+          }
+          frontDone = true;
+        }
+        if (made != 0u) { idle = 0; continue; }
+      }
+      if (got == 0u) {
+        if (dry && fq_load(&ctl[FC_ALIVE]) == 0u) break;
+        if (++idle > (wb.watchdog ? wb.watchdog : FQ_WATCHDOG)) {
+          if (lane == 0 && wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_SHADE_WATCHDOG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if (COUNT && lane == 0) { for (uint32_t k = 0; k < 8u; k++) atomicMax(wb.counters + 40 + k, (unsigned long long)fq_load(&ctl[k]) + 1ull); atomicAdd(wb.counters + 48, 1ull); }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        continue;
+      }
+      idle = 0;
+      const bool mine = lane < got && id != WF_INVALID;
+      if (flx_ballot(lane < got && id == WF_INVALID) != 0ull && lane == 0 && wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_RING_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (inject & WF_INJECT_NO_SHADING) continue;
+      if (mine) shade_path<COUNT>(argBase, id, cnt);
+      fq_push(walkRing, ctl + FC_WQ, mine, id, lane);
+    }
+    { FLX_FRAME_ARGS(); flush_counters<COUNT>(cnt, wb.counters); }
+    return;
+  }
+
+  /* ================================ walk wave: two jobs per lane ================================ */
+  const long long tStart = COUNT ? clock64() : 0;
+  if (wave < (uint32_t)FLX_FRAME2_PROLOGUE_WAVES) while (makeTile() == 1u) {}
+  const float4 *walkG; { FLX_FRAME_ARGS(); walkG = pinnedWalkCopy(sc); }
+  WalkJob j0, j1;
+  {
+    Ray z; z.origin = F3(0.f, 0.f, 0.f); z.dir = z.origin;
+    j0.st = P_EMPTY; j0.pathId = 0; j0.flags = 0; j0.pathBounce = 0; j0.base = 0.0f; j0.nextRay = z; j0.shadowRay = z; j0.shadowLen = 0.0f;
+    walkClearResults(j0.w);
+    j0.w.src = z; j0.w.tR = z; j0.w.minLen = 0.0f; j0.w.i = 0; j0.w.cachedTI = 0; j0.w.mode = 2;
+    j0.cur.e0 = j0.cur.e1 = j0.cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
+    j1 = j0;
+    j0.rays = raysBase + (size_t)threadIdx.x * 2u * nTransforms * 5u;      /* (walk waves are the first waves of the workgroup) */
+    j1.rays = j0.rays + (size_t)nTransforms * 5u;
+  }
+  uint32_t chunkNext = 0, chunkEnd = 0;
+  uint32_t idleSpins = 0;
+  uint32_t last = 0;                                           /* per lane: the job advanced last (the other one's entry has had the longer time to arrive) */
+  uint32_t triWait = 0;                                        /* wave-uniform: trips the lanes at triangles have waited */
+  unsigned long long diagBoxTrips = 0, diagBoxLanes = 0, diagTriTrips = 0, diagTriLanes = 0;      /* COUNT builds */
+
+  auto pixPart = [&](const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id) -> const float4 * {
+    uint32_t tile0, s0;
+    item_tile(fr, id, tile0, s0);
+    return wb.pix0 + (((size_t)tile0 << 6) | (id & 63u)) * 3;
+  };
+  /* ---- fold a job's finished path: fragment:445-460, 580, 593-598 and the guard of :475; a path that goes on is handed to the shade waves ---- */
+  auto foldJob = [&](WalkJob &J) {
+    if (flx_ballot(J.st == P_DONE) == 0ull) return;
+    FLX_FRAME_ARGS();
+    bool toShade = false, ended = false;
+    if (J.st == P_DONE) {
+      float4 *rec = wb.rec + (size_t)J.pathId * 8;
+      const bool compact = compactRecs && J.pathBounce == 0;
+      float4 q4, q5, q6, q7;
+      const float4 *pp = nullptr;
+      if (compact) {
+        pp = pixPart(fr, wb, J.pathId);
+        q4 = wb.rec0[(size_t)J.pathId * 3 + 2]; q7 = pp[2];
+        q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+      } else {
+        q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
+      }
+      const bool shadowed = (J.flags & RF_SHADOWED_NO_WALK) || ((J.flags & RF_NEED_SHADOW) && J.w.shadowed);
+      const f3 localColor = shadowed ? F3(J.base, J.base, J.base) : F3(q4.x, q4.y, q4.z);
+      const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
+      const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
+      bool cont = J.w.tri != -1;
+      if (cont) cont = (J.pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+      if (cont) {
+        if (compact) {
+          const float4 a = wb.rec0[(size_t)J.pathId * 3], bq = wb.rec0[(size_t)J.pathId * 3 + 1], p0 = pp[0];
+          rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
+          rec[1] = make_float4(a.x, a.y, a.z, bq.w);
+          rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+          rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+          rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
+        }
+        rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
+        rec[2] = make_float4(J.w.suv.x, J.w.suv.y, J.w.suv.z, __int_as_float(J.w.tri));
+        toShade = true;
+      } else {
+        finalize_path(fr, wb, J.pathId, finalColor, importancy, originalColor);
+        ended = true;
+      }
+      J.st = P_EMPTY;
+    }
+    fq_push(shadeRing, ctl + FC_SQ, toShade, J.pathId, lane);
+    const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
+    if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
+  };
+  /* ---- refill a job's free lanes: paths that came back from shading first, then fresh (tile, sample) units of this workgroup's shade waves; false: nothing more to be had now ---- */
+  auto refillJob = [&](WalkJob &J) -> bool {
+    for (;;) {
+      const unsigned long long idle = flx_ballot(J.st == P_EMPTY);
+      if (idle == 0ull) return true;
+      FLX_FRAME_ARGS();
+      const uint32_t nIdle = (uint32_t)__popcll(idle);
+      uint32_t id = WF_INVALID;
+      bool fresh = false;
+      const uint32_t back = fq_pop(walkRing, ctl + FC_WQ, idle, nIdle, 1u, lane, id);
+      if (back == 0u) {
+        if (chunkNext == chunkEnd) {
+          if (fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT) return false;
+          uint32_t unit = WF_INVALID;
+          if (fq_pop(readyRing, ctl + FC_RQ, 1ull, 1u, 1u, lane, unit) == 0u) return false;
+          unit = __builtin_amdgcn_readfirstlane(unit);
+          if (unit == WF_INVALID) {
+            if (lane == 0) { atomicSub(&ctl[FC_ALIVE], 64u); if (wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_RING_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            return false;
+          }
+          chunkNext = unit << 6; chunkEnd = chunkNext + 64u;
+        }
+        const uint32_t avail = chunkEnd - chunkNext;
+        const uint32_t take = nIdle < avail ? nIdle : avail;
+        const uint32_t r = lane_rank(idle);
+        if (J.st == P_EMPTY && r < take) { id = chunkNext + r; fresh = true; }
+        chunkNext += take;
+      }
+      bool dead = false;
+      if (id != WF_INVALID) {
+        const float4 *rec = wb.rec + (size_t)id * 8;
+        float4 q0, q1, q2, q3;
+        if (fresh && compactRecs) {
+          const float4 *pp = pixPart(fr, wb, id);
+          const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
+          const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+          q0 = make_float4(p0.x, p0.y, p0.z, a.w);
+          q1 = make_float4(a.x, a.y, a.z, bq.w);
+          q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
+          q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+        } else {
+          q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+        }
+        const int fl = __float_as_int(q0.w);
+        if (fl & RF_DEAD) {
+          dead = true;
+        } else {
+          J.pathId = id; J.flags = fl; J.base = q2.w; J.pathBounce = __float_as_int(q3.w);
+          J.nextRay.origin = F3(q0.x, q0.y, q0.z);
+          J.nextRay.dir = F3(q1.x, q1.y, q1.z);
+          J.shadowRay.origin = F3(q2.x, q2.y, q2.z);
+          J.shadowRay.dir = F3(q3.x, q3.y, q3.z);
+          J.shadowLen = q1.w;
+          walkClearResults(J.w);
+          J.w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
+          if (COUNT) { if (J.w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
+          J.st = (J.w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;
+        }
+      }
+      const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
+      if (nDead != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nDead);
+    }
+  };
+  /* ---- set up a job's walks: fresh ones (shadow or closest) and the closest-hit walk of a job whose shadow walk just ended ---- */
+  auto setupJob = [&](WalkJob &J) {
+    if (J.st == P_SWITCH) {
+      if (J.flags & RF_NO_CLOSEST) J.st = P_DONE;
+      else { J.w.mode = 1; J.st = P_SETUP; }
+    }
+    if (flx_ballot(J.st == P_SETUP) != 0ull) {
+      FLX_FRAME_ARGS();
+      if (J.st == P_SETUP) {
+        const bool shadowMode = J.w.mode == 0;
+        const Ray src = shadowMode ? J.shadowRay : J.nextRay;
+        walkSetupRays(sc, nTransforms, ldsXf, J.rays, src, shadowMode);
+        J.w.tR = src; J.w.cachedTI = 0; J.w.minLen = shadowMode ? J.shadowLen : POW32; J.w.i = (int)sc.walk_root;
+        reciprocalOfDir(sc, src.dir, src.origin, J.w.inv, J.w.fastDiv);
+        J.st = P_WALKING;
+        if (walkFetchG<COUNT>(walkG, ldsEntries, ldsCount, J.rays, J.w, J.cur, cnt)) J.st = shadowMode ? P_SWITCH : P_DONE;
+      }
+    }
+  };
+  /* After a phase's test: the entry the stepped job's link names — ONE fetch for the lanes of both jobs (the address, the visit count, the object-space check and the
+   * terminator test are common; only the three loads are issued per job, each into its job's own registers).  p1: the lane stepped job 1; ended: the test ended the walk. */
+  auto stepEnd = [&](bool p1, bool ended) {
+    const uint32_t link = (uint32_t)selv(p1, j1.w.i, j0.w.i);
+    if (link == WALK_END) ended = true;
+    if (!ended) {
+      const uint32_t i = linkIndex(link);
+      const float4 *src = (i < ldsCount) ? ldsEntries + 3u * i : walkG + 3 * (size_t)i;
+      /* (the two arms must not look alike to the optimiser: it would merge them into ONE set of loads stored through a pointer to either job, and both jobs would live in scratch memory) */
+      if (p1) { asm volatile("; job 1"); j1.cur.e0 = src[0]; j1.cur.e1 = src[1]; j1.cur.e2 = src[2]; asm volatile("; job 1 loaded"); }
+      else { asm volatile("; job 0"); j0.cur.e0 = src[0]; j0.cur.e1 = src[1]; j0.cur.e2 = src[2]; asm volatile("; job 0 loaded"); }
+      const int mode = selv(p1, j1.w.mode, j0.w.mode);
+      if (COUNT) { if (mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
+      const int meta = __float_as_int(selv(p1, j1.cur.e2.z, j0.cur.e2.z));
+      const int tI = (meta >> 2) << 1;
+      if (FLX_UNLIKELY(tI != selv(p1, j1.w.cachedTI, j0.w.cachedTI))) {
+        if (p1) { asm volatile("; job 1"); j1.w.cachedTI = tI; walkLoadRay(j1.rays, tI >> 1, j1.w); asm volatile("; job 1 ray"); }
+        else { asm volatile("; job 0"); j0.w.cachedTI = tI; walkLoadRay(j0.rays, tI >> 1, j0.w); asm volatile("; job 0 ray"); }
+      }
+      ended = (meta & 3) == 0;
+    }
+    if (ended) {
+      const int endSt = selv(p1, j1.w.mode, j0.w.mode) == 0 ? P_SWITCH : P_DONE;
+      j1.st = selv(p1, endSt, j1.st);
+      j0.st = selv(p1, j0.st, endSt);
+    }
+  };
+
+  for (;;) {
+    const unsigned long long wk0 = flx_ballot(j0.st == P_WALKING), wk1 = flx_ballot(j1.st == P_WALKING);
+    if ((wk0 | wk1) != 0ull) idleSpins = 0;
+    const unsigned long long workMask = flx_ballot(j0.st == P_DONE || j0.st == P_SWITCH || j1.st == P_DONE || j1.st == P_SWITCH);
+    const uint32_t parked = 128u - (uint32_t)__popcll(wk0) - (uint32_t)__popcll(wk1);
+    const bool mayRefill = fq_load(&ctl[FC_RQ + 2]) != 0u || chunkNext != chunkEnd || fq_load(&ctl[FC_WQ + 2]) != 0u;
+    if ((wk0 | wk1) == 0ull || (parked >= (uint32_t)FLX_FRAME2_BATCH && (workMask != 0ull || mayRefill))) {
+      foldJob(j0);
+      foldJob(j1);
+      if (refillJob(j0)) (void)refillJob(j1);
+      setupJob(j0);
+      setupJob(j1);
+      if (flx_ballot(j0.st == P_WALKING || j1.st == P_WALKING) == 0ull) {
+        if (flx_ballot(j0.st != P_EMPTY || j1.st != P_EMPTY) != 0ull) continue;      /* jobs that had nothing to walk wait for the fold */
+        if (fq_load(&ctl[FC_DRY]) != 0u && chunkNext == chunkEnd && fq_load(&ctl[FC_ALIVE]) == 0u) break;
+        if (fq_load(&ctl[FC_WQ + 2]) == 0u && (fq_load(&ctl[FC_RQ + 2]) == 0u || fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT)) {
+          FLX_FRAME_ARGS();
+          if (++idleSpins > (wb.watchdog ? wb.watchdog : FQ_WATCHDOG)) {
+            if (lane == 0 && wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_WALK_WATCHDOG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (COUNT && lane == 0) { for (uint32_t k = 0; k < 8u; k++) atomicMax(wb.counters + 50 + k, (unsigned long long)fq_load(&ctl[k]) + 1ull); atomicAdd(wb.counters + 58, 1ull); }
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        continue;
+      }
+    }
+    /* ---- FLX_WF_INNER trips: a box phase, and a triangle phase when enough lanes want one ---- */
+#pragma unroll 1
+    for (int it = 0; it < FLX_WF_INNER; it++) {
+      {
+        const bool b0 = j0.st == P_WALKING && walkIsBoxT(j0.cur), b1 = j1.st == P_WALKING && walkIsBoxT(j1.cur);
+        if (COUNT) { const unsigned long long m = flx_ballot(b0 | b1); if (m) { diagBoxTrips++; diagBoxLanes += (unsigned long long)__popcll(m); } }
+        if (b0 | b1) {
+          const bool p1 = b1 & (!b0 | (last == 0u));          /* job 1 unless only job 0 stands at a box, or both do and job 1 went last */
+          WalkState ws;
+          ws.tR.origin = sel3(p1, j1.w.tR.origin, j0.w.tR.origin);
+          ws.inv = sel3(p1, j1.w.inv, j0.w.inv);
+          ws.fastDiv = selv(p1, j1.w.fastDiv, j0.w.fastDiv);
+          const float l = selv(p1, j1.w.minLen, j0.w.minLen);
+          const f3 lo = sel3(p1, F3(j1.cur.e0.x, j1.cur.e0.y, j1.cur.e0.z), F3(j0.cur.e0.x, j0.cur.e0.y, j0.cur.e0.z));
+          const f3 hi = sel3(p1, F3(j1.cur.e0.w, j1.cur.e1.x, j1.cur.e1.y), F3(j0.cur.e0.w, j0.cur.e1.x, j0.cur.e1.y));
+          bool sure;
+          bool hit = rayCuboidInterval(l, ws, lo, hi, sure);
+          if (FLX_UNLIKELY(flx_ballot(!sure) != 0ull)) {       /* rare: the exact quotients, from the job's own state */
+            if (!sure) {
+              if (p1) { asm volatile("; job 1"); hit = rayCuboidRecip(l, j1.w, lo, hi); asm volatile("; job 1 exact"); }
+              else { asm volatile("; job 0"); hit = rayCuboidRecip(l, j0.w, lo, hi); asm volatile("; job 0 exact"); }
+            }
+          }
+          const float lx = selv(p1, j1.cur.e2.x, j0.cur.e2.x), ly = selv(p1, j1.cur.e2.y, j0.cur.e2.y);
+          const int nxt = __float_as_int(hit ? lx : ly);
+          j1.w.i = selv(p1, nxt, j1.w.i);
+          j0.w.i = selv(p1, j0.w.i, nxt);
+          stepEnd(p1, false);
+          last = p1 ? 1u : 0u;
+        }
+      }
+      {
+        const bool w0 = j0.st == P_WALKING, w1 = j1.st == P_WALKING;
+        const bool k0 = walkIsBoxT(j0.cur), k1 = walkIsBoxT(j1.cur);
+        const bool t0 = w0 & !k0, t1 = w1 & !k1;
+        const unsigned long long tm = flx_ballot(t0 | t1);
+        if (tm != 0ull) {
+          const unsigned long long bm = flx_ballot((w0 & k0) | (w1 & k1));
+          if ((uint32_t)__popcll(tm) >= (uint32_t)FLX_FRAME2_TRI_MIN || bm == 0ull || ++triWait >= (uint32_t)FLX_FRAME2_TRI_WAIT) {
+            triWait = 0;
+            if (COUNT) { diagTriTrips++; diagTriLanes += (unsigned long long)__popcll(tm); }
+            if (t0 | t1) {
+              const bool p1 = t1 & (!t0 | (last == 0u));
+              const f3 a = sel3(p1, F3(j1.cur.e0.x, j1.cur.e0.y, j1.cur.e0.z), F3(j0.cur.e0.x, j0.cur.e0.y, j0.cur.e0.z));
+              const f3 edge1 = sel3(p1, F3(j1.cur.e0.w, j1.cur.e1.x, j1.cur.e1.y), F3(j0.cur.e0.w, j0.cur.e1.x, j0.cur.e1.y));
+              const f3 edge2 = sel3(p1, F3(j1.cur.e1.z, j1.cur.e1.w, j1.cur.e2.x), F3(j0.cur.e1.z, j0.cur.e1.w, j0.cur.e2.x));
+              Ray ray;
+              ray.origin = sel3(p1, j1.w.tR.origin, j0.w.tR.origin);
+              ray.dir = sel3(p1, j1.w.tR.dir, j0.w.tR.dir);
+              const float l = selv(p1, j1.w.minLen, j0.w.minLen);
+              const bool cull = selv(p1, j1.w.mode, j0.w.mode) == 0;
+              f3 suv;
+              const bool hit = moellerTrumboreAny(a, edge1, edge2, ray, l, cull, suv);
+              bool ended;
+              if (p1) { asm volatile("; job 1"); ended = walkTriApply(j1.w, j1.cur, hit, suv); asm volatile("; job 1 applied"); }
+              else { asm volatile("; job 0"); ended = walkTriApply(j0.w, j0.cur, hit, suv); asm volatile("; job 0 applied"); }
+              stepEnd(p1, ended);
+              last = p1 ? 1u : 0u;
+            }
+          }
+        }
+      }
+    }
+  }
+  FLX_FRAME_ARGS();
+  if (COUNT && (cnt.closest_visits | cnt.shadow_visits) != 0u) atomicAdd(wb.counters + 23, (unsigned long long)cnt.closest_visits + cnt.shadow_visits);
+  if (COUNT && lane == 0) {
+    const unsigned long long life = (unsigned long long)(clock64() - tStart);
+    atomicAdd(wb.counters + 64, life); atomicMax(wb.counters + 65, life); atomicAdd(wb.counters + 66, 1ull);
+    atomicAdd(wb.counters + 67, diagBoxTrips); atomicAdd(wb.counters + 68, diagBoxLanes); atomicAdd(wb.counters + 69, diagTriTrips); atomicAdd(wb.counters + 70, diagTriLanes);      /* flx_get_tail_diag 27..30 */
+  }
+  flush_counters<COUNT>(cnt, wb.counters);
+#undef FLX_FRAME_ARGS
+}
+
+/* Can the two-job frame kernel take this frame? */
+static bool frame2_kernel_fits(const DeviceScene &sc, uint32_t &ldsCount, uint32_t &ldsBytes) {
+  const uint32_t T = sc.n_transforms;
+  const uint32_t walkThreads = FLX_FRAME2_THREADS - 64u * (uint32_t)FLX_FRAME2_SHADERS;
+  const uint32_t fixed = walkThreads * 2u * T * 40u + T * 64u + FC_WORDS * 4u;
+  if (!FLX_WF_PRETRANSFORM || fixed + 4096u > (uint32_t)FLX_WF_LDS_TOTAL) return false;
+  ldsCount = ((uint32_t)FLX_WF_LDS_TOTAL - fixed) / 48u;
+  if (ldsCount > sc.walk_hot) ldsCount = sc.walk_hot;
+  ldsBytes = ldsCount * 48u + fixed;
+  return true;
+}
+
+#endif /* FLX_EXPERIMENTS: k_wf_frame2 */
+
 /* Can the frame kernel take this frame?  Its LDS holds the rays of its walk threads, the staged transforms, the two rings and
  * at least a little of the tree's top. */
 static bool frame_kernel_fits(const DeviceScene &sc, bool withFront, uint32_t &ldsCount, uint32_t &ldsBytes) {
@@ -1232,8 +1680,8 @@ static bool frame_kernel_fits(const DeviceScene &sc, bool withFront, uint32_t &l
  * limit that cannot be raised is remembered and the launch refused, so that the caller falls back or reports it.) */
 template <typename SetAttributes>
 static bool dynamic_lds_ready(int family, SetAttributes set) {
-  static std::once_flag once[2][64];
-  static bool ok[2][64];
+  static std::once_flag once[3][64];
+  static bool ok[3][64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   std::call_once(once[family][dev], [&]() { ok[family][dev] = set(); });
@@ -1294,6 +1742,18 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
       const uint32_t tilesPerGroup = (total / ((uint32_t)fr.samples * 64u)) / compute_units;
       uint32_t readyUnits = tilesPerGroup >= 48u ? (uint32_t)FLX_FRAME_READY_UNITS : tilesPerGroup / 2u;
       readyUnits = readyUnits < (uint32_t)FLX_FRAME_READY_UNITS / 4u ? (uint32_t)FLX_FRAME_READY_UNITS / 4u : (readyUnits > (uint32_t)FLX_FRAME_READY_UNITS ? (uint32_t)FLX_FRAME_READY_UNITS : readyUnits);
+#if FLX_EXPERIMENTS
+      /* two walk jobs per lane (k_wf_frame2: 512-thread workgroups) where the front of the frame is inside the launch */
+      uint32_t ldsCount2 = 0, ldsBytes2 = 0;
+      if (wb.front && wb.walkJobs == 2u && frame2_kernel_fits(sc, ldsCount2, ldsBytes2) &&
+          dynamic_lds_ready(2, []() { return (int)set_lds_limit((const void *)k_wf_frame2<true>) & (int)set_lds_limit((const void *)k_wf_frame2<false>); })) {
+        const dim3 block2(FLX_FRAME2_THREADS);
+        if (count) hipLaunchKernelGGL((k_wf_frame2<true>), grid, block2, ldsBytes2, stream, fa, total, ldsCount2, sc.n_transforms, (uint32_t)FLX_FRAME2_SHADERS, readyUnits);
+        else hipLaunchKernelGGL((k_wf_frame2<false>), grid, block2, ldsBytes2, stream, fa, total, ldsCount2, sc.n_transforms, (uint32_t)FLX_FRAME2_SHADERS, readyUnits);
+        if (walk0_end) (void)hipEventRecord(walk0_end, stream);
+        return 3;
+      }
+#endif
       if (wb.front) {
         if (count) hipLaunchKernelGGL((k_wf_frame<true, true>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
         else hipLaunchKernelGGL((k_wf_frame<false, true>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
