@@ -44,6 +44,10 @@ flx_status flx_debug_inject_fault(flx_context *ctx, uint32_t watchdog_polls, uin
 /* The shading keeps a per-triangle table of what fragment:500-512 derives from a triangle and its transform alone (three acos and three tan per shade otherwise),
  * made again at scene / transform uploads.  0: every shade computes the values itself — the same floats; for A/B runs. */
 flx_status flx_debug_set_angle_table(flx_context *ctx, int on);
+/* The per-pixel kernel (filter / temporal frames, small scenes) with the samples of a pixel side by side: k_trace_samples — a workgroup per 8 x 8 screen tile, a wave per
+ * sample, the cross-sample globals of the shader (fragment:83-89) replayed in the shader's order afterwards — for frames of 2, 4 or 8 samples and at most 4 bounces; 0: the
+ * sample-sequential k_trace_pixels always.  Frames, G-buffers and work counters are identical; for A/B runs (profiles/r05_sample_parallel.txt). */
+flx_status flx_debug_set_sample_parallel(flx_context *ctx, int on);
 /* Walk jobs per lane of the frame kernel's walk waves: 1 = k_wf_frame (1 024-thread workgroups, a path's walks per lane), 2 = k_wf_frame2 (512-thread workgroups, two
  * independent jobs per lane, a box phase and a triangle phase per trip; only where the front of the frame is inside the launch), 0 = the library's default.  Frames and
  * work counters are identical; for A/B runs (profiles/r05_two_walks.txt). */

@@ -733,7 +733,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     DeviceScene scT = sc;
     { flx_status es = angle_table(ctx, scT); if (es) return es; }
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k0, ctx->stream));
-    launch_trace_pixels(scT, fr, d_out, gb, cnt, ctx->stream);
+    launch_trace_pixels(scT, fr, d_out, gb, cnt, ctx->stream, ctx->sample_parallel);
     FLX_HIP(ctx, hipGetLastError());
     FLX_HIP(ctx, hipEventRecord(ctx->ev_k1, ctx->stream));
   } else if (pipeline == 2) {
@@ -1994,6 +1994,13 @@ extern "C" flx_status flx_frame_target_set8(flx_context *ctx, void *const *d_ima
 extern "C" int flx_frame_target_index(const flx_context *ctx) {
   if (!ctx || !ctx->sv_target_slots || !ctx->sv_running) return -1;
   return (int)((ctx->sv_next_slot + ctx->sv_depth - 1u) % ctx->sv_depth);
+}
+/* the per-pixel kernel with a pixel's samples side by side (k_trace_samples) where the frame allows it (2, 4 or 8 samples, at most 4 bounces): 1 (default) / 0; for A/B runs */
+extern "C" flx_status flx_debug_set_sample_parallel(flx_context *ctx, int on) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_sample_parallel: frames are in flight");
+  ctx->sample_parallel = on ? 1 : 0;
+  return FLX_OK;
 }
 /* walk jobs per lane of the frame kernel's walk waves (1: k_wf_frame, 2: k_wf_frame2 where the front of the frame is inside the launch); for A/B runs */
 extern "C" flx_status flx_debug_set_walk_jobs(flx_context *ctx, int jobs) {

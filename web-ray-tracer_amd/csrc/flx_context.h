@@ -25,6 +25,9 @@ typedef struct ncclComm *flx_nccl_comm;          /* = ncclComm_t (rccl.h), kept 
 #endif
 constexpr int WF_MAX_GROUPS = 4;
 #ifndef FLX_FRAME_CHAIN_DEFAULT
+#ifndef FLX_SAMPLE_PARALLEL_DEFAULT
+#define FLX_SAMPLE_PARALLEL_DEFAULT 1
+#endif
 #ifndef FLX_WALK_JOBS_DEFAULT
 #define FLX_WALK_JOBS_DEFAULT 1
 #endif
@@ -55,6 +58,7 @@ struct flx_context {
   bool lock_use = true;                          /* flx_set_lockstep */
   bool gb_float_wanted = false;                  /* flx_render was given `gbuffers`: the filter frame keeps its float G-buffers */
   int walk_scheduler = 0;
+  int sample_parallel = FLX_SAMPLE_PARALLEL_DEFAULT;      /* flx_debug_set_sample_parallel: k_trace_samples instead of k_trace_pixels where the frame allows it */
   uint32_t walk_jobs = FLX_WALK_JOBS_DEFAULT;    /* flx_debug_set_walk_jobs: walk jobs per lane of the frame kernel's walk waves */
   int32_t *d_ids = nullptr;
   float *d_lights = nullptr;

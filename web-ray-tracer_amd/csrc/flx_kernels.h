@@ -18,7 +18,7 @@ struct GBufferPtrs {
 
 /* counters: 8 x u64 in flx_counters order, or nullptr (no counting code is compiled in). */
 void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *out, const GBufferPtrs &gb,
-                         unsigned long long *counters, hipStream_t stream);
+                         unsigned long long *counters, hipStream_t stream, int sample_parallel = 0);
 /* v2 pipeline: primary hits (float4 s,u,v,triangleId-as-bits per pixel) -> persistent path kernel -> resolve. */
 uint32_t path_item_count(const DeviceFrame &fr);
 uint64_t path_item_count64(const DeviceFrame &fr);

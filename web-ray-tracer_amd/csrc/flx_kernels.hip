@@ -146,10 +146,218 @@ __global__ __launch_bounds__(FLX_TRACE_BLOCK, LOCK ? FLX_TRACE_WAVES : FLX_TRACE
   flush_counters<COUNT>(cnt, counters);
 }
 
+/* ---- v1s: the per-pixel kernel with the SAMPLES of a pixel side by side (round 5; profiles/r05_sample_parallel.txt) --------------------------------
+ * k_trace_pixels runs a pixel's samples one after the other because the shader's globals carry state from sample to sample (fragment:83-89: firstRayLength,
+ * glassFilter, originalRMEx, originalTPOx, renderId, renderOriginalId; originalColor of the LAST sample scales the sum, :632).  That makes a wave 12 bounces long on
+ * configs[1] (4 spp x 3 bounces) and a 1080p frame 5 073 covered waves over 4 096 wave slots: a second round that is a quarter full.
+ * None of those globals is READ by a sample's own arithmetic — they are written (+=, =, min) and reach the G-buffers after the loop — so the samples of a pixel
+ * are independent and what each bounce would have done to the globals can be written down and applied afterwards, in the shader's order:
+ *   workgroup = one 8 x 8 screen tile x S samples, wave s = sample s of the tile's 64 pixels (neighbouring pixels per wave, as before: the lockstep walk stays coherent);
+ *   wave 0 walks the tile's primary rays (the wave-wide walk of k_primary) and leaves the hits in LDS; every wave shades the surface for its sample (the per-triangle
+ *   table makes that cheap: round 2's sample-parallel forms lost to three acos + three tan in double per lane) and runs its path's bounces with the globals zeroed before
+ *   every bounce, so that afterwards they hold exactly what the bounce contributes: 0 + x = x for the sums, the assigned value for `=`, min(x, +inf) = x for the minimum
+ *   (NaN included); the contributions go to LDS (24 B per bounce and lane);
+ *   after a barrier wave 0 replays them per pixel in sample-major, bounce-minor order — the order of the sequential loop — adds the samples' colours in sample order and
+ *   writes the pixel.  Same floats in the same order: bit-identical G-buffers (tests/test_parity_gpu.py's filter cases, tests/test_filter_parity_gpu.py).
+ * S = 2, 4 or 8 and at most FLX_TS_MAX_BOUNCES bounces (the log must fit in LDS at four workgroups per CU); anything else runs k_trace_pixels. */
+#ifndef FLX_TS_MAX_BOUNCES
+#define FLX_TS_MAX_BOUNCES 4
+#endif
+#ifndef FLX_TS_WAVES
+#define FLX_TS_WAVES 4                     /* waves per SIMD the register allocation must allow */
+#endif
+template <bool COUNT, bool LOCK, int S>
+__global__ __launch_bounds__(64 * S, FLX_TS_WAVES) void k_trace_samples(DeviceScene sc, DeviceFrame fr, float4 *__restrict__ out, GBufferPtrs gb,
+                                                                        unsigned long long *__restrict__ counters, int maxB) {
+  /* LDS: [64 hits][64 x originalColor of the last sample][S x 64 per-sample results: colour.xyz, firstRayLength candidate | renderOriginalId.xyz, flag bits]
+   *      [maxB x S x 64 log entries of 24 B: rme.x, renderId.xyz contribution, tpo.x, renderId.w] */
+  extern __shared__ float4 ldsTS[];
+  float4 *ldsHit = ldsTS;
+  float4 *ldsLast = ldsTS + 64;
+  float4 *ldsRes = ldsTS + 128;
+  float2 *ldsLog = (float2 *)(ldsRes + 2 * S * 64);
+  const uint32_t lane = threadIdx.x & 63u, smp = threadIdx.x >> 6;
+  const uint32_t tile = blockIdx.x;
+  uint32_t px, k;
+  tile8_pixel(fr, tile, lane, px, k);
+  WorkCounters cnt = {};
+  const bool inImage = px < fr.width && k < fr.rows;
+  PixelState ps;
+  ps.ndc_x = ps.ndc_y = 0.0f;
+  float viewDepthPerS = 0.0f;
+  uint32_t frameIdx = 0;
+  f3 dir0 = F3(0.0f, 0.0f, 1.0f), camera = F3(0.0f, 0.0f, 0.0f);
+  if (inImage) {
+    const uint32_t py_gl = fr.height - 1u - image_row(fr, k);
+    frameIdx = frame_index(fr, k);
+    dir0 = primary_dir(fr, frameIdx, px, py_gl, ps.ndc_x, ps.ndc_y, viewDepthPerS);
+    camera = frame_camera(fr, frameIdx);
+  }
+  Ray pr; pr.origin = camera; pr.dir = dir0;
+  if (smp == 0u) {
+    const Hit h = primaryWalkF(sc, inImage, pr, viewDepthPerS, cnt.primary_visits);      /* the wave walks together: every lane goes in */
+    ldsHit[lane] = make_float4(h.suv.x, h.suv.y, h.suv.z, __int_as_float(inImage ? h.triangleId : -1));
+  }
+  __syncthreads();
+  Hit hit0;
+  { const float4 h = ldsHit[lane]; hit0.suv = F3(h.x, h.y, h.z); hit0.triangleId = __float_as_int(h.w); hit0.transformId = 0; }
+  const bool covered = hit0.triangleId != -1;
+  const bool anyCovered = flx_ballot(covered) != 0ull;        /* (every wave looks at the same 64 hits: uniform over the workgroup) */
+  if (!anyCovered && smp != 0u) return;                        /* sky: nothing to trace; wave 0 writes the tile's pixels below (no barrier follows on this path) */
+  if (covered) hit0.transformId = (int)sc.geometry[3 * hit0.triangleId + 2].y << 1;      /* (what primaryWalkF's Hit carries: 2 x the entry's transform number) */
+  const uint32_t slot = smp * 64u + lane;
+  float4 res0 = make_float4(0.f, 0.f, 0.f, __int_as_float(0x7f800000)), res1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t bits = 0;                                           /* per bounce i, bits 4i .. 4i + 3: present, tpo assigned, renderId.w assigned, glassFilter's increment */
+  if (covered) {
+    if (COUNT && smp == 0u) cnt.primary_hits++;
+    ps.seed = fr.view[frameIdx].random_seed;
+    ps.originalTPOx = 0.0f;
+    const bool firstBounce = fr.max_reflections > 0 && length(F3(1.0f, 1.0f, 1.0f) * F3(1.0f, 1.0f, 1.0f)) >= fr.min_importancy * SQRT3;
+    const float cosSampleN = flx_cos((float)smp);
+    PathState p;
+    p.dontFilter = true;
+    p.finalColor = F3(0.0f, 0.0f, 0.0f);
+    p.importancyFactor = F3(1.0f, 1.0f, 1.0f);
+    ps.originalColor = F3(1.0f, 1.0f, 1.0f);
+    p.ray.origin = camera; p.ray.dir = dir0;
+    p.lastHitPoint = camera;
+    p.hit = hit0;
+    bool alive = firstBounce;
+    for (int i = 0; alive && i < fr.max_reflections && (i == 0 || length(p.importancyFactor * ps.originalColor) >= fr.min_importancy * SQRT3); i++) {
+      /* the globals as the bounce finds them when nothing has touched them: what it leaves is its contribution */
+      const bool oldDontFilter = p.dontFilter;
+      ps.originalRMEx = 0.0f; ps.glassFilter = 0.0f; ps.firstRayLength = __int_as_float(0x7f800000);
+      ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+      ps.renderOriginalId = ps.renderId;
+      bool goesOn;
+      if (i == 0) {
+        SurfaceCtx sf0;
+        shadeSurface<COUNT>(sc, fr, hit0, pr, camera, sf0, cnt);
+        goesOn = bounceOn<COUNT, LOCK>(sc, fr, sf0, ps, p, camera, cosSampleN, 0, cnt);
+        res1 = make_float4(ps.renderOriginalId.x, ps.renderOriginalId.y, ps.renderOriginalId.z, 0.0f);
+      } else {
+        goesOn = bounce<COUNT, LOCK>(sc, fr, ps, p, camera, cosSampleN, i, cnt);
+        if (i == 1) res0.w = ps.firstRayLength;
+      }
+      bits |= (1u | (oldDontFilter ? 2u : 0u) | ((p.dontFilter || i == 0) ? 4u : 0u) | (ps.glassFilter != 0.0f ? 8u : 0u)) << (4 * i);
+      float2 *L = ldsLog + ((size_t)(i * S) * 64u + slot) * 3u;
+      L[0] = make_float2(ps.originalRMEx, ps.renderId.x);
+      L[1] = make_float2(ps.renderId.y, ps.renderId.z);
+      L[2] = make_float2(ps.originalTPOx, ps.renderId.w);
+      alive = goesOn;
+    }
+    const f3 v = p.finalColor + p.importancyFactor * frame_ambient(fr, frameIdx);      /* fragment:613 for this sample */
+    res0.x = v.x; res0.y = v.y; res0.z = v.z;
+    res1.w = __int_as_float((int)bits);
+    if (smp == (uint32_t)(S - 1)) ldsLast[lane] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
+  }
+  if (anyCovered) {
+    ldsRes[slot * 2u] = res0; ldsRes[slot * 2u + 1u] = res1;
+    __syncthreads();
+  }
+  if (smp != 0u) { flush_counters<COUNT>(cnt, counters); return; }
+  /* ---- wave 0: the pixel, with the samples' contributions applied in the shader's order ---- */
+  if (inImage) {
+    ps.firstRayLength = 1.0f; ps.glassFilter = 0.0f; ps.originalRMEx = 0.0f; ps.originalTPOx = 0.0f;
+    ps.originalColor = F3(0.0f, 0.0f, 0.0f);
+    ps.renderId.x = ps.renderId.y = ps.renderId.z = ps.renderId.w = 0.0f;
+    ps.renderOriginalId = ps.renderId;
+    const size_t o = (size_t)k * fr.width + px;
+    float4 color = make_float4(0.f, 0.f, 0.f, 0.f), colorIp = color, origColor = color, rid = color, roid = color, loc = color;
+    if (covered) {
+      f3 finalColor = F3(0.0f, 0.0f, 0.0f);
+      for (int s = 0; s < S; s++) {
+        const uint32_t sl = (uint32_t)s * 64u + lane;
+        const float4 r0 = ldsRes[sl * 2u], r1 = ldsRes[sl * 2u + 1u];
+        uint32_t fl = (uint32_t)__float_as_int(r1.w);
+        for (int i = 0; (fl & 1u) != 0u; i++, fl >>= 4) {      /* the bounces the sample ran: a prefix */
+          const float2 *L = ldsLog + ((size_t)(i * S) * 64u + sl) * 3u;
+          const float2 a = L[0], b = L[1], c = L[2];
+          if (fl & 2u) {                                        /* fragment:544-558, while the path's dontFilter held */
+            ps.originalTPOx = c.x;
+            ps.originalRMEx += a.x;
+            if (fr.use_filter) {
+              ps.renderId.x += a.y; ps.renderId.y += b.x; ps.renderId.z += b.y; ps.renderId.w += 0.0f;
+              if (i == 0) { ps.renderOriginalId.x += r1.x; ps.renderOriginalId.y += r1.y; ps.renderOriginalId.z += r1.z; ps.renderOriginalId.w += 0.0f; }
+            }
+            if (fl & 8u) ps.glassFilter += 1.0f;
+          }
+          if (i == 1) ps.firstRayLength = flx_min(r0.w, ps.firstRayLength);      /* fragment:565 */
+          if (fl & 4u) ps.renderId.w = c.y;                     /* fragment:437 (and :1275's + 1 / 255 where the light was shadowed) */
+        }
+        finalColor = finalColor + F3(r0.x, r0.y, r0.z);
+      }
+      { const float4 lc = ldsLast[lane]; ps.originalColor = F3(lc.x, lc.y, lc.z); }      /* the global holds the LAST sample's after the loop (fragment:632) */
+      float invSamples = 1.0f / (float)fr.samples;
+      finalColor = finalColor * invSamples;
+      if (fr.use_filter == 1) {
+        color = make_float4(flx_fract(finalColor.x), flx_fract(finalColor.y), flx_fract(finalColor.z), 1.0f);
+        colorIp = make_float4(flx_floor(finalColor.x) * INV_256, flx_floor(finalColor.y) * INV_256, flx_floor(finalColor.z) * INV_256, ps.glassFilter);
+      } else {
+        finalColor = finalColor * ps.originalColor;
+        if (fr.is_temporal == 1) {
+          color = make_float4(flx_fract(finalColor.x), flx_fract(finalColor.y), flx_fract(finalColor.z), 1.0f);
+          colorIp = make_float4(flx_floor(finalColor.x) * INV_256, flx_floor(finalColor.y) * INV_256, flx_floor(finalColor.z) * INV_256, 1.0f);
+        } else {
+          color = make_float4(finalColor.x, finalColor.y, finalColor.z, 1.0f);
+        }
+      }
+      origColor = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, flx_min(ps.originalRMEx, ps.firstRayLength) + INV_255);
+      rid = make_float4(ps.renderId.x, ps.renderId.y, ps.renderId.z, ps.renderId.w + INV_255);
+      roid = make_float4(0.0f, 0.0f, 0.0f, ps.originalTPOx + INV_255);
+      if (gb.location_id) {
+        const float4 g0 = sc.geometry[3 * hit0.triangleId], g1 = sc.geometry[3 * hit0.triangleId + 1], g2 = sc.geometry[3 * hit0.triangleId + 2];
+        const float w0 = 1.0f - hit0.suv.y - hit0.suv.z;
+        const f3 rel = (F3(g0.x, g0.y, g0.z) * w0 + F3(g0.w, g1.x, g1.y) * hit0.suv.y) + F3(g1.z, g1.w, g2.x) * hit0.suv.z;
+        const float div = 2.0f * distance(rel, camera);
+        loc = make_float4(flx_mod(rel.x, div) / div, flx_mod(rel.y, div) / div, flx_mod(rel.z, div) / div, INV_255);
+      }
+    }
+    if (out) out[o] = color;
+    if (gb.color) gb.color[o] = color;
+    if (gb.color_ip) gb.color_ip[o] = colorIp;
+    if (gb.original_color) gb.original_color[o] = origColor;
+    if (gb.id) gb.id[o] = rid;
+    if (gb.original_id) gb.original_id[o] = roid;
+    if (gb.location_id) gb.location_id[o] = loc;
+    if (gb.q_color) gb.q_color[o] = pack_rgba8(color.x, color.y, color.z, color.w);
+    if (gb.q_color_ip) gb.q_color_ip[o] = pack_rgba8(colorIp.x, colorIp.y, colorIp.z, colorIp.w);
+    if (gb.q_original_color) gb.q_original_color[o] = pack_rgba8(origColor.x, origColor.y, origColor.z, origColor.w);
+    if (gb.q_id) gb.q_id[o] = pack_rgba8(rid.x, rid.y, rid.z, rid.w);
+    if (gb.q_original_id) gb.q_original_id[o] = pack_rgba8(roid.x, roid.y, roid.z, roid.w);
+  }
+  flush_counters<COUNT>(cnt, counters);
+}
+
+template <bool LOCK, int S>
+static void launch_trace_samples_s(const DeviceScene &sc, const DeviceFrame &fr, float4 *out, const GBufferPtrs &gb, unsigned long long *counters, hipStream_t stream) {
+  const uint32_t tiles = ((fr.width + 7u) >> 3) * ((fr.rows + 7u) >> 3);
+  const int maxB = fr.max_reflections > 0 ? fr.max_reflections : 1;
+  const size_t lds = (size_t)(128 + 2 * S * 64) * sizeof(float4) + (size_t)maxB * S * 64 * 24;
+  if (counters) hipLaunchKernelGGL((k_trace_samples<true, LOCK, S>), dim3(tiles), dim3(64 * S), lds, stream, sc, fr, out, gb, counters, maxB);
+  else hipLaunchKernelGGL((k_trace_samples<false, LOCK, S>), dim3(tiles), dim3(64 * S), lds, stream, sc, fr, out, gb, counters, maxB);
+}
+/* the samples of a pixel side by side (k_trace_samples) where the frame allows it; false: not such a frame */
+static bool launch_trace_samples(const DeviceScene &sc, const DeviceFrame &fr, float4 *out, const GBufferPtrs &gb, unsigned long long *counters, hipStream_t stream, bool lock) {
+  if (fr.max_reflections > FLX_TS_MAX_BOUNCES || !(fr.samples == 2 || fr.samples == 4 || fr.samples == 8)) return false;
+  if ((size_t)(128 + 2 * fr.samples * 64) * sizeof(float4) + (size_t)(fr.max_reflections > 0 ? fr.max_reflections : 1) * fr.samples * 64 * 24 > 64u * 1024u) return false;      /* (8 samples x 4 bounces: 67 KB) */
+  if (lock) {
+    if (fr.samples == 2) launch_trace_samples_s<true, 2>(sc, fr, out, gb, counters, stream);
+    else if (fr.samples == 4) launch_trace_samples_s<true, 4>(sc, fr, out, gb, counters, stream);
+    else launch_trace_samples_s<true, 8>(sc, fr, out, gb, counters, stream);
+  } else {
+    if (fr.samples == 2) launch_trace_samples_s<false, 2>(sc, fr, out, gb, counters, stream);
+    else if (fr.samples == 4) launch_trace_samples_s<false, 4>(sc, fr, out, gb, counters, stream);
+    else launch_trace_samples_s<false, 8>(sc, fr, out, gb, counters, stream);
+  }
+  return true;
+}
+
 void launch_trace_pixels(const DeviceScene &sc, const DeviceFrame &fr, float4 *out, const GBufferPtrs &gb,
-                         unsigned long long *counters, hipStream_t stream) {
+                         unsigned long long *counters, hipStream_t stream, int sample_parallel) {
   const uint32_t tiles = ((fr.width + 15u) >> 4) * ((fr.rows + 15u) >> 4);
   const bool lock = FLX_LOCKSTEP && sc.lock_entries != 0u;      /* small scene in one object space: the variant with the wave-wide walk */
+  if (sample_parallel && launch_trace_samples(sc, fr, out, gb, counters, stream, lock)) return;
   if (lock) {
     if (counters) hipLaunchKernelGGL((k_trace_pixels<true, true>), dim3(tiles * (256u / FLX_TRACE_BLOCK)), dim3(FLX_TRACE_BLOCK), 0, stream, sc, fr, out, gb, counters);
     else hipLaunchKernelGGL((k_trace_pixels<false, true>), dim3(tiles * (256u / FLX_TRACE_BLOCK)), dim3(FLX_TRACE_BLOCK), 0, stream, sc, fr, out, gb, counters);

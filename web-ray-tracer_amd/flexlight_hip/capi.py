@@ -29,7 +29,7 @@ EXPORTS = [
     "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
     "flx_frame_server_takes", "flx_frame_target_set", "flx_frame_target_index", "flx_debug_set_server_groups",
     "flx_share_create", "flx_share_join", "flx_share_leave", "flx_frame_begin_shared", "flx_frame_end_shared",
-    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table", "flx_frame_target_set8", "flx_debug_set_walk_jobs",
+    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table", "flx_frame_target_set8", "flx_debug_set_walk_jobs", "flx_debug_set_sample_parallel",
 ]
 
 
@@ -160,6 +160,7 @@ def _load():
         "flx_share_join": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "flx_share_leave": (C.c_int, [vp]),
         "flx_debug_set_walk_jobs": (C.c_int, [vp, C.c_int]),
+        "flx_debug_set_sample_parallel": (C.c_int, [vp, C.c_int]),
         "flx_frame_begin_shared": (C.c_int, [vp, C.POINTER(FrameParams)]),
         "flx_frame_end_shared": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
     }
@@ -388,6 +389,10 @@ class Context:
         d = {n: int(out[i]) for i, n in enumerate(names)}
         d["host_done"] = (int(out[13]) >> 32, int(out[13]) & 0xffffffff); d["host_posted"] = (int(out[14]) >> 32, int(out[14]) & 0xffffffff); d["next_seq_stop"] = (int(out[15]) >> 32, int(out[15]) & 0xffffffff)
         return d
+
+    def set_sample_parallel(self, on):
+        """k_trace_samples (a pixel's samples side by side) instead of k_trace_pixels where the frame allows it (flx_debug_set_sample_parallel)"""
+        self._check(LIB.flx_debug_set_sample_parallel(self._h, int(bool(on))), "flx_debug_set_sample_parallel")
 
     def set_walk_jobs(self, jobs):
         """walk jobs per lane of the frame kernel's walk waves (flx_debug_set_walk_jobs): 1, 2, or 0 = the library's default"""
