@@ -690,6 +690,26 @@ def main():
         ctx.sync()
         verified = bool(torch.equal(whole.view(torch.int32), frames_out[0].view(torch.int32)))
 
+    # N > 1: the same frame on ONE context (rank 0's GPU alone, the other ranks wait at a barrier), one frame per pass: the denominator of the speed-ups the line states in
+    # both currencies (`speedup`: latency mode = the timed region, gather included; throughput mode = the fastest verified frame loop, with its frames in flight)
+    single_ms = None
+    if multi and world > 1:
+        dist.barrier()
+        if rank == 0:
+            torch.cuda.synchronize()
+            whole1 = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+            for _ in range(3):
+                ctx.render_device(full, whole1.data_ptr())
+            ctx.sync()
+            t1 = time.perf_counter()
+            n1 = max(5, min(args.steps, 20))
+            for _ in range(n1):
+                ctx.render_device(full, whole1.data_ptr())
+            ctx.sync()
+            single_ms = (time.perf_counter() - t1) / n1 * 1e3
+            del whole1
+        dist.barrier()
+
     # ---- secondary measurements, outside the timed region --------------------------------------------------
     # per-frame GPU time between HIP events on the launch stream (median of >= 20 frames) and the dominant kernel's
     gpu_ms, kernel_ms = [], []
@@ -953,6 +973,19 @@ def main():
                                        "note": "the K frames of the `%s` loop (%s): every frame rendered in full and complete in order, timed between barrier + synchronize on both sides, max over "
                                                "ranks, its last frame equal to one context's frame bit for bit.  A throughput figure (latency per frame: that loop's frame_gpu_ms_median), NOT `value`" % (name, how)}
         line["headline"] = {"mode": "one_frame_per_pass", "frames_in_flight": 1}
+        if single_ms:
+            # both currencies side by side: SURVEY.md 8d's frame time (one frame at a time, gather included) and the frame loop's throughput
+            sp = {"single_context_ms": single_ms, "single_context": "the whole frame on rank 0's GPU alone (the other ranks wait at a barrier), one frame per pass, measured in this run",
+                  "latency_mode": {"ms_per_frame": line["ms_per_step"], "speedup": single_ms / line["ms_per_step"], "frames_in_flight": 1, "frames_of_latency": 1,
+                                   "what": "the timed region = `value`: every frame complete and gathered before the next begins (SURVEY.md 8d)"}}
+            if line.get("throughput_best"):
+                tb = line["throughput_best"]
+                src = shared if tb["mode"] == "shared" else pipelined
+                sp["throughput_mode"] = {"mode": tb["mode"], "ms_per_frame": tb["ms_per_frame"], "speedup": single_ms / tb["ms_per_frame"], "frames_in_flight": tb["frames_in_flight"],
+                                         "frames_of_latency": tb["frames_in_flight"], "frame_latency_ms": (src or {}).get("frame_gpu_ms_median") or (src or {}).get("latency_ms_median"),
+                                         "what": "a frame completes every ms_per_frame while `frames_in_flight` are in flight: the application sees each frame that many frames after it began it"}
+            sp["note"] = "two different quantities: do not read the throughput figure as SURVEY.md 8d's frame time; the driver computes scaling from `value` (latency mode) of the per-N runs"
+            line["speedup"] = sp
         print(json.dumps(line), flush=True)
     if rccl:
         ctx.sync()

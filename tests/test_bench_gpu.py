@@ -89,10 +89,27 @@ def test_bench_two_ranks_complete_one_image_without_a_collective():
     assert d["shared"]["frames"] == 12 and d["shared"]["image_equals_single_context_frame"] is True
     assert d["headline"]["mode"] == "one_frame_per_pass" and d["ms_per_step"] == d["one_frame_per_pass"]["ms_per_step"]
     assert d["throughput_best"]["mode"] in ("shared", "pipelined") and d["throughput_best"]["ms_per_frame"] <= d["shared"]["ms_per_frame"]
+    # the speed-up in both currencies, against the same frame on one context measured in this run
+    sp = d["speedup"]
+    assert sp["single_context_ms"] > 0 and sp["latency_mode"]["frames_in_flight"] == 1 and abs(sp["latency_mode"]["speedup"] - sp["single_context_ms"] / d["ms_per_step"]) < 1e-9
+    assert sp["throughput_mode"]["mode"] == d["throughput_best"]["mode"] and sp["throughput_mode"]["frames_in_flight"] >= 2
+    assert abs(sp["throughput_mode"]["speedup"] - sp["single_context_ms"] / d["throughput_best"]["ms_per_frame"]) < 1e-9
     # a frame the server does not take (a last strip of 6 rows): every rank's two lanes, the strips copied into the image
     out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device", "--batch", "0", "--no-pmc"] + SMALL, timeout=1200, env=env, stderr=subprocess.DEVNULL)
     sh = _last_json(out)["shared"]
     assert sh.get("error") is None and sh["frame_server"] is False and sh["image_equals_single_context_frame"] is True, sh
+
+
+def test_bench_six_ranks_on_one_device():
+    """the N-rank code path with as many ranks as a one-GPU box lets near its card (6: an eighth rank is the driver's to start, on eight GPUs): the share page with six
+    ranks' done words, the tile policy of six, six servers beside each other on a sixth of the CUs each — the image they complete equals one context's frame bit for bit"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    args = ["--width", "480", "--height", "288", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--gpus", "6", "--one-device", "--batch", "0", "--no-pmc"]      # 288 rows = 6 ranks x 6 strips of 8
+    d = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py")] + args, timeout=1200, env=env, stderr=subprocess.DEVNULL))
+    assert d["n_gpus"] == 6 and d["gathered_frame_equals_single_context_frame"] is True
+    sh = d["shared"]
+    assert sh.get("error") is None and sh["frame_server"] is True and sh["image_equals_single_context_frame"] is True and sh["frames"] == 12, sh
+    assert d["headline"]["mode"] == "one_frame_per_pass" and d["speedup"]["latency_mode"]["speedup"] > 0 and d["speedup"]["throughput_mode"]["speedup"] > 0
 
 
 def test_bench_line_survives_a_secondary_measurement_that_hangs():
