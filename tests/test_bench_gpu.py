@@ -100,13 +100,14 @@ def test_bench_two_ranks_complete_one_image_without_a_collective():
     assert sh.get("error") is None and sh["frame_server"] is False and sh["image_equals_single_context_frame"] is True, sh
 
 
-def test_bench_six_ranks_on_one_device():
-    """the N-rank code path with as many ranks as a one-GPU box lets near its card (6: an eighth rank is the driver's to start, on eight GPUs): the share page with six
-    ranks' done words, the tile policy of six, six servers beside each other on a sixth of the CUs each — the image they complete equals one context's frame bit for bit"""
+def test_bench_five_ranks_on_one_device():
+    """the N-rank code path with as many ranks as a one-GPU box lets near its card beside the test runner (the box allows six processes on the GPU; the eight-rank case is the
+    driver's to start, on eight GPUs): the share page with five ranks' done words, the tile policy of five, five servers beside each other on a fifth of the CUs each — the image
+    they complete equals one context's frame bit for bit, and the line states the speed-up in both currencies"""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    args = ["--width", "480", "--height", "288", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--gpus", "6", "--one-device", "--batch", "0", "--no-pmc"]      # 288 rows = 6 ranks x 6 strips of 8
+    args = ["--width", "480", "--height", "280", "--steps", "12", "--warmup", "2", "--no-cpu-baseline", "--gpus", "5", "--one-device", "--batch", "0", "--no-pmc"]      # 280 rows = 5 ranks x 7 strips of 8
     d = _last_json(subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py")] + args, timeout=1200, env=env, stderr=subprocess.DEVNULL))
-    assert d["n_gpus"] == 6 and d["gathered_frame_equals_single_context_frame"] is True
+    assert d["n_gpus"] == 5 and d["gathered_frame_equals_single_context_frame"] is True
     sh = d["shared"]
     assert sh.get("error") is None and sh["frame_server"] is True and sh["image_equals_single_context_frame"] is True and sh["frames"] == 12, sh
     assert d["headline"]["mode"] == "one_frame_per_pass" and d["speedup"]["latency_mode"]["speedup"] > 0 and d["speedup"]["throughput_mode"]["speedup"] > 0

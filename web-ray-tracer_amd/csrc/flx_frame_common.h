@@ -223,6 +223,129 @@ FLX_DEV void shade_path(FrameArgsP ab, uint32_t pathId, WorkCounters &cnt, const
   rec[7] = make_float4(ps.originalColor.x, ps.originalColor.y, ps.originalColor.z, 0.0f);
 }
 
+/* ---- a walk lane of the persistent frame kernels ------------------------------------------------------------------------------------------------------
+ * What a lane of a walk wave holds and does is the same in every persistent kernel (k_wf_frame, the frame server's k_wf_server, the experiments' k_wf_frame2): a path —
+ * its shadow walk, then its closest-hit walk — whose record it loads, walks and folds.  The kernels differ in where path ids come from and go to (one set of rings, rings
+ * per frame slot, a mailbox); that stays with them.  One body here, so that a change to the walk is a change to all of them. */
+struct WalkLane {
+  int st;                                  /* P_EMPTY .. P_SETUP */
+  uint32_t pathId; int flags; int pathBounce; float base;
+  Ray nextRay, shadowRay; float shadowLen;
+  WalkState w; WalkEntry cur;
+};
+FLX_DEV void walkLaneInit(WalkLane &L) {
+  L.st = P_EMPTY; L.pathId = 0; L.flags = 0; L.pathBounce = 0; L.base = 0.0f;
+  L.nextRay.origin = F3(0.f, 0.f, 0.f); L.nextRay.dir = L.nextRay.origin;
+  L.shadowRay = L.nextRay; L.shadowLen = 0.0f;
+  walkClearResults(L.w);
+  L.w.src = L.nextRay; L.w.tR = L.nextRay; L.w.minLen = 0.0f; L.w.i = 0; L.w.cachedTI = 0;
+  L.w.mode = 2;
+  L.cur.e0 = L.cur.e1 = L.cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+/* the per-pixel part of a bounce-0 path's compact record */
+FLX_DEV const float4 *pix_part(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id) {
+  uint32_t tile0, s0;
+  item_tile(fr, id, tile0, s0);
+  return wb.pix0 + (((size_t)tile0 << 6) | (id & 63u)) * 3;
+}
+/* Fold a lane whose walks are done (st == P_DONE): fragment:445-460, 580, 593-598 and the guard of :475.  A path that goes on gets its record completed (toShade: the caller
+ * hands it to the shade waves); one that ends has its radiance stored (ended: the caller takes it off its count).  The lane is free afterwards. */
+template <bool LV>
+FLX_DEV void walkLaneFold(const DeviceFrame &fr, const WavefrontBuffers &wb, bool compactRecs, WalkLane &L, const FrameView *lv, bool &toShade, bool &ended) {
+  float4 *rec = wb.rec + (size_t)L.pathId * 8;
+  const bool compact = compactRecs && L.pathBounce == 0;
+  float4 q4, q5, q6, q7;
+  const float4 *pp = nullptr;
+  if (compact) {
+    pp = pix_part(fr, wb, L.pathId);
+    q4 = wb.rec0[(size_t)L.pathId * 3 + 2]; q7 = pp[2];
+    q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+  } else {
+    q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
+  }
+  const bool shadowed = (L.flags & RF_SHADOWED_NO_WALK) || ((L.flags & RF_NEED_SHADOW) && L.w.shadowed);
+  const f3 localColor = shadowed ? F3(L.base, L.base, L.base) : F3(q4.x, q4.y, q4.z);
+  const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
+  const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
+  bool cont = L.w.tri != -1;
+  if (cont) cont = (L.pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
+  if (cont) {
+    if (compact) {                                    /* the path goes on: now it gets its full record (what shade0 would have written) */
+      const float4 a = wb.rec0[(size_t)L.pathId * 3], bq = wb.rec0[(size_t)L.pathId * 3 + 1], p0 = pp[0];
+      rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
+      rec[1] = make_float4(a.x, a.y, a.z, bq.w);
+      rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+      rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+      rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
+    }
+    rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
+    rec[2] = make_float4(L.w.suv.x, L.w.suv.y, L.w.suv.z, __int_as_float(L.w.tri));
+    toShade = true;
+  } else {
+    finalize_path<LV>(fr, wb, L.pathId, finalColor, importancy, originalColor, lv);
+    ended = true;
+  }
+  L.st = P_EMPTY;
+}
+/* Take path `id` into a free lane: its record (the compact bounce-0 form where `compactFresh`).  true: the item is dead (a pixel without a path), the lane stays free. */
+template <bool COUNT>
+FLX_DEV bool walkLaneLoad(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id, bool compactFresh, WalkLane &L, WorkCounters &cnt) {
+  const float4 *rec = wb.rec + (size_t)id * 8;
+  float4 q0, q1, q2, q3;
+  if (compactFresh) {
+    const float4 *pp = pix_part(fr, wb, id);
+    const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
+    const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
+    q0 = make_float4(p0.x, p0.y, p0.z, a.w);
+    q1 = make_float4(a.x, a.y, a.z, bq.w);
+    q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
+    q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+  } else {
+    q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+  }
+  const int fl = __float_as_int(q0.w);
+  if (fl & RF_DEAD) return true;
+  L.pathId = id; L.flags = fl; L.base = q2.w; L.pathBounce = __float_as_int(q3.w);
+  L.nextRay.origin = F3(q0.x, q0.y, q0.z);
+  L.nextRay.dir = F3(q1.x, q1.y, q1.z);
+  L.shadowRay.origin = F3(q2.x, q2.y, q2.z);
+  L.shadowRay.dir = F3(q3.x, q3.y, q3.z);
+  L.shadowLen = q1.w;
+  walkClearResults(L.w);
+  L.w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
+  if (COUNT) { if (L.w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
+  L.st = (L.w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;      /* nothing to walk: straight to the fold */
+  return false;
+}
+/* Set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended (P_SWITCH).  xf: the staged inverse transforms the lane's path reads. */
+template <bool COUNT>
+FLX_DEV void walkLaneSetup(const DeviceScene &sc, uint32_t nTransforms, const float4 *xf, float2 *myRays, const float4 *walkG, const float4 *ldsEntries, uint32_t ldsCount,
+                           WalkLane &L, WorkCounters &cnt) {
+  const bool shadowMode = L.w.mode == 0;
+  const Ray src = shadowMode ? L.shadowRay : L.nextRay;
+  walkSetupRays(sc, nTransforms, xf, myRays, src, shadowMode);
+  L.w.tR = src; L.w.cachedTI = 0; L.w.minLen = shadowMode ? L.shadowLen : POW32; L.w.i = (int)sc.walk_root;
+  reciprocalOfDir(sc, src.dir, src.origin, L.w.inv, L.w.fastDiv);
+  L.st = P_WALKING;
+  if (walkFetchG<COUNT>(walkG, ldsEntries, ldsCount, myRays, L.w, L.cur, cnt)) L.st = shadowMode ? P_SWITCH : P_DONE;
+}
+FLX_DEV void walkLaneSwitch(WalkLane &L) {                  /* the shadow walk is over: the closest-hit walk next, unless the path ends after this bounce (nextBounceRuns) */
+  if (L.st == P_SWITCH) {
+    if (L.flags & RF_NO_CLOSEST) L.st = P_DONE;
+    else { L.w.mode = 1; L.st = P_SETUP; }
+  }
+}
+/* One entry for a walking lane: the test its entry asks for, then the entry its link names. */
+template <bool COUNT>
+FLX_DEV void walkLaneStep(const float4 *walkG, const float4 *ldsEntries, uint32_t ldsCount, const float2 *myRays, WalkLane &L, WorkCounters &cnt) {
+  if (L.st == P_WALKING) {
+    bool ended = false;
+    if (walkIsBoxT(L.cur)) walkBoxP(L.w, L.cur); else ended = walkTriT(L.w, L.cur);
+    if (!ended) ended = walkFetchG<COUNT>(walkG, ldsEntries, ldsCount, myRays, L.w, L.cur, cnt);
+    if (ended) L.st = (L.w.mode == 0) ? P_SWITCH : P_DONE;
+  }
+}
+
 constexpr uint32_t FQ_SIZE = WF_FRAME_RING;   /* ids per ring (the rings live in HBM-backed memory private to the workgroup, their counts in LDS) */
 #ifndef FLX_FQ_LIMIT
 #define FLX_FQ_LIMIT 4096

@@ -394,82 +394,29 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   /* ================================ walk wave ================================ */
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
   const float4 *walkG; { FLX_ARGS_OF(ab); walkG = pinnedWalkCopy(sc); }      /* the global copy of the tree, for the entries beyond the LDS top: in registers for the stepping loop */
-  int st = P_EMPTY;
-  uint32_t pathId = 0;
-  int flags = 0;
-  int pathBounce = 0;
-  float base = 0.0f;
-  Ray nextRay; nextRay.origin = F3(0.f, 0.f, 0.f); nextRay.dir = nextRay.origin;
-  Ray shadowRay = nextRay;
-  float shadowLen = 0.0f;
-  WalkState w;
-  walkClearResults(w);
-  w.src = nextRay; w.tR = nextRay; w.minLen = 0.0f; w.i = 0; w.cachedTI = 0;
-  w.mode = 2;
-  WalkEntry cur;
-  cur.e0 = cur.e1 = cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  WalkLane L;                                                  /* the lane's path and its walks (flx_frame_common.h: the body k_wf_frame's walk waves run) */
+  walkLaneInit(L);
   uint32_t chunkNext = 0, chunkEnd = 0;          /* wave-uniform: the rest of a (tile, sample) unit of fresh paths */
   uint32_t statTrips = 0, statLaneTrips = 0;
 
-  auto pixPart = [&](const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id) -> const float4 * {
-    uint32_t tile0, s0;
-    item_tile(fr, id, tile0, s0);
-    return wb.pix0 + (((size_t)tile0 << 6) | (id & 63u)) * 3;
-  };
-
   for (;;) {
-    const unsigned long long walking = flx_ballot(st == P_WALKING);
-    const unsigned long long workMask = flx_ballot(st == P_DONE || st == P_SWITCH);
+    const unsigned long long walking = flx_ballot(L.st == P_WALKING);
+    const unsigned long long workMask = flx_ballot(L.st == P_DONE || L.st == P_SWITCH);
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
     bool mayRefill = chunkNext != chunkEnd;
     for (uint32_t s = 0; s < depth && !mayRefill; s++) mayRefill = fq_load(&rctl(RK_WALK, s)[2]) != 0u || fq_load(&rctl(RK_READY, s)[2]) != 0u;
     statTrips += (uint32_t)FLX_WF_INNER; statLaneTrips += (uint32_t)__popcll(walking) * (uint32_t)FLX_WF_INNER;
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
-      /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475; a path that goes on is handed to the shade waves ---- */
-      if (flx_ballot(st == P_DONE) != 0ull) {
+      /* ---- fold the finished lanes (walkLaneFold); a path that goes on is handed to the shade waves of its frame's slot ---- */
+      if (flx_ballot(L.st == P_DONE) != 0ull) {
         FLX_ARGS_OF(ab);
         const bool compactRecs = wb.rec0 != nullptr;
         bool toShade = false, ended = false;
-        const uint32_t slot = slotOf(pathId);
-        if (st == P_DONE) {
-          float4 *rec = wb.rec + (size_t)pathId * 8;
-          const bool compact = compactRecs && pathBounce == 0;
-          float4 q4, q5, q6, q7;
-          const float4 *pp = nullptr;
-          if (compact) {
-            pp = pixPart(fr, wb, pathId);
-            q4 = wb.rec0[(size_t)pathId * 3 + 2]; q7 = pp[2];
-            q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-          } else {
-            q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
-          }
-          const bool shadowed = (flags & RF_SHADOWED_NO_WALK) || ((flags & RF_NEED_SHADOW) && w.shadowed);
-          const f3 localColor = shadowed ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
-          const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
-          const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
-          bool cont = w.tri != -1;
-          if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
-          if (cont) {
-            if (compact) {                                    /* the path goes on: now it gets its full record (what shade0 would have written) */
-              const float4 a = wb.rec0[(size_t)pathId * 3], bq = wb.rec0[(size_t)pathId * 3 + 1], p0 = pp[0];
-              rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
-              rec[1] = make_float4(a.x, a.y, a.z, bq.w);
-              rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
-              rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-              rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
-            }
-            rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
-            rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
-            toShade = true;
-          } else {
-            finalize_path<true>(fr, wb, pathId, finalColor, importancy, originalColor, lv);
-            ended = true;
-          }
-          st = P_EMPTY;
-        }
+        const uint32_t slot = slotOf(L.pathId);
+        if (L.st == P_DONE) walkLaneFold<true>(fr, wb, compactRecs, L, lv, toShade, ended);
         if (flx_ballot(ended) != 0ull) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* the radiance stored, before the paths leave the count (tryRotate publishes what is counted off) */
         for (uint32_t s = 0; s < depth; s++) {
-          fq_push(ring(RK_SHADE, s), rctl(RK_SHADE, s), toShade && slot == s, pathId, lane);
+          fq_push(ring(RK_SHADE, s), rctl(RK_SHADE, s), toShade && slot == s, L.pathId, lane);
           const uint32_t e = (uint32_t)__popcll(flx_ballot(ended && slot == s));
           if (e != 0u && lane == 0) atomicSub(&ctl[SC_ALIVE + s], e);
         }
@@ -478,7 +425,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       /* ---- refill the free lanes: older frames before younger ones; per frame the paths that came back from shading, then fresh ones ---- */
       const uint32_t P = fq_load(&ctl[SC_SLOTP]);
       for (;;) {
-        const unsigned long long idle = flx_ballot(st == P_EMPTY);
+        const unsigned long long idle = flx_ballot(L.st == P_EMPTY);
         if (idle == 0ull) break;
         FLX_ARGS_OF(ab);
         const uint32_t nIdle = (uint32_t)__popcll(idle);
@@ -502,7 +449,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           if (chunkNext != chunkEnd && slotOf(chunkNext) == slot) {
             const uint32_t avail = chunkEnd - chunkNext;
             const uint32_t take = nIdle < avail ? nIdle : avail;
-            if (st == P_EMPTY && rk < take) { id = chunkNext + rk; fresh = true; }
+            if (L.st == P_EMPTY && rk < take) { id = chunkNext + rk; fresh = true; }
             chunkNext += take;
             got = true;
             break;
@@ -510,61 +457,22 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         }
         if (!got) break;
         bool dead = false;
-        if (id != WF_INVALID) {
-          const float4 *rec = wb.rec + (size_t)id * 8;
-          float4 q0, q1, q2, q3;
-          if (fresh) {
-            const float4 *pp = pixPart(fr, wb, id);
-            const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
-            const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
-            q0 = make_float4(p0.x, p0.y, p0.z, a.w);
-            q1 = make_float4(a.x, a.y, a.z, bq.w);
-            q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
-            q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
-          } else {
-            q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
-          }
-          const int fl = __float_as_int(q0.w);
-          if (fl & RF_DEAD) {
-            dead = true;
-          } else {
-            pathId = id; flags = fl; base = q2.w; pathBounce = __float_as_int(q3.w);
-            nextRay.origin = F3(q0.x, q0.y, q0.z);
-            nextRay.dir = F3(q1.x, q1.y, q1.z);
-            shadowRay.origin = F3(q2.x, q2.y, q2.z);
-            shadowRay.dir = F3(q3.x, q3.y, q3.z);
-            shadowLen = q1.w;
-            walkClearResults(w);
-            w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
-            st = (w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;      /* nothing to walk: straight to the fold */
-          }
-        }
+        if (id != WF_INVALID) dead = walkLaneLoad<false>(fr, wb, id, fresh, L, cnt);
         const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
         if (nDead != 0u && lane == 0) atomicSub(&ctl[SC_ALIVE + slot], nDead);      /* (a dead item's finalisation was stored by the wave that made the tile, before the tile was handed over) */
       }
       if (FLX_SERVER_PRIO) {
         const bool tail = fq_load(&ctl[SC_TILEDRY + P]) != 0u;
-        if (tail && flx_ballot(st != P_EMPTY && slotOf(pathId) == P) != 0ull) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        if (tail && flx_ballot(L.st != P_EMPTY && slotOf(L.pathId) == P) != 0ull) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
       }
       /* ---- set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended ---- */
-      if (st == P_SWITCH) {
-        if (flags & RF_NO_CLOSEST) st = P_DONE;
-        else { w.mode = 1; st = P_SETUP; }
-      }
-      if (flx_ballot(st == P_SETUP) != 0ull) {
+      walkLaneSwitch(L);
+      if (flx_ballot(L.st == P_SETUP) != 0ull) {
         FLX_ARGS_OF(ab);
-        if (st == P_SETUP) {
-          const bool shadowMode = w.mode == 0;
-          const Ray src = shadowMode ? shadowRay : nextRay;
-          walkSetupRays(sc, nTransforms, VER ? ldsXf + (size_t)slotOf(pathId) * nTransforms * 4u : ldsXf, myRays, src, shadowMode);
-          w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
-          reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);
-          st = P_WALKING;
-          if (walkFetchG<false>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
-        }
+        if (L.st == P_SETUP) walkLaneSetup<false>(sc, nTransforms, VER ? ldsXf + (size_t)slotOf(L.pathId) * nTransforms * 4u : ldsXf, myRays, walkG, ldsEntries, ldsCount, L, cnt);
       }
-      if (flx_ballot(st == P_WALKING) == 0ull) {
-        if (flx_ballot(st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
+      if (flx_ballot(L.st == P_WALKING) == 0ull) {
+        if (flx_ballot(L.st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
         /* nothing in this wave: wait for the shade waves (or for the next frame), or end with the workgroup */
         if (fq_load(&ctl[SC_EXIT]) != 0u) break;
         tryRotate();
@@ -575,14 +483,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     /* ---- FLX_WF_INNER entries for every walking lane (the few scene words the fetch needs are read before the loop) ---- */
     {
 #pragma unroll FLX_WF_UNROLL
-      for (int it = 0; it < FLX_WF_INNER; it++) {
-        if (st == P_WALKING) {
-          bool ended = false;
-          if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-          if (!ended) ended = walkFetchG<false>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt);
-          if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
-        }
-      }
+      for (int it = 0; it < FLX_WF_INNER; it++) walkLaneStep<false>(walkG, ldsEntries, ldsCount, myRays, L, cnt);
     }
   }
   statAdd(SVS_WALK_TRIPS, statTrips); statAdd(SVS_WALK_LANE_TRIPS, statLaneTrips);

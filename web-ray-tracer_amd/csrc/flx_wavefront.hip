@@ -982,84 +982,31 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   uint32_t inChunk = n / (nWaves * FLX_WF_DRAWS_PER_WAVE);
   inChunk = inChunk < 64u ? 64u : (inChunk > WF_IN_CHUNK ? WF_IN_CHUNK : inChunk);
 
-  int st = P_EMPTY;
-  uint32_t pathId = 0;
-  int flags = 0;
-  int pathBounce = 0;
-  float base = 0.0f;
-  Ray nextRay; nextRay.origin = F3(0.f, 0.f, 0.f); nextRay.dir = nextRay.origin;
-  Ray shadowRay = nextRay;
-  float shadowLen = 0.0f;
-  WalkState w;
-  walkClearResults(w);
-  w.src = nextRay; w.tR = nextRay; w.minLen = 0.0f; w.i = 0; w.cachedTI = 0;
-  w.mode = 2;
-  WalkEntry cur;
-  cur.e0 = cur.e1 = cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
+  WalkLane L;                                                  /* the lane's path and its walks (flx_frame_common.h: one body for every persistent kernel) */
+  walkLaneInit(L);
   uint32_t chunkNext = 0, chunkEnd = 0;
   bool itemsLeft = true;
   uint32_t idleSpins = 0;
 
-  auto pixPart = [&](const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id) -> const float4 * {
-    uint32_t tile0, s0;
-    item_tile(fr, id, tile0, s0);
-    return wb.pix0 + (((size_t)tile0 << 6) | (id & 63u)) * 3;
-  };
-
   for (;;) {
-    const unsigned long long walking = flx_ballot(st == P_WALKING);
+    const unsigned long long walking = flx_ballot(L.st == P_WALKING);
     if (walking != 0ull) idleSpins = 0;
-    const unsigned long long workMask = flx_ballot(st == P_DONE || st == P_SWITCH);
+    const unsigned long long workMask = flx_ballot(L.st == P_DONE || L.st == P_SWITCH);
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
     const bool mayRefill = (front ? fq_load(&ctl[FC_RQ + 2]) != 0u : itemsLeft) || chunkNext != chunkEnd || fq_load(&ctl[FC_WQ + 2]) != 0u;
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
-      /* ---- fold the finished lanes: fragment:445-460, 580, 593-598 and the guard of :475; a path that goes on is handed to the shade waves ---- */
-      if (flx_ballot(st == P_DONE) != 0ull) {
+      /* ---- fold the finished lanes (walkLaneFold); a path that goes on is handed to the shade waves ---- */
+      if (flx_ballot(L.st == P_DONE) != 0ull) {
         FLX_FRAME_ARGS();
         bool toShade = false, ended = false;
-        if (st == P_DONE) {
-          float4 *rec = wb.rec + (size_t)pathId * 8;
-          const bool compact = compactRecs && pathBounce == 0;
-          float4 q4, q5, q6, q7;
-          const float4 *pp = nullptr;
-          if (compact) {
-            pp = pixPart(fr, wb, pathId);
-            q4 = wb.rec0[(size_t)pathId * 3 + 2]; q7 = pp[2];
-            q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-          } else {
-            q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
-          }
-          const bool shadowed = (flags & RF_SHADOWED_NO_WALK) || ((flags & RF_NEED_SHADOW) && w.shadowed);
-          const f3 localColor = shadowed ? F3(base, base, base) : F3(q4.x, q4.y, q4.z);
-          const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
-          const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
-          bool cont = w.tri != -1;
-          if (cont) cont = (pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
-          if (cont) {
-            if (compact) {                                    /* the path goes on: now it gets its full record (what shade0 would have written) */
-              const float4 a = wb.rec0[(size_t)pathId * 3], bq = wb.rec0[(size_t)pathId * 3 + 1], p0 = pp[0];
-              rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
-              rec[1] = make_float4(a.x, a.y, a.z, bq.w);
-              rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
-              rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-              rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
-            }
-            rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
-            rec[2] = make_float4(w.suv.x, w.suv.y, w.suv.z, __int_as_float(w.tri));
-            toShade = true;
-          } else {
-            finalize_path(fr, wb, pathId, finalColor, importancy, originalColor);
-            ended = true;
-          }
-          st = P_EMPTY;
-        }
-        fq_push(shadeRing, ctl + FC_SQ, toShade, pathId, lane);
+        if (L.st == P_DONE) walkLaneFold<false>(fr, wb, compactRecs, L, nullptr, toShade, ended);
+        fq_push(shadeRing, ctl + FC_SQ, toShade, L.pathId, lane);
         const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
         if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
       }
       /* ---- refill the free lanes: paths that came back from shading first, then fresh ones from the frame's item queue ---- */
       for (;;) {
-        const unsigned long long idle = flx_ballot(st == P_EMPTY);
+        const unsigned long long idle = flx_ballot(L.st == P_EMPTY);
         if (idle == 0ull) break;
         FLX_FRAME_ARGS();
         uint32_t *__restrict__ queue = wb.walkQueue;
@@ -1117,62 +1064,22 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           const uint32_t avail = chunkEnd - chunkNext;
           const uint32_t take = nIdle < avail ? nIdle : avail;
           const uint32_t r = lane_rank(idle);
-          if (st == P_EMPTY && r < take) { id = (front ? 0u : wb.item_base) + chunkNext + r; fresh = true; }
+          if (L.st == P_EMPTY && r < take) { id = (front ? 0u : wb.item_base) + chunkNext + r; fresh = true; }
           chunkNext += take;
         }
         bool dead = false;
-        if (id != WF_INVALID) {
-          const float4 *rec = wb.rec + (size_t)id * 8;
-          float4 q0, q1, q2, q3;
-          if (fresh && compactRecs) {
-            const float4 *pp = pixPart(fr, wb, id);
-            const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
-            const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
-            q0 = make_float4(p0.x, p0.y, p0.z, a.w);
-            q1 = make_float4(a.x, a.y, a.z, bq.w);
-            q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
-            q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
-          } else {
-            q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
-          }
-          const int fl = __float_as_int(q0.w);
-          if (fl & RF_DEAD) {
-            dead = true;
-          } else {
-            pathId = id; flags = fl; base = q2.w; pathBounce = __float_as_int(q3.w);
-            nextRay.origin = F3(q0.x, q0.y, q0.z);
-            nextRay.dir = F3(q1.x, q1.y, q1.z);
-            shadowRay.origin = F3(q2.x, q2.y, q2.z);
-            shadowRay.dir = F3(q3.x, q3.y, q3.z);
-            shadowLen = q1.w;
-            walkClearResults(w);
-            w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
-            if (COUNT) { if (w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
-            st = (w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;      /* nothing to walk: straight to the fold */
-          }
-        }
+        if (id != WF_INVALID) dead = walkLaneLoad<COUNT>(fr, wb, id, fresh && compactRecs, L, cnt);
         const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
         if (nDead != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nDead);
       }
       /* ---- set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended ---- */
-      if (st == P_SWITCH) {
-        if (flags & RF_NO_CLOSEST) st = P_DONE;
-        else { w.mode = 1; st = P_SETUP; }
-      }
-      if (flx_ballot(st == P_SETUP) != 0ull) {
+      walkLaneSwitch(L);
+      if (flx_ballot(L.st == P_SETUP) != 0ull) {
         FLX_FRAME_ARGS();
-        if (st == P_SETUP) {
-          const bool shadowMode = w.mode == 0;
-          const Ray src = shadowMode ? shadowRay : nextRay;
-          walkSetupRays(sc, nTransforms, ldsXf, myRays, src, shadowMode);
-          w.tR = src; w.cachedTI = 0; w.minLen = shadowMode ? shadowLen : POW32; w.i = (int)sc.walk_root;
-          reciprocalOfDir(sc, src.dir, src.origin, w.inv, w.fastDiv);
-          st = P_WALKING;
-          if (walkFetchG<COUNT>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt)) st = shadowMode ? P_SWITCH : P_DONE;
-        }
+        if (L.st == P_SETUP) walkLaneSetup<COUNT>(sc, nTransforms, ldsXf, myRays, walkG, ldsEntries, ldsCount, L, cnt);
       }
-      if (flx_ballot(st == P_WALKING) == 0ull) {
-        if (flx_ballot(st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
+      if (flx_ballot(L.st == P_WALKING) == 0ull) {
+        if (flx_ballot(L.st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
         /* nothing in this wave: done when the item queue is dry and no path of the workgroup is alive; else wait for the shade waves */
         if (front) {
           if (fq_load(&ctl[FC_DRY]) != 0u && chunkNext == chunkEnd && fq_load(&ctl[FC_ALIVE]) == 0u) break;
@@ -1193,14 +1100,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     /* ---- FLX_WF_INNER entries for every walking lane (the one scene word the fetch needs — the global copy's address — is in registers: walkG) ---- */
     {
 #pragma unroll FLX_WF_UNROLL
-      for (int it = 0; it < FLX_WF_INNER; it++) {
-        if (st == P_WALKING) {
-          bool ended = false;
-          if (walkIsBoxT(cur)) walkBoxP(w, cur); else ended = walkTriT(w, cur);
-          if (!ended) ended = walkFetchG<COUNT>(walkG, ldsEntries, ldsCount, myRays, w, cur, cnt);
-          if (ended) st = (w.mode == 0) ? P_SWITCH : P_DONE;
-        }
-      }
+      for (int it = 0; it < FLX_WF_INNER; it++) walkLaneStep<COUNT>(walkG, ldsEntries, ldsCount, myRays, L, cnt);
     }
   }
   FLX_FRAME_ARGS();
@@ -1252,11 +1152,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #define FLX_FRAME2_PROLOGUE_WAVES 1
 #endif
 template <typename T> FLX_DEV T selv(bool c, T a, T b) { return c ? a : b; }      /* operands by VALUE: a select of two loaded values, never of two addresses (that would put the jobs in scratch memory) */
-struct WalkJob {
-  int st; uint32_t pathId; int flags; int pathBounce; float base;
-  Ray nextRay, shadowRay; float shadowLen;
-  WalkState w; WalkEntry cur; float2 *rays;
-};
+struct WalkJob : WalkLane { float2 *rays; };      /* a lane's job: what a lane of k_wf_frame holds (flx_frame_common.h) and where its pre-transformed rays live */
 template <bool COUNT>
 __global__ __launch_bounds__(FLX_FRAME2_THREADS, FLX_FRAME2_WAVES_PER_EU) void k_wf_frame2(FrameArgs /* read through argBase */, uint32_t total_items,
                                                                                        uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves, uint32_t readyUnits) {
@@ -1369,68 +1265,21 @@ __global__ __launch_bounds__(FLX_FRAME2_THREADS, FLX_FRAME2_WAVES_PER_EU) void k
   if (wave < (uint32_t)FLX_FRAME2_PROLOGUE_WAVES) while (makeTile() == 1u) {}
   const float4 *walkG; { FLX_FRAME_ARGS(); walkG = pinnedWalkCopy(sc); }
   WalkJob j0, j1;
-  {
-    Ray z; z.origin = F3(0.f, 0.f, 0.f); z.dir = z.origin;
-    j0.st = P_EMPTY; j0.pathId = 0; j0.flags = 0; j0.pathBounce = 0; j0.base = 0.0f; j0.nextRay = z; j0.shadowRay = z; j0.shadowLen = 0.0f;
-    walkClearResults(j0.w);
-    j0.w.src = z; j0.w.tR = z; j0.w.minLen = 0.0f; j0.w.i = 0; j0.w.cachedTI = 0; j0.w.mode = 2;
-    j0.cur.e0 = j0.cur.e1 = j0.cur.e2 = make_float4(0.f, 0.f, 0.f, 0.f);
-    j1 = j0;
-    j0.rays = raysBase + (size_t)threadIdx.x * 2u * nTransforms * 5u;      /* (walk waves are the first waves of the workgroup) */
-    j1.rays = j0.rays + (size_t)nTransforms * 5u;
-  }
+  walkLaneInit(j0); walkLaneInit(j1);
+  j0.rays = raysBase + (size_t)threadIdx.x * 2u * nTransforms * 5u;      /* (walk waves are the first waves of the workgroup) */
+  j1.rays = j0.rays + (size_t)nTransforms * 5u;
   uint32_t chunkNext = 0, chunkEnd = 0;
   uint32_t idleSpins = 0;
   uint32_t last = 0;                                           /* per lane: the job advanced last (the other one's entry has had the longer time to arrive) */
   uint32_t triWait = 0;                                        /* wave-uniform: trips the lanes at triangles have waited */
   unsigned long long diagBoxTrips = 0, diagBoxLanes = 0, diagTriTrips = 0, diagTriLanes = 0;      /* COUNT builds */
 
-  auto pixPart = [&](const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id) -> const float4 * {
-    uint32_t tile0, s0;
-    item_tile(fr, id, tile0, s0);
-    return wb.pix0 + (((size_t)tile0 << 6) | (id & 63u)) * 3;
-  };
-  /* ---- fold a job's finished path: fragment:445-460, 580, 593-598 and the guard of :475; a path that goes on is handed to the shade waves ---- */
+  /* ---- fold a job's finished path (walkLaneFold); a path that goes on is handed to the shade waves ---- */
   auto foldJob = [&](WalkJob &J) {
     if (flx_ballot(J.st == P_DONE) == 0ull) return;
     FLX_FRAME_ARGS();
     bool toShade = false, ended = false;
-    if (J.st == P_DONE) {
-      float4 *rec = wb.rec + (size_t)J.pathId * 8;
-      const bool compact = compactRecs && J.pathBounce == 0;
-      float4 q4, q5, q6, q7;
-      const float4 *pp = nullptr;
-      if (compact) {
-        pp = pixPart(fr, wb, J.pathId);
-        q4 = wb.rec0[(size_t)J.pathId * 3 + 2]; q7 = pp[2];
-        q5 = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q6 = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-      } else {
-        q4 = rec[4]; q5 = rec[5]; q6 = rec[6]; q7 = rec[7];
-      }
-      const bool shadowed = (J.flags & RF_SHADOWED_NO_WALK) || ((J.flags & RF_NEED_SHADOW) && J.w.shadowed);
-      const f3 localColor = shadowed ? F3(J.base, J.base, J.base) : F3(q4.x, q4.y, q4.z);
-      const f3 importancy = F3(q6.x, q6.y, q6.z), originalColor = F3(q7.x, q7.y, q7.z);
-      const f3 finalColor = F3(q5.x, q5.y, q5.z) + localColor * importancy;
-      bool cont = J.w.tri != -1;
-      if (cont) cont = (J.pathBounce + 1) < fr.max_reflections && length(importancy * originalColor) >= fr.min_importancy * SQRT3;
-      if (cont) {
-        if (compact) {
-          const float4 a = wb.rec0[(size_t)J.pathId * 3], bq = wb.rec0[(size_t)J.pathId * 3 + 1], p0 = pp[0];
-          rec[0] = make_float4(p0.x, p0.y, p0.z, a.w);
-          rec[1] = make_float4(a.x, a.y, a.z, bq.w);
-          rec[3] = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
-          rec[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
-          rec[7] = make_float4(q7.x, q7.y, q7.z, 0.0f);
-        }
-        rec[5] = make_float4(finalColor.x, finalColor.y, finalColor.z, 0.0f);
-        rec[2] = make_float4(J.w.suv.x, J.w.suv.y, J.w.suv.z, __int_as_float(J.w.tri));
-        toShade = true;
-      } else {
-        finalize_path(fr, wb, J.pathId, finalColor, importancy, originalColor);
-        ended = true;
-      }
-      J.st = P_EMPTY;
-    }
+    if (J.st == P_DONE) walkLaneFold<false>(fr, wb, compactRecs, J, nullptr, toShade, ended);
     fq_push(shadeRing, ctl + FC_SQ, toShade, J.pathId, lane);
     const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
     if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
@@ -1464,57 +1313,17 @@ __global__ __launch_bounds__(FLX_FRAME2_THREADS, FLX_FRAME2_WAVES_PER_EU) void k
         chunkNext += take;
       }
       bool dead = false;
-      if (id != WF_INVALID) {
-        const float4 *rec = wb.rec + (size_t)id * 8;
-        float4 q0, q1, q2, q3;
-        if (fresh && compactRecs) {
-          const float4 *pp = pixPart(fr, wb, id);
-          const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
-          const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
-          q0 = make_float4(p0.x, p0.y, p0.z, a.w);
-          q1 = make_float4(a.x, a.y, a.z, bq.w);
-          q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
-          q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
-        } else {
-          q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
-        }
-        const int fl = __float_as_int(q0.w);
-        if (fl & RF_DEAD) {
-          dead = true;
-        } else {
-          J.pathId = id; J.flags = fl; J.base = q2.w; J.pathBounce = __float_as_int(q3.w);
-          J.nextRay.origin = F3(q0.x, q0.y, q0.z);
-          J.nextRay.dir = F3(q1.x, q1.y, q1.z);
-          J.shadowRay.origin = F3(q2.x, q2.y, q2.z);
-          J.shadowRay.dir = F3(q3.x, q3.y, q3.z);
-          J.shadowLen = q1.w;
-          walkClearResults(J.w);
-          J.w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
-          if (COUNT) { if (J.w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
-          J.st = (J.w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;
-        }
-      }
+      if (id != WF_INVALID) dead = walkLaneLoad<COUNT>(fr, wb, id, fresh && compactRecs, J, cnt);
       const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
       if (nDead != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nDead);
     }
   };
   /* ---- set up a job's walks: fresh ones (shadow or closest) and the closest-hit walk of a job whose shadow walk just ended ---- */
   auto setupJob = [&](WalkJob &J) {
-    if (J.st == P_SWITCH) {
-      if (J.flags & RF_NO_CLOSEST) J.st = P_DONE;
-      else { J.w.mode = 1; J.st = P_SETUP; }
-    }
+    walkLaneSwitch(J);
     if (flx_ballot(J.st == P_SETUP) != 0ull) {
       FLX_FRAME_ARGS();
-      if (J.st == P_SETUP) {
-        const bool shadowMode = J.w.mode == 0;
-        const Ray src = shadowMode ? J.shadowRay : J.nextRay;
-        walkSetupRays(sc, nTransforms, ldsXf, J.rays, src, shadowMode);
-        J.w.tR = src; J.w.cachedTI = 0; J.w.minLen = shadowMode ? J.shadowLen : POW32; J.w.i = (int)sc.walk_root;
-        reciprocalOfDir(sc, src.dir, src.origin, J.w.inv, J.w.fastDiv);
-        J.st = P_WALKING;
-        if (walkFetchG<COUNT>(walkG, ldsEntries, ldsCount, J.rays, J.w, J.cur, cnt)) J.st = shadowMode ? P_SWITCH : P_DONE;
-      }
+      if (J.st == P_SETUP) walkLaneSetup<COUNT>(sc, nTransforms, ldsXf, J.rays, walkG, ldsEntries, ldsCount, J, cnt);
     }
   };
   /* After a phase's test: the entry the stepped job's link names — ONE fetch for the lanes of both jobs (the address, the visit count, the object-space check and the
