@@ -407,13 +407,13 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     for (uint32_t s = 0; s < depth && !mayRefill; s++) mayRefill = fq_load(&rctl(RK_WALK, s)[2]) != 0u || fq_load(&rctl(RK_READY, s)[2]) != 0u;
     statTrips += (uint32_t)FLX_WF_INNER; statLaneTrips += (uint32_t)__popcll(walking) * (uint32_t)FLX_WF_INNER;
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
-      /* ---- fold the finished lanes (walkLaneFold); a path that goes on is handed to the shade waves of its frame's slot ---- */
+      /* ---- fold the finished lanes (FLX_WALK_LANE_FOLD); a path that goes on is handed to the shade waves of its frame's slot ---- */
       if (flx_ballot(L.st == P_DONE) != 0ull) {
         FLX_ARGS_OF(ab);
         const bool compactRecs = wb.rec0 != nullptr;
         bool toShade = false, ended = false;
         const uint32_t slot = slotOf(L.pathId);
-        if (L.st == P_DONE) walkLaneFold<true>(fr, wb, compactRecs, L, lv, toShade, ended);
+        if (L.st == P_DONE) FLX_WALK_LANE_FOLD(true, fr, wb, compactRecs, L, lv, toShade, ended);
         if (flx_ballot(ended) != 0ull) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* the radiance stored, before the paths leave the count (tryRotate publishes what is counted off) */
         for (uint32_t s = 0; s < depth; s++) {
           fq_push(ring(RK_SHADE, s), rctl(RK_SHADE, s), toShade && slot == s, L.pathId, lane);
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     /* ---- FLX_WF_INNER entries for every walking lane (the few scene words the fetch needs are read before the loop) ---- */
     {
 #pragma unroll FLX_WF_UNROLL
-      for (int it = 0; it < FLX_WF_INNER; it++) walkLaneStep<false>(walkG, ldsEntries, ldsCount, myRays, L, cnt);
+      for (int it = 0; it < FLX_WF_INNER; it++) FLX_WALK_LANE_STEP(false, walkG, ldsEntries, ldsCount, myRays, L, cnt);
     }
   }
   statAdd(SVS_WALK_TRIPS, statTrips); statAdd(SVS_WALK_LANE_TRIPS, statLaneTrips);

@@ -995,11 +995,11 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
     const bool mayRefill = (front ? fq_load(&ctl[FC_RQ + 2]) != 0u : itemsLeft) || chunkNext != chunkEnd || fq_load(&ctl[FC_WQ + 2]) != 0u;
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
-      /* ---- fold the finished lanes (walkLaneFold); a path that goes on is handed to the shade waves ---- */
+      /* ---- fold the finished lanes (FLX_WALK_LANE_FOLD); a path that goes on is handed to the shade waves ---- */
       if (flx_ballot(L.st == P_DONE) != 0ull) {
         FLX_FRAME_ARGS();
         bool toShade = false, ended = false;
-        if (L.st == P_DONE) walkLaneFold<false>(fr, wb, compactRecs, L, nullptr, toShade, ended);
+        if (L.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, L, nullptr, toShade, ended);
         fq_push(shadeRing, ctl + FC_SQ, toShade, L.pathId, lane);
         const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
         if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     /* ---- FLX_WF_INNER entries for every walking lane (the one scene word the fetch needs — the global copy's address — is in registers: walkG) ---- */
     {
 #pragma unroll FLX_WF_UNROLL
-      for (int it = 0; it < FLX_WF_INNER; it++) walkLaneStep<COUNT>(walkG, ldsEntries, ldsCount, myRays, L, cnt);
+      for (int it = 0; it < FLX_WF_INNER; it++) FLX_WALK_LANE_STEP(COUNT, walkG, ldsEntries, ldsCount, myRays, L, cnt);
     }
   }
   FLX_FRAME_ARGS();
@@ -1274,12 +1274,12 @@ __global__ __launch_bounds__(FLX_FRAME2_THREADS, FLX_FRAME2_WAVES_PER_EU) void k
   uint32_t triWait = 0;                                        /* wave-uniform: trips the lanes at triangles have waited */
   unsigned long long diagBoxTrips = 0, diagBoxLanes = 0, diagTriTrips = 0, diagTriLanes = 0;      /* COUNT builds */
 
-  /* ---- fold a job's finished path (walkLaneFold); a path that goes on is handed to the shade waves ---- */
+  /* ---- fold a job's finished path (FLX_WALK_LANE_FOLD); a path that goes on is handed to the shade waves ---- */
   auto foldJob = [&](WalkJob &J) {
     if (flx_ballot(J.st == P_DONE) == 0ull) return;
     FLX_FRAME_ARGS();
     bool toShade = false, ended = false;
-    if (J.st == P_DONE) walkLaneFold<false>(fr, wb, compactRecs, J, nullptr, toShade, ended);
+    if (J.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, J, nullptr, toShade, ended);
     fq_push(shadeRing, ctl + FC_SQ, toShade, J.pathId, lane);
     const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
     if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
