@@ -743,8 +743,9 @@ def main():
         k_ms = float(np.median(kernel_ms))
         frame_bytes = algorithmic_bytes(cnt, n_lights, rows_local * W, use_filter)      # this rank's share of one frame
         if pipe == 1:              # per-pixel kernel: the whole trace
-            kernel_sym = next((n for n in pmc if n.startswith("k_trace_pixels<false")), "k_trace_pixels<false, false>")      # <COUNT, LOCK>
-            kernel_name, bytes_launch = "k_trace_pixels", frame_bytes - (244 * rows_local * W if use_filter else 0)
+            # k_trace_samples<COUNT, LOCK, S> where the frame has 2, 4 or 8 samples and at most 4 bounces (a pixel's samples side by side), else k_trace_pixels<COUNT, LOCK>
+            kernel_sym = next((n for n in pmc if n.startswith("k_trace_samples<false")), None) or next((n for n in pmc if n.startswith("k_trace_pixels<false")), "k_trace_pixels<false, false>")
+            kernel_name, bytes_launch = kernel_sym.split("<")[0], frame_bytes - (244 * rows_local * W if use_filter else 0)
         elif pipe == 2:            # persistent path kernel (tiny scenes): every bounce of every path, no primary walk, no output
             kernel_name, kernel_sym = "k_paths (persistent path kernel)", next((n for n in pmc if n.startswith("k_paths<false")), "k_paths<false, false>")
             bytes_launch = 48 * (cnt["closest_visits"] + cnt["shadow_visits"]) + (160 + 24 * n_lights) * cnt["shades"] + 4 * cnt["atlas_texels"]
