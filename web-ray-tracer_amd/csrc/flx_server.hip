@@ -394,6 +394,9 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   /* ================================ walk wave ================================ */
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
   const float4 *walkG; { FLX_ARGS_OF(ab); walkG = pinnedWalkCopy(sc); }      /* the global copy of the tree, for the entries beyond the LDS top: in registers for the stepping loop */
+  /* ... both homes of an entry as flat addresses in VECTOR registers (flx_wavefront.hip: FLX_WF_FETCH_VBASE) */
+  const float4 *ldsEntriesV = ldsEntries, *walkGV = walkG;
+  asm volatile("" : "+v"(ldsEntriesV), "+v"(walkGV));
   WalkLane L;                                                  /* the lane's path and its walks (flx_frame_common.h: the body k_wf_frame's walk waves run) */
   walkLaneInit(L);
   uint32_t chunkNext = 0, chunkEnd = 0;          /* wave-uniform: the rest of a (tile, sample) unit of fresh paths */
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       walkLaneSwitch(L);
       if (flx_ballot(L.st == P_SETUP) != 0ull) {
         FLX_ARGS_OF(ab);
-        if (L.st == P_SETUP) walkLaneSetup<false>(sc, nTransforms, VER ? ldsXf + (size_t)slotOf(L.pathId) * nTransforms * 4u : ldsXf, myRays, walkG, ldsEntries, ldsCount, L, cnt);
+        if (L.st == P_SETUP) walkLaneSetup<false>(sc, nTransforms, VER ? ldsXf + (size_t)slotOf(L.pathId) * nTransforms * 4u : ldsXf, myRays, walkGV, ldsEntriesV, ldsCount, L, cnt);
       }
       if (flx_ballot(L.st == P_WALKING) == 0ull) {
         if (flx_ballot(L.st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
@@ -483,7 +486,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     /* ---- FLX_WF_INNER entries for every walking lane (the few scene words the fetch needs are read before the loop) ---- */
     {
 #pragma unroll FLX_WF_UNROLL
-      for (int it = 0; it < FLX_WF_INNER; it++) FLX_WALK_LANE_STEP(false, walkG, ldsEntries, ldsCount, myRays, L, cnt);
+      for (int it = 0; it < FLX_WF_INNER; it++) FLX_WALK_LANE_STEP(false, walkGV, ldsEntriesV, ldsCount, myRays, L, cnt);
     }
   }
   statAdd(SVS_WALK_TRIPS, statTrips); statAdd(SVS_WALK_LANE_TRIPS, statLaneTrips);

@@ -99,6 +99,9 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
 #ifndef FLX_EXPERIMENTS
 #define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 adds the queue scheduler, the cooperative finisher and walk suspension */
 #endif
+#ifndef FLX_WF_FETCH_VBASE
+#define FLX_WF_FETCH_VBASE 1
+#endif
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */
 #endif
@@ -977,6 +980,17 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   if (FLX_FRAME_WALK_PRIO) __builtin_amdgcn_s_setprio(FLX_FRAME_WALK_PRIO);
   float2 *myRays = raysBase + (size_t)threadIdx.x * nTransforms * 5u;
   const float4 *walkG; { FLX_FRAME_ARGS(); walkG = pinnedWalkCopy(sc); }      /* the global copy of the tree, for the entries beyond the LDS top */
+#if FLX_WF_FETCH_VBASE
+  /* both homes of an entry as flat addresses in VECTOR registers: the fetch picks one with two selects; from scalar registers the pick costs four moves more (a VALU
+   * instruction reads one scalar operand) and the LDS pointer's conversion to a flat one three scalar instructions, every trip */
+  const float4 *ldsEntriesV = ldsEntries, *walkGV = walkG;
+  asm volatile("" : "+v"(ldsEntriesV), "+v"(walkGV));
+#define FLX_FETCH_G walkGV
+#define FLX_FETCH_L ldsEntriesV
+#else
+#define FLX_FETCH_G walkG
+#define FLX_FETCH_L ldsEntries
+#endif
   const uint32_t nWaves = gridDim.x * WALK_WAVES;
   uint32_t lastBase = 0;
   uint32_t inChunk = n / (nWaves * FLX_WF_DRAWS_PER_WAVE);
@@ -1076,7 +1090,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       walkLaneSwitch(L);
       if (flx_ballot(L.st == P_SETUP) != 0ull) {
         FLX_FRAME_ARGS();
-        if (L.st == P_SETUP) walkLaneSetup<COUNT>(sc, nTransforms, ldsXf, myRays, walkG, ldsEntries, ldsCount, L, cnt);
+        if (L.st == P_SETUP) walkLaneSetup<COUNT>(sc, nTransforms, ldsXf, myRays, FLX_FETCH_G, FLX_FETCH_L, ldsCount, L, cnt);
       }
       if (flx_ballot(L.st == P_WALKING) == 0ull) {
         if (flx_ballot(L.st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
@@ -1100,7 +1114,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     /* ---- FLX_WF_INNER entries for every walking lane (the one scene word the fetch needs — the global copy's address — is in registers: walkG) ---- */
     {
 #pragma unroll FLX_WF_UNROLL
-      for (int it = 0; it < FLX_WF_INNER; it++) FLX_WALK_LANE_STEP(COUNT, walkG, ldsEntries, ldsCount, myRays, L, cnt);
+      for (int it = 0; it < FLX_WF_INNER; it++) FLX_WALK_LANE_STEP(COUNT, FLX_FETCH_G, FLX_FETCH_L, ldsCount, myRays, L, cnt);
     }
   }
   FLX_FRAME_ARGS();
@@ -1110,6 +1124,8 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     atomicAdd(wb.counters + 64, life); atomicMax(wb.counters + 65, life); atomicAdd(wb.counters + 66, 1ull);
   }
   flush_counters<COUNT>(cnt, wb.counters);
+#undef FLX_FETCH_G
+#undef FLX_FETCH_L
 #undef FLX_FRAME_ARGS
 }
 
