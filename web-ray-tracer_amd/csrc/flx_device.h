@@ -108,7 +108,8 @@ struct DeviceScene {
  *                  triangle  e0 = a.xyz b.x     | e1 = b.yz c.xy      | e2 = c.z        bits(next)     bits(meta) bits(origIndex)
  *                  terminator                                           e2 = -          -              bits(meta = 0)
  * meta = type | transform << 2; successor WALK_END = the loop bound of fragment:184 was reached (no fetch). */
-constexpr uint32_t WALK_END = 0xffffffffu;
+constexpr uint32_t WALK_END = 0x30000000u;      /* kind 3, index 0: as an index it names the threaded copy's shared terminator (entry 0), so a kernel that does not count visits needs
+                                                 * no test for it — it fetches the terminator and ends there (walkFetchG); larger than every real index, for the copies whose links are plain indices */
 /* A successor link = threaded index | kind of the entry it names << 28 | (that entry's transform differs from this
  * entry's) << 30.  Kinds: 0 terminator, 1 box, 2 triangle, 3 = WALK_END.  The queue scheduler (flx_walkq.hip) routes a
  * walk to its next test from the link alone, without fetching the entry. */
@@ -245,6 +246,13 @@ FLX_DEV float recipFast(float d) {
 #define FLX_LIKELY(x) (x)
 #define FLX_UNLIKELY(x) (x)
 #endif
+/* 1 / det of the triangle tests: a lane whose det is `bad` (below BIAS = 2^-16 in magnitude, or in value for the culling test) never reads the result, and one that does has
+ * |det| >= 2^-16 — inside recipFast's range from below: only the upper end (and NaN, which is not `bad`) is left to test */
+FLX_DEV float recipOfDet(float d, bool bad) {
+  const bool ok = bad || flx_abs(d) <= 1.152921504606847e18f;      /* 2^60; NaN is not ok */
+  if (FLX_LIKELY(flx_ballot(!ok) == 0ull)) return recipFast(d);
+  return 1.0f / d;
+}
 FLX_DEV float recipOf(float d, bool needed) {
   const float a = flx_abs(d);
   const bool ok = !needed || (a >= 8.673617379884035e-19f && a <= 1.152921504606847e18f);      /* 2^-60, 2^60; NaN is not ok */
@@ -904,7 +912,7 @@ FLX_DEV bool moellerTrumboreAny(f3 a, f3 edge1, f3 edge2, const Ray &ray, float 
   f3 pvec = cross(ray.dir, edge2);
   float det = dot(edge1, pvec);
   bool detBad = cull ? (det < BIAS) : (flx_abs(det) < BIAS);
-  float inv_det = recipOf(det, !detBad);                 /* a rejected lane's u, v, s are never read */
+  float inv_det = recipOfDet(det, detBad);               /* a rejected lane's u, v, s are never read */
   f3 tvec = ray.origin - a;
   float u = dot(tvec, pvec) * inv_det;
   f3 qvec = cross(tvec, edge1);
@@ -1019,7 +1027,9 @@ FLX_DEV void walkLoadRay(const float2 *raysGeneric, int t, WalkState &w) {
 template <bool COUNT>
 FLX_DEV bool walkFetchG(const float4 *walkG, const float4 *lds, uint32_t ldsCount, const float2 *rays, WalkState &w, WalkEntry &cur,
                         WorkCounters &cnt) {
-  if (((uint32_t)w.i == WALK_END)) return true;
+  /* the loop bound of fragment:184: no fetch, so no visit is counted.  Uncounted kernels skip the test (four instructions a trip): WALK_END's index bits name the shared
+   * terminator, whose fetch ends the walk all the same */
+  if (COUNT) { if (((uint32_t)w.i == WALK_END)) return true; }
   const uint32_t i = linkIndex((uint32_t)w.i);
 #if FLX_WF_FLAT_FETCH
   {   /* one instruction stream for both homes of an entry: a generic pointer into LDS or into the global copy (flat_load) */
