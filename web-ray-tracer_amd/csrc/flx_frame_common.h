@@ -20,7 +20,8 @@ namespace flx {
 #define FLX_WF_INNER 8
 #endif
 #ifndef FLX_WF_UNROLL
-#define FLX_WF_UNROLL 1
+#define FLX_WF_UNROLL 8                 /* the FLX_WF_INNER trips of the stepping loop unrolled: no loop counter, compare and branch per trip (round 5: dragon 1080p 6.25 -> 6.14 ms, 4K 23.4 -> 23.0;
+                                         * 2: 6.20, 4: 6.16; with six trips per check 6.12 but the frame server's eighth 0.94 -> 0.96: profiles/r05_trip_instructions.txt) */
 #endif
 #ifndef FLX_WF_BATCH
 #define FLX_WF_BATCH 24                     /* parked lanes that trigger a fold + refill */

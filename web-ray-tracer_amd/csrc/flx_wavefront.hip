@@ -76,7 +76,8 @@ namespace flx {
  * next round's words before a slow wave had cleared them.) */
 enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT = 8, TC_WORDS = 32 };
 #ifndef FLX_WF_UNROLL
-#define FLX_WF_UNROLL 1
+#define FLX_WF_UNROLL 8                 /* the FLX_WF_INNER trips of the stepping loop unrolled: no loop counter, compare and branch per trip (round 5: dragon 1080p 6.25 -> 6.14 ms, 4K 23.4 -> 23.0;
+                                         * 2: 6.20, 4: 6.16; with six trips per check 6.12 but the frame server's eighth 0.94 -> 0.96: profiles/r05_trip_instructions.txt) */
 #endif
 #ifndef FLX_WF_WAVES_PER_EU
 #define FLX_WF_WAVES_PER_EU 4               /* occupancy the register allocation of k_wf_walk_pre must allow */
