@@ -935,6 +935,9 @@ FLX_DEV bool moellerTrumboreAny(f3 a, f3 edge1, f3 edge2, const Ray &ray, float 
   return !detBad && !uBad && !vBad && sOk;
 #endif
 }
+#ifndef FLX_WF_LINK_XFORM
+#define FLX_WF_LINK_XFORM 1
+#endif
 #ifndef FLX_WF_FLAT_FETCH
 #define FLX_WF_FLAT_FETCH 1      /* entry fetch through one generic pointer (flat_load) instead of an LDS branch and a global branch: nine
                                   * instructions fewer per trip, +0.3 % frame after frame, +0.6 % in batches (profiles/r02_ab_walk_kernel.txt) */
@@ -1042,11 +1045,21 @@ FLX_DEV bool walkFetchG(const float4 *walkG, const float4 *lds, uint32_t ldsCoun
 #endif
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
   const int meta = __float_as_int(cur.e2.z);
+#if FLX_WF_LINK_XFORM
+  /* the link says whether the entry it names stands in another object space than the entry it came from (LINK_XFORM, build_threaded) — which is the space the walk's ray
+   * is in: no comparison with the space cached, and the verdict does not wait for the entry */
+  if (FLX_UNLIKELY(((uint32_t)w.i & LINK_XFORM) != 0u)) {
+    const int tI = (meta >> 2) << 1;
+    w.cachedTI = tI;
+    walkLoadRay(rays, tI >> 1, w);
+  }
+#else
   const int tI = (meta >> 2) << 1;
   if (FLX_UNLIKELY(tI != w.cachedTI)) {
     w.cachedTI = tI;
     walkLoadRay(rays, tI >> 1, w);
   }
+#endif
   return (meta & 3) == 0;
 }
 template <bool COUNT>
