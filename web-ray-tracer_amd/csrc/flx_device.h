@@ -894,6 +894,8 @@ FLX_DEV bool walkFetchT(const DeviceScene &sc, const float4 *lds, uint32_t ldsCo
   return (meta & 3) == 0;
 }
 FLX_DEV bool walkIsBoxT(const WalkEntry &cur) { return (__float_as_int(cur.e2.z) & 3) == 1; }
+/* ... the same from the link the walk followed to the entry (w.i names the entry `cur` holds until the test has chosen the next link) */
+FLX_DEV bool walkIsBoxL(const WalkState &w) { return linkKind((uint32_t)w.i) == 1u; }
 FLX_DEV void walkBoxT(WalkState &w, const WalkEntry &cur) {
   const bool hit = rayCuboidR(w.minLen, w, F3(cur.e0.x, cur.e0.y, cur.e0.z), F3(cur.e0.w, cur.e1.x, cur.e1.y));
   w.i = hit ? __float_as_int(cur.e2.x) : __float_as_int(cur.e2.y);
@@ -937,6 +939,12 @@ FLX_DEV bool moellerTrumboreAny(f3 a, f3 edge1, f3 edge2, const Ray &ray, float 
 }
 #ifndef FLX_WF_LINK_XFORM
 #define FLX_WF_LINK_XFORM 1
+#endif
+#ifndef FLX_WF_LINK_KIND
+#define FLX_WF_LINK_KIND 1
+#endif
+#ifndef FLX_WF_LINK_ISBOX
+#define FLX_WF_LINK_ISBOX 1
 #endif
 #ifndef FLX_WF_FLAT_FETCH
 #define FLX_WF_FLAT_FETCH 1      /* entry fetch through one generic pointer (flat_load) instead of an LDS branch and a global branch: nine
@@ -1030,9 +1038,19 @@ FLX_DEV void walkLoadRay(const float2 *raysGeneric, int t, WalkState &w) {
 template <bool COUNT>
 FLX_DEV bool walkFetchG(const float4 *walkG, const float4 *lds, uint32_t ldsCount, const float2 *rays, WalkState &w, WalkEntry &cur,
                         WorkCounters &cnt) {
+#if FLX_WF_LINK_KIND
+  /* What the entry a link names IS, the link says itself (build_threaded: kind 0 terminator, 1 box, 2 triangle, 3 = WALK_END, the loop bound of fragment:184): a walk ends
+   * on kinds 0 and 3 without waiting for — or, the terminator's fetch being a counted visit and nothing else, issuing — a load; kinds 1 and 2 are fetched, and nothing the
+   * trip decides next (another object space? box or triangle? still walking?) reads the loaded words, so the wait for them moves down to the test that uses them. */
+  /* (No branch around the loads: a link of kind 0 or 3 has index 0 — the shared terminator, the first entry of the LDS top — and its lanes load that, a broadcast, once per
+   * walk; a branch would be one more mask region in every trip.) */
+  const uint32_t link0 = (uint32_t)w.i;
+  const bool stop = ((link0 + (1u << LINK_KIND_SHIFT)) & (2u << LINK_KIND_SHIFT)) == 0u;      /* kind + 1 has bit 1 set for the kinds 1 and 2 only */
+#else
   /* the loop bound of fragment:184: no fetch, so no visit is counted.  Uncounted kernels skip the test (four instructions a trip): WALK_END's index bits name the shared
    * terminator, whose fetch ends the walk all the same */
   if (COUNT) { if (((uint32_t)w.i == WALK_END)) return true; }
+#endif
   const uint32_t i = linkIndex((uint32_t)w.i);
 #if FLX_WF_FLAT_FETCH
   {   /* one instruction stream for both homes of an entry: a generic pointer into LDS or into the global copy (flat_load) */
@@ -1043,24 +1061,31 @@ FLX_DEV bool walkFetchG(const float4 *walkG, const float4 *lds, uint32_t ldsCoun
   if (i < ldsCount) { const lds_cf4 *L = (const lds_cf4 *)lds + __umul24(i, 3u); cur.e0 = ldsLoad4(L); cur.e1 = ldsLoad4(L + 1); cur.e2 = ldsLoad4(L + 2); }      /* (i < ldsCount <= 3 328) */
   else { cur.e0 = walkG[3 * (size_t)i]; cur.e1 = walkG[3 * (size_t)i + 1]; cur.e2 = walkG[3 * (size_t)i + 2]; }
 #endif
+#if FLX_WF_LINK_KIND
+  if (COUNT) { if (linkKind(link0) != 3u) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; } }      /* (the loop bound is no visit; the terminator's fetch is one, fragment:208) */
+#else
   if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
-  const int meta = __float_as_int(cur.e2.z);
+#endif
 #if FLX_WF_LINK_XFORM
   /* the link says whether the entry it names stands in another object space than the entry it came from (LINK_XFORM, build_threaded) — which is the space the walk's ray
    * is in: no comparison with the space cached, and the verdict does not wait for the entry */
   if (FLX_UNLIKELY(((uint32_t)w.i & LINK_XFORM) != 0u)) {
-    const int tI = (meta >> 2) << 1;
+    const int tI = (__float_as_int(cur.e2.z) >> 2) << 1;
     w.cachedTI = tI;
     walkLoadRay(rays, tI >> 1, w);
   }
 #else
-  const int tI = (meta >> 2) << 1;
+  const int tI = (__float_as_int(cur.e2.z) >> 2) << 1;
   if (FLX_UNLIKELY(tI != w.cachedTI)) {
     w.cachedTI = tI;
     walkLoadRay(rays, tI >> 1, w);
   }
 #endif
-  return (meta & 3) == 0;
+#if FLX_WF_LINK_KIND
+  return stop;
+#else
+  return (__float_as_int(cur.e2.z) & 3) == 0;
+#endif
 }
 template <bool COUNT>
 FLX_DEV bool walkFetchP(const DeviceScene &sc, const float4 *lds, uint32_t ldsCount, const float2 *rays, WalkState &w, WalkEntry &cur,

@@ -345,7 +345,7 @@ FLX_DEV void walkLaneSwitch(WalkLane &L) {                  /* the shadow walk i
   do {                                                                                                                           \
     if ((L_).st == P_WALKING) {                                                                                                  \
       bool ended_ = false;                                                                                                       \
-      if (walkIsBoxT((L_).cur)) walkBoxP((L_).w, (L_).cur); else ended_ = walkTriT((L_).w, (L_).cur);                             \
+      if (FLX_WF_LINK_ISBOX ? walkIsBoxL((L_).w) : walkIsBoxT((L_).cur)) walkBoxP((L_).w, (L_).cur); else ended_ = walkTriT((L_).w, (L_).cur);                             \
       if (!ended_) ended_ = walkFetchG<COUNT_>(walkG_, ldsEntries_, ldsCount_, myRays_, (L_).w, (L_).cur, cnt_);                 \
       if (ended_) (L_).st = ((L_).w.mode == 0) ? P_SWITCH : P_DONE;                                                              \
     }                                                                                                                            \
