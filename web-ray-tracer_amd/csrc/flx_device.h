@@ -1285,15 +1285,20 @@ FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, bool needClosest
     w.tR = w.src; w.cachedTI = 0;
     reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
     uint32_t link = sc.walk_root;
-    while (link != WALK_END) {
+    /* what the entry a link names is — box, triangle, the terminator, the loop bound — and whether it stands in another object space the link says itself (build_threaded):
+     * the loop's control does not wait for the entry's loads (as in walkFetchG, FLX_WF_LINK_KIND) */
+    for (;;) {
+      if (((link + (1u << LINK_KIND_SHIFT)) & (2u << LINK_KIND_SHIFT)) == 0u) {      /* kind 0 or 3: the walk ends; the terminator's fetch is a counted visit and nothing else */
+        if (COUNT) { if (linkKind(link) == 0u) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; } }
+        break;
+      }
       const size_t i = (size_t)linkIndex(link) * 3u;
       WalkEntry cur;
       cur.e0 = sc.walk[i]; cur.e1 = sc.walk[i + 1]; cur.e2 = sc.walk[i + 2];
       if (COUNT) { if (w.mode == 0) cnt.shadow_visits++; else cnt.closest_visits++; }
-      const int meta = __float_as_int(cur.e2.z);
-      if ((meta & 3) == 0) break;                          /* terminator */
-      const int tI = (meta >> 2) << 1;
-      if (tI != w.cachedTI) {
+      const bool isBox = linkKind(link) == 1u;
+      if (FLX_UNLIKELY((link & LINK_XFORM) != 0u)) {
+        const int tI = (__float_as_int(cur.e2.z) >> 2) << 1;
         const int iI = tI + 1;
         const M3 rotationII = rotation_at(sc, iI);
         w.cachedTI = tI;
@@ -1302,7 +1307,7 @@ FLX_DEV void walkBounce(const DeviceScene &sc, bool needShadow, bool needClosest
         w.tR.dir = (w.mode == 0) ? normalize(d) : d;        /* fragment:261 normalises, fragment:201 does not */
         reciprocalOfDir(sc, w.tR.dir, w.tR.origin, w.inv, w.fastDiv);
       }
-      if ((meta & 3) == 1) {
+      if (isBox) {
         walkBoxP(w, cur);
         link = (uint32_t)w.i;
       } else {
