@@ -327,7 +327,7 @@ def usable_cores():
     return n, quota
 
 
-def cpu_baseline(scene, params_full, seconds_budget=12.0):
+def cpu_baseline(scene, params_full, seconds_budget=12.0, js_workload=None):
     """CPU oracle (kind 'port': this repo's C restatement of the reference GLSL — the reference has no CPU path) on a bounded
     sample of the same workload, on ALL host cores of this box: the same scene / spp / bounces, the full frame when one frame
     fits the budget (repeated until ~seconds_budget of CPU work), otherwise a centred sub-resolution frame sized from a probe."""
@@ -359,12 +359,43 @@ def cpu_baseline(scene, params_full, seconds_budget=12.0):
     t1 = time.time()
     flx_oracle.render(scene, p1, threads=1)
     dt1 = max(time.time() - t1, 1e-6)
+    js = js_baseline(scene, params_full) if js_workload else None
     return {
+        **({"js": js} if js else {}),
         "value": frames * spp * bounces * w * h / dt / 1e6, "unit": "Mray/s", "cores": threads, "kind": "port", "nproc": os.cpu_count(), "cpu_quota": quota,
         "sample": "same scene/spp/bounces, %dx%d frame x %d (%.1f s of CPU oracle, %d OpenMP threads = every core this process can run on: nproc %d, cgroup quota %s; filter off)" % (w, h, frames, dt, threads, os.cpu_count() or 0, ("%.1f cores" % quota) if quota else "none"),
         "single_thread": {"value": spp * bounces * w * rows1 / dt1 / 1e6, "unit": "Mray/s", "cores": 1,
                           "sample": "every 16th 8-row strip of that frame (%d rows, %.1f s)" % (rows1, dt1)},
     }
+
+
+def js_baseline(scene, params_full, seconds_budget=6.0):
+    """BASELINE configs[0] names "the reference JS/CPU headless path"; the reference has no CPU renderer (its only CPU ray code is modules/math.js:113-137), so this is
+    THIS REPOSITORY'S restatement of the fragment program in plain JavaScript (oracle/js/flx_oracle_js.js: bit-identical to the C oracle, tests/test_oracle_js_cpu.py),
+    single thread under Node, on the whole configs[0] frame repeated for a few seconds: what a JavaScript fallback of the reference's shader would cost."""
+    import shutil
+    node = shutil.which("node")
+    if not node:
+        return {"error": "no node on this box"}
+    import tempfile
+    p = params_full
+    pj = {"width": int(p.width), "height": int(p.height), "camera": [float(v) for v in p.camera], "view_matrix": [float(v) for v in p.view_matrix], "samples": int(p.samples),
+          "max_reflections": int(p.max_reflections), "min_importancy": float(p.min_importancy), "ambient": [float(v) for v in p.ambient], "random_seed": float(p.random_seed),
+          "texture_width": int(p.texture_width), "use_filter": 0, "is_temporal": 0}
+    fixture = os.path.join(ROOT, "tests", "golden", "ref_%s.flxs.gz" % scene.meta.get("name", "cornell"))
+    with tempfile.TemporaryDirectory(prefix="flx_js_") as tmp:
+        pf = os.path.join(tmp, "params.json")
+        with open(pf, "w") as fh:
+            json.dump(pj, fh)
+        cmd = [node, os.path.join(ROOT, "oracle", "js", "flx_oracle_js.js"), fixture, pf]
+        try:
+            one = json.loads(subprocess.check_output(cmd + ["--repeat", "1"], timeout=120).decode().splitlines()[-1])
+            reps = max(1, min(50, int(seconds_budget * 1e3 / max(one["ms_per_frame"], 1e-3))))
+            r = json.loads(subprocess.check_output(cmd + ["--repeat", str(reps)], timeout=180).decode().splitlines()[-1])
+        except Exception as e:      # noqa: BLE001 — a baseline that cannot run is reported, not fatal
+            return {"error": repr(e)[:200]}
+    return {"value": r["mray_per_s"], "unit": "Mray/s", "cores": 1, "kind": "port (JavaScript)", "ms_per_frame": r["ms_per_frame"], "node": r.get("node"),
+            "sample": "the whole frame x %d, filter off, one thread under Node (oracle/js/flx_oracle_js.js: this repository's restatement of the shader — the reference has no JS/CPU renderer)" % r["frames"]}
 
 
 def moved(scene, p, i):
@@ -822,7 +853,7 @@ def main():
         if verified is not None:
             line["gathered_frame_equals_single_context_frame"] = verified
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene, full)
+            line["cpu_baseline"] = cpu_baseline(scene, full, js_workload=(args.workload == "cornell"))      # configs[0]: also this repository's JavaScript restatement (one thread under Node)
 
     # ---- the batched mode and the frame loops: measured LAST, under a wall-clock limit -------------------------------------------
     # Everything the line must carry is in it now.  What follows runs code paths that no hardware with N > 1 GPUs has executed yet (the frame loop over a split
