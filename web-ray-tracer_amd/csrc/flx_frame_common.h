@@ -291,35 +291,44 @@ FLX_DEV const float4 *pix_part(const DeviceFrame &fr, const WavefrontBuffers &wb
     (L_).st = P_EMPTY;                                                                                                           \
   } while (0)
 
-/* Take path `id` into a free lane: its record (the compact bounce-0 form where `compactFresh`).  true: the item is dead (a pixel without a path), the lane stays free. */
-template <bool COUNT>
-FLX_DEV bool walkLaneLoad(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id, bool compactFresh, WalkLane &L, WorkCounters &cnt) {
+/* Take path `id` into a free lane: its record (the compact bounce-0 form where `compactFresh`).  true: the item is dead (a pixel without a path), the lane stays free.
+ * In two halves — the loads, and what they mean for the lane — so that a kernel can have the loads in flight while it does something else (k_wf_frame folds the lane's old path). */
+struct WalkRecord { float4 q0, q1, q2, q3; };
+FLX_DEV void walkLaneFetchRecord(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id, bool compactFresh, WalkRecord &R) {
   const float4 *rec = wb.rec + (size_t)id * 8;
-  float4 q0, q1, q2, q3;
   if (compactFresh) {
     const float4 *pp = pix_part(fr, wb, id);
     const float4 a = wb.rec0[(size_t)id * 3], bq = wb.rec0[(size_t)id * 3 + 1];
     const float4 p0 = pp[0], p1 = pp[1], p2 = pp[2];
-    q0 = make_float4(p0.x, p0.y, p0.z, a.w);
-    q1 = make_float4(a.x, a.y, a.z, bq.w);
-    q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
-    q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
+    R.q0 = make_float4(p0.x, p0.y, p0.z, a.w);
+    R.q1 = make_float4(a.x, a.y, a.z, bq.w);
+    R.q2 = make_float4(p1.x, p1.y, p1.z, p2.w);
+    R.q3 = make_float4(bq.x, bq.y, bq.z, __int_as_float(0));
   } else {
-    q0 = rec[0]; q1 = rec[1]; q2 = rec[2]; q3 = rec[3];
+    R.q0 = rec[0]; R.q1 = rec[1]; R.q2 = rec[2]; R.q3 = rec[3];
   }
-  const int fl = __float_as_int(q0.w);
+}
+template <bool COUNT>
+FLX_DEV bool walkLaneInstall(uint32_t id, const WalkRecord &R, WalkLane &L, WorkCounters &cnt) {
+  const int fl = __float_as_int(R.q0.w);
   if (fl & RF_DEAD) return true;
-  L.pathId = id; L.flags = fl; L.base = q2.w; L.pathBounce = __float_as_int(q3.w);
-  L.nextRay.origin = F3(q0.x, q0.y, q0.z);
-  L.nextRay.dir = F3(q1.x, q1.y, q1.z);
-  L.shadowRay.origin = F3(q2.x, q2.y, q2.z);
-  L.shadowRay.dir = F3(q3.x, q3.y, q3.z);
-  L.shadowLen = q1.w;
+  L.pathId = id; L.flags = fl; L.base = R.q2.w; L.pathBounce = __float_as_int(R.q3.w);
+  L.nextRay.origin = F3(R.q0.x, R.q0.y, R.q0.z);
+  L.nextRay.dir = F3(R.q1.x, R.q1.y, R.q1.z);
+  L.shadowRay.origin = F3(R.q2.x, R.q2.y, R.q2.z);
+  L.shadowRay.dir = F3(R.q3.x, R.q3.y, R.q3.z);
+  L.shadowLen = R.q1.w;
   walkClearResults(L.w);
   L.w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
   if (COUNT) { if (L.w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
   L.st = (L.w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;      /* nothing to walk: straight to the fold */
   return false;
+}
+template <bool COUNT>
+FLX_DEV bool walkLaneLoad(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id, bool compactFresh, WalkLane &L, WorkCounters &cnt) {
+  WalkRecord R;
+  walkLaneFetchRecord(fr, wb, id, compactFresh, R);
+  return walkLaneInstall<COUNT>(id, R, L, cnt);
 }
 /* Set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended (P_SWITCH).  xf: the staged inverse transforms the lane's path reads. */
 template <bool COUNT>

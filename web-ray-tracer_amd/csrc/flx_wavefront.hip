@@ -100,6 +100,9 @@ enum { TC_LIVE = 0, TC_TAIL = 1, TC_POOL = 2, TC_TAKE = 3, TC_MASK = 4, TC_SLOT 
 #ifndef FLX_EXPERIMENTS
 #define FLX_EXPERIMENTS 0                   /* Makefile: EXPERIMENTS=1 adds the queue scheduler, the cooperative finisher and walk suspension */
 #endif
+#ifndef FLX_FRAME_EARLY_REFILL
+#define FLX_FRAME_EARLY_REFILL 1
+#endif
 #ifndef FLX_WF_FETCH_VBASE
 #define FLX_WF_FETCH_VBASE 1
 #endif
@@ -997,6 +1000,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   uint32_t inChunk = n / (nWaves * FLX_WF_DRAWS_PER_WAVE);
   inChunk = inChunk < 64u ? 64u : (inChunk > WF_IN_CHUNK ? WF_IN_CHUNK : inChunk);
 
+  long long tBlock = 0, tFoldT = 0, tRefillT = 0, tSetupT = 0, tTrips = 0; unsigned long long nBlocks = 0, nOuter = 0;      /* COUNT builds: where a walk wave's time goes (flx_get_tail_diag 27..33) */
   WalkLane L;                                                  /* the lane's path and its walks (flx_frame_common.h: one body for every persistent kernel) */
   walkLaneInit(L);
   uint32_t chunkNext = 0, chunkEnd = 0;
@@ -1009,7 +1013,46 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     const unsigned long long workMask = flx_ballot(L.st == P_DONE || L.st == P_SWITCH);
     const uint32_t parked = 64u - (uint32_t)__popcll(walking);
     const bool mayRefill = (front ? fq_load(&ctl[FC_RQ + 2]) != 0u : itemsLeft) || chunkNext != chunkEnd || fq_load(&ctl[FC_WQ + 2]) != 0u;
+    if (COUNT) nOuter++;
+    const long long tB0 = COUNT ? clock64() : 0;
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
+      if (COUNT) nBlocks++;
+      /* ---- with the front inside the launch: the free lanes' NEXT paths first — ids (LDS only), then their records' loads, issued here and not waited for: the fold of the
+       * lanes' old paths below has its own loads, and one wait then covers both (a walk wave spent 29 % of its time in this block, 6 800 cycles a time, most of it three
+       * memory round trips one after the other: tools/frame_wave_time.py) ---- */
+      uint32_t newId = WF_INVALID;
+      bool newFresh = false;
+      WalkRecord newRec;
+      newRec.q0 = newRec.q1 = newRec.q2 = newRec.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (FRONT && FLX_FRAME_EARLY_REFILL) {
+        const bool want = L.st == P_EMPTY || L.st == P_DONE;      /* (a lane at P_DONE is free once it is folded, whatever becomes of its path) */
+        for (;;) {
+          const unsigned long long idle = flx_ballot(want && newId == WF_INVALID);
+          if (idle == 0ull) break;
+          FLX_FRAME_ARGS();
+          const uint32_t nIdle = (uint32_t)__popcll(idle);
+          uint32_t id = WF_INVALID;
+          const uint32_t back = fq_pop(walkRing, ctl + FC_WQ, idle, nIdle, 1u, lane, id);
+          if (back != 0u) { if (((idle >> lane) & 1ull) != 0ull && id != WF_INVALID) newId = id; if (flx_ballot(((idle >> lane) & 1ull) != 0ull && id != WF_INVALID) == 0ull) break; continue; }
+          if (chunkNext == chunkEnd) {
+            if (fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT) break;
+            uint32_t unit = WF_INVALID;
+            if (fq_pop(readyRing, ctl + FC_RQ, 1ull, 1u, 1u, lane, unit) == 0u) break;
+            unit = __builtin_amdgcn_readfirstlane(unit);
+            if (unit == WF_INVALID) {
+              if (lane == 0) { atomicSub(&ctl[FC_ALIVE], 64u); if (wb.error) __hip_atomic_fetch_or(wb.error, WF_ERR_RING_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+              break;
+            }
+            chunkNext = unit << 6; chunkEnd = chunkNext + 64u;
+          }
+          const uint32_t avail = chunkEnd - chunkNext;
+          const uint32_t take = nIdle < avail ? nIdle : avail;
+          const uint32_t r = lane_rank(idle);
+          if (((idle >> lane) & 1ull) != 0ull && r < take) { newId = chunkNext + r; newFresh = true; }
+          chunkNext += take;
+        }
+        if (newId != WF_INVALID) { FLX_FRAME_ARGS(); walkLaneFetchRecord(fr, wb, newId, newFresh && compactRecs, newRec); }
+      }
       /* ---- fold the finished lanes (FLX_WALK_LANE_FOLD); a path that goes on is handed to the shade waves ---- */
       if (flx_ballot(L.st == P_DONE) != 0ull) {
         FLX_FRAME_ARGS();
@@ -1019,6 +1062,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
         if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
       }
+      const long long tB1 = COUNT ? clock64() : 0; if (COUNT) tFoldT += tB1 - tB0;
+      if (FRONT && FLX_FRAME_EARLY_REFILL) {
+        /* ... the lanes' next paths (their records arrived while the old ones were folded) */
+        bool dead = false;
+        if (newId != WF_INVALID) dead = walkLaneInstall<COUNT>(newId, newRec, L, cnt);
+        const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
+        if (nDead != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nDead);
+      } else
       /* ---- refill the free lanes: paths that came back from shading first, then fresh ones from the frame's item queue ---- */
       for (;;) {
         const unsigned long long idle = flx_ballot(L.st == P_EMPTY);
@@ -1087,12 +1138,14 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
         if (nDead != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nDead);
       }
+      const long long tB2 = COUNT ? clock64() : 0; if (COUNT) tRefillT += tB2 - tB1;
       /* ---- set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended ---- */
       walkLaneSwitch(L);
       if (flx_ballot(L.st == P_SETUP) != 0ull) {
         FLX_FRAME_ARGS();
         if (L.st == P_SETUP) walkLaneSetup<COUNT>(sc, nTransforms, ldsXf, myRays, FLX_FETCH_G, FLX_FETCH_L, ldsCount, L, cnt);
       }
+      if (COUNT) { const long long tB3 = clock64(); tSetupT += tB3 - tB2; tBlock += tB3 - tB0; }
       if (flx_ballot(L.st == P_WALKING) == 0ull) {
         if (flx_ballot(L.st != P_EMPTY) != 0ull) continue;      /* lanes that had nothing to walk wait for the fold */
         /* nothing in this wave: done when the item queue is dry and no path of the workgroup is alive; else wait for the shade waves */
@@ -1113,16 +1166,20 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       }
     }
     /* ---- FLX_WF_INNER entries for every walking lane (the one scene word the fetch needs — the global copy's address — is in registers: walkG) ---- */
+    const long long tT0 = COUNT ? clock64() : 0;
     {
 #pragma unroll FLX_WF_UNROLL
       for (int it = 0; it < FLX_WF_INNER; it++) FLX_WALK_LANE_STEP(COUNT, FLX_FETCH_G, FLX_FETCH_L, ldsCount, myRays, L, cnt);
     }
+    if (COUNT) tTrips += clock64() - tT0;
   }
   FLX_FRAME_ARGS();
   if (COUNT && (cnt.closest_visits | cnt.shadow_visits) != 0u) atomicAdd(wb.counters + 23, (unsigned long long)cnt.closest_visits + cnt.shadow_visits);
   if (COUNT && lane == 0) {                                     /* wave lifetimes: sum / max / count (flx_get_tail_diag 24..26) */
     const unsigned long long life = (unsigned long long)(clock64() - tStart);
     atomicAdd(wb.counters + 64, life); atomicMax(wb.counters + 65, life); atomicAdd(wb.counters + 66, 1ull);
+    atomicAdd(wb.counters + 67, (unsigned long long)tBlock); atomicAdd(wb.counters + 68, (unsigned long long)tFoldT); atomicAdd(wb.counters + 69, (unsigned long long)tRefillT); atomicAdd(wb.counters + 70, (unsigned long long)tSetupT);
+    atomicAdd(wb.counters + 71, (unsigned long long)tTrips); atomicAdd(wb.counters + 72, nBlocks); atomicAdd(wb.counters + 73, nOuter);
   }
   flush_counters<COUNT>(cnt, wb.counters);
 #undef FLX_FETCH_G
