@@ -410,6 +410,54 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     for (uint32_t s = 0; s < depth && !mayRefill; s++) mayRefill = fq_load(&rctl(RK_WALK, s)[2]) != 0u || fq_load(&rctl(RK_READY, s)[2]) != 0u;
     statTrips += (uint32_t)FLX_WF_INNER; statLaneTrips += (uint32_t)__popcll(walking) * (uint32_t)FLX_WF_INNER;
     if (walking == 0ull || (parked >= (uint32_t)FLX_WF_BATCH && (workMask != 0ull || mayRefill))) {
+      /* ---- the free lanes' NEXT paths first — ids (LDS only), then their records' loads, issued here and not waited for: the fold of the lanes' old paths below has its
+       * own loads, and one wait covers both round trips (flx_wavefront.hip: FLX_FRAME_EARLY_REFILL).  Older frames before younger ones; per frame the paths that came back
+       * from shading, then fresh ones. ---- */
+      uint32_t newId = WF_INVALID;
+      bool newFresh = false;
+      WalkRecord newRec;
+      newRec.q0 = newRec.q1 = newRec.q2 = newRec.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint32_t P = fq_load(&ctl[SC_SLOTP]);
+      {
+        const bool want = L.st == P_EMPTY || L.st == P_DONE;      /* (a lane at P_DONE is free once it is folded, whatever becomes of its path) */
+        for (;;) {
+          const unsigned long long idle = flx_ballot(want && newId == WF_INVALID);
+          if (idle == 0ull) break;
+          const bool mineIdle = ((idle >> lane) & 1ull) != 0ull;
+          const uint32_t nIdle = (uint32_t)__popcll(idle);
+          const uint32_t rk = lane_rank(idle);
+          bool got = false, any = false;
+          for (uint32_t r = 0; r < depth; r++) {
+            const uint32_t slot = slotAt(P, r);
+            if (fq_load(&ctl[SC_SAVAIL + slot]) != 1u) break;
+            uint32_t id = WF_INVALID;
+            if (fq_pop(ring(RK_WALK, slot), rctl(RK_WALK, slot), idle, nIdle, 1u, lane, id) != 0u) {
+              if (mineIdle && id != WF_INVALID) newId = id;
+              any = flx_ballot(mineIdle && id != WF_INVALID) != 0ull;
+              got = true;
+              break;
+            }
+            if (chunkNext == chunkEnd && fq_load(&rctl(RK_SHADE, slot)[2]) < FQ_LIMIT) {      /* (the shade waves are not behind with this frame) */
+              uint32_t unit = WF_INVALID;
+              if (fq_pop(ring(RK_READY, slot), rctl(RK_READY, slot), 1ull, 1u, 1u, lane, unit) != 0u) {
+                unit = __builtin_amdgcn_readfirstlane(unit);
+                if (unit != WF_INVALID) { chunkNext = unit << 6; chunkEnd = chunkNext + 64u; }
+                else if (lane == 0) { FLX_SERVER_ARGS(); atomicSub(&ctl[SC_ALIVE + slot], 64u); __hip_atomic_fetch_or(sa.error, WF_ERR_RING_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+              }
+            }
+            if (chunkNext != chunkEnd && slotOf(chunkNext) == slot) {
+              const uint32_t avail = chunkEnd - chunkNext;
+              const uint32_t take = nIdle < avail ? nIdle : avail;
+              if (mineIdle && rk < take) { newId = chunkNext + rk; newFresh = true; }
+              chunkNext += take;
+              got = true; any = true;
+              break;
+            }
+          }
+          if (!got || !any) break;
+        }
+        if (newId != WF_INVALID) { FLX_ARGS_OF(ab); walkLaneFetchRecord(fr, wb, newId, newFresh, newRec); }
+      }
       /* ---- fold the finished lanes (FLX_WALK_LANE_FOLD); a path that goes on is handed to the shade waves of its frame's slot ---- */
       if (flx_ballot(L.st == P_DONE) != 0ull) {
         FLX_ARGS_OF(ab);
@@ -425,44 +473,17 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         }
         worked();
       }
-      /* ---- refill the free lanes: older frames before younger ones; per frame the paths that came back from shading, then fresh ones ---- */
-      const uint32_t P = fq_load(&ctl[SC_SLOTP]);
-      for (;;) {
-        const unsigned long long idle = flx_ballot(L.st == P_EMPTY);
-        if (idle == 0ull) break;
-        FLX_ARGS_OF(ab);
-        const uint32_t nIdle = (uint32_t)__popcll(idle);
-        const uint32_t rk = lane_rank(idle);
-        uint32_t id = WF_INVALID;
-        bool fresh = false;                                    /* a bounce-0 item: compact record, may be dead */
-        bool got = false;
-        uint32_t slot = 0;
-        for (uint32_t r = 0; r < depth; r++) {
-          slot = slotAt(P, r);
-          if (fq_load(&ctl[SC_SAVAIL + slot]) != 1u) break;
-          if (fq_pop(ring(RK_WALK, slot), rctl(RK_WALK, slot), idle, nIdle, 1u, lane, id) != 0u) { got = true; break; }
-          if (chunkNext == chunkEnd && fq_load(&rctl(RK_SHADE, slot)[2]) < FQ_LIMIT) {      /* (the shade waves are not behind with this frame) */
-            uint32_t unit = WF_INVALID;
-            if (fq_pop(ring(RK_READY, slot), rctl(RK_READY, slot), 1ull, 1u, 1u, lane, unit) != 0u) {
-              unit = __builtin_amdgcn_readfirstlane(unit);
-              if (unit != WF_INVALID) { chunkNext = unit << 6; chunkEnd = chunkNext + 64u; }
-              else if (lane == 0) { FLX_SERVER_ARGS(); atomicSub(&ctl[SC_ALIVE + slot], 64u); __hip_atomic_fetch_or(sa.error, WF_ERR_RING_SLOT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-            }
-          }
-          if (chunkNext != chunkEnd && slotOf(chunkNext) == slot) {
-            const uint32_t avail = chunkEnd - chunkNext;
-            const uint32_t take = nIdle < avail ? nIdle : avail;
-            if (L.st == P_EMPTY && rk < take) { id = chunkNext + rk; fresh = true; }
-            chunkNext += take;
-            got = true;
-            break;
+      /* ... the lanes' next paths: their records arrived while the old ones were folded */
+      {
+        bool dead = false;
+        if (newId != WF_INVALID) dead = walkLaneInstall<false>(newId, newRec, L, cnt);
+        if (flx_ballot(dead) != 0ull) {
+          const uint32_t dslot = slotOf(newId);
+          for (uint32_t sl = 0; sl < depth; sl++) {
+            const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead && dslot == sl));
+            if (nDead != 0u && lane == 0) atomicSub(&ctl[SC_ALIVE + sl], nDead);      /* (a dead item's finalisation was stored by the wave that made the tile, before the tile was handed over) */
           }
         }
-        if (!got) break;
-        bool dead = false;
-        if (id != WF_INVALID) dead = walkLaneLoad<false>(fr, wb, id, fresh, L, cnt);
-        const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
-        if (nDead != 0u && lane == 0) atomicSub(&ctl[SC_ALIVE + slot], nDead);      /* (a dead item's finalisation was stored by the wave that made the tile, before the tile was handed over) */
       }
       if (FLX_SERVER_PRIO) {
         const bool tail = fq_load(&ctl[SC_TILEDRY + P]) != 0u;
