@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Does the ORDER in which the frame kernel draws a frame's screen tiles matter?  A counted frame gives the entries visited per 8 x 8 tile (flx_debug_tile_cost);
+the frame is then timed (flx_last_frame_ms, min and median of N) with the tiles drawn in several orders (flx_debug_set_tile_order); frames must be the same bits.
+usage: tile_order_ab.py [width height [spp bounces]]   env FLX_TILES=8: a rank's eighth"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "web-ray-tracer_amd"))
+from flexlight_hip import capi
+from flexlight_hip.scene_io import Scene
+sc = Scene.golden(os.environ.get("FLX_SCENE", "dragon"))
+a = [int(x) for x in sys.argv[1:5]] + [1920, 1080, 8, 4][len(sys.argv[1:5]):]
+ctx = capi.Context(0)
+ctx.update_scene(sc)
+ctx.set_frame_chain(0)
+p = sc.frame_params(width=a[0], height=a[1], samples=a[2], max_reflections=a[3], use_filter=0)
+rows = a[1]
+if os.environ.get("FLX_TILES"):
+    p.tile_rows, p.tile_count, p.tile_index = 8, int(os.environ["FLX_TILES"]), int(os.environ.get("FLX_TILE_INDEX", "0"))
+    rows = ((a[1] + 7) // 8 - p.tile_index + p.tile_count - 1) // p.tile_count * 8
+tx, ty = (a[0] + 7) // 8, (rows + 7) // 8
+n = tx * ty
+ctx.tile_cost(n)
+ctx.render(p, counters=True)
+cost = ctx.tile_cost(n, read=True).astype(np.float64)
+ctx.tile_cost(0)
+print("%d x %d tiles, visits per tile: min %.0f median %.0f mean %.0f max %.0f" % (tx, ty, cost.min(), np.median(cost), cost.mean(), cost.max()))
+g = cost.reshape(ty, tx)
+for y in range(ty - 1, -1, -max(1, ty // 27)):
+    print("".join(" .:-=+*#%@"[min(9, int(10 * g[y, x] / (cost.max() + 1)))] for x in range(0, tx, max(1, tx // 120))))
+N = int(os.environ.get("N", "25"))
+def timed(order, label):
+    ctx.set_tile_order(order)
+    for _ in range(3): out = ctx.render(p)[0]
+    ms = []
+    for _ in range(N):
+        out = ctx.render(p)[0]
+        ms.append(ctx.last_frame_ms()[0])
+    print("%-46s frame min %.3f median %.3f ms" % (label, min(ms), float(np.median(ms))), flush=True)
+    return out
+rng = np.random.default_rng(1)
+ident = np.arange(n, dtype=np.uint32)
+base = timed(None, "tile q (the default)")
+desc = np.argsort(-cost, kind="stable").astype(np.uint32)
+orders = [("heaviest first", desc), ("lightest first", desc[::-1].copy()), ("random", rng.permutation(n).astype(np.uint32)), ("rows bottom-up", ident[::-1].copy())]
+# heavy first in coarse classes, screen order inside a class (keeps neighbours together)
+for k in (4, 16):
+    cls = np.minimum(k - 1, (np.argsort(np.argsort(-cost, kind="stable"), kind="stable") * k // n))
+    orders.append(("heaviest first in %d classes, screen order inside" % k, np.lexsort((ident, cls)).astype(np.uint32)))
+# the lightest 10 % last, the rest in screen order
+rank = np.argsort(np.argsort(-cost, kind="stable"), kind="stable")
+for frac in (0.05, 0.1, 0.2):
+    late = rank >= int(n * (1 - frac))
+    orders.append(("the lightest %2.0f %% last, else screen order" % (100 * frac), np.concatenate([ident[~late], ident[late][np.argsort(-cost[late], kind="stable")]]).astype(np.uint32)))
+for label, o in orders:
+    out = timed(o, label)
+    if not np.array_equal(out.view(np.uint32), base.view(np.uint32)): print("   FRAME DIFFERS")
+timed(None, "tile q again")

@@ -30,7 +30,7 @@ using namespace flx;
 #define FLX_FRONT_FUSED_MAX_ITEMS (128u << 20)
 #endif
 #ifndef FLX_FRONT_MIN_TILES_PER_CU
-#define FLX_FRONT_MIN_TILES_PER_CU 32
+#define FLX_FRONT_MIN_TILES_PER_CU 24     /* (a quarter of a 1080p frame, 31.6 tiles per workgroup: 2.02 ms inside against 2.19 in front; an eighth, 15.9: 1.46 against 1.45; a sixteenth 1.27 against 1.21 — tools/front_rule.py) */
 #endif
 #ifndef FLX_COMM_RESERVED_CUS
 #define FLX_COMM_RESERVED_CUS 8u            /* CUs a context with two gathering lanes leaves free of persistent walk workgroups */
@@ -113,7 +113,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_send, ctx->d_send8, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_angle_tan, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings, ctx->d_qbatch,
+                   ctx->d_send, ctx->d_send8, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_angle_tan, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings, ctx->d_qbatch, ctx->d_tile_order, ctx->d_tile_cost,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -799,6 +799,8 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       wb.frameRings = ctx->d_frame_rings + (size_t)g * cus * WF_FRAME_RINGS * WF_FRAME_RING;
       wb.front = front ? 1u : (fusedFront ? 2u : 0u);
       wb.error = ctx->d_dev_error; wb.watchdog = ctx->inject_watchdog; wb.inject = ctx->inject_flags; wb.walkJobs = ctx->walk_jobs;
+      wb.tileOrder = (groups == 1 && ctx->d_tile_order && ctx->tile_order_n == tiles) ? ctx->d_tile_order : nullptr;
+      wb.tileCost = (cnt && ctx->d_tile_cost && ctx->tile_cost_n >= tiles) ? ctx->d_tile_cost : nullptr;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
       wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
@@ -2011,6 +2013,45 @@ extern "C" flx_status flx_debug_set_walk_jobs(flx_context *ctx, int jobs) {
 #endif
   if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_walk_jobs: frames are in flight");
   ctx->walk_jobs = jobs ? (uint32_t)jobs : (uint32_t)FLX_WALK_JOBS_DEFAULT;
+  return FLX_OK;
+}
+/* The order in which the frame kernel's workgroups draw the frame's 8 x 8 screen tiles (k_wf_frame with its front inside): order[q] = the tile the q-th draw makes, a permutation of
+ * 0 .. n - 1 (n = the frame's tiles), or n = 0: tile q (the default).  Frames do not depend on it (every path writes its own slot); a launch's drain does. */
+extern "C" flx_status flx_debug_set_tile_order(flx_context *ctx, const uint32_t *order, uint32_t n) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_tile_order: frames are in flight");
+  flx_status s = flx_server_stop(ctx);
+  if (s) return s;
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->d_tile_order) { (void)hipFree(ctx->d_tile_order); ctx->d_tile_order = nullptr; }
+  ctx->tile_order_n = 0;
+  if (n == 0u) return FLX_OK;
+  if (!order) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_tile_order: no order");
+  std::vector<uint8_t> seen(n, 0);
+  for (uint32_t q = 0; q < n; q++) {
+    if (order[q] >= n || seen[order[q]]) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_tile_order: not a permutation of the frame's tiles");
+    seen[order[q]] = 1;
+  }
+  FLX_HIP(ctx, hipMalloc(&ctx->d_tile_order, (size_t)n * sizeof(uint32_t)));
+  FLX_HIP(ctx, hipMemcpy(ctx->d_tile_order, order, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  ctx->tile_order_n = n;
+  return FLX_OK;
+}
+/* Counted frames add, per 8 x 8 screen tile, the entries its paths' walks visited (bounce loop only): n > 0 turns that on for frames of up to n tiles and zeroes the sums,
+ * out != nullptr copies them out first (as many as were asked for when it was turned on); n = 0 turns it off. */
+extern "C" flx_status flx_debug_tile_cost(flx_context *ctx, unsigned long long *out, uint32_t n) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_debug_tile_cost: frames are in flight");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (out && ctx->d_tile_cost) FLX_HIP(ctx, hipMemcpy(out, ctx->d_tile_cost, (size_t)(n && n < ctx->tile_cost_n ? n : ctx->tile_cost_n) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (n != ctx->tile_cost_n) {
+    if (ctx->d_tile_cost) { (void)hipFree(ctx->d_tile_cost); ctx->d_tile_cost = nullptr; }
+    ctx->tile_cost_n = 0;
+    if (n) { FLX_HIP(ctx, hipMalloc(&ctx->d_tile_cost, (size_t)n * sizeof(unsigned long long))); ctx->tile_cost_n = n; }
+  }
+  if (ctx->d_tile_cost) FLX_HIP(ctx, hipMemset(ctx->d_tile_cost, 0, (size_t)ctx->tile_cost_n * sizeof(unsigned long long)));
   return FLX_OK;
 }
 /* the shading's per-triangle table (DeviceScene::angle_tan) off: every shade computes the values itself, as before round 4 — for A/B runs and the test that both agree */

@@ -59,6 +59,8 @@ struct flx_context {
   bool gb_float_wanted = false;                  /* flx_render was given `gbuffers`: the filter frame keeps its float G-buffers */
   int walk_scheduler = 0;
   int sample_parallel = FLX_SAMPLE_PARALLEL_DEFAULT;      /* flx_debug_set_sample_parallel: k_trace_samples instead of k_trace_pixels where the frame allows it */
+  uint32_t *d_tile_order = nullptr; uint32_t tile_order_n = 0;      /* flx_debug_set_tile_order: the frame kernel's draw order over the frame's screen tiles */
+  unsigned long long *d_tile_cost = nullptr; uint32_t tile_cost_n = 0;      /* flx_debug_tile_cost: counted frames' visits per screen tile */
   uint32_t walk_jobs = FLX_WALK_JOBS_DEFAULT;    /* flx_debug_set_walk_jobs: walk jobs per lane of the frame kernel's walk waves */
   int32_t *d_ids = nullptr;
   float *d_lights = nullptr;

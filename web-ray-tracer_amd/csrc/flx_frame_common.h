@@ -233,8 +233,10 @@ struct WalkLane {
   uint32_t pathId; int flags; int pathBounce; float base;
   Ray nextRay, shadowRay; float shadowLen;
   WalkState w; WalkEntry cur;
+  uint32_t v0;                             /* counted builds: the lane's visit count when its path came in (flx_debug_tile_cost) */
 };
 FLX_DEV void walkLaneInit(WalkLane &L) {
+  L.v0 = 0u;
   L.st = P_EMPTY; L.pathId = 0; L.flags = 0; L.pathBounce = 0; L.base = 0.0f;
   L.nextRay.origin = F3(0.f, 0.f, 0.f); L.nextRay.dir = L.nextRay.origin;
   L.shadowRay = L.nextRay; L.shadowLen = 0.0f;
@@ -320,7 +322,7 @@ FLX_DEV bool walkLaneInstall(uint32_t id, const WalkRecord &R, WalkLane &L, Work
   L.shadowLen = R.q1.w;
   walkClearResults(L.w);
   L.w.mode = (fl & RF_NEED_SHADOW) ? 0 : 1;
-  if (COUNT) { if (L.w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; }
+  if (COUNT) { if (L.w.mode == 0) cnt.shadow_walks++; if (!(fl & RF_NO_CLOSEST)) cnt.closest_walks++; L.v0 = cnt.closest_visits + cnt.shadow_visits; }
   L.st = (L.w.mode == 1 && (fl & RF_NO_CLOSEST)) ? P_DONE : P_SETUP;      /* nothing to walk: straight to the fold */
   return false;
 }

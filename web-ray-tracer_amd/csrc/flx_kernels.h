@@ -57,6 +57,8 @@ struct WavefrontBuffers {
   uint32_t watchdog;            /* frame kernels: polls after which a wave that waits gives up (0: FQ_WATCHDOG, seconds); fault injection sets it low */
   uint32_t inject;              /* fault injection (flx_debug_inject_fault): WF_INJECT_* */
   uint32_t walkJobs;            /* frame kernel with its front inside: 2 = two walk jobs per lane (k_wf_frame2); else one (k_wf_frame) */
+  const uint32_t *tileOrder;    /* frame kernel with its front inside: the screen tile the q-th draw from the frame's tile queue makes (a permutation of the frame's tiles), or nullptr: tile q */
+  unsigned long long *tileCost; /* counted frames: entries visited by the paths of every screen tile (flx_debug_tile_cost), or nullptr */
 };
 /* the arguments of the shade kernels and the frame kernels, read from the kernarg segment where they are used (flx_frame_common.h) */
 struct FrameArgs { DeviceScene sc; DeviceFrame fr; WavefrontBuffers wb; };

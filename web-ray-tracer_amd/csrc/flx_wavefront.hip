@@ -914,6 +914,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       if (lane == 0) atomicSub(&ctl[FC_ALIVE], perTile);
       return 2u;
     }
+    if (wb.tileOrder) tile = __builtin_amdgcn_readfirstlane(wb.tileOrder[tile]);      /* (set only for a launch that owns the whole frame: item_base 0) */
     tile += wb.item_base / perTile;
     const float4 h = primary_tile<COUNT>(argBase, tile, lane, cnt);
     const bool runs = shade0_tile<COUNT>(argBase, tile, lane, h, cnt);
@@ -1007,6 +1008,52 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   bool itemsLeft = true;
   uint32_t idleSpins = 0;
 
+  /* front in its own kernel: fresh paths come from the frame's item queue (guided self-scheduling: draws shrink as the queue empties).  false: none now */
+  auto drawChunk = [&]() -> bool {
+    FLX_FRAME_ARGS();
+    uint32_t *__restrict__ queue = wb.walkQueue;
+    if (!itemsLeft) return false;
+    if (fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT) return false;  /* the shade waves are behind: no new paths for now */
+    uint32_t want = (n - lastBase) / (nWaves * 2u);    /* guided self-scheduling: draws shrink as the queue empties */
+    want = want < 64u ? 64u : (want > inChunk ? inChunk : want);
+    /* The workgroup's live paths are counted BEFORE they are drawn (the count never runs behind) and never exceed FQ_ALIVE_MAX: a
+     * path is in one place at a time — a lane, a ring, a shade wave's batch — so neither ring can hold more than that, and a slot
+     * is read and cleared before its position comes round again. */
+    uint32_t base0 = 0, room = 1;
+    if (lane == 0) {
+      const uint32_t before = atomicAdd(&ctl[FC_ALIVE], want);
+      if (before + want > FQ_ALIVE_MAX) { atomicSub(&ctl[FC_ALIVE], want); room = 0; }
+      else base0 = atomicAdd(queue, want);
+    }
+    room = __builtin_amdgcn_readfirstlane(room);
+    if (room == 0u) return false;                              /* as many live paths as the rings hold: no new ones until some end */
+    base0 = __builtin_amdgcn_readfirstlane(base0);
+    if (base0 >= n) {
+      if (lane == 0) {
+        atomicSub(&ctl[FC_ALIVE], want);
+        const uint32_t was = atomicExch(&ctl[FC_DRY], 1u);
+        if (COUNT && was == 0u) {                       /* frame-kernel profile (flx_get_tail_diag 20..): when did this workgroup find the item queue dry, with how many paths alive */
+          const unsigned long long now = (unsigned long long)(clock64() - tStart);
+          atomicAdd(wb.counters + 60, now); atomicMax(wb.counters + 61, now); atomicAdd(wb.counters + 62, 1ull);
+          atomicAdd(wb.counters + 63, (unsigned long long)fq_load(&ctl[FC_ALIVE]));
+        }
+      }
+      itemsLeft = false;
+      return false;
+    }
+    const uint32_t have = (base0 + want < n) ? want : n - base0;
+    if (have < want && lane == 0) atomicSub(&ctl[FC_ALIVE], want - have);
+    lastBase = base0;
+    chunkNext = base0; chunkEnd = base0 + have;
+      return true;
+  };
+  /* the path item at position q of the frame's queue (flx_debug_set_tile_order: the q-th tile of the queue is tile order[q]) */
+  auto itemOfQueue = [&](uint32_t q) -> uint32_t {
+    FLX_FRAME_ARGS();
+    uint32_t id = wb.item_base + q;
+    if (wb.tileOrder) { uint32_t tile_, s_; item_tile(fr, id, tile_, s_); id = ((wb.tileOrder[tile_] * (uint32_t)fr.samples + s_) << 6) | (id & 63u); }
+    return id;
+  };
   for (;;) {
     const unsigned long long walking = flx_ballot(L.st == P_WALKING);
     if (walking != 0ull) idleSpins = 0;
@@ -1024,7 +1071,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       bool newFresh = false;
       WalkRecord newRec;
       newRec.q0 = newRec.q1 = newRec.q2 = newRec.q3 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (FRONT && FLX_FRAME_EARLY_REFILL) {
+      if (FLX_FRAME_EARLY_REFILL) {
         const bool want = L.st == P_EMPTY || L.st == P_DONE;      /* (a lane at P_DONE is free once it is folded, whatever becomes of its path) */
         for (;;) {
           const unsigned long long idle = flx_ballot(want && newId == WF_INVALID);
@@ -1034,7 +1081,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           uint32_t id = WF_INVALID;
           const uint32_t back = fq_pop(walkRing, ctl + FC_WQ, idle, nIdle, 1u, lane, id);
           if (back != 0u) { if (((idle >> lane) & 1ull) != 0ull && id != WF_INVALID) newId = id; if (flx_ballot(((idle >> lane) & 1ull) != 0ull && id != WF_INVALID) == 0ull) break; continue; }
-          if (chunkNext == chunkEnd) {
+          if (chunkNext == chunkEnd && front) {
             if (fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT) break;
             uint32_t unit = WF_INVALID;
             if (fq_pop(readyRing, ctl + FC_RQ, 1ull, 1u, 1u, lane, unit) == 0u) break;
@@ -1044,11 +1091,13 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
               break;
             }
             chunkNext = unit << 6; chunkEnd = chunkNext + 64u;
+          } else if (chunkNext == chunkEnd) {
+            if (!drawChunk()) break;
           }
           const uint32_t avail = chunkEnd - chunkNext;
           const uint32_t take = nIdle < avail ? nIdle : avail;
           const uint32_t r = lane_rank(idle);
-          if (((idle >> lane) & 1ull) != 0ull && r < take) { newId = chunkNext + r; newFresh = true; }
+          if (((idle >> lane) & 1ull) != 0ull && r < take) { newId = front ? chunkNext + r : itemOfQueue(chunkNext + r); newFresh = true; }
           chunkNext += take;
         }
         if (newId != WF_INVALID) { FLX_FRAME_ARGS(); walkLaneFetchRecord(fr, wb, newId, newFresh && compactRecs, newRec); }
@@ -1057,13 +1106,17 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       if (flx_ballot(L.st == P_DONE) != 0ull) {
         FLX_FRAME_ARGS();
         bool toShade = false, ended = false;
+        if (COUNT && wb.tileCost && L.st == P_DONE) {              /* flx_debug_tile_cost: what this bounce of the lane's path visited, to its screen tile */
+          uint32_t tile_, s_; item_tile(fr, L.pathId, tile_, s_);
+          atomicAdd(wb.tileCost + tile_, (unsigned long long)(cnt.closest_visits + cnt.shadow_visits - L.v0));
+        }
         if (L.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, L, nullptr, toShade, ended);
         fq_push(shadeRing, ctl + FC_SQ, toShade, L.pathId, lane);
         const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
         if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
       }
       const long long tB1 = COUNT ? clock64() : 0; if (COUNT) tFoldT += tB1 - tB0;
-      if (FRONT && FLX_FRAME_EARLY_REFILL) {
+      if (FLX_FRAME_EARLY_REFILL) {
         /* ... the lanes' next paths (their records arrived while the old ones were folded) */
         bool dead = false;
         if (newId != WF_INVALID) dead = walkLaneInstall<COUNT>(newId, newRec, L, cnt);
@@ -1075,7 +1128,6 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         const unsigned long long idle = flx_ballot(L.st == P_EMPTY);
         if (idle == 0ull) break;
         FLX_FRAME_ARGS();
-        uint32_t *__restrict__ queue = wb.walkQueue;
         const uint32_t nIdle = (uint32_t)__popcll(idle);
         uint32_t id = WF_INVALID;
         bool fresh = false;                                    /* a bounce-0 item: compact record, may be dead */
@@ -1093,44 +1145,12 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
             }
             chunkNext = unit << 6; chunkEnd = chunkNext + 64u;
           } else if (chunkNext == chunkEnd) {
-            if (!itemsLeft) break;
-            if (fq_load(&ctl[FC_SQ + 2]) >= FQ_LIMIT) break;  /* the shade waves are behind: no new paths for now */
-            uint32_t want = (n - lastBase) / (nWaves * 2u);    /* guided self-scheduling: draws shrink as the queue empties */
-            want = want < 64u ? 64u : (want > inChunk ? inChunk : want);
-            /* The workgroup's live paths are counted BEFORE they are drawn (the count never runs behind) and never exceed FQ_ALIVE_MAX: a
-             * path is in one place at a time — a lane, a ring, a shade wave's batch — so neither ring can hold more than that, and a slot
-             * is read and cleared before its position comes round again. */
-            uint32_t base0 = 0, room = 1;
-            if (lane == 0) {
-              const uint32_t before = atomicAdd(&ctl[FC_ALIVE], want);
-              if (before + want > FQ_ALIVE_MAX) { atomicSub(&ctl[FC_ALIVE], want); room = 0; }
-              else base0 = atomicAdd(queue, want);
-            }
-            room = __builtin_amdgcn_readfirstlane(room);
-            if (room == 0u) break;                              /* as many live paths as the rings hold: no new ones until some end */
-            base0 = __builtin_amdgcn_readfirstlane(base0);
-            if (base0 >= n) {
-              if (lane == 0) {
-                atomicSub(&ctl[FC_ALIVE], want);
-                const uint32_t was = atomicExch(&ctl[FC_DRY], 1u);
-                if (COUNT && was == 0u) {                       /* frame-kernel profile (flx_get_tail_diag 20..): when did this workgroup find the item queue dry, with how many paths alive */
-                  const unsigned long long now = (unsigned long long)(clock64() - tStart);
-                  atomicAdd(wb.counters + 60, now); atomicMax(wb.counters + 61, now); atomicAdd(wb.counters + 62, 1ull);
-                  atomicAdd(wb.counters + 63, (unsigned long long)fq_load(&ctl[FC_ALIVE]));
-                }
-              }
-              itemsLeft = false;
-              break;
-            }
-            const uint32_t have = (base0 + want < n) ? want : n - base0;
-            if (have < want && lane == 0) atomicSub(&ctl[FC_ALIVE], want - have);
-            lastBase = base0;
-            chunkNext = base0; chunkEnd = base0 + have;
+            if (!drawChunk()) break;
           }
           const uint32_t avail = chunkEnd - chunkNext;
           const uint32_t take = nIdle < avail ? nIdle : avail;
           const uint32_t r = lane_rank(idle);
-          if (L.st == P_EMPTY && r < take) { id = (front ? 0u : wb.item_base) + chunkNext + r; fresh = true; }
+          if (L.st == P_EMPTY && r < take) { id = front ? chunkNext + r : itemOfQueue(chunkNext + r); fresh = true; }
           chunkNext += take;
         }
         bool dead = false;

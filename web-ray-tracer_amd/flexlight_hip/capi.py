@@ -29,7 +29,7 @@ EXPORTS = [
     "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
     "flx_frame_server_takes", "flx_frame_target_set", "flx_frame_target_index", "flx_debug_set_server_groups",
     "flx_share_create", "flx_share_join", "flx_share_leave", "flx_frame_begin_shared", "flx_frame_end_shared",
-    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table", "flx_frame_target_set8", "flx_debug_set_walk_jobs", "flx_debug_set_sample_parallel",
+    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table", "flx_frame_target_set8", "flx_debug_set_walk_jobs", "flx_debug_set_sample_parallel", "flx_debug_set_tile_order", "flx_debug_tile_cost",
 ]
 
 
@@ -161,6 +161,8 @@ def _load():
         "flx_share_leave": (C.c_int, [vp]),
         "flx_debug_set_walk_jobs": (C.c_int, [vp, C.c_int]),
         "flx_debug_set_sample_parallel": (C.c_int, [vp, C.c_int]),
+        "flx_debug_set_tile_order": (C.c_int, [vp, C.POINTER(u32), u32]),
+        "flx_debug_tile_cost": (C.c_int, [vp, C.POINTER(C.c_uint64), u32]),
         "flx_frame_begin_shared": (C.c_int, [vp, C.POINTER(FrameParams)]),
         "flx_frame_end_shared": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_float)]),
     }
@@ -393,6 +395,17 @@ class Context:
     def set_sample_parallel(self, on):
         """k_trace_samples (a pixel's samples side by side) instead of k_trace_pixels where the frame allows it (flx_debug_set_sample_parallel)"""
         self._check(LIB.flx_debug_set_sample_parallel(self._h, int(bool(on))), "flx_debug_set_sample_parallel")
+
+    def set_tile_order(self, order):
+        """the frame kernel's draw order over a frame's 8 x 8 screen tiles (flx_debug_set_tile_order): a permutation, or None / empty for the default"""
+        o = np.ascontiguousarray(order if order is not None else [], np.uint32)
+        self._check(LIB.flx_debug_set_tile_order(self._h, o.ctypes.data_as(C.POINTER(C.c_uint32)), int(o.size)), "flx_debug_set_tile_order")
+
+    def tile_cost(self, n, read=False):
+        """counted frames' visits per screen tile (flx_debug_tile_cost): turn on for n tiles (0: off); read=True returns the sums gathered so far first"""
+        out = np.zeros(max(int(n), 1), np.uint64) if read else None
+        self._check(LIB.flx_debug_tile_cost(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)) if read else None, int(n)), "flx_debug_tile_cost")
+        return out
 
     def set_walk_jobs(self, jobs):
         """walk jobs per lane of the frame kernel's walk waves (flx_debug_set_walk_jobs): 1, 2, or 0 = the library's default"""
