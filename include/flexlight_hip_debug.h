@@ -54,6 +54,8 @@ flx_status flx_debug_set_sample_parallel(flx_context *ctx, int on);
 flx_status flx_debug_set_walk_jobs(flx_context *ctx, int jobs);
 /* the order in which the frame kernel draws a frame's 8 x 8 screen tiles: order[q] = the tile of the q-th draw (a permutation of the frame's n tiles; n = 0: tile q); frames do not depend on it */
 flx_status flx_debug_set_tile_order(flx_context *ctx, const uint32_t *order, uint32_t n);
+/* the adaptive tile order — the draw order made from what every tile cost in the last frame of the same shape (the lightest tiles last) — on (1, the default) or off (0: screen order) */
+flx_status flx_debug_set_adaptive_order(flx_context *ctx, int on);
 /* counted frames sum the entries visited by the paths of every screen tile: n > 0 turns that on (and zeroes the sums) for frames of up to n tiles, out copies the sums out first, n = 0 turns it off */
 flx_status flx_debug_tile_cost(flx_context *ctx, unsigned long long *out, uint32_t n);
 /* Rehearsal of a device group on ONE GPU: the frame server's launch takes `groups` CUs only (0: all), so that the launches of several contexts run beside

@@ -1,0 +1,74 @@
+"""The order in which the frame kernel draws a frame's 8 x 8 screen tiles (include/flexlight_hip_debug.h: flx_debug_set_tile_order, flx_debug_set_adaptive_order)
+is a matter of scheduling only: every path writes its radiance to its own slot (flx_wavefront_common.h: finalize_path), so a frame is the same bits whatever
+the order — screen order, an explicit permutation, or the adaptive order the library makes from what the tiles cost in the frame before (thin frames: k_resolve sums
+the paths' time in the walk lanes per tile, k_tile_order sorts)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("front", [3, 2], ids=["front_in_its_own_kernel", "front_inside"])
+def test_frames_do_not_depend_on_the_tile_order(hip, oracle, scenes, front):
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    p = sc.frame_params(width=320, height=184, samples=2, max_reflections=4, use_filter=0)
+    n = (320 // 8) * (184 // 8)
+    hip.set_frame_chain(0)
+    hip.set_frame_front(front)
+    hip.set_adaptive_order(0)
+    try:
+        base, base_cnt, _ = hip.render(p, counters=True)
+        want, want_cnt = oracle.render(sc, p)[:2]
+        assert np.array_equal(_bits(base), _bits(want)) and base_cnt == want_cnt
+        rng = np.random.default_rng(7)
+        for order in (np.arange(n)[::-1], rng.permutation(n), rng.permutation(n)):
+            hip.set_tile_order(order.astype(np.uint32))
+            got, cnt, _ = hip.render(p, counters=True)
+            assert np.array_equal(_bits(got), _bits(base)) and cnt == base_cnt
+            got = hip.render(p)[0]                       # (the uncounted kernels)
+            assert np.array_equal(_bits(got), _bits(base))
+        hip.set_tile_order(None)
+        with pytest.raises(Exception):
+            hip.set_tile_order(np.zeros(n, np.uint32))   # not a permutation
+        with pytest.raises(Exception):
+            hip.set_tile_order(np.arange(n, dtype=np.uint32) + 1)
+        # an order for another frame shape is not used (and does no harm)
+        hip.set_tile_order(np.arange(n // 2, dtype=np.uint32))
+        assert np.array_equal(_bits(hip.render(p)[0]), _bits(base))
+    finally:
+        hip.set_tile_order(None)
+        hip.set_adaptive_order(1)
+        hip.set_frame_front(1)
+        hip.set_frame_chain(2)
+
+
+def test_the_adaptive_order_leaves_every_frame_as_it_is(hip, scenes):
+    """frame after frame with the adaptive order on (the default): the second frame on is drawn in an order made from the frame before; a change of the frame's
+    shape, of the camera and of the share starts over; all of them equal the frames rendered in screen order"""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    hip.set_frame_chain(0)
+    try:
+        def frames(adaptive):
+            hip.set_adaptive_order(adaptive)
+            out = []
+            for shape in ((384, 216, None), (384, 216, (8, 1, 2)), (320, 200, None), (384, 216, None)):
+                for f in range(3):
+                    p = sc.frame_params(width=shape[0], height=shape[1], samples=2, max_reflections=3, use_filter=0)
+                    p.camera[0] += 0.05 * f                  # (a moving camera: last frame's costs are only a guess)
+                    if shape[2]:
+                        p.tile_rows, p.tile_index, p.tile_count = shape[2]
+                    out.append(hip.render(p)[0].copy())
+            return out
+        a, b = frames(1), frames(0)
+        assert hip.last_organisation() >= 2                  # the frame kernel ran (what the order is for)
+        for x, y in zip(a, b):
+            assert np.array_equal(_bits(x), _bits(y))
+    finally:
+        hip.set_adaptive_order(1)
+        hip.set_frame_chain(2)

@@ -13,6 +13,7 @@ a = [int(x) for x in sys.argv[1:5]] + [1920, 1080, 8, 4][len(sys.argv[1:5]):]
 ctx = capi.Context(0)
 ctx.update_scene(sc)
 ctx.set_frame_chain(0)
+ctx.set_adaptive_order(0)
 p = sc.frame_params(width=a[0], height=a[1], samples=a[2], max_reflections=a[3], use_filter=0)
 rows = a[1]
 if os.environ.get("FLX_TILES"):
@@ -20,10 +21,14 @@ if os.environ.get("FLX_TILES"):
     rows = ((a[1] + 7) // 8 - p.tile_index + p.tile_count - 1) // p.tile_count * 8
 tx, ty = (a[0] + 7) // 8, (rows + 7) // 8
 n = tx * ty
-ctx.tile_cost(n)
+ctx.tile_cost(2 * n)
 ctx.render(p, counters=True)
-cost = ctx.tile_cost(n, read=True).astype(np.float64)
+both = ctx.tile_cost(2 * n, read=True).astype(np.float64)
+cost, prim = both[:n], both[n:]
 ctx.tile_cost(0)
+def ranks(v): return np.argsort(np.argsort(v, kind="stable"), kind="stable").astype(np.float64)
+print("primary rays' visits per tile: min %.0f median %.0f max %.0f; rank correlation with the bounces' visits %.3f, linear %.3f" % (
+    prim.min(), np.median(prim), prim.max(), np.corrcoef(ranks(prim), ranks(cost))[0, 1], np.corrcoef(prim, cost)[0, 1]))
 print("%d x %d tiles, visits per tile: min %.0f median %.0f mean %.0f max %.0f" % (tx, ty, cost.min(), np.median(cost), cost.mean(), cost.max()))
 g = cost.reshape(ty, tx)
 for y in range(ty - 1, -1, -max(1, ty // 27)):
@@ -42,7 +47,8 @@ rng = np.random.default_rng(1)
 ident = np.arange(n, dtype=np.uint32)
 base = timed(None, "tile q (the default)")
 desc = np.argsort(-cost, kind="stable").astype(np.uint32)
-orders = [("heaviest first", desc), ("lightest first", desc[::-1].copy()), ("random", rng.permutation(n).astype(np.uint32)), ("rows bottom-up", ident[::-1].copy())]
+pdesc = np.argsort(-prim, kind="stable").astype(np.uint32)
+orders = [("heaviest first", desc), ("heaviest PRIMARY rays first", pdesc), ("lightest first", desc[::-1].copy()), ("random", rng.permutation(n).astype(np.uint32)), ("rows bottom-up", ident[::-1].copy())]
 # heavy first in coarse classes, screen order inside a class (keeps neighbours together)
 for k in (4, 16):
     cls = np.minimum(k - 1, (np.argsort(np.argsort(-cost, kind="stable"), kind="stable") * k // n))
@@ -52,7 +58,17 @@ rank = np.argsort(np.argsort(-cost, kind="stable"), kind="stable")
 for frac in (0.05, 0.1, 0.2):
     late = rank >= int(n * (1 - frac))
     orders.append(("the lightest %2.0f %% last, else screen order" % (100 * frac), np.concatenate([ident[~late], ident[late][np.argsort(-cost[late], kind="stable")]]).astype(np.uint32)))
+prank = np.argsort(np.argsort(-prim, kind="stable"), kind="stable")
+for k in (4, 16):
+    cls = np.minimum(k - 1, prank * k // n)
+    orders.append(("heaviest primary first in %d classes, screen order inside" % k, np.lexsort((ident, cls)).astype(np.uint32)))
+for frac in (0.1, 0.2):
+    late = prank >= int(n * (1 - frac))
+    orders.append(("the lightest-primary %2.0f %% last, else screen order" % (100 * frac), np.concatenate([ident[~late], ident[late][np.argsort(-prim[late], kind="stable")]]).astype(np.uint32)))
 for label, o in orders:
     out = timed(o, label)
     if not np.array_equal(out.view(np.uint32), base.view(np.uint32)): print("   FRAME DIFFERS")
 timed(None, "tile q again")
+ctx.set_adaptive_order(1)
+out = timed(None, "adaptive (the library's default)")
+if not np.array_equal(out.view(np.uint32), base.view(np.uint32)): print("   FRAME DIFFERS")

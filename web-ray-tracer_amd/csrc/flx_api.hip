@@ -113,7 +113,7 @@ extern "C" void flx_context_destroy(flx_context *ctx) {
   void *bufs[] = { ctx->d_geometry, ctx->d_attributes, ctx->d_rotation, ctx->d_shift, ctx->d_ids, ctx->d_lights,
                    ctx->d_atlas[0], ctx->d_atlas[1], ctx->d_atlas[2], ctx->d_out, ctx->d_gb[0], ctx->d_gb[1], ctx->d_gb[2],
                    ctx->d_gb[3], ctx->d_gb[4], ctx->d_gb[5], ctx->d_counters, ctx->d_hits, ctx->d_samples, ctx->d_last, ctx->d_queue,
-                   ctx->d_send, ctx->d_send8, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_angle_tan, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings, ctx->d_qbatch, ctx->d_tile_order, ctx->d_tile_cost,
+                   ctx->d_send, ctx->d_send8, ctx->d_recv, ctx->d_frames, ctx->d_gplanes, ctx->d_angle_tan, ctx->d_rec, ctx->d_rec0, ctx->d_pix0, ctx->d_tail_pool, ctx->d_strag, ctx->d_live[0], ctx->d_live[1], ctx->d_wfcounts, ctx->d_walk, ctx->d_fwd, ctx->d_frame_rings, ctx->d_qbatch, ctx->d_tile_order, ctx->d_tile_cost, ctx->d_tile_time, ctx->d_auto_order,
                    ctx->d_planes[0], ctx->d_planes[1], ctx->d_planes[2], ctx->d_planes[3], ctx->d_planes[4], ctx->d_planes[5], ctx->d_planes[6],
                    ctx->d_planes[7], ctx->d_planes[8], ctx->d_planes[9], ctx->d_planes[10], ctx->d_planes[11], ctx->d_planes[12] };
   for (void *b : bufs) if (b) (void)hipFree(b);
@@ -786,6 +786,22 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     const uint32_t perTile = (uint32_t)fr.samples * 64u;
     const uint32_t tiles = total / perTile;
     const int groups = wf_chains;                      /* (counted frames: one chain, so the scheduler statistics describe whole kernels) */
+    /* adaptive tile order: a single frame in one chain whose front runs in its own kernel — a thin frame (k_resolve measures, k_tile_order sorts — below; the order
+     * is used, and the cost stamped, by the frame kernel only: `measured`) */
+    const bool adaptive = ctx->adaptive_order && !front && groups == 1 && fr.frames <= 1u && !ctx->d_tile_order && cnt == nullptr;
+    const int orderMode = 1;                                  /* sixteen classes, heaviest first (k_tile_order) */
+    if (adaptive && ctx->tile_time_cap < tiles) {
+      FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (void *b : { (void *)ctx->d_tile_time, (void *)ctx->d_auto_order }) if (b) (void)hipFree(b);
+      ctx->d_tile_time = nullptr; ctx->d_auto_order = nullptr; ctx->tile_time_cap = 0; ctx->auto_order_tiles = 0;
+      FLX_HIP(ctx, hipMalloc(&ctx->d_tile_time, (size_t)tiles * sizeof(float)));
+      FLX_HIP(ctx, hipMalloc(&ctx->d_auto_order, (size_t)tiles * sizeof(uint32_t)));
+      ctx->tile_time_cap = tiles;
+    }
+    if (adaptive && !(ctx->auto_order_tiles == tiles && ctx->auto_order_width == fr.width && ctx->auto_order_rows == fr.rows && ctx->auto_order_mode == orderMode)) {
+      ctx->auto_order_tiles = 0;                              /* another shape: this frame in screen order, measured from zero */
+      FLX_HIP(ctx, hipMemsetAsync(ctx->d_tile_time, 0, (size_t)tiles * sizeof(float), ctx->stream));
+    }
     const size_t listSlice = ctx->live_capacity / (size_t)groups;
     if (groups > 1) {
       FLX_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -800,7 +816,10 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       wb.front = front ? 1u : (fusedFront ? 2u : 0u);
       wb.error = ctx->d_dev_error; wb.watchdog = ctx->inject_watchdog; wb.inject = ctx->inject_flags; wb.walkJobs = ctx->walk_jobs;
       wb.tileOrder = (groups == 1 && ctx->d_tile_order && ctx->tile_order_n == tiles) ? ctx->d_tile_order : nullptr;
+      if (!wb.tileOrder && adaptive && ctx->auto_order_tiles == tiles && ctx->auto_order_width == fr.width && ctx->auto_order_rows == fr.rows && ctx->auto_order_mode == orderMode)
+        wb.tileOrder = ctx->d_auto_order;                     /* made by the last frame of this shape */
       wb.tileCost = (cnt && ctx->d_tile_cost && ctx->tile_cost_n >= tiles) ? ctx->d_tile_cost : nullptr;
+      wb.tileCostPrimary = (wb.tileCost && ctx->tile_cost_n >= 2u * tiles) ? 1u : 0u;
       wb.live[0] = ctx->d_live[0] + listSlice * g; wb.live[1] = ctx->d_live[1] + listSlice * g;
       wb.counts = ctx->d_wfcounts + (size_t)g * 4 * (WF_MAX_ROUNDS + 2); wb.walkQueue = wb.counts + (WF_MAX_ROUNDS + 2); wb.stragCount = wb.walkQueue + (WF_MAX_ROUNDS + 2);
       wb.coopQueue = wb.stragCount + (WF_MAX_ROUNDS + 2);
@@ -823,8 +842,14 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
         FLX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join[g - 1], 0));
       }
     }
-    launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream);
+    const bool measured = adaptive && ctx->last_organisation >= 2;      /* (the frame kernel ran: its walk lanes stamp what a path cost) */
+    launch_resolve(fr, ctx->d_hits, ctx->d_samples, ctx->d_last, d_out, ctx->stream, 0, measured ? ctx->d_tile_time : nullptr);
     FLX_HIP(ctx, hipGetLastError());
+    if (measured) {
+      launch_tile_order(ctx->d_tile_time, ctx->d_auto_order, tiles, orderMode, ctx->stream);
+      FLX_HIP(ctx, hipGetLastError());
+      ctx->auto_order_tiles = tiles; ctx->auto_order_width = fr.width; ctx->auto_order_rows = fr.rows; ctx->auto_order_mode = orderMode;
+    } else if (adaptive) ctx->auto_order_tiles = 0;
   }
   FLX_HIP(ctx, hipEventRecord(ctx->ev_frame1, ctx->stream));
   ctx->timed = true;
@@ -2036,6 +2061,15 @@ extern "C" flx_status flx_debug_set_tile_order(flx_context *ctx, const uint32_t 
   FLX_HIP(ctx, hipMalloc(&ctx->d_tile_order, (size_t)n * sizeof(uint32_t)));
   FLX_HIP(ctx, hipMemcpy(ctx->d_tile_order, order, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
   ctx->tile_order_n = n;
+  return FLX_OK;
+}
+/* The adaptive tile order (on by default): the frame kernel draws a frame's screen tiles in an order made from what the tiles cost in the last frame of the same shape
+ * (flx_context.h).  0 turns it off (screen order), for A/B runs and for tests that want launches to be reproducible in their scheduling. */
+extern "C" flx_status flx_debug_set_adaptive_order(flx_context *ctx, int on) {
+  if (!ctx) return FLX_ERR_INVALID;
+  if (ctx->fifo_n) return fail(ctx, FLX_ERR_INVALID, "flx_debug_set_adaptive_order: frames are in flight");
+  ctx->adaptive_order = on ? 1 : 0;
+  ctx->auto_order_tiles = 0;
   return FLX_OK;
 }
 /* Counted frames add, per 8 x 8 screen tile, the entries its paths' walks visited (bounce loop only): n > 0 turns that on for frames of up to n tiles and zeroes the sums,

@@ -59,6 +59,11 @@ struct flx_context {
   bool gb_float_wanted = false;                  /* flx_render was given `gbuffers`: the filter frame keeps its float G-buffers */
   int walk_scheduler = 0;
   int sample_parallel = FLX_SAMPLE_PARALLEL_DEFAULT;      /* flx_debug_set_sample_parallel: k_trace_samples instead of k_trace_pixels where the frame allows it */
+  /* Adaptive tile order (flx_debug_set_adaptive_order; on by default): k_resolve sums what every screen tile's paths cost (time in walk lanes), k_tile_order makes the
+   * next frame's draw order of it — the lightest tiles last, so that the launch does not end in the chains of a heavy tile's paths.  Frames do not depend on the order. */
+  int adaptive_order = 1;
+  float *d_tile_time = nullptr; uint32_t *d_auto_order = nullptr; uint32_t tile_time_cap = 0;
+  uint32_t auto_order_tiles = 0, auto_order_width = 0, auto_order_rows = 0; int auto_order_mode = -1;      /* the frame shape d_auto_order is for (0 tiles: none yet) */
   uint32_t *d_tile_order = nullptr; uint32_t tile_order_n = 0;      /* flx_debug_set_tile_order: the frame kernel's draw order over the frame's screen tiles */
   unsigned long long *d_tile_cost = nullptr; uint32_t tile_cost_n = 0;      /* flx_debug_tile_cost: counted frames' visits per screen tile */
   uint32_t walk_jobs = FLX_WALK_JOBS_DEFAULT;    /* flx_debug_set_walk_jobs: walk jobs per lane of the frame kernel's walk waves */

@@ -171,7 +171,12 @@ FLX_DEV float4 primary_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, WorkCou
     pr.dir = primary_dir_v(fr, v, px, py_gl, nx, ny, viewDepthPerS);
     pr.origin = view_camera(v);
   }
+  const uint32_t visitsBefore = cnt.primary_visits;
   const Hit hp = primaryWalkF(sc, inImage, pr, viewDepthPerS, cnt.primary_visits, xfBase);
+  if (COUNT && wb.tileCost && wb.tileCostPrimary) {              /* flx_debug_tile_cost with room for two sums per tile: the primary rays' visits in the second half */
+    const uint32_t nTiles = ((fr.width + 7u) >> 3) * ((fr.rows + 7u) >> 3);
+    atomicAdd(wb.tileCost + nTiles + tile, (unsigned long long)(cnt.primary_visits - visitsBefore));
+  }
   float4 h = make_float4(hp.suv.x, hp.suv.y, hp.suv.z, __int_as_float(inImage ? hp.triangleId : -1));
   if (inImage) {
     if (COUNT && hp.triangleId != -1) cnt.primary_hits++;
@@ -255,7 +260,7 @@ FLX_DEV const float4 *pix_part(const DeviceFrame &fr, const WavefrontBuffers &wb
  * caller hands it to the shade waves); one that ends has its radiance stored (ended_: the caller takes it off its count).  The lane is free afterwards.
  * A macro for the reason FLX_WALK_LANE_STEP is one: as an inlined function taking the lane by reference the same statements schedule differently in the frame kernel's
  * fold (loads hoisted over a mask change, eight more instructions) and the dragon frame measures 0.65 % slower (6.39 -> 6.44 ms, same lease, three runs each). */
-#define FLX_WALK_LANE_FOLD(LV_, fr_, wb_, compactRecs_, L_, lv_, toShade_, ended_)                                               \
+#define FLX_WALK_LANE_FOLD(LV_, fr_, wb_, compactRecs_, L_, lv_, toShade_, ended_, costed_, stamp_)                              \
   do {                                                                                                                           \
     float4 *rec_ = (wb_).rec + (size_t)(L_).pathId * 8;                                                                          \
     const bool compact_ = (compactRecs_) && (L_).pathBounce == 0;                                                                \
@@ -272,6 +277,8 @@ FLX_DEV const float4 *pix_part(const DeviceFrame &fr, const WavefrontBuffers &wb
     const f3 localColor_ = shadowed_ ? F3((L_).base, (L_).base, (L_).base) : F3(q4_.x, q4_.y, q4_.z);                            \
     const f3 importancy_ = F3(q6_.x, q6_.y, q6_.z), originalColor_ = F3(q7_.x, q7_.y, q7_.z);                                    \
     const f3 finalColor_ = F3(q5_.x, q5_.y, q5_.z) + localColor_ * importancy_;                                                  \
+    /* what the path has cost so far (time in the walk lanes, 10 ns ticks; q5.w, then the w of its radiance slot: the adaptive tile order's measure) */ \
+    const float cost_ = (costed_) ? q5_.w + (float)(((stamp_) - ((uint32_t)(L_).flags >> 8)) & 0xffffffu) : 1.0f;     /* (costed_: a compile-time constant) */ \
     bool cont_ = (L_).w.tri != -1;                                                                                               \
     if (cont_) cont_ = ((L_).pathBounce + 1) < (fr_).max_reflections && length(importancy_ * originalColor_) >= (fr_).min_importancy * SQRT3;      \
     if (cont_) {                                                                                                                 \
@@ -283,11 +290,11 @@ FLX_DEV const float4 *pix_part(const DeviceFrame &fr, const WavefrontBuffers &wb
         rec_[6] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);                                                                           \
         rec_[7] = make_float4(q7_.x, q7_.y, q7_.z, 0.0f);                                                                        \
       }                                                                                                                          \
-      rec_[5] = make_float4(finalColor_.x, finalColor_.y, finalColor_.z, 0.0f);                                                  \
+      rec_[5] = make_float4(finalColor_.x, finalColor_.y, finalColor_.z, (costed_) ? cost_ : 0.0f);                                                 \
       rec_[2] = make_float4((L_).w.suv.x, (L_).w.suv.y, (L_).w.suv.z, __int_as_float((L_).w.tri));                               \
       toShade_ = true;                                                                                                           \
     } else {                                                                                                                     \
-      finalize_path<LV_>(fr_, wb_, (L_).pathId, finalColor_, importancy_, originalColor_, lv_);                                  \
+      finalize_path<LV_>(fr_, wb_, (L_).pathId, finalColor_, importancy_, originalColor_, lv_, cost_);                           \
       ended_ = true;                                                                                                             \
     }                                                                                                                            \
     (L_).st = P_EMPTY;                                                                                                           \
@@ -311,10 +318,10 @@ FLX_DEV void walkLaneFetchRecord(const DeviceFrame &fr, const WavefrontBuffers &
   }
 }
 template <bool COUNT>
-FLX_DEV bool walkLaneInstall(uint32_t id, const WalkRecord &R, WalkLane &L, WorkCounters &cnt) {
+FLX_DEV bool walkLaneInstall(uint32_t id, const WalkRecord &R, WalkLane &L, WorkCounters &cnt, uint32_t stamp = 0u /* 24 bits: when the path came in (the fold takes the difference) */) {
   const int fl = __float_as_int(R.q0.w);
   if (fl & RF_DEAD) return true;
-  L.pathId = id; L.flags = fl; L.base = R.q2.w; L.pathBounce = __float_as_int(R.q3.w);
+  L.pathId = id; L.flags = fl | (int)(stamp << 8); L.base = R.q2.w; L.pathBounce = __float_as_int(R.q3.w);
   L.nextRay.origin = F3(R.q0.x, R.q0.y, R.q0.z);
   L.nextRay.dir = F3(R.q1.x, R.q1.y, R.q1.z);
   L.shadowRay.origin = F3(R.q2.x, R.q2.y, R.q2.z);
@@ -327,10 +334,10 @@ FLX_DEV bool walkLaneInstall(uint32_t id, const WalkRecord &R, WalkLane &L, Work
   return false;
 }
 template <bool COUNT>
-FLX_DEV bool walkLaneLoad(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id, bool compactFresh, WalkLane &L, WorkCounters &cnt) {
+FLX_DEV bool walkLaneLoad(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t id, bool compactFresh, WalkLane &L, WorkCounters &cnt, uint32_t stamp = 0u) {
   WalkRecord R;
   walkLaneFetchRecord(fr, wb, id, compactFresh, R);
-  return walkLaneInstall<COUNT>(id, R, L, cnt);
+  return walkLaneInstall<COUNT>(id, R, L, cnt, stamp);
 }
 /* Set up walks: fresh lanes (shadow or closest) and lanes whose shadow walk just ended (P_SWITCH).  xf: the staged inverse transforms the lane's path reads. */
 template <bool COUNT>

@@ -44,14 +44,17 @@ __device__ __forceinline__ bool item_pixel(const DeviceFrame &fr, uint32_t item,
 /* fragment:608-632 for one pixel: the samples added in order, averaged, times originalColor of the last sample (the shader's global still holds it after
  * the loop).  o: the pixel in the (stacked) planes, sampleStride: float4 between two samples' planes. */
 __device__ __forceinline__ float4 resolve_pixel(const DeviceFrame &fr, const float4 *__restrict__ hits, const float4 *__restrict__ sampleRadiance, const float4 *__restrict__ lastOriginal,
-                                                size_t o, size_t sampleStride) {
+                                                size_t o, size_t sampleStride, float *cost = nullptr /* -> the sum of the slots' w: what the pixel's paths cost (finalize_path) */) {
   float4 color = make_float4(0.f, 0.f, 0.f, 0.f);
+  float c = 0.0f;
   if (__float_as_int(hits[o].w) != -1) {
     f3 finalColor = F3(0.0f, 0.0f, 0.0f);
     for (int s = 0; s < fr.samples; s++) {
       const float4 r = sampleRadiance[(size_t)s * sampleStride + o];
       finalColor = finalColor + F3(r.x, r.y, r.z);
+      c += r.w;
     }
+    if (cost) *cost = c;
     const float invSamples = 1.0f / (float)fr.samples;
     finalColor = finalColor * invSamples;
     const float4 oc = lastOriginal[o];

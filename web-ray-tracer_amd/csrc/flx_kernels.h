@@ -26,8 +26,12 @@ void launch_primary(const DeviceScene &sc, const DeviceFrame &fr, float4 *hits, 
 void launch_paths(const DeviceScene &sc, const DeviceFrame &fr, const float4 *hits, float4 *sampleRadiance, float4 *lastOriginal,
                   uint32_t *queue, uint32_t blocks, unsigned long long *counters, hipStream_t stream);
 /* sampleStride: float4 between the planes of two samples (0: the frame's own pixel count; the chained frame loop resolves one slot of a stacked workspace) */
+/* tileTime (or nullptr): += what the paths of every 8 x 8 screen tile cost, for launch_tile_order */
 void launch_resolve(const DeviceFrame &fr, const float4 *hits, const float4 *sampleRadiance, const float4 *lastOriginal, float4 *out,
-                    hipStream_t stream, size_t sampleStride = 0);
+                    hipStream_t stream, size_t sampleStride = 0, float *tileTime = nullptr);
+/* the frame kernel's draw order over n screen tiles from their cost in the last frame (cleared for the next); mode 0: the lightest tenth last,
+ * 1: sixteen classes, heaviest first; screen order inside a class */
+void launch_tile_order(float *tileTime, uint32_t *order, uint32_t n, int mode, hipStream_t stream);
 /* pipeline 3 (flx_wavefront.hip): per bounce a dense shade kernel and a persistent walk kernel; path state in HBM. */
 constexpr int WF_MAX_BOUNCES = 250;
 struct WavefrontBuffers {
@@ -57,6 +61,7 @@ struct WavefrontBuffers {
   uint32_t watchdog;            /* frame kernels: polls after which a wave that waits gives up (0: FQ_WATCHDOG, seconds); fault injection sets it low */
   uint32_t inject;              /* fault injection (flx_debug_inject_fault): WF_INJECT_* */
   uint32_t walkJobs;            /* frame kernel with its front inside: 2 = two walk jobs per lane (k_wf_frame2); else one (k_wf_frame) */
+  uint32_t tileCostPrimary;     /* tileCost (below) has a second half for the primary rays' visits per tile */
   const uint32_t *tileOrder;    /* frame kernel with its front inside: the screen tile the q-th draw from the frame's tile queue makes (a permutation of the frame's tiles), or nullptr: tile q */
   unsigned long long *tileCost; /* counted frames: entries visited by the paths of every screen tile (flx_debug_tile_cost), or nullptr */
 };

@@ -464,7 +464,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         const bool compactRecs = wb.rec0 != nullptr;
         bool toShade = false, ended = false;
         const uint32_t slot = slotOf(L.pathId);
-        if (L.st == P_DONE) FLX_WALK_LANE_FOLD(true, fr, wb, compactRecs, L, lv, toShade, ended);
+        if (L.st == P_DONE) FLX_WALK_LANE_FOLD(true, fr, wb, compactRecs, L, lv, toShade, ended, false, 0u);
         if (flx_ballot(ended) != 0ull) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      /* the radiance stored, before the paths leave the count (tryRotate publishes what is counted off) */
         for (uint32_t s = 0; s < depth; s++) {
           fq_push(ring(RK_SHADE, s), rctl(RK_SHADE, s), toShade && slot == s, L.pathId, lane);

@@ -1067,6 +1067,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       /* ---- with the front inside the launch: the free lanes' NEXT paths first — ids (LDS only), then their records' loads, issued here and not waited for: the fold of the
        * lanes' old paths below has its own loads, and one wait then covers both (a walk wave spent 29 % of its time in this block, 6 800 cycles a time, most of it three
        * memory round trips one after the other: tools/frame_wave_time.py) ---- */
+      /* 10 ns ticks: a path's cost is the time it spends in walk lanes (the adaptive tile order's measure; flx_api.hip).  Only where the front ran in its own kernel — thin
+       * frames, whose items all workgroups draw 64 paths at a time: there the order is worth 4 % (a rank's eighth 1.47 -> 1.41 ms); with the front inside, the stamp alone
+       * cost 2 % of the dragon frame (its wait is one more synchronisation of the block) and the order's gain did not cover the sort */
+      const uint32_t stamp = FRONT ? 0u : ((uint32_t)__builtin_amdgcn_s_memrealtime() & 0xffffffu);
       uint32_t newId = WF_INVALID;
       bool newFresh = false;
       WalkRecord newRec;
@@ -1110,7 +1114,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           uint32_t tile_, s_; item_tile(fr, L.pathId, tile_, s_);
           atomicAdd(wb.tileCost + tile_, (unsigned long long)(cnt.closest_visits + cnt.shadow_visits - L.v0));
         }
-        if (L.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, L, nullptr, toShade, ended);
+        if (L.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, L, nullptr, toShade, ended, !FRONT, stamp);
         fq_push(shadeRing, ctl + FC_SQ, toShade, L.pathId, lane);
         const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
         if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
@@ -1119,7 +1123,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       if (FLX_FRAME_EARLY_REFILL) {
         /* ... the lanes' next paths (their records arrived while the old ones were folded) */
         bool dead = false;
-        if (newId != WF_INVALID) dead = walkLaneInstall<COUNT>(newId, newRec, L, cnt);
+        if (newId != WF_INVALID) dead = walkLaneInstall<COUNT>(newId, newRec, L, cnt, stamp);
         const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
         if (nDead != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nDead);
       } else
@@ -1154,7 +1158,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           chunkNext += take;
         }
         bool dead = false;
-        if (id != WF_INVALID) dead = walkLaneLoad<COUNT>(fr, wb, id, fresh && compactRecs, L, cnt);
+        if (id != WF_INVALID) dead = walkLaneLoad<COUNT>(fr, wb, id, fresh && compactRecs, L, cnt, stamp);
         const uint32_t nDead = (uint32_t)__popcll(flx_ballot(dead));
         if (nDead != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nDead);
       }
@@ -1373,7 +1377,7 @@ __global__ __launch_bounds__(FLX_FRAME2_THREADS, FLX_FRAME2_WAVES_PER_EU) void k
     if (flx_ballot(J.st == P_DONE) == 0ull) return;
     FLX_FRAME_ARGS();
     bool toShade = false, ended = false;
-    if (J.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, J, nullptr, toShade, ended);
+    if (J.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, J, nullptr, toShade, ended, false, 0u);
     fq_push(shadeRing, ctl + FC_SQ, toShade, J.pathId, lane);
     const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
     if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);

@@ -22,13 +22,13 @@ constexpr int RF_NO_CLOSEST = 16;      /* the loop guard ends the path after thi
 
 template <bool LV = false>
 __device__ __forceinline__ void finalize_path(const DeviceFrame &fr, const WavefrontBuffers &wb, uint32_t pathId, f3 finalColor,
-                                              f3 importancy, f3 originalColor, const FrameView *lv = nullptr) {
+                                              f3 importancy, f3 originalColor, const FrameView *lv = nullptr, float cost = 1.0f /* the slot's w: what the path cost (k_resolve sums it per screen tile) */) {
   uint32_t px, k, s;
   item_pixel(fr, pathId, px, k, s);
   const size_t P = (size_t)fr.rows * fr.width;
   const size_t o = (size_t)k * fr.width + px;
   const f3 r = finalColor + importancy * view_ambient(view_at<LV>(fr, lv, frame_index(fr, k)));          /* fragment:598 */
-  wb.sampleRadiance[(size_t)s * P + o] = make_float4(r.x, r.y, r.z, 1.0f);
+  wb.sampleRadiance[(size_t)s * P + o] = make_float4(r.x, r.y, r.z, cost);
   if (s == (uint32_t)fr.samples - 1u) wb.lastOriginal[o] = make_float4(originalColor.x, originalColor.y, originalColor.z, 1.0f);
 }
 
