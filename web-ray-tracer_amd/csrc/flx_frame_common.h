@@ -153,23 +153,6 @@ FLX_DEV bool shade0_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, float4 h, 
 
 /* The primary ray of the lane's pixel of screen tile `tile` (what k_primary does for it, flx_kernels.hip): the wave walks the forward-ordered copy
  * together.  -> suv + triangle id as bits (-1: no hit, or no pixel), also stored for k_resolve. */
-/* A kernel that starts on a cold L2 (the frame before streamed gigabytes of path records through it) and then chases pointers through an array pays a miss to
- * the memory side for every entry the first time its XCD touches it — the longest primary ray of a thin frame, 477 dependent fetches, IS k_primary's duration
- * (0.29 ms: 600 ns an entry).  So the workgroups first read the array once, together and coalesced: those of one XCD (blockIdx.x mod 8: workgroups are dealt round
- * robin) cover all of it between them.  The values go nowhere (the asm keeps the loads). */
-#ifndef FLX_WARM_L2
-#define FLX_WARM_L2 1
-#endif
-FLX_DEV void warm_l2(const float4 *__restrict__ p, size_t n /* float4 */) {
-  if (!FLX_WARM_L2) return;
-  const uint32_t xcds = 8u;
-  const size_t perXcd = (gridDim.x + xcds - 1u) / xcds;       /* workgroups of this one's XCD (at most) */
-  const size_t stride = perXcd * blockDim.x;
-  float acc = 0.0f;
-  for (size_t i = (size_t)(blockIdx.x / xcds) * blockDim.x + threadIdx.x; i < n; i += stride) { const float4 v = p[i]; acc += v.x; }
-  asm volatile("" :: "v"(acc));
-}
-
 template <bool COUNT, bool LV = false, bool VER = false>
 FLX_DEV float4 primary_tile(FrameArgsP ab, uint32_t tile, uint32_t lane, WorkCounters &cnt, const FrameView *lv = nullptr) {
   FLX_ARGS_OF(ab);

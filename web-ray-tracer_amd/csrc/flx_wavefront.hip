@@ -139,7 +139,6 @@ __global__ __launch_bounds__(256, FLX_WF_FRONT_WAVES) void k_wf_front(FrameArgs 
   const uint32_t t = blockIdx.x * 256u + threadIdx.x;
   const uint32_t lane = t & 63u;
   const uint32_t tileLocal = t >> 6;
-  warm_l2(sc.fwd, (size_t)sc.fwd_entries * 3u);
   if (tileLocal * S * 64u >= total_items) return;
   const uint32_t tile = wb.item_base / (S * 64u) + tileLocal;
   WorkCounters cnt = {};
