@@ -22,4 +22,5 @@ print("walk waves %d, lifetime %.2f M cycles each" % (waves, life / waves / 1e6)
 print("  trips            %5.1f %% of the lifetime (%d outer iterations per wave, %.0f cycles per 8 trips)" % (100.0 * trips / life, no / waves, trips / no))
 print("  fold/refill/setup %5.1f %%   (%d blocks per wave = every %.2f outer iterations, %.0f cycles per block: fold %.0f, refill %.0f, set-up %.0f)" % (
     100.0 * blk / life, nb / waves, no / nb, blk / nb, fold / nb, refill / nb, setup / nb))
+print("      of the fold's %.0f: popping the next paths' ids and issuing their loads %.0f, the fold proper (its loads' wait included) %.0f, the hand-over to the shade ring %.0f" % (fold / nb, t[34] / nb, t[35] / nb, (fold - t[34] - t[35]) / nb))
 print("  the rest          %5.1f %%   (prologue tiles, waiting with nothing to walk)" % (100.0 * (life - trips - blk) / life))

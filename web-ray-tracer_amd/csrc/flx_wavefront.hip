@@ -1001,7 +1001,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
   uint32_t inChunk = n / (nWaves * FLX_WF_DRAWS_PER_WAVE);
   inChunk = inChunk < 64u ? 64u : (inChunk > WF_IN_CHUNK ? WF_IN_CHUNK : inChunk);
 
-  long long tBlock = 0, tFoldT = 0, tRefillT = 0, tSetupT = 0, tTrips = 0; unsigned long long nBlocks = 0, nOuter = 0;      /* COUNT builds: where a walk wave's time goes (flx_get_tail_diag 27..33) */
+  long long tBlock = 0, tFoldT = 0, tRefillT = 0, tSetupT = 0, tTrips = 0, tAcqT = 0, tFoldOnlyT = 0; unsigned long long nBlocks = 0, nOuter = 0;      /* COUNT builds: where a walk wave's time goes (flx_get_tail_diag 27..33) */
   WalkLane L;                                                  /* the lane's path and its walks (flx_frame_common.h: one body for every persistent kernel) */
   walkLaneInit(L);
   uint32_t chunkNext = 0, chunkEnd = 0;
@@ -1106,6 +1106,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
         }
         if (newId != WF_INVALID) { FLX_FRAME_ARGS(); walkLaneFetchRecord(fr, wb, newId, newFresh && compactRecs, newRec); }
       }
+      const long long tBa = COUNT ? clock64() : 0; if (COUNT) tAcqT += tBa - tB0;
       /* ---- fold the finished lanes (FLX_WALK_LANE_FOLD); a path that goes on is handed to the shade waves ---- */
       if (flx_ballot(L.st == P_DONE) != 0ull) {
         FLX_FRAME_ARGS();
@@ -1115,6 +1116,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           atomicAdd(wb.tileCost + tile_, (unsigned long long)(cnt.closest_visits + cnt.shadow_visits - L.v0));
         }
         if (L.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, L, nullptr, toShade, ended, !FRONT, stamp);
+        const long long tBf = COUNT ? clock64() : 0; if (COUNT) tFoldOnlyT += tBf - tBa;
         fq_push(shadeRing, ctl + FC_SQ, toShade, L.pathId, lane);
         const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
         if (nEnded != 0u && lane == 0) atomicSub(&ctl[FC_ALIVE], nEnded);
@@ -1204,6 +1206,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     atomicAdd(wb.counters + 64, life); atomicMax(wb.counters + 65, life); atomicAdd(wb.counters + 66, 1ull);
     atomicAdd(wb.counters + 67, (unsigned long long)tBlock); atomicAdd(wb.counters + 68, (unsigned long long)tFoldT); atomicAdd(wb.counters + 69, (unsigned long long)tRefillT); atomicAdd(wb.counters + 70, (unsigned long long)tSetupT);
     atomicAdd(wb.counters + 71, (unsigned long long)tTrips); atomicAdd(wb.counters + 72, nBlocks); atomicAdd(wb.counters + 73, nOuter);
+    atomicAdd(wb.counters + 74, (unsigned long long)tAcqT); atomicAdd(wb.counters + 75, (unsigned long long)tFoldOnlyT);
   }
   flush_counters<COUNT>(cnt, wb.counters);
 #undef FLX_FETCH_G
