@@ -1167,9 +1167,17 @@ FLX_DEV bool rayCuboidFast(float l, const WalkState &w, f3 lo, f3 hi) {
 #if FLX_WF_BOX_INTERVAL
   bool sure;
   bool hit = rayCuboidInterval(l, w, lo, hi, sure);
+#ifndef FLX_BOX_UNSURE_BALLOT
+#define FLX_BOX_UNSURE_BALLOT 0
+#endif
+#if FLX_BOX_UNSURE_BALLOT
   if (FLX_UNLIKELY(flx_ballot(!sure) != 0ull)) {                         /* rare */
     if (!sure) hit = rayCuboidRecip(l, w, lo, hi);
   }
+#else
+  /* (a plain divergent branch: the ballot around it cost two vector instructions per box test — the compiler brings the mask into a VGPR to compare it with zero) */
+  if (FLX_UNLIKELY(!sure)) hit = rayCuboidRecip(l, w, lo, hi);           /* rare */
+#endif
   return hit;
 #else
   return rayCuboidRecip(l, w, lo, hi);
