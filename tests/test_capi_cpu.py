@@ -104,3 +104,15 @@ def test_batch_limit_matches_the_header():
     assert int(re.search(r"#define FLX_MAX_BATCH_FRAMES (\d+)", text).group(1)) == capi.MAX_BATCH_FRAMES
     dev = open(os.path.join(ROOT, "web-ray-tracer_amd", "csrc", "flx_device.h")).read()
     assert int(re.search(r"#define FLX_MAX_BATCH (\d+)", dev).group(1)) == capi.MAX_BATCH_FRAMES
+
+
+def test_the_drivers_build_check_accepts_the_shipped_library():
+    """__graft_entry__.build() ends with this check: every function the bindings list is exported, except the chain of launches' five, which are in the experiments library only
+    (a check that asked for those too would fail every round's build step)"""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    from flexlight_hip import capi
+    entry.check_exports()
+    if not capi.has_experiments():
+        assert all(not hasattr(capi.LIB, n) for n in capi.EXPERIMENTS_ONLY)
