@@ -26,3 +26,5 @@ if t[22]:
     print("item queue found dry: %d workgroups, mean %.0f max %.0f cycles after their start, %.0f paths alive per workgroup then" % (t[22], t[20] / t[22], t[21], t[23] / t[22]))
 if t[26]:
     print("walk waves: %d, lifetime mean %.0f max %.0f cycles  -> after the queue ran dry: mean %.0f, max %.0f cycles" % (t[26], t[24] / t[26], t[25], t[24] / t[26] - t[20] / max(1, t[22]), t[25] - t[20] / max(1, t[22])))
+if t[39]:
+    print("after the queue ran dry, paths alive per workgroup <= 256 / 64 / 16 at (mean over %d workgroups, cycles after the workgroup's start): %.0f / %.0f / %.0f" % (t[39], t[36] / t[39], t[37] / t[39], t[38] / t[39]))

@@ -934,9 +934,17 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
     uint32_t inject; { FLX_FRAME_ARGS(); inject = wb.inject; } asm volatile("" : "+s"(inject));      /* (read once: a scalar load per batch — and its wait — measures 0.3 % of the frame) */
     if (FLX_FRAME_SHADE_PRIO) __builtin_amdgcn_s_setprio(FLX_FRAME_SHADE_PRIO);
     const long long tStartShade = COUNT ? clock64() : 0;
+    uint32_t thinMarks = 0;                                  /* COUNT: which of the "paths alive <= 256 / 64 / 16" moments this wave has stamped (flx_get_tail_diag 36 .. 39) */
     for (;;) {
       FLX_FRAME_ARGS();
       const bool dry = fq_load(&ctl[FC_DRY]) != 0u;
+      if (COUNT && dry && wave == WALK_WAVES && lane == 0 && thinMarks != 7u) {      /* counted frames: when did the workgroup thin out after its queue ran dry? */
+        const uint32_t alive = fq_load(&ctl[FC_ALIVE]);
+        const unsigned long long now = (unsigned long long)(clock64() - tStartShade);
+        for (uint32_t k = 0; k < 3u; k++)
+          if ((thinMarks & (1u << k)) == 0u && alive <= (256u >> (2u * k))) { thinMarks |= 1u << k; atomicAdd(wb.counters + 76 + k, now); }
+        if (thinMarks == 7u) atomicAdd(wb.counters + 79, 1ull);
+      }
       uint32_t id = WF_INVALID;
       const uint32_t got = fq_pop(shadeRing, ctl + FC_SQ, ~0ull, 64u, dry ? 1u : 64u, lane, id);
       if (got == 0u && !frontDone) {
