@@ -72,3 +72,33 @@ def test_the_adaptive_order_leaves_every_frame_as_it_is(hip, scenes):
     finally:
         hip.set_adaptive_order(1)
         hip.set_frame_chain(2)
+
+
+@pytest.mark.parametrize("front", [3, 2], ids=["front_in_its_own_kernel", "front_inside"])
+def test_the_per_tile_visit_counts_add_up_to_the_frames_counters(hip, scenes, front):
+    """flx_debug_tile_cost (the measure tools/tile_order_ab.py orders tiles by): a counted frame's visits per 8 x 8 screen tile — first half: the bounce loop's walks, second
+    half: the primary rays — sum to the frame's own work counters, and tiles outside the dragon's silhouette cost less than tiles inside"""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    w, h = 320, 184
+    p = sc.frame_params(width=w, height=h, samples=2, max_reflections=4, use_filter=0)
+    n = (w // 8) * (h // 8)
+    hip.set_frame_chain(0)
+    hip.set_frame_front(front)
+    try:
+        hip.tile_cost(2 * n)
+        _, cnt, _ = hip.render(p, counters=True)
+        assert hip.last_organisation() >= 2
+        both = hip.tile_cost(2 * n, read=True)
+        bounce, primary = both[:n], both[n:]
+        assert int(bounce.sum()) == cnt["closest_visits"] + cnt["shadow_visits"]
+        assert int(primary.sum()) == cnt["primary_visits"]
+        assert bounce.max() > 4 * np.median(bounce)          # (the dragon's tiles against the floor's)
+        # a second counted frame starts from zero again (the read above cleared the sums)
+        _, cnt2, _ = hip.render(p, counters=True)
+        again = hip.tile_cost(0, read=True)
+        assert cnt2 == cnt and np.array_equal(again[:2 * n], both)
+    finally:
+        hip.tile_cost(0)
+        hip.set_frame_front(1)
+        hip.set_frame_chain(2)

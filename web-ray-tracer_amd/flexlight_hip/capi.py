@@ -408,8 +408,10 @@ class Context:
 
     def tile_cost(self, n, read=False):
         """counted frames' visits per screen tile (flx_debug_tile_cost): turn on for n tiles (0: off); read=True returns the sums gathered so far first"""
-        out = np.zeros(max(int(n), 1), np.uint64) if read else None
+        have = getattr(self, "_tile_cost_n", 0)               # (the library copies min(n or all, what it holds): room for all of it)
+        out = np.zeros(max(int(n), have, 1), np.uint64) if read else None
         self._check(LIB.flx_debug_tile_cost(self._h, out.ctypes.data_as(C.POINTER(C.c_uint64)) if read else None, int(n)), "flx_debug_tile_cost")
+        self._tile_cost_n = int(n)
         return out
 
     def set_walk_jobs(self, jobs):
