@@ -32,6 +32,9 @@ using namespace flx;
 #ifndef FLX_FRONT_MIN_TILES_PER_CU
 #define FLX_FRONT_MIN_TILES_PER_CU 24     /* (a quarter of a 1080p frame, 31.6 tiles per workgroup: 2.02 ms inside against 2.19 in front; an eighth, 15.9: 1.46 against 1.45; a sixteenth 1.27 against 1.21 — tools/front_rule.py) */
 #endif
+#ifndef FLX_ADAPTIVE_FRONT_MAX_TILES_PER_CU
+#define FLX_ADAPTIVE_FRONT_MAX_TILES_PER_CU 48      /* front inside the frame kernel: frames below this get the stamped kernel and the adaptive tile order */
+#endif
 #ifndef FLX_COMM_RESERVED_CUS
 #define FLX_COMM_RESERVED_CUS 8u            /* CUs a context with two gathering lanes leaves free of persistent walk workgroups */
 #endif
@@ -786,9 +789,10 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
     const uint32_t perTile = (uint32_t)fr.samples * 64u;
     const uint32_t tiles = total / perTile;
     const int groups = wf_chains;                      /* (counted frames: one chain, so the scheduler statistics describe whole kernels) */
-    /* adaptive tile order: a single frame in one chain whose front runs in its own kernel — a thin frame (k_resolve measures, k_tile_order sorts — below; the order
-     * is used, and the cost stamped, by the frame kernel only: `measured`) */
-    const bool adaptive = ctx->adaptive_order && !front && groups == 1 && fr.frames <= 1u && !ctx->d_tile_order && cnt == nullptr;
+    /* adaptive tile order: a single frame in one chain whose front runs in its own kernel, or inside the frame kernel where a workgroup gets fewer than
+     * FLX_ADAPTIVE_FRONT_MAX_TILES_PER_CU screen tiles (a rank's quarter: 2.05 -> 1.78 ms heaviest-first; a half and a whole frame want another policy and gain 2 - 3 %:
+     * profiles/r05_tile_order.txt) — k_resolve measures, k_tile_order sorts (below); the order is used, and the cost stamped, by the frame kernel only: `measured` */
+    const bool adaptive = ctx->adaptive_order && (!front || tiles < (uint32_t)FLX_ADAPTIVE_FRONT_MAX_TILES_PER_CU * cus) && groups == 1 && fr.frames <= 1u && !ctx->d_tile_order && cnt == nullptr;
     const int orderMode = 1;                                  /* sixteen classes, heaviest first (k_tile_order) */
     if (adaptive && ctx->tile_time_cap < tiles) {
       FLX_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -814,7 +818,7 @@ flx_status flx_run_frame(flx_context *ctx, const DeviceScene &sc, const DeviceFr
       wb.tailPool = ctx->d_tail_pool + (size_t)g * cus * 8u * WF_TAIL_POOL_F4;
       wb.frameRings = ctx->d_frame_rings + (size_t)g * cus * WF_FRAME_RINGS * WF_FRAME_RING;
       wb.front = front ? 1u : (fusedFront ? 2u : 0u);
-      wb.error = ctx->d_dev_error; wb.watchdog = ctx->inject_watchdog; wb.inject = ctx->inject_flags; wb.walkJobs = ctx->walk_jobs;
+      wb.error = ctx->d_dev_error; wb.watchdog = ctx->inject_watchdog; wb.inject = ctx->inject_flags; wb.walkJobs = ctx->walk_jobs | ((adaptive && front) ? WF_STAMP_COSTS : 0u);
       wb.tileOrder = (groups == 1 && ctx->d_tile_order && ctx->tile_order_n == tiles) ? ctx->d_tile_order : nullptr;
       if (!wb.tileOrder && adaptive && ctx->auto_order_tiles == tiles && ctx->auto_order_width == fr.width && ctx->auto_order_rows == fr.rows && ctx->auto_order_mode == orderMode)
         wb.tileOrder = ctx->d_auto_order;                     /* made by the last frame of this shape */

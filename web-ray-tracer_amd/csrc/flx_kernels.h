@@ -60,7 +60,7 @@ struct WavefrontBuffers {
   uint32_t *error;              /* the context's device error word (pinned host memory, WF_ERR_* bits), or nullptr: a watchdog that trips says so here (flx_status FLX_ERR_DEVICE at the next point the host waits) */
   uint32_t watchdog;            /* frame kernels: polls after which a wave that waits gives up (0: FQ_WATCHDOG, seconds); fault injection sets it low */
   uint32_t inject;              /* fault injection (flx_debug_inject_fault): WF_INJECT_* */
-  uint32_t walkJobs;            /* frame kernel with its front inside: 2 = two walk jobs per lane (k_wf_frame2); else one (k_wf_frame) */
+  uint32_t walkJobs;            /* frame kernel with its front inside: low byte 2 = two walk jobs per lane (k_wf_frame2), else one (k_wf_frame); | WF_STAMP_COSTS: the variant whose walk lanes stamp what a path cost (adaptive tile order) */
   uint32_t tileCostPrimary;     /* tileCost (below) has a second half for the primary rays' visits per tile */
   const uint32_t *tileOrder;    /* frame kernel with its front inside: the screen tile the q-th draw from the frame's tile queue makes (a permutation of the frame's tiles), or nullptr: tile q */
   unsigned long long *tileCost; /* counted frames: entries visited by the paths of every screen tile (flx_debug_tile_cost), or nullptr */
@@ -68,6 +68,7 @@ struct WavefrontBuffers {
 /* the arguments of the shade kernels and the frame kernels, read from the kernarg segment where they are used (flx_frame_common.h) */
 struct FrameArgs { DeviceScene sc; DeviceFrame fr; WavefrontBuffers wb; };
 constexpr uint32_t WF_FRAME_RING = 16384;
+constexpr uint32_t WF_STAMP_COSTS = 0x100u;   /* WavefrontBuffers::walkJobs */
 /* device error word: who gave up */
 constexpr uint32_t WF_ERR_SHADE_WATCHDOG = 1u, WF_ERR_WALK_WATCHDOG = 2u, WF_ERR_LIST = 4u, WF_ERR_LEFTOVER = 8u, WF_ERR_RING_SLOT = 16u, WF_ERR_SERVER_IDLE = 32u, WF_ERR_SERVER_TIMEOUT = 64u;
 constexpr uint32_t WF_INJECT_NO_SHADING = 1u;      /* the shade waves of a frame kernel drop what they pop: the paths never come back and the walk waves' watchdog must trip */

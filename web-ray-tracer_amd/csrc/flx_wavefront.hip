@@ -855,9 +855,10 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #ifndef FLX_FRAME_AUTO_MAX_ITEMS_FRONT
 #define FLX_FRAME_AUTO_MAX_ITEMS_FRONT (128u << 20)
 #endif
-template <bool COUNT, bool FRONT>
-__global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_frame(FrameArgs /* read through argBase */, uint32_t total_items,
-                                                                                    uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves, uint32_t readyUnits) {
+/* (the kernel's body: STAMP — the walk lanes stamp what a path cost, the measure of the adaptive tile order — is its own instantiation, because the stamp's few instructions
+ * re-roll the register allocation of the whole kernel: whole frames run the unstamped code, k_wf_frame<COUNT, true>, the commit-before's to the instruction) */
+template <bool COUNT, bool FRONT, bool STAMP>
+__device__ __forceinline__ void wf_frame_body(uint32_t total_items, uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves, uint32_t readyUnits) {
   const uint32_t n = total_items;
   if (n == 0u) return;
   const FrameArgsP argBase = kernel_frame_args();
@@ -1078,7 +1079,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
       /* 10 ns ticks: a path's cost is the time it spends in walk lanes (the adaptive tile order's measure; flx_api.hip).  Only where the front ran in its own kernel — thin
        * frames, whose items all workgroups draw 64 paths at a time: there the order is worth 4 % (a rank's eighth 1.47 -> 1.41 ms); with the front inside, the stamp alone
        * cost 2 % of the dragon frame (its wait is one more synchronisation of the block) and the order's gain did not cover the sort */
-      const uint32_t stamp = FRONT ? 0u : ((uint32_t)__builtin_amdgcn_s_memrealtime() & 0xffffffu);
+      const uint32_t stamp = STAMP ? ((uint32_t)__builtin_amdgcn_s_memrealtime() & 0xffffffu) : 0u;
       uint32_t newId = WF_INVALID;
       bool newFresh = false;
       WalkRecord newRec;
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
           uint32_t tile_, s_; item_tile(fr, L.pathId, tile_, s_);
           atomicAdd(wb.tileCost + tile_, (unsigned long long)(cnt.closest_visits + cnt.shadow_visits - L.v0));
         }
-        if (L.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, L, nullptr, toShade, ended, !FRONT, stamp);
+        if (L.st == P_DONE) FLX_WALK_LANE_FOLD(false, fr, wb, compactRecs, L, nullptr, toShade, ended, STAMP, stamp);
         const long long tBf = COUNT ? clock64() : 0; if (COUNT) tFoldOnlyT += tBf - tBa;
         fq_push(shadeRing, ctl + FC_SQ, toShade, L.pathId, lane);
         const uint32_t nEnded = (uint32_t)__popcll(flx_ballot(ended));
@@ -1220,6 +1221,17 @@ __global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf
 #undef FLX_FETCH_G
 #undef FLX_FETCH_L
 #undef FLX_FRAME_ARGS
+}
+template <bool COUNT, bool FRONT>
+__global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_frame(FrameArgs /* read through kernel_frame_args() */, uint32_t total_items,
+                                                                                    uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves, uint32_t readyUnits) {
+  wf_frame_body<COUNT, FRONT, !FRONT>(total_items, ldsCount, nTransforms, shadeWaves, readyUnits);      /* (front in its own kernel: thin frames, always stamped) */
+}
+/* the frame kernel with its front inside AND the cost stamps: frames of fewer than FLX_ADAPTIVE_FRONT_MAX_TILES_PER_CU screen tiles per workgroup (a rank's quarter) */
+template <bool COUNT>
+__global__ __launch_bounds__(FLX_WF_WALK_THREADS, FLX_WF_WAVES_PER_EU) void k_wf_frame_stamped(FrameArgs /* read through kernel_frame_args() */, uint32_t total_items,
+                                                                                            uint32_t ldsCount, uint32_t nTransforms, uint32_t shadeWaves, uint32_t readyUnits) {
+  wf_frame_body<COUNT, true, true>(total_items, ldsCount, nTransforms, shadeWaves, readyUnits);
 }
 
 /* ---- the frame kernel with TWO WALK JOBS PER LANE (round 5; profiles/r05_two_walks.txt) ------------------------------------------------------------
@@ -1640,7 +1652,8 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
     if (wb.frameRings != nullptr && frame_kernel_wanted(sc, fr, wb.item_count, walk_scheduler, suspend_max, organisation, wb.front != 0u, ldsCountF, ldsBytesF) &&
         dynamic_lds_ready(0, []() {
           return (int)set_lds_limit((const void *)k_wf_frame<true, false>) & (int)set_lds_limit((const void *)k_wf_frame<false, false>) &
-                 (int)set_lds_limit((const void *)k_wf_frame<true, true>) & (int)set_lds_limit((const void *)k_wf_frame<false, true>);
+                 (int)set_lds_limit((const void *)k_wf_frame<true, true>) & (int)set_lds_limit((const void *)k_wf_frame<false, true>) &
+                 (int)set_lds_limit((const void *)k_wf_frame_stamped<true>) & (int)set_lds_limit((const void *)k_wf_frame_stamped<false>);
         })) {
       const uint32_t total = wb.item_count;
       const uint32_t pixels = total / (uint32_t)(fr.samples > 0 ? fr.samples : 1);
@@ -1663,7 +1676,7 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
 #if FLX_EXPERIMENTS
       /* two walk jobs per lane (k_wf_frame2: 512-thread workgroups) where the front of the frame is inside the launch */
       uint32_t ldsCount2 = 0, ldsBytes2 = 0;
-      if (wb.front && wb.walkJobs == 2u && frame2_kernel_fits(sc, ldsCount2, ldsBytes2) &&
+      if (wb.front && (wb.walkJobs & 0xffu) == 2u && frame2_kernel_fits(sc, ldsCount2, ldsBytes2) &&
           dynamic_lds_ready(2, []() { return (int)set_lds_limit((const void *)k_wf_frame2<true>) & (int)set_lds_limit((const void *)k_wf_frame2<false>); })) {
         const dim3 block2(FLX_FRAME2_THREADS);
         if (count) hipLaunchKernelGGL((k_wf_frame2<true>), grid, block2, ldsBytes2, stream, fa, total, ldsCount2, sc.n_transforms, (uint32_t)FLX_FRAME2_SHADERS, readyUnits);
@@ -1672,7 +1685,10 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
         return 3;
       }
 #endif
-      if (wb.front) {
+      if (wb.front && (wb.walkJobs & WF_STAMP_COSTS)) {
+        if (count) hipLaunchKernelGGL((k_wf_frame_stamped<true>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
+        else hipLaunchKernelGGL((k_wf_frame_stamped<false>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
+      } else if (wb.front) {
         if (count) hipLaunchKernelGGL((k_wf_frame<true, true>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
         else hipLaunchKernelGGL((k_wf_frame<false, true>), grid, block, ldsBytesF, stream, fa, total, ldsCountF, sc.n_transforms, shadeWaves, readyUnits);
       } else {
