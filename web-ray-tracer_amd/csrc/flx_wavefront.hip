@@ -1671,7 +1671,10 @@ int launch_wavefront(const DeviceScene &sc, const DeviceFrame &fr, const Wavefro
        * that half a unit per tile it can expect but FLX_FRAME_READY_UNITS / 4 at the least (whole 1080p frame, 127 tiles per workgroup: 16 -> 6.61, 32 -> 6.43, 64 -> 6.49 ms; a quarter of
        * it, 31 tiles: 8 -> 2.40, 16 -> 2.33, 32 -> 2.57 ms; an eighth: 8 -> 1.76, 16 -> 1.83, 32 -> 2.0 ms) */
       const uint32_t tilesPerGroup = (total / ((uint32_t)fr.samples * 64u)) / compute_units;
-      uint32_t readyUnits = tilesPerGroup >= 48u ? (uint32_t)FLX_FRAME_READY_UNITS : tilesPerGroup / 2u;
+#ifndef FLX_FRAME_READY_DIV
+#define FLX_FRAME_READY_DIV 2u
+#endif
+      uint32_t readyUnits = tilesPerGroup >= 48u ? (uint32_t)FLX_FRAME_READY_UNITS : tilesPerGroup / FLX_FRAME_READY_DIV;
       readyUnits = readyUnits < (uint32_t)FLX_FRAME_READY_UNITS / 4u ? (uint32_t)FLX_FRAME_READY_UNITS / 4u : (readyUnits > (uint32_t)FLX_FRAME_READY_UNITS ? (uint32_t)FLX_FRAME_READY_UNITS : readyUnits);
 #if FLX_EXPERIMENTS
       /* two walk jobs per lane (k_wf_frame2: 512-thread workgroups) where the front of the frame is inside the launch */
