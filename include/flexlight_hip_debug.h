@@ -56,6 +56,9 @@ flx_status flx_debug_set_walk_jobs(flx_context *ctx, int jobs);
 flx_status flx_debug_set_tile_order(flx_context *ctx, const uint32_t *order, uint32_t n);
 /* the adaptive tile order — the draw order made from what every tile cost in the last frame of the same shape (the lightest tiles last) — on (1, the default) or off (0: screen order) */
 flx_status flx_debug_set_adaptive_order(flx_context *ctx, int on);
+/* the sort behind it on its own (tests): the order k_tile_order makes of n per-tile costs — mode 1: sixteen classes of equal size, heaviest first, screen order inside a class (what the library uses);
+ * 0: two classes, the lightest tenth last */
+flx_status flx_debug_tile_order_of(flx_context *ctx, const float *cost, uint32_t n, int mode, uint32_t *order);
 /* counted frames sum the entries visited by the paths of every screen tile: n > 0 turns that on (and zeroes the sums) for frames of up to n tiles, out copies the sums out first, n = 0 turns it off */
 flx_status flx_debug_tile_cost(flx_context *ctx, unsigned long long *out, uint32_t n);
 /* Rehearsal of a device group on ONE GPU: the frame server's launch takes `groups` CUs only (0: all), so that the launches of several contexts run beside

@@ -102,3 +102,33 @@ def test_the_per_tile_visit_counts_add_up_to_the_frames_counters(hip, scenes, fr
         hip.tile_cost(0)
         hip.set_frame_front(1)
         hip.set_frame_chain(2)
+
+
+def test_the_sort_makes_a_permutation_heaviest_classes_first(hip):
+    """k_tile_order on its own (flx_debug_tile_order_of): whatever the costs — equal, zero, huge, NaN, infinite, any count of tiles — the order is a permutation of the tiles
+    (a tile that is missing would never be drawn, one that is there twice drawn twice); classes come heaviest first, screen order inside a class"""
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 63, 64, 511, 512, 513, 4080, 8100, 32400, 129600):
+        cases = [np.zeros(n, np.float32), np.ones(n, np.float32), rng.random(n).astype(np.float32) * 1e4,
+                 np.exp(rng.normal(9.0, 1.5, n)).astype(np.float32)]
+        odd = np.exp(rng.normal(9.0, 1.5, n)).astype(np.float32)
+        odd[rng.integers(0, n, max(1, n // 50))] = np.nan
+        odd[rng.integers(0, n, max(1, n // 50))] = np.inf
+        odd[rng.integers(0, n, max(1, n // 50))] = 0.0
+        odd[rng.integers(0, n, max(1, n // 50))] = 3.0e38
+        cases.append(odd)
+        for cost in cases:
+            for mode in (1, 0):
+                order = hip.tile_order_of(cost, mode)
+                assert np.array_equal(np.sort(order), np.arange(n, dtype=np.uint32)), (n, mode)
+        # heaviest first: with sixteen classes of (about) equal size the heaviest sixteenth of the tiles comes before the lightest sixteenth, and equal costs keep screen order
+        cost = cases[3]
+        order = hip.tile_order_of(cost, 1).astype(np.int64)
+        if n >= 512:
+            k = n // 16
+            assert np.median(cost[order[:k]]) > np.median(cost[order[-k:]]) * 4
+            pos = np.empty(n, np.int64); pos[order] = np.arange(n)
+            heavy = np.argsort(-cost, kind="stable")[: k // 2]
+            light = np.argsort(cost, kind="stable")[: k // 2]
+            assert pos[heavy].max() < pos[light].min()
+        assert np.array_equal(hip.tile_order_of(np.full(n, 7.0, np.float32), 1), np.arange(n, dtype=np.uint32))

@@ -2076,6 +2076,23 @@ extern "C" flx_status flx_debug_set_adaptive_order(flx_context *ctx, int on) {
   ctx->auto_order_tiles = 0;
   return FLX_OK;
 }
+/* k_tile_order on its own (tests): the draw order it makes of n per-tile costs; mode as launch_tile_order's */
+extern "C" flx_status flx_debug_tile_order_of(flx_context *ctx, const float *cost, uint32_t n, int mode, uint32_t *order) {
+  if (!ctx || !cost || !order || n == 0u) return FLX_ERR_INVALID;
+  if (mode < 0 || mode > 1) return fail(ctx, FLX_ERR_INVALID, "flx_debug_tile_order_of: mode 0 (the lightest tenth last) or 1 (sixteen classes, heaviest first)");
+  FLX_HIP(ctx, hipSetDevice(ctx->device));
+  float *d_c = nullptr; uint32_t *d_o = nullptr;
+  FLX_HIP(ctx, hipMalloc(&d_c, (size_t)n * sizeof(float)));
+  if (hipMalloc(&d_o, (size_t)n * sizeof(uint32_t)) != hipSuccess) { (void)hipFree(d_c); return fail(ctx, FLX_ERR_DEVICE, "flx_debug_tile_order_of: hipMalloc"); }
+  hipError_t e = hipMemcpy(d_c, cost, (size_t)n * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemset(d_o, 0xff, (size_t)n * sizeof(uint32_t));
+  if (e == hipSuccess) { launch_tile_order(d_c, d_o, n, mode, ctx->stream); e = hipGetLastError(); }
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e == hipSuccess) e = hipMemcpy(order, d_o, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d_c); (void)hipFree(d_o);
+  if (e != hipSuccess) return fail(ctx, FLX_ERR_DEVICE, hipGetErrorString(e));
+  return FLX_OK;
+}
 /* Counted frames add, per 8 x 8 screen tile, the entries its paths' walks visited (bounce loop only): n > 0 turns that on for frames of up to n tiles and zeroes the sums,
  * out != nullptr copies them out first (as many as were asked for when it was turned on); n = 0 turns it off. */
 extern "C" flx_status flx_debug_tile_cost(flx_context *ctx, unsigned long long *out, uint32_t n) {

@@ -29,7 +29,7 @@ EXPORTS = [
     "flx_group_frame_begin", "flx_group_frame_end", "flx_group_frames_in_flight", "flx_group_set_frame_lanes",
     "flx_frame_server_takes", "flx_frame_target_set", "flx_frame_target_index", "flx_debug_set_server_groups",
     "flx_share_create", "flx_share_join", "flx_share_leave", "flx_frame_begin_shared", "flx_frame_end_shared",
-    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table", "flx_frame_target_set8", "flx_debug_set_walk_jobs", "flx_debug_set_sample_parallel", "flx_debug_set_tile_order", "flx_debug_tile_cost", "flx_debug_set_adaptive_order",
+    "flx_render_gathered_rgba8_device", "flx_group_render_rgba8", "flx_debug_set_angle_table", "flx_frame_target_set8", "flx_debug_set_walk_jobs", "flx_debug_set_sample_parallel", "flx_debug_set_tile_order", "flx_debug_tile_cost", "flx_debug_set_adaptive_order", "flx_debug_tile_order_of",
 ]
 
 
@@ -162,6 +162,7 @@ def _load():
         "flx_debug_set_walk_jobs": (C.c_int, [vp, C.c_int]),
         "flx_debug_set_sample_parallel": (C.c_int, [vp, C.c_int]),
         "flx_debug_set_adaptive_order": (C.c_int, [vp, C.c_int]),
+        "flx_debug_tile_order_of": (C.c_int, [vp, C.POINTER(C.c_float), u32, C.c_int, C.POINTER(u32)]),
         "flx_debug_set_tile_order": (C.c_int, [vp, C.POINTER(u32), u32]),
         "flx_debug_tile_cost": (C.c_int, [vp, C.POINTER(C.c_uint64), u32]),
         "flx_frame_begin_shared": (C.c_int, [vp, C.POINTER(FrameParams)]),
@@ -400,6 +401,13 @@ class Context:
     def set_adaptive_order(self, on):
         """the frame kernel's draw order made from the last frame's per-tile cost (flx_debug_set_adaptive_order): on by default"""
         self._check(LIB.flx_debug_set_adaptive_order(self._h, int(bool(on))), "flx_debug_set_adaptive_order")
+
+    def tile_order_of(self, cost, mode=1):
+        """the draw order k_tile_order makes of per-tile costs (flx_debug_tile_order_of)"""
+        c = np.ascontiguousarray(cost, np.float32)
+        out = np.zeros(c.size, np.uint32)
+        self._check(LIB.flx_debug_tile_order_of(self._h, c.ctypes.data_as(C.POINTER(C.c_float)), int(c.size), int(mode), out.ctypes.data_as(C.POINTER(C.c_uint32))), "flx_debug_tile_order_of")
+        return out
 
     def set_tile_order(self, order):
         """the frame kernel's draw order over a frame's 8 x 8 screen tiles (flx_debug_set_tile_order): a permutation, or None / empty for the default"""
