@@ -132,3 +132,35 @@ def test_the_sort_makes_a_permutation_heaviest_classes_first(hip):
             light = np.argsort(cost, kind="stable")[: k // 2]
             assert pos[heavy].max() < pos[light].min()
         assert np.array_equal(hip.tile_order_of(np.full(n, 7.0, np.float32), 1), np.arange(n, dtype=np.uint32))
+
+
+def test_the_frame_loop_on_two_lanes_with_the_adaptive_order(hip, scenes):
+    """flx_frame_begin / _end with every frame its own launches on two lanes (flx_set_frame_chain 0): each lane keeps its own measure and order; thin frames with a moving
+    camera, two in flight, equal the same frames rendered synchronously in screen order"""
+    sc = scenes("dragon")
+    hip.update_scene(sc)
+    hip.set_frame_chain(0)
+    hip.set_frame_lanes(2)
+    try:
+        def params(f):
+            p = sc.frame_params(width=640, height=360, samples=2, max_reflections=3, use_filter=0)
+            p.camera[0] += 0.03 * f
+            p.tile_rows, p.tile_index, p.tile_count = 8, f % 2, 2        # (the lanes see the two shares in turn: the order each made is for the other share's frame next time)
+            return p
+        hip.set_adaptive_order(1)
+        got = []
+        n = 12
+        for f in range(n):
+            if hip.frames_in_flight() == 2:
+                got.append(hip.frame_end()[0].copy())
+            hip.frame_begin(params(f))
+        while hip.frames_in_flight():
+            got.append(hip.frame_end()[0].copy())
+        hip.set_adaptive_order(0)
+        for f in range(n):
+            want = hip.render(params(f))[0]
+            assert np.array_equal(_bits(got[f]), _bits(want)), f
+    finally:
+        hip.set_adaptive_order(1)
+        hip.set_frame_lanes(2)
+        hip.set_frame_chain(2)
